@@ -1,0 +1,141 @@
+/*
+ * rfops.h -- C ABI of librfops.so: RFNet's point-cloud operator hot path on MI355X (gfx950).
+ *
+ * This is the drop-in boundary.  Each entry point replaces one of the reference's
+ * C++-mangled "Launcher" functions that its TensorFlow OpKernels call (the native ABI
+ * under tf_ops/ and pc_distance/); the reference interface each
+ * one replaces is cited as file:line.  Conventions, identical to the reference's:
+ *
+ *   - all pointers are DEVICE pointers (HIP), row-major contiguous; xyz tensors are
+ *     (b, npts, 3) float32, index tensors int32;
+ *   - the caller owns every buffer (outputs, gradients, scratch); the library never
+ *     allocates or frees device memory, and never synchronises the stream;
+ *   - gradient outputs are zero-filled by the call itself (the reference's ops do the
+ *     cudaMemset inside the launcher / OpKernel);
+ *   - kernels are stateless and re-entrant; all work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the null stream).  The reference launches
+ *     on the legacy default stream with no error checking; here every call returns a status.
+ *
+ * Status codes: 0 = success; > 0 = the hipError_t of the failing HIP call;
+ *               < 0 = RF_EINVAL-style argument errors below.
+ *
+ * No torch / TensorFlow types appear here; bind with ctypes, cgo, JNI ... as needed
+ * (INTEGRATION.md shows the reference-side stub).
+ */
+#ifndef RFOPS_H_
+#define RFOPS_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RF_OK 0
+#define RF_EINVAL (-1)     /* negative size, NULL pointer with non-zero size, bad attribute */
+#define RF_EWORKSPACE (-2) /* workspace smaller than rf_*_workspace_bytes() says            */
+#define RF_ENODEVICE (-3)  /* no gfx950 device / code object could not be loaded            */
+
+typedef void *rf_stream_t; /* hipStream_t */
+
+const char *rf_version(void);
+const char *rf_status_string(int status);
+
+/* ---------------------------------------------------------------- Chamfer (tf_ops/CD) --- */
+/* Replaces NmDistanceKernelLauncher(b,n,xyz,m,xyz2,result,result_i,result2,result2_i)
+ * (tf_ops/CD/tf_nndistance.cpp:168, tf_nndistance_g.cu:127-130; same op duplicated under
+ * pc_distance/).  dist1[i,j] = min_k |xyz2[i,k]-xyz1[i,j]|^2, idx1 = lowest argmin;
+ * dist2/idx2 symmetric.  `workspace` holds per-split partial minima. */
+size_t rf_nn_distance_workspace_bytes(int b, int n, int m);
+int rf_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist1,
+                   int *idx1, float *dist2, int *idx2, void *workspace, size_t workspace_bytes,
+                   rf_stream_t stream);
+
+/* Replaces NmDistanceGradKernelLauncher (tf_nndistance.cpp:208, tf_nndistance_g.cu:151-156).
+ * grad_xyz1 (b,n,3) and grad_xyz2 (b,m,3) are zero-filled here, then accumulated. */
+int rf_nn_distance_grad(int b, int n, int m, const float *xyz1, const float *xyz2,
+                        const float *grad_dist1, const int *idx1, const float *grad_dist2,
+                        const int *idx2, float *grad_xyz1, float *grad_xyz2, rf_stream_t stream);
+
+/* ----------------------------------------------------------- EMD (pc_distance) ---------- */
+/* Replaces approxmatchLauncher(b,n,m,xyz1,xyz2,match,temp) (pc_distance/tf_approxmatch.cpp:141,
+ * tf_approxmatch.cu:180-182).  xyz1 (b,n,3) "dataset", xyz2 (b,m,3) "query"; match is
+ * (b,m,n) (tf_approxmatch.cpp:164).  The reference's `temp` (b,2(n+m)) becomes `workspace`
+ * (larger: it keeps the per-level ratio vectors so that match is written once). */
+size_t rf_approxmatch_workspace_bytes(int b, int n, int m, int nlevels /* 0 = reference's 10 */);
+int rf_approxmatch(int b, int n, int m, const float *xyz1, const float *xyz2, float *match,
+                   void *workspace, size_t workspace_bytes, rf_stream_t stream);
+/* Same with an explicit annealing schedule (host array of `nlevels` values, each the
+ * multiplier of d^2 inside exp(); the reference's is {-4^7..-4^-1, 0}, tf_approxmatch.cu:21-25). */
+int rf_approxmatch_levels(int b, int n, int m, const float *xyz1, const float *xyz2, float *match,
+                          const float *levels_host, int nlevels, void *workspace,
+                          size_t workspace_bytes, rf_stream_t stream);
+
+/* Replaces matchcostLauncher (tf_approxmatch.cpp:142, tf_approxmatch.cu:226-228): cost (b). */
+size_t rf_matchcost_workspace_bytes(int b, int n, int m);
+int rf_matchcost(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match,
+                 float *cost, void *workspace, size_t workspace_bytes, rf_stream_t stream);
+
+/* Replaces matchcostgradLauncher (tf_approxmatch.cpp:143, tf_approxmatch.cu:292-295):
+ * grad1 (b,n,3), grad2 (b,m,3), fully overwritten. */
+int rf_matchcost_grad(int b, int n, int m, const float *xyz1, const float *xyz2,
+                      const float *match, float *grad1, float *grad2, rf_stream_t stream);
+
+/* ------------------------------------------------------- sampling (tf_ops/sampling) ------ */
+/* Replaces farthestpointsamplingLauncher(b,n,m,inp,temp,out) (tf_sampling.cpp:94,
+ * tf_sampling_g.cu:203-205).  inp (b,n,3); out (b,m) int32; temp: caller scratch of
+ * b*n floats, used only when n exceeds the register-resident limit (may be NULL otherwise,
+ * see rf_farthestpointsampling_temp_floats). */
+size_t rf_farthestpointsampling_temp_floats(int b, int n);
+int rf_farthestpointsampling(int b, int n, int m, const float *inp, float *temp, int *out,
+                             rf_stream_t stream);
+
+/* Replaces gatherpointLauncher (tf_sampling.cpp:125, tf_sampling_g.cu:206-208). */
+int rf_gatherpoint(int b, int n, int m, const float *inp, const int *idx, float *out,
+                   rf_stream_t stream);
+/* Replaces scatteraddpointLauncher + the cudaMemset before it (tf_sampling.cpp:150,174). */
+int rf_scatteraddpoint(int b, int n, int m, const float *out_g, const int *idx, float *inp_g,
+                       rf_stream_t stream);
+
+/* ------------------------------------------------------- grouping (tf_ops/grouping) ------ */
+/* Replaces queryBallPointLauncher(b,n,m,radius*,nsample,xyz1,xyz2,idx,pts_cnt)
+ * (tf_grouping.cpp:67, tf_grouping_g.cu:125-128).  xyz1 (b,n,3) dataset, xyz2 (b,m,3)
+ * queries; idx (b,m,nsample), pts_cnt (b,m).  The reference passes `radius` as a device
+ * pointer to one float (an op input tensor); here it is passed by value.  Rows with an
+ * empty ball are left untouched, as in the reference. */
+int rf_queryballpoint(int b, int n, int m, float radius, int nsample, const float *xyz1,
+                      const float *xyz2, int *idx, int *pts_cnt, rf_stream_t stream);
+
+/* Replaces groupPointLauncher / groupPointGradLauncher (tf_grouping.cpp:146,177,208).
+ * points (b,n,c); idx (b,m,nsample); out / grad_out (b,m,nsample,c); grad_points (b,n,c)
+ * zero-filled here. */
+int rf_grouppoint(int b, int n, int c, int m, int nsample, const float *points, const int *idx,
+                  float *out, rf_stream_t stream);
+int rf_grouppoint_grad(int b, int n, int c, int m, int nsample, const float *grad_out,
+                       const int *idx, float *grad_points, rf_stream_t stream);
+
+/* -------------------------------------------------- interpolation (tf_ops/interpolation) - */
+/* Replace threenn_cpu / threeinterpolate_cpu / threeinterpolate_grad_cpu
+ * (tf_interpolate.cpp:60-153; CPU-only ops in the reference).  xyz1 (b,n,3) unknown,
+ * xyz2 (b,m,3) known; dist/idx (b,n,3).  points (b,m,c), weight (b,n,3), out (b,n,c);
+ * grad_points (b,m,c) zero-filled here. */
+int rf_threenn(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist, int *idx,
+               rf_stream_t stream);
+int rf_threeinterpolate(int b, int m, int c, int n, const float *points, const int *idx,
+                        const float *weight, float *out, rf_stream_t stream);
+int rf_threeinterpolate_grad(int b, int n, int c, int m, const float *grad_out, const int *idx,
+                             const float *weight, float *grad_points, rf_stream_t stream);
+
+/* ------------------------------------------------------------------ measurement hooks --- */
+/* When enabled, every kernel launch made by this library is bracketed by hipEvents recorded
+ * on the launch stream.  rf_profile_collect() waits for them and returns the per-kernel sums
+ * since the last collect.  Used by bench.py for roofline.achieved; off by default. */
+void rf_profile_enable(int on);
+/* Fills up to `cap` entries; returns the number of distinct kernel names seen.  names[i] is a
+ * pointer to a static string; ms[i] the summed duration in milliseconds; launches[i] the count. */
+int rf_profile_collect(const char **names, double *ms, long *launches, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RFOPS_H_ */

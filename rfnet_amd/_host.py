@@ -1,0 +1,99 @@
+"""Host-side plumbing shared by the op wrappers: argument staging, output allocation,
+workspace cache, stream hand-off.  PyTorch is used only for device memory and streams.
+
+Inputs may be torch tensors on the GPU (zero-copy), or CPU tensors / numpy arrays (staged to
+the current GPU and the results copied back in the same kind).  There is no CPU execution
+path: without a HIP device every op raises.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class Staged:
+    """Remembers how the caller passed its arrays so results come back the same way."""
+
+    def __init__(self):
+        self.kind = "cuda"  # "cuda" | "cpu" | "numpy"
+        self.device = None
+
+    def take(self, x, dtype):
+        """Normalise one argument to a contiguous tensor of `dtype` WITHOUT touching the GPU,
+        so shape validation (and its reference-worded errors) works before any staging."""
+        if isinstance(x, torch.Tensor):
+            t = x.detach()
+            if t.is_cuda:
+                if self.device is None:
+                    self.device = t.device
+            elif self.kind == "cuda":
+                self.kind = "cpu"
+        else:
+            self.kind = "numpy"
+            t = torch.from_numpy(np.ascontiguousarray(np.asarray(x)))
+        if t.dtype != dtype:
+            t = t.to(dtype)
+        return t.contiguous()
+
+    def up(self, *ts):
+        """Stage validated arguments onto the GPU (no-op for tensors already there)."""
+        dev = self._dev()
+        return tuple(t if t.is_cuda else t.to(dev) for t in ts)
+
+    def _dev(self):
+        if self.device is None:
+            if not torch.cuda.is_available():
+                raise _lib.RfopsError(
+                    "rfnet_amd ops run on an MI355X (gfx950) only: no HIP device is visible "
+                    "and there is no CPU fallback"
+                )
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        return self.device
+
+    def device_(self):
+        return self._dev()
+
+    def give(self, t):
+        if self.kind == "cuda":
+            return t
+        if self.kind == "cpu":
+            return t.cpu()
+        return t.cpu().numpy()
+
+
+def empty(shape, dtype, dev):
+    return torch.empty(shape, dtype=dtype, device=dev)
+
+
+def zeros(shape, dtype, dev):
+    return torch.zeros(shape, dtype=dtype, device=dev)
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, dev, tag):
+    """A cached per-(device, op) scratch buffer, grown on demand (caller-owned scratch, like
+    the reference's allocate_temp)."""
+    if nbytes == 0:
+        return None, 0
+    key = (dev.index, tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        _ws_cache[key] = buf
+    return buf, int(buf.numel())
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def invalid(msg):
+    """The reference raises tf.errors.InvalidArgumentError with this wording (OP_REQUIRES in
+    the OpKernels); here it is a ValueError with the same text."""
+    return ValueError(msg)

@@ -1,0 +1,78 @@
+"""ctypes binding of librfops.so (the C ABI declared in include/rfops.h).
+
+The library is the product: there is NO CPU fallback.  If the shared object is missing the
+import-time loader raises, and if no HIP device is present every op raises at call time.
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "librfops.so")
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/rfops.h declares
+SIGNATURES = {
+    "rf_version": (C.c_char_p, []),
+    "rf_status_string": (C.c_char_p, [_i]),
+    "rf_nn_distance_workspace_bytes": (_sz, [_i, _i, _i]),
+    "rf_nn_distance": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "rf_nn_distance_grad": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rf_approxmatch_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "rf_approxmatch": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "rf_approxmatch_levels": (_i, [_i, _i, _i, _vp, _vp, _vp, C.POINTER(_f), _i, _vp, _sz, _vp]),
+    "rf_matchcost_workspace_bytes": (_sz, [_i, _i, _i]),
+    "rf_matchcost": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "rf_matchcost_grad": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rf_farthestpointsampling_temp_floats": (_sz, [_i, _i]),
+    "rf_farthestpointsampling": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "rf_gatherpoint": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "rf_scatteraddpoint": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "rf_queryballpoint": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rf_grouppoint": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "rf_grouppoint_grad": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "rf_threenn": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rf_threeinterpolate": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rf_threeinterpolate_grad": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rf_profile_enable": (None, [_i]),
+    "rf_profile_collect": (_i, [C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_long), _i]),
+}
+
+
+class RfopsError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise RfopsError(
+            f"{LIB_PATH} is missing: build it with `python -m rfnet_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(status, what):
+    if status != 0:
+        raise RfopsError(f"{what} failed: status {status} ({lib.rf_status_string(status).decode()})")
+
+
+def profile_enable(on=True):
+    lib.rf_profile_enable(1 if on else 0)
+
+
+def profile_collect(cap=64):
+    """-> {kernel name: (total ms, launches)} since the previous collect."""
+    names = (C.c_char_p * cap)()
+    ms = (C.c_double * cap)()
+    cnt = (C.c_long * cap)()
+    k = lib.rf_profile_collect(names, ms, cnt, cap)
+    return {names[i].decode(): (ms[i], cnt[i]) for i in range(k)}

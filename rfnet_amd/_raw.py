@@ -1,0 +1,332 @@
+"""Raw (non-differentiable) calls into librfops.so, one per reference OpKernel.
+
+Each function validates shapes with the reference OpKernel's own checks and wording
+(`OP_REQUIRES(... errors::InvalidArgument(msg))`, cited per function), allocates outputs and
+scratch on the caller's GPU (what TF's allocate_output / allocate_temp did), and enqueues the
+HIP kernels on torch's current stream through the C ABI.  No computation happens in Python.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _host as H
+from ._lib import check, lib
+
+F32, I32 = torch.float32, torch.int32
+
+
+def _shape3(t, last=None):
+    return t.dim() == 3 and (last is None or t.shape[2] == last)
+
+
+# ------------------------------------------------------------------ Chamfer ----------------
+def nn_distance(xyz1, xyz2):
+    """NnDistanceGpuOp::Compute, tf_ops/CD/tf_nndistance.cpp:172-204."""
+    st = H.Staged()
+    a, b_ = st.take(xyz1, F32), st.take(xyz2, F32)
+    if a.dim() != 3:
+        raise H.invalid("NnDistance requires xyz1 be of shape (batch,#points,3)")
+    if a.shape[2] != 3:
+        raise H.invalid("NnDistance only accepts 3d point set xyz1")
+    if b_.dim() != 3:
+        raise H.invalid("NnDistance requires xyz2 be of shape (batch,#points,3)")
+    if b_.shape[2] != 3:
+        raise H.invalid("NnDistance only accepts 3d point set xyz2")
+    if b_.shape[0] != a.shape[0]:
+        raise H.invalid("NnDistance expects xyz1 and xyz2 have same batch size")
+    b, n, m = a.shape[0], a.shape[1], b_.shape[1]
+    dev = st.device_()
+    a, b_ = st.up(a, b_)
+    d1, i1 = H.empty((b, n), F32, dev), H.empty((b, n), I32, dev)
+    d2, i2 = H.empty((b, m), F32, dev), H.empty((b, m), I32, dev)
+    ws, wsz = H.workspace(lib.rf_nn_distance_workspace_bytes(b, n, m), dev, "nn")
+    check(lib.rf_nn_distance(b, n, m, H.ptr(a), H.ptr(b_), H.ptr(d1), H.ptr(i1), H.ptr(d2),
+                             H.ptr(i2), H.ptr(ws), wsz, H.stream(dev)), "rf_nn_distance")
+    return tuple(st.give(t) for t in (d1, i1, d2, i2))
+
+
+def nn_distance_grad(xyz1, xyz2, grad_dist1, idx1, grad_dist2, idx2):
+    """NnDistanceGradGpuOp::Compute, tf_ops/CD/tf_nndistance.cpp:216-251."""
+    st = H.Staged()
+    a, b_ = st.take(xyz1, F32), st.take(xyz2, F32)
+    gd1, gd2 = st.take(grad_dist1, F32), st.take(grad_dist2, F32)
+    i1, i2 = st.take(idx1, I32), st.take(idx2, I32)
+    if a.dim() != 3:
+        raise H.invalid("NnDistanceGrad requires xyz1 be of shape (batch,#points,3)")
+    if a.shape[2] != 3:
+        raise H.invalid("NnDistanceGrad only accepts 3d point set xyz1")
+    if b_.dim() != 3:
+        raise H.invalid("NnDistanceGrad requires xyz2 be of shape (batch,#points,3)")
+    if b_.shape[2] != 3:
+        raise H.invalid("NnDistanceGrad only accepts 3d point set xyz2")
+    if b_.shape[0] != a.shape[0]:
+        raise H.invalid("NnDistanceGrad expects xyz1 and xyz2 have same batch size")
+    b, n, m = a.shape[0], a.shape[1], b_.shape[1]
+    if tuple(gd1.shape) != (b, n):
+        raise H.invalid("NnDistanceGrad requires grad_dist1 be of shape(batch,#points)")
+    if tuple(i1.shape) != (b, n):
+        raise H.invalid("NnDistanceGrad requires idx1 be of shape(batch,#points)")
+    if tuple(gd2.shape) != (b, m):
+        raise H.invalid("NnDistanceGrad requires grad_dist2 be of shape(batch,#points)")
+    if tuple(i2.shape) != (b, m):
+        raise H.invalid("NnDistanceGrad requires idx2 be of shape(batch,#points)")
+    dev = st.device_()
+    a, b_, gd1, gd2, i1, i2 = st.up(a, b_, gd1, gd2, i1, i2)
+    g1, g2 = H.empty((b, n, 3), F32, dev), H.empty((b, m, 3), F32, dev)
+    check(lib.rf_nn_distance_grad(b, n, m, H.ptr(a), H.ptr(b_), H.ptr(gd1), H.ptr(i1), H.ptr(gd2),
+                                  H.ptr(i2), H.ptr(g1), H.ptr(g2), H.stream(dev)),
+          "rf_nn_distance_grad")
+    return st.give(g1), st.give(g2)
+
+
+# ------------------------------------------------------------------ EMD --------------------
+def _emd_inputs(st, xyz1, xyz2, opname):
+    a, b_ = st.take(xyz1, F32), st.take(xyz2, F32)
+    if not _shape3(a, 3):
+        raise H.invalid(f"{opname} expects (batch_size,num_points,3) xyz1 shape")
+    if not (_shape3(b_, 3) and b_.shape[0] == a.shape[0]):
+        raise H.invalid(f"{opname} expects (batch_size,num_points,3) xyz2 shape, and batch_size must match")
+    return a, b_
+
+
+def approx_match(xyz1, xyz2, levels=None):
+    """ApproxMatchGpuOp::Compute, pc_distance/tf_approxmatch.cpp:148-172 -> match (b,m,n).
+
+    `levels` (optional, extension): explicit annealing schedule; default = the reference's 10.
+    """
+    st = H.Staged()
+    a, b_ = _emd_inputs(st, xyz1, xyz2, "ApproxMatch")
+    b, n, m = a.shape[0], a.shape[1], b_.shape[1]
+    dev = st.device_()
+    a, b_ = st.up(a, b_)
+    match = H.empty((b, m, n), F32, dev)
+    nlv = 0 if levels is None else len(levels)
+    ws, wsz = H.workspace(lib.rf_approxmatch_workspace_bytes(b, n, m, nlv), dev, "am")
+    if levels is None:
+        check(lib.rf_approxmatch(b, n, m, H.ptr(a), H.ptr(b_), H.ptr(match), H.ptr(ws), wsz,
+                                 H.stream(dev)), "rf_approxmatch")
+    else:
+        lv = (C.c_float * nlv)(*[float(v) for v in levels])
+        check(lib.rf_approxmatch_levels(b, n, m, H.ptr(a), H.ptr(b_), H.ptr(match), lv, nlv,
+                                        H.ptr(ws), wsz, H.stream(dev)), "rf_approxmatch_levels")
+    return st.give(match)
+
+
+def _match_check(mt, b, n, m):
+    if not (mt.dim() == 3 and mt.shape[0] == b and mt.shape[1] == m and mt.shape[2] == n):
+        raise H.invalid("MatchCost expects (batch_size,#query,#dataset) match shape")
+
+
+def match_cost(xyz1, xyz2, match):
+    """MatchCostGpuOp::Compute, pc_distance/tf_approxmatch.cpp:204-230 -> cost (b)."""
+    st = H.Staged()
+    a, b_ = _emd_inputs(st, xyz1, xyz2, "MatchCost")
+    mt = st.take(match, F32)
+    b, n, m = a.shape[0], a.shape[1], b_.shape[1]
+    _match_check(mt, b, n, m)
+    dev = st.device_()
+    a, b_, mt = st.up(a, b_, mt)
+    cost = H.empty((b,), F32, dev)
+    ws, wsz = H.workspace(lib.rf_matchcost_workspace_bytes(b, n, m), dev, "mc")
+    check(lib.rf_matchcost(b, n, m, H.ptr(a), H.ptr(b_), H.ptr(mt), H.ptr(cost), H.ptr(ws), wsz,
+                           H.stream(dev)), "rf_matchcost")
+    return st.give(cost)
+
+
+def match_cost_grad(xyz1, xyz2, match):
+    """MatchCostGradGpuOp::Compute, pc_distance/tf_approxmatch.cpp:265-295."""
+    st = H.Staged()
+    a, b_ = _emd_inputs(st, xyz1, xyz2, "MatchCostGrad")
+    mt = st.take(match, F32)
+    b, n, m = a.shape[0], a.shape[1], b_.shape[1]
+    _match_check(mt, b, n, m)
+    dev = st.device_()
+    a, b_, mt = st.up(a, b_, mt)
+    g1, g2 = H.empty((b, n, 3), F32, dev), H.empty((b, m, 3), F32, dev)
+    check(lib.rf_matchcost_grad(b, n, m, H.ptr(a), H.ptr(b_), H.ptr(mt), H.ptr(g1), H.ptr(g2),
+                                H.stream(dev)), "rf_matchcost_grad")
+    return st.give(g1), st.give(g2)
+
+
+# ------------------------------------------------------------------ sampling ---------------
+def farthest_point_sample(npoint, inp):
+    """FarthestPointSampleGpuOp, tf_ops/sampling/tf_sampling.cpp:95-123 -> (b,npoint) int32."""
+    npoint = int(npoint)
+    if npoint <= 0:
+        raise H.invalid("FarthestPointSample expects positive npoint")
+    st = H.Staged()
+    p = st.take(inp, F32)
+    if not _shape3(p, 3):
+        raise H.invalid("FarthestPointSample expects (batch_size,num_points,3) inp shape")
+    b, n = p.shape[0], p.shape[1]
+    dev = st.device_()
+    p, = st.up(p)
+    out = H.empty((b, npoint), I32, dev)
+    nt = lib.rf_farthestpointsampling_temp_floats(b, n)
+    temp = H.empty((nt,), F32, dev) if nt else None
+    check(lib.rf_farthestpointsampling(b, n, npoint, H.ptr(p), H.ptr(temp), H.ptr(out),
+                                       H.stream(dev)), "rf_farthestpointsampling")
+    return st.give(out)
+
+
+def gather_point(inp, idx):
+    """GatherPointGpuOp, tf_sampling.cpp:126-148 -> (b,m,3)."""
+    st = H.Staged()
+    p, ix = st.take(inp, F32), st.take(idx, I32)
+    if not _shape3(p, 3):
+        raise H.invalid("GatherPoint expects (batch_size,num_points,3) inp shape")
+    if not (ix.dim() == 2 and ix.shape[0] == p.shape[0]):
+        raise H.invalid("GatherPoint expects (batch_size,num_result) idx shape")
+    b, n, m = p.shape[0], p.shape[1], ix.shape[1]
+    dev = st.device_()
+    p, ix = st.up(p, ix)
+    out = H.empty((b, m, 3), F32, dev)
+    check(lib.rf_gatherpoint(b, n, m, H.ptr(p), H.ptr(ix), H.ptr(out), H.stream(dev)),
+          "rf_gatherpoint")
+    return st.give(out)
+
+
+def gather_point_grad(inp, idx, out_g):
+    """GatherPointGradGpuOp, tf_sampling.cpp:151-178 -> (b,n,3)."""
+    st = H.Staged()
+    p, ix, og = st.take(inp, F32), st.take(idx, I32), st.take(out_g, F32)
+    if not _shape3(p, 3):
+        raise H.invalid("GatherPointGradGpuOp expects (batch_size,num_points,3) inp")
+    if not (ix.dim() == 2 and ix.shape[0] == p.shape[0]):
+        raise H.invalid("GatherPointGradGpuOp expects (batch_size,num_result) idx shape")
+    b, n, m = p.shape[0], p.shape[1], ix.shape[1]
+    if tuple(og.shape) != (b, m, 3):
+        raise H.invalid("GatherPointGradGpuOp expects (batch_size,num_result,3) out_g shape")
+    dev = st.device_()
+    p, ix, og = st.up(p, ix, og)
+    g = H.empty((b, n, 3), F32, dev)
+    check(lib.rf_scatteraddpoint(b, n, m, H.ptr(og), H.ptr(ix), H.ptr(g), H.stream(dev)),
+          "rf_scatteraddpoint")
+    return st.give(g)
+
+
+# ------------------------------------------------------------------ grouping ---------------
+def query_ball_point(radius, nsample, xyz1, xyz2):
+    """QueryBallPointGpuOp, tf_ops/grouping/tf_grouping.cpp:68-110 -> idx (b,m,nsample), pts_cnt (b,m).
+
+    Rows whose ball is empty are not written by the kernel (as in the reference, whose output
+    buffer is then uninitialised); this wrapper allocates idx zero-filled so they read 0.
+    """
+    nsample = int(nsample)
+    if nsample <= 0:
+        raise H.invalid("QueryBallPoint expects positive nsample")
+    st = H.Staged()
+    d, q = st.take(xyz1, F32), st.take(xyz2, F32)
+    if not _shape3(d, 3):
+        raise H.invalid("QueryBallPoint expects (batch_size, ndataset, 3) xyz1 shape.")
+    if not _shape3(q, 3):
+        raise H.invalid("QueryBallPoint expects (batch_size, npoint, 3) xyz2 shape.")
+    b, n, m = d.shape[0], d.shape[1], q.shape[1]
+    dev = st.device_()
+    d, q = st.up(d, q)
+    idx = H.zeros((b, m, nsample), I32, dev)
+    cnt = H.empty((b, m), I32, dev)
+    r = float(np.float32(radius))
+    check(lib.rf_queryballpoint(b, n, m, r, nsample, H.ptr(d), H.ptr(q), H.ptr(idx), H.ptr(cnt),
+                                H.stream(dev)), "rf_queryballpoint")
+    return st.give(idx), st.give(cnt)
+
+
+def group_point(points, idx):
+    """GroupPointGpuOp, tf_grouping.cpp:147-175 -> (b,m,nsample,c)."""
+    st = H.Staged()
+    p, ix = st.take(points, F32), st.take(idx, I32)
+    if p.dim() != 3:
+        raise H.invalid("GroupPoint expects (batch_size, num_points, channel) points shape")
+    if not (ix.dim() == 3 and ix.shape[0] == p.shape[0]):
+        raise H.invalid("GroupPoint expects (batch_size, npoints, nsample) idx shape")
+    b, n, c = p.shape
+    m, ns = ix.shape[1], ix.shape[2]
+    dev = st.device_()
+    p, ix = st.up(p, ix)
+    out = H.empty((b, m, ns, c), F32, dev)
+    check(lib.rf_grouppoint(b, n, c, m, ns, H.ptr(p), H.ptr(ix), H.ptr(out), H.stream(dev)),
+          "rf_grouppoint")
+    return st.give(out)
+
+
+def group_point_grad(points, idx, grad_out):
+    """GroupPointGradGpuOp, tf_grouping.cpp:178-212 -> (b,n,c)."""
+    st = H.Staged()
+    p, ix, go = st.take(points, F32), st.take(idx, I32), st.take(grad_out, F32)
+    if p.dim() != 3:
+        raise H.invalid("GroupPointGrad expects (batch_size, num_points, channel) points shape")
+    if not (ix.dim() == 3 and ix.shape[0] == p.shape[0]):
+        raise H.invalid("GroupPointGrad expects (batch_size, npoints, nsample) idx shape")
+    b, n, c = p.shape
+    m, ns = ix.shape[1], ix.shape[2]
+    if tuple(go.shape) != (b, m, ns, c):
+        raise H.invalid("GroupPointGrad expects (batch_size, npoints, nsample, channel) grad_out shape")
+    dev = st.device_()
+    p, ix, go = st.up(p, ix, go)
+    g = H.empty((b, n, c), F32, dev)
+    check(lib.rf_grouppoint_grad(b, n, c, m, ns, H.ptr(go), H.ptr(ix), H.ptr(g), H.stream(dev)),
+          "rf_grouppoint_grad")
+    return st.give(g)
+
+
+# ------------------------------------------------------------------ interpolation ----------
+def three_nn(xyz1, xyz2):
+    """ThreeNNOp, tf_ops/interpolation/tf_interpolate.cpp:157-187 -> dist (b,n,3), idx (b,n,3)."""
+    st = H.Staged()
+    u, k = st.take(xyz1, F32), st.take(xyz2, F32)
+    if not _shape3(u, 3):
+        raise H.invalid("ThreeNN expects (b,n,3) xyz1 shape.")
+    if not _shape3(k, 3):
+        raise H.invalid("ThreeNN expects (b,m,3) xyz2 shape.")
+    b, n, m = u.shape[0], u.shape[1], k.shape[1]
+    dev = st.device_()
+    u, k = st.up(u, k)
+    dist, idx = H.empty((b, n, 3), F32, dev), H.empty((b, n, 3), I32, dev)
+    check(lib.rf_threenn(b, n, m, H.ptr(u), H.ptr(k), H.ptr(dist), H.ptr(idx), H.stream(dev)),
+          "rf_threenn")
+    return st.give(dist), st.give(idx)
+
+
+def three_interpolate(points, idx, weight):
+    """ThreeInterpolateOp, tf_interpolate.cpp:191-222 -> (b,n,c)."""
+    st = H.Staged()
+    p, ix, w = st.take(points, F32), st.take(idx, I32), st.take(weight, F32)
+    if p.dim() != 3:
+        raise H.invalid("ThreeInterpolate expects (b,m,c) points shape")
+    b, m, c = p.shape
+    if not (ix.dim() == 3 and ix.shape[0] == b and ix.shape[2] == 3):
+        raise H.invalid("ThreeInterpolate expects (b,n,3) idx shape")
+    n = ix.shape[1]
+    if tuple(w.shape) != (b, n, 3):
+        raise H.invalid("ThreeInterpolate expects (b,n,3) weight shape")
+    dev = st.device_()
+    p, ix, w = st.up(p, ix, w)
+    out = H.empty((b, n, c), F32, dev)
+    check(lib.rf_threeinterpolate(b, m, c, n, H.ptr(p), H.ptr(ix), H.ptr(w), H.ptr(out),
+                                  H.stream(dev)), "rf_threeinterpolate")
+    return st.give(out)
+
+
+def three_interpolate_grad(points, idx, weight, grad_out):
+    """ThreeInterpolateGradOp, tf_interpolate.cpp:225-262 -> (b,m,c)."""
+    st = H.Staged()
+    p, ix, w, go = (st.take(points, F32), st.take(idx, I32), st.take(weight, F32),
+                    st.take(grad_out, F32))
+    if p.dim() != 3:
+        raise H.invalid("ThreeInterpolateGrad expects (b,m,c) points shape")
+    b, m, c = p.shape
+    if not (ix.dim() == 3 and ix.shape[0] == b):
+        raise H.invalid("ThreeInterpolateGrad expects (b,n,3) idx shape")
+    n = ix.shape[1]
+    if tuple(w.shape) != (b, n, 3):
+        raise H.invalid("ThreeInterpolateGrad expects (b,n,3) weight shape")
+    if tuple(go.shape) != (b, n, c):
+        raise H.invalid("ThreeInterpolateGrad expects (b,n,c) grad_out shape")
+    dev = st.device_()
+    p, ix, w, go = st.up(p, ix, w, go)
+    g = H.empty((b, m, c), F32, dev)
+    check(lib.rf_threeinterpolate_grad(b, n, c, m, H.ptr(go), H.ptr(ix), H.ptr(w), H.ptr(g),
+                                       H.stream(dev)), "rf_threeinterpolate_grad")
+    return st.give(g)

@@ -1,0 +1,46 @@
+// common.hpp -- shared helpers for the gfx950 kernels of librfops.so.
+// Compiled with -ffp-contract=off: every FMA in this library is an explicit fmaf(), so the
+// fp32 instruction sequence is the one the reference's CUDA ops execute
+// and matches oracle/rfops_oracle.c bit for bit where that is required.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/rfops.h"
+
+namespace rf {
+
+constexpr int kWave = 64;  // gfx950 wavefront
+
+// squared distance, the reference CUDA arithmetic: fma(dz,dz, fma(dx,dx, dy*dy))
+__device__ __forceinline__ float d2_fma(float dx, float dy, float dz) {
+    return fmaf(dz, dz, fmaf(dx, dx, dy * dy));
+}
+
+inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- profiling hook (rf_profile_enable / rf_profile_collect) --------------------------
+struct ProfScope {
+    ProfScope(const char *name, hipStream_t s);
+    ~ProfScope();
+    const char *name;
+    hipStream_t stream;
+    int slot;
+};
+
+}  // namespace rf
+
+#define RF_HIP(expr)                            \
+    do {                                        \
+        hipError_t _e = (expr);                 \
+        if (_e != hipSuccess) return (int)_e;   \
+    } while (0)
+
+// Launch + per-kernel event bracket (no-op unless profiling is enabled) + launch check.
+#define RF_LAUNCH(name, kernel, grid, block, shmem, stream, ...)             \
+    do {                                                                     \
+        rf::ProfScope _p(name, stream);                                      \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__); \
+    } while (0);                                                             \
+    RF_HIP(hipGetLastError())

@@ -1,0 +1,263 @@
+// sampling.hip -- farthest_point_sample, gather_point and its gradient for gfx950.
+//
+// Replaces farthestpointsamplingKernel / gatherpointKernel / scatteraddpointKernel
+// (tf_ops/sampling/tf_sampling_g.cu:105-192).  Indices are bit-exact with
+// oracle/rfops_oracle.c, including the reference's tie order, which its 512-thread launch
+// defines: largest running min-distance; among equals the smallest (k mod 512); among those
+// the smallest k (tf_sampling_g.cu:146,158).
+//
+// MI355X design: FPS is a chain of m-1 dependent block-wide arg-max reductions -- latency
+// bound, one workgroup per cloud.  The reference keeps the running min-distances in global
+// memory and re-reads points beyond its 3072-point LDS cache from global every iteration.
+// Here one 1024-thread workgroup holds the WHOLE cloud (up to 16384 points) in registers:
+// 16 points x (x,y,z,running-min) per lane, so an iteration touches no memory except a
+// 16-entry LDS exchange: per-lane scan -> wave64 butterfly arg-max on a packed 64-bit key
+// (distance bits | inverted tie rank) -> one LDS slot per wave (double-buffered: ONE barrier
+// per iteration) -> every wave re-reduces the 16 slots and picks up the winner's xyz.
+#include "common.hpp"
+
+namespace {
+
+constexpr int FPS_MAX_REG_POINTS = 16384;
+
+// tie rank of point k under the reference's 512-thread layout: lower is preferred
+__device__ __forceinline__ unsigned tie_rank(int k) { return ((unsigned)(k & 511) << 22) | (unsigned)(k >> 9); }
+
+__device__ __forceinline__ unsigned long long make_key(float d2, int k) {
+    return ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned long long)(0xFFFFFFFFu - tie_rank(k));
+}
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned lo = __shfl_xor((unsigned)(v & 0xFFFFFFFFu), o, 64);
+        unsigned hi = __shfl_xor((unsigned)(v >> 32), o, 64);
+        unsigned long long w = ((unsigned long long)hi << 32) | lo;
+        v = w > v ? w : v;
+    }
+    return v;
+}
+
+struct Slot {
+    unsigned long long key;
+    float x, y, z;
+    int k;
+};
+
+// NT threads (multiple of 512), PPT points per thread, all register resident.
+// Thread t owns k = (t & 511) + 512 * (s * (NT/512) + (t >> 9)), s = 0..PPT-1, so all its points
+// share (k mod 512) and ascend with s.
+template <int NT, int PPT>
+__global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, const float *__restrict__ inp,
+                                                     int *__restrict__ out) {
+    constexpr int NW = NT / 64;
+    constexpr int HALVES = NT / 512;
+    __shared__ Slot slots[2][NW];
+    const int bi = blockIdx.x;
+    const int t = threadIdx.x;
+    const float *P = inp + (size_t)bi * n * 3;
+    int *O = out + (size_t)bi * m;
+
+    float px[PPT], py[PPT], pz[PPT], td[PPT];
+#pragma unroll
+    for (int s = 0; s < PPT; s++) {
+        int k = (t & 511) + 512 * (s * HALVES + (t >> 9));
+        if (k < n) {
+            px[s] = P[k * 3 + 0];
+            py[s] = P[k * 3 + 1];
+            pz[s] = P[k * 3 + 2];
+            td[s] = 1e38f;
+        } else {
+            px[s] = py[s] = pz[s] = 0.f;
+            td[s] = -1.0f;  // min(d,-1) = -1 is never '>' the initial best of -1
+        }
+    }
+    if (t == 0) O[0] = 0;
+    float ox = P[0], oy = P[1], oz = P[2];  // old = 0
+    for (int j = 1; j < m; j++) {
+        float best = -1.0f;
+        int bs = 0;
+#pragma unroll
+        for (int s = 0; s < PPT; s++) {
+            float d = rf::d2_fma(px[s] - ox, py[s] - oy, pz[s] - oz);
+            float d2 = fminf(d, td[s]);
+            td[s] = d2;
+            if (d2 > best) {
+                best = d2;
+                bs = s;
+            }
+        }
+        float bx = px[0], by = py[0], bz = pz[0];
+#pragma unroll
+        for (int s = 1; s < PPT; s++)
+            if (bs == s) {
+                bx = px[s];
+                by = py[s];
+                bz = pz[s];
+            }
+        const int bk = (t & 511) + 512 * (bs * HALVES + (t >> 9));
+        // a thread with no valid point keeps best = -1: give it the lowest possible key
+        const unsigned long long key = best >= 0.f ? make_key(best, bk) : 0ull;
+        const unsigned long long wmax = wave_max_u64(key);
+        const int buf = j & 1;
+        if (key == wmax && (key != 0ull || (t & 63) == 0)) {
+            Slot sl;
+            sl.key = key;
+            sl.x = bx; sl.y = by; sl.z = bz;
+            sl.k = key != 0ull ? bk : 0;
+            slots[buf][t >> 6] = sl;
+        }
+        __syncthreads();
+        unsigned long long gk = slots[buf][0].key;
+        int gw = 0;
+#pragma unroll
+        for (int w = 1; w < NW; w++) {
+            unsigned long long kw = slots[buf][w].key;
+            if (kw > gk) {
+                gk = kw;
+                gw = w;
+            }
+        }
+        ox = slots[buf][gw].x;
+        oy = slots[buf][gw].y;
+        oz = slots[buf][gw].z;
+        if (t == 0) O[j] = slots[buf][gw].k;
+    }
+}
+
+// Fallback for clouds beyond the register-resident limit: running min-distances in the
+// caller's temp buffer (b*n floats), points re-read from global/L2.  Same selection rule.
+__global__ __launch_bounds__(1024) void fps_mem_kernel(int n, int m, const float *__restrict__ inp,
+                                                       float *__restrict__ temp, int *__restrict__ out) {
+    constexpr int NT = 1024, NW = NT / 64;
+    __shared__ Slot slots[2][NW];
+    const int bi = blockIdx.x;
+    const int t = threadIdx.x;
+    const float *P = inp + (size_t)bi * n * 3;
+    float *T = temp + (size_t)bi * n;
+    int *O = out + (size_t)bi * m;
+    for (int k = t; k < n; k += NT) T[k] = 1e38f;
+    if (t == 0) O[0] = 0;
+    float ox = P[0], oy = P[1], oz = P[2];
+    for (int j = 1; j < m; j++) {
+        float best = -1.0f;
+        int bk = 0;
+        for (int k = (t & 511) + 512 * (t >> 9); k < n; k += NT) {
+            float d = rf::d2_fma(P[k * 3] - ox, P[k * 3 + 1] - oy, P[k * 3 + 2] - oz);
+            float d2 = fminf(d, T[k]);
+            T[k] = d2;
+            if (d2 > best) {
+                best = d2;
+                bk = k;
+            }
+        }
+        const unsigned long long key = best >= 0.f ? make_key(best, bk) : 0ull;
+        const unsigned long long wmax = wave_max_u64(key);
+        const int buf = j & 1;
+        if (key == wmax && (key != 0ull || (t & 63) == 0)) {
+            Slot sl;
+            sl.key = key;
+            int kk = key != 0ull ? bk : 0;
+            sl.x = P[kk * 3]; sl.y = P[kk * 3 + 1]; sl.z = P[kk * 3 + 2];
+            sl.k = kk;
+            slots[buf][t >> 6] = sl;
+        }
+        __syncthreads();
+        unsigned long long gk = slots[buf][0].key;
+        int gw = 0;
+        for (int w = 1; w < NW; w++) {
+            unsigned long long kw = slots[buf][w].key;
+            if (kw > gk) {
+                gk = kw;
+                gw = w;
+            }
+        }
+        ox = slots[buf][gw].x;
+        oy = slots[buf][gw].y;
+        oz = slots[buf][gw].z;
+        if (t == 0) O[j] = slots[buf][gw].k;
+    }
+}
+
+__global__ void gather_kernel(int n, int m, long total, const float *__restrict__ inp,
+                              const int *__restrict__ idx, float *__restrict__ out) {
+    long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    long bi = g / m;
+    int a = idx[g];
+    const float *p = inp + (bi * n + a) * 3;
+    out[g * 3 + 0] = p[0];
+    out[g * 3 + 1] = p[1];
+    out[g * 3 + 2] = p[2];
+}
+
+__global__ void scatteradd_kernel(int n, int m, long total, const float *__restrict__ out_g,
+                                  const int *__restrict__ idx, float *__restrict__ inp_g) {
+    long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    long bi = g / m;
+    int a = idx[g];
+    float *p = inp_g + (bi * n + a) * 3;
+    atomicAdd(p + 0, out_g[g * 3 + 0]);
+    atomicAdd(p + 1, out_g[g * 3 + 1]);
+    atomicAdd(p + 2, out_g[g * 3 + 2]);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t rf_farthestpointsampling_temp_floats(int b, int n) {
+    return n > FPS_MAX_REG_POINTS ? (size_t)b * n : 0;
+}
+
+int rf_farthestpointsampling(int b, int n, int m, const float *inp, float *temp, int *out,
+                             rf_stream_t stream) {
+    if (b < 0 || n < 0 || m < 0) return RF_EINVAL;
+    if (b == 0 || m == 0) return RF_OK;
+    if (n == 0) return RF_EINVAL;  // cannot sample from an empty cloud
+    if (!inp || !out) return RF_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+#define FPS_CASE(NT, PPT)                                                                      \
+    RF_LAUNCH("fps_reg", (fps_reg_kernel<NT, PPT>), dim3(b), dim3(NT), 0, s, n, m, inp, out); \
+    return RF_OK
+    if (n <= 512) { FPS_CASE(512, 1); }
+    if (n <= 1024) { FPS_CASE(1024, 1); }
+    if (n <= 2048) { FPS_CASE(1024, 2); }
+    if (n <= 4096) { FPS_CASE(1024, 4); }
+    if (n <= 8192) { FPS_CASE(1024, 8); }
+    if (n <= 16384) { FPS_CASE(1024, 16); }
+#undef FPS_CASE
+    if (!temp) return RF_EINVAL;
+    RF_LAUNCH("fps_mem", fps_mem_kernel, dim3(b), dim3(1024), 0, s, n, m, inp, temp, out);
+    return RF_OK;
+}
+
+int rf_gatherpoint(int b, int n, int m, const float *inp, const int *idx, float *out,
+                   rf_stream_t stream) {
+    if (b < 0 || n < 0 || m < 0) return RF_EINVAL;
+    long total = (long)b * m;
+    if (total == 0) return RF_OK;
+    if (!inp || !idx || !out) return RF_EINVAL;
+    RF_LAUNCH("gather_point", gather_kernel, dim3(rf::ceil_div(total, 256)), dim3(256), 0,
+              (hipStream_t)stream, n, m, total, inp, idx, out);
+    return RF_OK;
+}
+
+int rf_scatteraddpoint(int b, int n, int m, const float *out_g, const int *idx, float *inp_g,
+                       rf_stream_t stream) {
+    if (b < 0 || n < 0 || m < 0) return RF_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if ((size_t)b * n) {
+        if (!inp_g) return RF_EINVAL;
+        RF_HIP(hipMemsetAsync(inp_g, 0, sizeof(float) * 3 * (size_t)b * n, s));
+    }
+    long total = (long)b * m;
+    if (total == 0 || n == 0) return RF_OK;
+    if (!out_g || !idx) return RF_EINVAL;
+    RF_LAUNCH("scatteradd_point", scatteradd_kernel, dim3(rf::ceil_div(total, 256)), dim3(256), 0, s, n,
+              m, total, out_g, idx, inp_g);
+    return RF_OK;
+}
+
+}  // extern "C"

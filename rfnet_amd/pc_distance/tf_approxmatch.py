@@ -1,0 +1,58 @@
+"""Approximate earth-mover matching: drop-in for the reference module
+pc_distance/tf_approxmatch.py (approx_match :10-18, match_cost :27-36, gradient :44-50)."""
+import torch
+
+from .. import _raw
+
+
+def approx_match(xyz1, xyz2):
+    '''
+input:
+    xyz1 : batch_size * #dataset_points * 3
+    xyz2 : batch_size * #query_points * 3
+returns:
+    match : batch_size * #query_points * #dataset_points
+(no gradient, like ops.NoGradient('ApproxMatch') in the reference)
+    '''
+    return _raw.approx_match(xyz1, xyz2)
+
+
+def approx_match_levels(xyz1, xyz2, levels):
+    """Extension (no reference counterpart): the same algorithm on an explicit schedule of
+    exp() multipliers; `levels=None` is the reference's {-4^7 .. -4^-1, 0}."""
+    return _raw.approx_match(xyz1, xyz2, levels=levels)
+
+
+class _MatchCost(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz1, xyz2, match):
+        ctx.save_for_backward(xyz1, xyz2, match)
+        return _raw.match_cost(xyz1, xyz2, match)
+
+    @staticmethod
+    def backward(ctx, grad_cost):
+        # reference :44-50: grads of the op scaled by grad_cost[:,None,None]; None for match
+        xyz1, xyz2, match = ctx.saved_tensors
+        g1, g2 = _raw.match_cost_grad(xyz1, xyz2, match)
+        s = grad_cost.reshape(-1, 1, 1)
+        return g1 * s, g2 * s, None
+
+
+def match_cost(xyz1, xyz2, match):
+    '''
+input:
+    xyz1 : batch_size * #dataset_points * 3
+    xyz2 : batch_size * #query_points * 3
+    match : batch_size * #query_points * #dataset_points
+returns:
+    cost : batch_size
+    '''
+    if all(isinstance(t, torch.Tensor) for t in (xyz1, xyz2, match)) and (
+            xyz1.requires_grad or xyz2.requires_grad):
+        return _MatchCost.apply(xyz1, xyz2, match)
+    return _raw.match_cost(xyz1, xyz2, match)
+
+
+def match_cost_grad(xyz1, xyz2, match):
+    """The reference's MatchCostGrad op (tf_approxmatch.cpp:16-21): (grad1, grad2)."""
+    return _raw.match_cost_grad(xyz1, xyz2, match)

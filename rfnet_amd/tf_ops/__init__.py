@@ -1,0 +1,1 @@
+"""Mirror of the reference package of the same name (see the modules inside)."""

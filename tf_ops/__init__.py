@@ -1,0 +1,1 @@
+"""Reference import path; the implementation lives in rfnet_amd/tf_ops."""

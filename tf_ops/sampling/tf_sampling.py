@@ -1,0 +1,4 @@
+"""Reference import path `tf_ops.sampling.tf_sampling` (vv_recon.py:8-20): re-exports the MI355X ops of
+rfnet_amd.tf_ops.sampling.tf_sampling so reference-style callers run unchanged."""
+from rfnet_amd.tf_ops.sampling.tf_sampling import *  # noqa: F401,F403
+from rfnet_amd.tf_ops.sampling.tf_sampling import __doc__ as _impl_doc  # noqa: F401
