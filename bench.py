@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline metric of BASELINE.json on MI355X:
+    "point-pairs/sec Chamfer (B x N x M)", configs[1] = Chamfer fwd+bwd, B=32, 2048 vs 16384.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  * N>1 is launched by torch.distributed.run, one rank per GPU (RANK/LOCAL_RANK/WORLD_SIZE);
+    the batch shards across ranks with no data-path collective ("scaling": "weak": every GPU
+    runs the full B=32 workload on its own samples); only barrier + max-over-ranks timing use RCCL.
+  * a "step" = one pass of the hot path over one batch: nn_distance forward (both directions)
+    + nn_distance_grad with upstream grads of ones (the reference bench's reduce_sum loss,
+    tf_ops/CD/tf_nndistance.py:50), inputs resident in HBM before the timed region.
+  * rank 0 prints ONE JSON line.  `value` = B*N*M*K*world / seconds (pairs/s, whole job).
+  * "roofline": the dominant kernel (nn_sweep, the fused two-direction Chamfer sweep) is
+    fp32-VALU bound; its algorithmic work is 16 flop per (B*N*M) pair (8 per
+    directed pair) against the fp32 peak of 157.3 TFLOP/s (= the dense f32 MFMA peak, which is
+    why the schema's "mfma" label is used); per-launch duration from hipEvents recorded by
+    librfops on the launch stream during the timed steps.  "roofline_hbm" gives the (small)
+    HBM figure north_star asks for: 20*B*(N+M) algorithmic bytes per launch.
+  * "cpu_baseline": the reference's own CPU kernel (nnsearch x2, oracle/_ref, kind "reference";
+    falls back to the C restatement, kind "port") on one host core, on a bounded sample of the
+    same workload.  Rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector == dense f32 MFMA peak
+HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def cpu_baseline(B, N, M, seed):
+    """Reference CPU path timed on this host: NnDistanceOp = nnsearch x2 (tf_nndistance.cpp:79-80),
+    single thread, on a bounded sample (batch elements of the same workload)."""
+    from oracle.oracle import Oracle, Ref, ref_available
+    rng = np.random.RandomState(seed)
+    sample_b = max(1, min(B, 16))  # ~5-10 s of CPU work
+    a = rng.randn(sample_b, N, 3).astype(np.float32)
+    c = rng.randn(sample_b, M, 3).astype(np.float32)
+    if ref_available():
+        impl, kind = Ref(), "reference"
+    else:
+        impl, kind = Oracle(), "port"
+    impl.nn_distance(a[:1, :256], c[:1, :256])  # warm
+    t0 = time.perf_counter()
+    impl.nn_distance(a, c)
+    dt = time.perf_counter() - t0
+    return {
+        "value": sample_b * N * M / dt,
+        "unit": "pairs/s",
+        "cores": 1,
+        "kind": kind,
+        "sample": f"nn_distance forward (both directions), {sample_b} of {B} batch elements of "
+                  f"{N}x{M}, {dt:.2f} s on 1 core",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--n", type=int, default=2048)
+    ap.add_argument("--m", type=int, default=16384)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from rfnet_amd import _lib, shard
+    from rfnet_amd._raw import nn_distance, nn_distance_grad
+
+    rank, world, local = shard.init_from_env()
+    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU fallback")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    B, N, M = args.batch, args.n, args.m
+
+    # synthetic data of configs[1]'s shape; each rank owns its own B samples (weak scaling)
+    rng = np.random.RandomState(100 + rank)
+    xyz1 = torch.from_numpy(rng.randn(B, N, 3).astype(np.float32)).to(dev)
+    xyz2 = torch.from_numpy(rng.randn(B, M, 3).astype(np.float32)).to(dev)
+    gd1 = torch.ones(B, N, device=dev)
+    gd2 = torch.ones(B, M, device=dev)
+
+    def step():
+        d1, i1, d2, i2 = nn_distance(xyz1, xyz2)
+        g1, g2 = nn_distance_grad(xyz1, xyz2, gd1, i1, gd2, i2)
+        return d1, g1, g2
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    # un-instrumented timing of exactly K steps -> value
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    # the same K steps again with per-kernel hipEvents (librfops records them on the launch
+    # stream) -> roofline.achieved; its wall time is reported next to the un-instrumented one
+    _lib.profile_collect()
+    _lib.profile_enable(True)
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt_prof = time.perf_counter() - t1
+    _lib.profile_enable(False)
+    prof = _lib.profile_collect()
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+    checksum = float(out[0].double().sum().item())
+
+    if rank == 0:
+        pairs_per_step = B * N * M
+        sweep_ms, sweep_n = prof.get("nn_sweep", (0.0, 0))
+        sweep_avg_s = (sweep_ms / max(sweep_n, 1)) * 1e-3
+        flops = 16.0 * B * N * M
+        hbm_bytes = 20.0 * B * (N + M)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("nn_sweep", {}).get(f"{B}x{N}x{M}")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "point-pairs/sec Chamfer (BxNxM)",
+            "value": world * pairs_per_step * args.steps / dt,
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"Chamfer nn_distance fwd+bwd, B={B} per GPU, {N} vs {M} points "
+                            "(BASELINE.json configs[1]), randn seed 100",
+                "batch_per_gpu": B, "n": N, "m": M, "sharding": f"batch x{world}",
+            },
+            "roofline": {
+                "bound": "mfma",
+                "pipe": "fp32 VALU (no MFMA use: peak = fp32 vector peak = dense f32 MFMA peak)",
+                "kernel": "nn_sweep",
+                "achieved": flops / sweep_avg_s / 1e12 if sweep_avg_s else None,
+                "peak": FP32_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": flops / sweep_avg_s / 1e12 / FP32_PEAK_TFLOPS if sweep_avg_s else None,
+                "traffic": traffic,
+                "flops_per_launch": flops,
+                "avg_launch_ms": sweep_avg_s * 1e3,
+                "launches": sweep_n,
+            },
+            "roofline_hbm": {
+                "bound": "hbm", "kernel": "nn_sweep",
+                "achieved": hbm_bytes / sweep_avg_s / 1e9 if sweep_avg_s else None,
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": hbm_bytes / sweep_avg_s / 1e9 / HBM_PEAK_GBPS if sweep_avg_s else None,
+                "bytes_per_launch": hbm_bytes,
+            },
+            "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items())},
+            "ms_per_step_instrumented": dt_prof / args.steps * 1e3,
+            "checksum": checksum,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(B, N, M, 100)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

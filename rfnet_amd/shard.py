@@ -1,0 +1,113 @@
+"""Batch sharding of the operator hot path over the GPUs of one node.
+
+Every kernel's outermost loop is the batch index and no sample reads another's data (the
+reference: `for (int i=blockIdx.x;i<b;i+=gridDim.x)`, e.g. tf_nndistance_g.cu:7), so the path
+shards by contiguous batch ranges with NO data-path collective: rank r of R owns samples
+[r*B/R, (r+1)*B/R).  The only exchange is the loss reduction -- an all-gather of per-sample
+losses (B x 4 bytes) -- plus an optional scatter of inputs from rank 0.  One process per GPU,
+`torch.distributed` backend "nccl" (= RCCL over xGMI on ROCm); "gloo" on CPU for the tests.
+The reference itself is single-GPU (vv_recon.py:32) and has no counterpart.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torchrun's env).
+    Returns (rank, world, local_rank).  No-op for WORLD_SIZE=1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local % torch.cuda.device_count())
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_bounds(batch, rank, world):
+    """Contiguous, balanced [lo, hi) of `batch` samples for `rank` (first B % R ranks get one more)."""
+    base, rem = divmod(batch, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_batch(tensors, rank, world):
+    """Slice every (B, ...) tensor to this rank's batch range (views, no copy)."""
+    out = []
+    for t in tensors:
+        lo, hi = shard_bounds(t.shape[0], rank, world)
+        out.append(t[lo:hi])
+    return out
+
+
+def scatter_from_rank0(full, rank, world, device=None, group=None):
+    """Optional input distribution: rank 0 holds `full` (B, ...); every rank receives its shard.
+    Uses dist.scatter on equal shards (B % R == 0), else a broadcast + local slice."""
+    if world == 1:
+        return full
+    meta = [None]
+    if rank == 0:
+        meta = [(tuple(full.shape), full.dtype)]
+    dist.broadcast_object_list(meta, src=0, group=group)
+    shape, dtype = meta[0]
+    dev = device if device is not None else (full.device if rank == 0 else torch.device("cpu"))
+    B = shape[0]
+    if B % world == 0:
+        mine = torch.empty((B // world,) + tuple(shape[1:]), dtype=dtype, device=dev)
+        chunks = list(full.contiguous().chunk(world, 0)) if rank == 0 else None
+        dist.scatter(mine, chunks, src=0, group=group)
+        return mine
+    buf = full.contiguous() if rank == 0 else torch.empty(shape, dtype=dtype, device=dev)
+    dist.broadcast(buf, src=0, group=group)
+    lo, hi = shard_bounds(B, rank, world)
+    return buf[lo:hi].clone()
+
+
+def all_gather_per_sample(local, batch, rank, world, group=None):
+    """Loss reduction: gather each rank's per-sample vector (its shard of B) into the full (B,...)
+    tensor on every rank.  Messages are ~1 KB: latency-bound, one direct all-gather."""
+    if world == 1:
+        return local
+    sizes = [shard_bounds(batch, r, world) for r in range(world)]
+    mx = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    return torch.cat([bufs[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], 0)
+
+
+def sharded_per_sample(op, tensors, batch=None, group=None):
+    """Apply `op(*shards) -> (b_local, ...)` per-sample results on this rank's batch shard of
+    `tensors` (each (B, ...), identical on every rank) and return the gathered (B, ...) result.
+
+    Example (Chamfer loss as vv_recon.py:381-385 `chamfer_big`):
+        op = lambda a, c: chamfer_per_sample(a, c)
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    B = tensors[0].shape[0] if batch is None else batch
+    local = op(*shard_batch(tensors, rank, world))
+    return all_gather_per_sample(local, B, rank, world, group)
+
+
+def chamfer_per_sample(xyz1, xyz2):
+    """Per-sample Chamfer loss as `chamfer_big` (vv_recon.py:381-385):
+    (mean sqrt(dist1) + mean sqrt(dist2)) / 2, one value per batch element."""
+    from .tf_ops.CD.tf_nndistance import nn_distance
+    d1, _, d2, _ = nn_distance(xyz1, xyz2)
+    return (torch.sqrt(d1).mean(1) + torch.sqrt(d2).mean(1)) / 2
+
+
+def emd_per_sample(xyz1, xyz2):
+    """Per-sample EMD as `earth_mover` (vv_recon.py:392-399): match_cost / num_points."""
+    from .pc_distance.tf_approxmatch import approx_match, match_cost
+    match = approx_match(xyz1, xyz2)
+    return match_cost(xyz1, xyz2, match) / float(xyz1.shape[1])

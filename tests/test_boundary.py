@@ -1,0 +1,155 @@
+"""CPU: the drop-in boundary.  The C-ABI library loads and exports every symbol that
+include/rfops.h declares; the Python mirrors keep the reference's module paths, names and error
+wording; the product path has no CPU fallback and never touches the oracle."""
+import ast
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "rfops.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rf_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from rfnet_amd import _lib
+    syms = _header_symbols()
+    assert len(syms) >= 23
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(raw, s), f"librfops.so lacks {s}"
+        assert s in _lib.SIGNATURES, f"ctypes binding lacks {s}"
+    assert sorted(_lib.SIGNATURES) == syms  # and binds nothing undeclared
+    assert b"gfx950" in _lib.lib.rf_version()
+    assert _lib.lib.rf_status_string(0) == b"ok"
+    assert _lib.lib.rf_status_string(-2) == b"workspace too small"
+
+
+def test_workspace_queries_are_pure_host_functions():
+    from rfnet_amd._lib import lib
+    assert lib.rf_nn_distance_workspace_bytes(0, 10, 10) == 0
+    # C2: 2048 queries need candidate splits -> partials; (dist,idx) pairs of 8 bytes
+    w = lib.rf_nn_distance_workspace_bytes(32, 2048, 16384)
+    assert w > 0 and w % 8 == 0
+    assert lib.rf_approxmatch_workspace_bytes(32, 2048, 2048, 0) == 32 * 4096 * 11 * 4
+    assert lib.rf_approxmatch_workspace_bytes(1, 10, 20, 50) == 30 * 51 * 4
+    assert lib.rf_farthestpointsampling_temp_floats(32, 16384) == 0
+    assert lib.rf_farthestpointsampling_temp_floats(2, 20000) == 40000
+
+
+def test_reference_module_paths_and_names():
+    """vv_recon.py:8-20 imports these modules and calls these names."""
+    import pc_distance.tf_approxmatch as am
+    import pc_distance.tf_nndistance as nd2
+    import tf_ops.CD.tf_nndistance as nd
+    import tf_ops.emd.tf_auctionmatch as au
+    import tf_ops.grouping.tf_grouping as gr
+    import tf_ops.interpolation.tf_interpolate as ip
+    import tf_ops.sampling.tf_sampling as sa
+    for mod, names in ((nd, ["nn_distance"]), (nd2, ["nn_distance"]),
+                       (am, ["approx_match", "match_cost"]),
+                       (sa, ["farthest_point_sample", "gather_point"]),
+                       (gr, ["query_ball_point", "group_point", "knn_point", "select_top_k"]),
+                       (ip, ["three_nn", "three_interpolate"]), (au, ["auction_match"])):
+        for n in names:
+            assert callable(getattr(mod, n)), (mod.__name__, n)
+    import inspect
+    assert list(inspect.signature(sa.farthest_point_sample).parameters) == ["npoint", "inp"]
+    assert list(inspect.signature(gr.query_ball_point).parameters) == ["radius", "nsample", "xyz1", "xyz2"]
+    assert list(inspect.signature(am.match_cost).parameters) == ["xyz1", "xyz2", "match"]
+    assert list(inspect.signature(ip.three_interpolate).parameters) == ["points", "idx", "weight"]
+
+
+@pytest.mark.parametrize("call,msg", [
+    (lambda: __import__("tf_ops.CD.tf_nndistance", fromlist=["x"]).nn_distance(
+        np.zeros((2, 4), np.float32), np.zeros((2, 4, 3), np.float32)),
+     "NnDistance requires xyz1 be of shape (batch,#points,3)"),
+    (lambda: __import__("tf_ops.CD.tf_nndistance", fromlist=["x"]).nn_distance(
+        np.zeros((2, 4, 3), np.float32), np.zeros((3, 4, 3), np.float32)),
+     "NnDistance expects xyz1 and xyz2 have same batch size"),
+    (lambda: __import__("pc_distance.tf_approxmatch", fromlist=["x"]).approx_match(
+        np.zeros((2, 4, 2), np.float32), np.zeros((2, 4, 3), np.float32)),
+     "ApproxMatch expects (batch_size,num_points,3) xyz1 shape"),
+    (lambda: __import__("pc_distance.tf_approxmatch", fromlist=["x"]).match_cost(
+        np.zeros((2, 4, 3), np.float32), np.zeros((2, 5, 3), np.float32), np.zeros((2, 4, 5), np.float32)),
+     "MatchCost expects (batch_size,#query,#dataset) match shape"),
+    (lambda: __import__("tf_ops.sampling.tf_sampling", fromlist=["x"]).farthest_point_sample(
+        0, np.zeros((2, 4, 3), np.float32)), "FarthestPointSample expects positive npoint"),
+    (lambda: __import__("tf_ops.sampling.tf_sampling", fromlist=["x"]).gather_point(
+        np.zeros((2, 4, 3), np.float32), np.zeros((3, 4), np.int32)),
+     "GatherPoint expects (batch_size,num_result) idx shape"),
+    (lambda: __import__("tf_ops.grouping.tf_grouping", fromlist=["x"]).query_ball_point(
+        0.1, 0, np.zeros((2, 4, 3), np.float32), np.zeros((2, 4, 3), np.float32)),
+     "QueryBallPoint expects positive nsample"),
+    (lambda: __import__("tf_ops.grouping.tf_grouping", fromlist=["x"]).group_point(
+        np.zeros((2, 4), np.float32), np.zeros((2, 4, 1), np.int32)),
+     "GroupPoint expects (batch_size, num_points, channel) points shape"),
+    (lambda: __import__("tf_ops.interpolation.tf_interpolate", fromlist=["x"]).three_nn(
+        np.zeros((2, 4, 3), np.float32), np.zeros((2, 4, 4), np.float32)),
+     "ThreeNN expects (b,m,3) xyz2 shape."),
+    (lambda: __import__("tf_ops.interpolation.tf_interpolate", fromlist=["x"]).three_interpolate(
+        np.zeros((2, 4, 3), np.float32), np.zeros((2, 6, 2), np.int32), np.zeros((2, 6, 3), np.float32)),
+     "ThreeInterpolate expects (b,n,3) idx shape"),
+])
+def test_argument_errors_use_the_reference_wording(call, msg):
+    """OP_REQUIRES(... errors::InvalidArgument(msg)) in the reference OpKernels -> ValueError(msg),
+    raised before anything touches the GPU."""
+    with pytest.raises(ValueError) as e:
+        call()
+    assert str(e.value) == msg
+
+
+def test_no_cpu_fallback_without_a_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    from rfnet_amd._lib import RfopsError
+    from tf_ops.CD.tf_nndistance import nn_distance
+    with pytest.raises(RfopsError, match="no CPU fallback"):
+        nn_distance(np.zeros((1, 4, 3), np.float32), np.zeros((1, 4, 3), np.float32))
+
+
+def test_product_path_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under rfnet_amd/, tf_ops/, pc_distance/ may import,
+    link or open it."""
+    offenders = []
+    for top in ("rfnet_amd", "tf_ops", "pc_distance"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                p = os.path.join(dirpath, f)
+                if f.endswith(".py"):
+                    tree = ast.parse(open(p).read())
+                    for node in ast.walk(tree):
+                        names = []
+                        if isinstance(node, ast.Import):
+                            names = [a.name for a in node.names]
+                        elif isinstance(node, ast.ImportFrom):
+                            names = [node.module or ""]
+                        if any(n == "oracle" or n.startswith("oracle.") for n in names):
+                            offenders.append(p)
+                    if "liboracle" in open(p).read() or "libref" in open(p).read():
+                        offenders.append(p)
+                elif f.endswith((".hip", ".hpp", ".h", ".cpp")):
+                    if re.search(r'#include\s+"[^"]*oracle', open(p).read()):
+                        offenders.append(p)
+    assert not offenders, offenders
+
+
+def test_knn_point_is_pure_tensor_ops():
+    """knn_point is pure TF ops in the reference (tf_grouping.py:64-73): val = top_k(-dist)."""
+    import torch
+    from tf_ops.grouping.tf_grouping import knn_point
+    rng = np.random.RandomState(0)
+    xyz1 = rng.rand(2, 50, 3).astype(np.float32)
+    xyz2 = rng.rand(2, 7, 3).astype(np.float32)
+    val, idx = knn_point(4, torch.from_numpy(xyz1), torch.from_numpy(xyz2))
+    d = ((xyz1[:, None] - xyz2[:, :, None]) ** 2).sum(-1)
+    assert np.array_equal(idx.numpy(), np.argsort(d, -1, kind="stable")[..., :4])
+    assert np.allclose(val.numpy(), -np.sort(d, -1)[..., :4], atol=1e-6)

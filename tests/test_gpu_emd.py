@@ -1,0 +1,115 @@
+"""GPU parity: approx_match / match_cost / match_cost_grad vs the CPU oracle.
+
+Tolerances: the hardware exp2/rsq approximations differ from the oracle's
+exp2f / 1/sqrtf, and row sums are accumulated per column segment, so
+   match entries: abs 1e-6 + rel 1e-4;   cost: rel 1e-5 (north_star);
+   gradients:     rel 1e-4 + abs 1e-5 of the row scale.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_rel
+
+pytestmark = pytest.mark.gpu
+
+
+def cu(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+@pytest.mark.parametrize("tag", ["sq", "rag"])
+def test_emd_golden(golden, tag):
+    from pc_distance.tf_approxmatch import approx_match, match_cost, match_cost_grad
+    g = golden("emd")
+    a, c = cu(g[f"{tag}_xyz1"]), cu(g[f"{tag}_xyz2"])
+    match = approx_match(a, c)
+    assert tuple(match.shape) == g[f"{tag}_cuda_match_mn"].shape  # (b, m, n)
+    assert_rel(match.cpu().numpy(), g[f"{tag}_cuda_match_mn"], 1e-4, 1e-6, what="match")
+    cost = match_cost(a, c, match)
+    assert_rel(cost.cpu().numpy(), g[f"{tag}_cuda_cost"], 1e-5, what="cost")
+    # on the oracle's own match, so only the cost kernel is compared
+    cost2 = match_cost(a, c, cu(g[f"{tag}_cuda_match_mn"]))
+    assert_rel(cost2.cpu().numpy(), g[f"{tag}_cuda_cost"], 1e-5, what="cost on oracle match")
+    g1, g2 = match_cost_grad(a, c, cu(g[f"{tag}_cuda_match_mn"]))
+    assert_rel(g1.cpu().numpy(), g[f"{tag}_cuda_grad1"], 1e-4, 1e-5, what="grad1")
+    assert_rel(g2.cpu().numpy(), g[f"{tag}_cuda_grad2"], 1e-4, 1e-5, what="grad2")
+
+
+@pytest.mark.parametrize("b,n,m", [(1, 1, 1), (2, 5, 3), (2, 64, 64), (3, 100, 1000), (2, 1024, 1024),
+                                   (2, 777, 130), (1, 130, 777)])
+def test_emd_random_shapes(orc, b, n, m):
+    from pc_distance.tf_approxmatch import approx_match, match_cost, match_cost_grad
+    rng = np.random.RandomState(n * 3 + m)
+    a = (rng.random_sample((b, n, 3)) - 0.5).astype(np.float32)
+    c = (rng.random_sample((b, m, 3)) - 0.5).astype(np.float32)
+    om = orc.approx_match(a, c)
+    match = approx_match(cu(a), cu(c))
+    assert_rel(match.cpu().numpy(), om, 1e-4, 1e-6, what="match")
+    assert_rel(match_cost(cu(a), cu(c), match).cpu().numpy(), orc.match_cost(a, c, om), 1e-5)
+    g1, g2 = match_cost_grad(cu(a), cu(c), cu(om))
+    o1, o2 = orc.match_cost_grad(a, c, om)
+    assert_rel(g1.cpu().numpy(), o1, 1e-4, 1e-5)
+    assert_rel(g2.cpu().numpy(), o2, 1e-4, 1e-5)
+
+
+def test_c4_config_full_size(orc):
+    """BASELINE.json configs[3]: B=32, 2048 vs 2048, reference 10-level schedule.  Oracle on one
+    batch element (1.3e8 exp evaluations), properties on all 32."""
+    from pc_distance.tf_approxmatch import approx_match, match_cost
+    rng = np.random.RandomState(100)
+    a = (rng.random_sample((32, 2048, 3)) - 0.5).astype(np.float32)
+    c = (rng.random_sample((32, 2048, 3)) - 0.5).astype(np.float32)
+    ta, tc = cu(a), cu(c)
+    match = approx_match(ta, tc)
+    cost = match_cost(ta, tc, match)
+    om = orc.approx_match(a[3:4], c[3:4])
+    # 4.2M entries, exp arguments down to -16384*d2: the 1-ulp differences between v_exp_f32
+    # and the oracle's exp2f are amplified by |argument| (~1e-5 relative on single entries)
+    # before the ten-level annealing mixes them, so the per-entry bar at this size is
+    # abs 1e-6 + rel 5e-4, with the bulk (99.99 %) inside the 1e-4 bar of the small cases.
+    gm = match[3:4].cpu().numpy()
+    assert_rel(gm, om, 5e-4, 1e-6, what="match[3]")
+    tight = np.abs(gm - om) <= 1e-6 + 1e-4 * np.abs(om)
+    assert tight.mean() > 0.9999
+    assert_rel(cost[3:4].cpu().numpy(), orc.match_cost(a[3:4], c[3:4], om), 1e-5, what="cost[3]")
+    # doubly stochastic (n == m): every point ships and receives unit mass
+    rows = match.sum(1).cpu().numpy()
+    cols = match.sum(2).cpu().numpy()
+    assert_rel(rows, np.ones_like(rows), 1e-3)
+    assert_rel(cols, np.ones_like(cols), 1e-3)
+    assert (match >= 0).all()
+    # EMD cost per point of two uniform clouds in the unit cube is O(n^-1/3): sanity band
+    per_point = cost.cpu().numpy() / 2048
+    assert (per_point > 0.02).all() and (per_point < 0.2).all()
+
+
+def test_extended_schedule_50_levels(orc):
+    """BASELINE's '50 Sinkhorn iters' has no reference counterpart: each of the 10
+    reference levels repeated 5x, checked against the oracle on the same schedule."""
+    from pc_distance.tf_approxmatch import approx_match_levels
+    lv = np.repeat(orc.default_levels(), 5)
+    rng = np.random.RandomState(50)
+    a = (rng.random_sample((2, 200, 3)) - 0.5).astype(np.float32)
+    c = (rng.random_sample((2, 200, 3)) - 0.5).astype(np.float32)
+    got = approx_match_levels(cu(a), cu(c), lv.tolist())
+    assert_rel(got.cpu().numpy(), orc.approx_match(a, c, levels=lv), 1e-4, 1e-6)
+
+
+def test_match_cost_autograd(orc):
+    """earth_mover's use (vv_recon.py:392-399): cost.backward() scales the op gradients by
+    grad_cost[:,None,None] and gives no gradient to match (tf_approxmatch.py:44-50)."""
+    from pc_distance.tf_approxmatch import approx_match, match_cost
+    rng = np.random.RandomState(12)
+    a = (rng.random_sample((2, 300, 3)) - 0.5).astype(np.float32)
+    c = (rng.random_sample((2, 300, 3)) - 0.5).astype(np.float32)
+    ta, tc = cu(a).requires_grad_(True), cu(c).requires_grad_(True)
+    match = approx_match(ta, tc)
+    assert not match.requires_grad
+    cost = match_cost(ta, tc, match)
+    scale = torch.tensor([0.5, -2.0], device="cuda")
+    (cost * scale).sum().backward()
+    o1, o2 = orc.match_cost_grad(a, c, match.cpu().numpy())
+    s = scale.cpu().numpy()[:, None, None]
+    assert_rel(ta.grad.cpu().numpy(), o1 * s, 1e-4, 1e-5)
+    assert_rel(tc.grad.cpu().numpy(), o2 * s, 1e-4, 1e-5)

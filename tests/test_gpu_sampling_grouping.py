@@ -1,0 +1,199 @@
+"""GPU parity: farthest_point_sample, gather_point(+grad), query_ball_point, group_point(+grad),
+three_nn, three_interpolate(+grad).  All index outputs are bit-exact vs the oracle; copies are
+bit-exact; atomically accumulated gradients within rel 1e-5 / abs 1e-6."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_rel
+
+pytestmark = pytest.mark.gpu
+
+
+def cu(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+# ------------------------------------------------------------------ FPS / gather
+def test_fps_golden_and_tie_rule(orc, golden):
+    from tf_ops.sampling.tf_sampling import farthest_point_sample, gather_point, gather_point_grad
+    g = golden("sampling")
+    idx = farthest_point_sample(64, cu(g["inp"]))
+    assert idx.dtype == torch.int32
+    assert np.array_equal(idx.cpu().numpy(), g["cuda_fps_idx"])
+    t = farthest_point_sample(40, cu(g["tie_inp"])).cpu().numpy()
+    assert np.array_equal(t, g["cuda_tie_fps_idx"])
+    out = gather_point(cu(g["inp"]), idx)
+    assert np.array_equal(out.cpu().numpy(), g["cuda_gathered"])
+    gi = gather_point_grad(cu(g["inp"]), idx, cu(g["grad_out"])).cpu().numpy()
+    assert_rel(gi, g["cuda_grad_inp"], 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize("b,n,m", [(1, 1, 1), (2, 1, 4), (3, 17, 17), (2, 17, 40), (2, 512, 64),
+                                   (3, 513, 100), (2, 1024, 128), (2, 1500, 77), (2, 3000, 32),
+                                   (1, 4096, 300), (2, 8000, 64), (2, 16384, 64), (33, 700, 9)])
+def test_fps_random_shapes(orc, b, n, m):
+    from tf_ops.sampling.tf_sampling import farthest_point_sample
+    rng = np.random.RandomState(n * 7 + m)
+    p = rng.rand(b, n, 3).astype(np.float32)
+    got = farthest_point_sample(m, cu(p)).cpu().numpy()
+    assert np.array_equal(got, orc.farthest_point_sample(m, p))
+
+
+def test_fps_ties_on_lattice(orc):
+    from tf_ops.sampling.tf_sampling import farthest_point_sample
+    rng = np.random.RandomState(2)
+    for n in (600, 2048, 5000):
+        p = rng.randint(0, 3, size=(2, n, 3)).astype(np.float32)  # 27 distinct sites: ties galore
+        got = farthest_point_sample(50, cu(p)).cpu().numpy()
+        assert np.array_equal(got, orc.farthest_point_sample(50, p)), n
+
+
+def test_fps_memory_fallback_beyond_16384(orc):
+    from tf_ops.sampling.tf_sampling import farthest_point_sample
+    p = np.random.RandomState(8).rand(2, 20000, 3).astype(np.float32)
+    got = farthest_point_sample(48, cu(p)).cpu().numpy()
+    assert np.array_equal(got, orc.farthest_point_sample(48, p))
+
+
+def test_c3_config_fps_ballquery_group(orc):
+    """BASELINE.json configs[2]: FPS 16384->1024 + query_ball_point(r=0.1,K=32) + group_point, B=32.
+    Oracle on 2 of the 32 clouds for FPS (serial 1023 x 16384 updates each), on all for the rest."""
+    from tf_ops.grouping.tf_grouping import group_point, query_ball_point
+    from tf_ops.sampling.tf_sampling import farthest_point_sample, gather_point
+    xyz = np.random.RandomState(100).random_sample((32, 16384, 3)).astype(np.float32)
+    t = cu(xyz)
+    idx = farthest_point_sample(1024, t)
+    hi = idx.cpu().numpy()
+    for bi in (0, 31):
+        assert np.array_equal(hi[bi], orc.farthest_point_sample(1024, xyz[bi:bi + 1])[0])
+    # size-independent properties on all clouds: a permutation prefix, first index 0
+    assert (hi[:, 0] == 0).all()
+    assert all(len(set(r.tolist())) == 1024 for r in hi)
+    new_xyz = gather_point(t, idx)
+    assert np.array_equal(new_xyz.cpu().numpy(), orc.gather_point(xyz, hi))
+    qidx, cnt = query_ball_point(0.1, 32, t, new_xyz)
+    oi, oc = orc.query_ball_point(0.1, 32, xyz, new_xyz.cpu().numpy())
+    assert np.array_equal(cnt.cpu().numpy(), oc)
+    assert np.array_equal(qidx.cpu().numpy(), oi)
+    grouped = group_point(t, qidx)
+    assert tuple(grouped.shape) == (32, 1024, 32, 3)
+    assert np.array_equal(grouped.cpu().numpy(), orc.group_point(xyz, oi))
+
+
+# ------------------------------------------------------------------ ball query / grouping
+@pytest.mark.parametrize("tag,radius,ns", [("r1_k32", 0.1, 32), ("r3_k64", 0.3, 64)])
+def test_grouping_golden(golden, tag, radius, ns):
+    from tf_ops.grouping.tf_grouping import group_point, group_point_grad, query_ball_point
+    g = golden("grouping")
+    idx, cnt = query_ball_point(radius, ns, cu(g["xyz1"]), cu(g["xyz2"]))
+    assert np.array_equal(idx.cpu().numpy(), g[f"{tag}_ref_idx"])
+    assert np.array_equal(cnt.cpu().numpy(), g[f"{tag}_cuda_pts_cnt"])
+    grouped = group_point(cu(g["points"]), idx)
+    assert np.array_equal(grouped.cpu().numpy(), g[f"{tag}_ref_grouped"])
+    gp = group_point_grad(cu(g["points"]), idx, cu(g[f"{tag}_grad_out"])).cpu().numpy()
+    assert_rel(gp, g[f"{tag}_ref_grad_points"], 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize("b,n,m,ns,r", [(1, 1, 1, 1, 0.5), (2, 63, 10, 8, 0.3), (2, 65, 33, 70, 0.4),
+                                        (3, 1000, 257, 16, 0.15), (2, 5000, 100, 300, 0.2),
+                                        (2, 200, 50, 4, 1e-6)])
+def test_query_ball_random(orc, b, n, m, ns, r):
+    from tf_ops.grouping.tf_grouping import query_ball_point
+    rng = np.random.RandomState(n + m + ns)
+    ds = rng.rand(b, n, 3).astype(np.float32)
+    q = rng.rand(b, m, 3).astype(np.float32)
+    q[:, : m // 2] = ds[:, : m // 2] if n >= m // 2 else q[:, : m // 2]
+    idx, cnt = query_ball_point(r, ns, cu(ds), cu(q))
+    oi, oc = orc.query_ball_point(r, ns, ds, q, fill=0)  # wrapper zero-fills empty rows
+    assert np.array_equal(cnt.cpu().numpy(), oc)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+
+
+def test_query_ball_radius_boundary_is_in_distance_domain(orc):
+    """Points whose sqrt_rn(d2) straddles the radius by one ulp: the compare must happen after
+    a correctly rounded sqrt, not in the squared domain."""
+    from tf_ops.grouping.tf_grouping import query_ball_point
+    rng = np.random.RandomState(4)
+    r = np.float32(0.1)
+    dirs = rng.randn(1, 4096, 3)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    scale = r * (1 + (rng.rand(1, 4096, 1) - 0.5) * 4e-7)  # within +-2e-7 relative of r
+    ds = (dirs * scale).astype(np.float32)
+    q = np.zeros((1, 1, 3), np.float32)
+    idx, cnt = query_ball_point(float(r), 4096, cu(ds), cu(q))
+    oi, oc = orc.query_ball_point(float(r), 4096, ds, q)
+    assert 100 < oc[0, 0] < 4000  # the set really straddles the boundary
+    assert np.array_equal(cnt.cpu().numpy(), oc) and np.array_equal(idx.cpu().numpy(), oi)
+
+
+def test_group_point_model_shape_and_autograd(orc):
+    """merge_layer's use: c=3, nsample=1 (vv_recon.py:135) and the reference's gradient test
+    shapes (tf_grouping_op_test.py: points (1,128,16), 8 queries, nsample 32)."""
+    from tf_ops.grouping.tf_grouping import group_point, query_ball_point
+    rng = np.random.RandomState(6)
+    pts = rng.rand(4, 1024, 3).astype(np.float32)
+    idx = rng.randint(0, 1024, size=(4, 3000, 1)).astype(np.int32)
+    out = group_point(cu(pts), cu(idx))
+    assert np.array_equal(out.cpu().numpy(), orc.group_point(pts, idx))
+    points = rng.rand(1, 128, 16).astype(np.float32)
+    xyz1 = rng.rand(1, 128, 3).astype(np.float32)
+    xyz2 = rng.rand(1, 8, 3).astype(np.float32)
+    qi, _ = query_ball_point(0.3, 32, cu(xyz1), cu(xyz2))
+    tp = cu(points).requires_grad_(True)
+    g = group_point(tp, qi)
+    w = cu(rng.rand(1, 8, 32, 16).astype(np.float32))
+    (g * w).sum().backward()
+    exp = orc.group_point_grad(points, qi.cpu().numpy(), w.cpu().numpy())
+    assert_rel(tp.grad.cpu().numpy(), exp, 1e-5, 1e-6)
+
+
+# ------------------------------------------------------------------ interpolation
+def test_interpolate_golden(golden):
+    from tf_ops.interpolation.tf_interpolate import three_interpolate, three_interpolate_grad, three_nn
+    g = golden("interpolate")
+    d, i = three_nn(cu(g["xyz1"]), cu(g["xyz2"]))
+    assert np.array_equal(d.cpu().numpy(), g["ref_dist"]) and np.array_equal(i.cpu().numpy(), g["ref_idx"])
+    out = three_interpolate(cu(g["points"]), i, cu(g["weight"]))
+    assert np.array_equal(out.cpu().numpy(), g["ref_out"])
+    gp = three_interpolate_grad(cu(g["points"]), i, cu(g["weight"]), cu(g["grad_out"]))
+    assert_rel(gp.cpu().numpy(), g["ref_grad_points"], 1e-5, 1e-6)
+    d, i = three_nn(cu(g["b_xyz1"]), cu(g["b_xyz2"]))
+    assert np.array_equal(d.cpu().numpy(), g["b_ref_dist"]) and np.array_equal(i.cpu().numpy(), g["b_ref_idx"])
+    out = three_interpolate(cu(g["b_points"]), i, cu(g["b_weight"]))
+    assert np.array_equal(out.cpu().numpy(), g["b_ref_out"])
+    d, i = three_nn(cu(g["b_xyz1"]), cu(g["b_xyz2_small"]))  # m = 2 < 3
+    assert np.array_equal(d.cpu().numpy(), g["b_small_ref_dist"])
+    assert np.array_equal(i.cpu().numpy(), g["b_small_ref_idx"])
+
+
+@pytest.mark.parametrize("b,n,m,c", [(1, 1, 1, 1), (2, 300, 3, 4), (2, 1000, 2500, 7), (3, 64, 1025, 32)])
+def test_interpolate_random(orc, b, n, m, c):
+    from tf_ops.interpolation.tf_interpolate import three_interpolate, three_nn
+    rng = np.random.RandomState(n + m)
+    u = rng.randn(b, n, 3).astype(np.float32)
+    k = rng.randn(b, m, 3).astype(np.float32)
+    if m > 10:
+        k[:, m // 2:m // 2 + 5] = k[:, :5]  # duplicates: earlier index wins
+    d, i = three_nn(cu(u), cu(k))
+    od, oi = orc.three_nn(u, k)
+    assert np.array_equal(d.cpu().numpy(), od) and np.array_equal(i.cpu().numpy(), oi)
+    pts = rng.randn(b, m, c).astype(np.float32)
+    w = rng.rand(b, n, 3).astype(np.float32)
+    tp = cu(pts).requires_grad_(True)
+    out = three_interpolate(tp, i, cu(w))
+    assert np.array_equal(out.detach().cpu().numpy(), orc.three_interpolate(pts, oi, w))
+    go = rng.randn(b, n, c).astype(np.float32)
+    out.backward(cu(go))
+    assert_rel(tp.grad.cpu().numpy(), orc.three_interpolate_grad(pts, oi, w, go), 1e-5, 1e-5)
+
+
+def test_numpy_and_cpu_tensor_inputs_round_trip(orc):
+    from tf_ops.sampling.tf_sampling import farthest_point_sample, gather_point
+    p = np.random.RandomState(1).rand(2, 700, 3).astype(np.float32)
+    i_np = farthest_point_sample(16, p)
+    assert isinstance(i_np, np.ndarray) and i_np.dtype == np.int32
+    i_cpu = farthest_point_sample(16, torch.from_numpy(p))
+    assert isinstance(i_cpu, torch.Tensor) and not i_cpu.is_cuda
+    assert np.array_equal(i_np, i_cpu.numpy()) and np.array_equal(i_np, orc.farthest_point_sample(16, p))
+    assert np.array_equal(gather_point(p, i_np), orc.gather_point(p, i_np))

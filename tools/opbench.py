@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Per-op timing at the BASELINE.json config sizes (C2/C3/C4 + north-star 16384^2), with the
+per-kernel hipEvent breakdown from librfops.  Development aid; bench.py is the judged metric.
+usage: python tools/opbench.py [chamfer|ns|fps|ball|emd|all] [--iters K]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+from rfnet_amd import _lib  # noqa: E402
+from rfnet_amd import _raw as R  # noqa: E402
+
+
+def timeit(name, fn, iters, work=None, unit=""):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    _lib.profile_collect()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    _lib.profile_enable(True)
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    _lib.profile_enable(False)
+    prof = _lib.profile_collect()
+    extra = f"  {work / ms / 1e6:.4g} G{unit}/s" if work else ""
+    print(f"{name:42s} {ms:9.4f} ms{extra}")
+    for k, (t, c) in sorted(prof.items()):
+        print(f"      {k:28s} {t / iters:9.4f} ms/iter  ({c // iters} launches/iter)")
+    return ms
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="?", default="all")
+    ap.add_argument("--iters", type=int, default=20)
+    a = ap.parse_args()
+    dev = "cuda"
+    rng = np.random.RandomState(100)
+    w = a.what
+    if w in ("chamfer", "all"):
+        x1 = torch.from_numpy(rng.randn(32, 2048, 3).astype(np.float32)).to(dev)
+        x2 = torch.from_numpy(rng.randn(32, 16384, 3).astype(np.float32)).to(dev)
+        timeit("C2 nn_distance fwd 32x2048x16384", lambda: R.nn_distance(x1, x2), a.iters,
+               32 * 2048 * 16384, "pairs")
+        d1, i1, d2, i2 = R.nn_distance(x1, x2)
+        g1, g2 = torch.ones_like(d1), torch.ones_like(d2)
+        timeit("C2 nn_distance_grad", lambda: R.nn_distance_grad(x1, x2, g1, i1, g2, i2), a.iters)
+        x3 = torch.from_numpy(rng.randn(32, 3000, 3).astype(np.float32)).to(dev)
+        timeit("nn_distance fwd 32x3000x16384", lambda: R.nn_distance(x3, x2), a.iters,
+               32 * 3000 * 16384, "pairs")
+    if w in ("ns", "all"):
+        y1 = torch.from_numpy(rng.randn(32, 16384, 3).astype(np.float32)).to(dev)
+        y2 = torch.from_numpy(rng.randn(32, 16384, 3).astype(np.float32)).to(dev)
+        timeit("north-star nn_distance fwd 32x16384x16384", lambda: R.nn_distance(y1, y2),
+               max(3, a.iters // 4), 32 * 16384 * 16384, "pairs")
+    if w in ("fps", "ball", "all"):
+        p = torch.from_numpy(rng.random_sample((32, 16384, 3)).astype(np.float32)).to(dev)
+        timeit("C3 FPS 32x16384->1024", lambda: R.farthest_point_sample(1024, p),
+               max(3, a.iters // 4), 32 * 16384 * 1023, "updates")
+        idx = R.farthest_point_sample(1024, p)
+        q = R.gather_point(p, idx)
+        timeit("C3 gather_point", lambda: R.gather_point(p, idx), a.iters)
+        timeit("C3 query_ball_point r=0.1 K=32", lambda: R.query_ball_point(0.1, 32, p, q), a.iters)
+        qi, _ = R.query_ball_point(0.1, 32, p, q)
+        timeit("C3 group_point c=3", lambda: R.group_point(p, qi), a.iters)
+        p3 = torch.from_numpy(rng.random_sample((32, 3000, 3)).astype(np.float32)).to(dev)
+        timeit("FPS 32x3000->32 (model)", lambda: R.farthest_point_sample(32, p3), a.iters)
+        timeit("three_nn 32x16384 vs 1024", lambda: R.three_nn(p, q), a.iters)
+    if w in ("emd", "all"):
+        u = torch.from_numpy((rng.random_sample((32, 2048, 3)) - 0.5).astype(np.float32)).to(dev)
+        v = torch.from_numpy((rng.random_sample((32, 2048, 3)) - 0.5).astype(np.float32)).to(dev)
+        timeit("C4 approx_match 32x2048x2048", lambda: R.approx_match(u, v), max(3, a.iters // 4),
+               30 * 32 * 2048 * 2048, "exp")
+        mt = R.approx_match(u, v)
+        timeit("C4 match_cost", lambda: R.match_cost(u, v, mt), a.iters, 32 * 2048 * 2048 * 4, "B")
+        timeit("C4 match_cost_grad", lambda: R.match_cost_grad(u, v, mt), a.iters,
+               32 * 2048 * 2048 * 4, "B")
+        u1 = u[:, :1024].contiguous()
+        v1 = v[:, :1024].contiguous()
+        timeit("approx_match 32x1024x1024 (training)", lambda: R.approx_match(u1, v1), a.iters)
+
+
+if __name__ == "__main__":
+    main()
