@@ -24,6 +24,9 @@ HIPCC_FLAGS = [
     "-fPIC",
     "-ffp-contract=off",
     "-fno-fast-math",
+    # packed fp32 (v_pk_*) is no faster than scalar fp32 on gfx950 VALU (tools/ubench/valu_rate.hip)
+    # and SLP-vectorising into it costs operand shuffles
+    "-fno-slp-vectorize",
     "-Wall",
     "-Wno-unused-function",
 ]

@@ -2,146 +2,266 @@
 //
 // Replaces NmDistanceKernel / NmDistanceGradKernel (tf_ops/CD/tf_nndistance_g.cu:4-156).
 // Results: bit-identical to oracle/rfops_oracle.c (d2 = fma(dz,dz,fma(dx,dx,dy*dy)),
-// differences "other - own", lowest index wins ties).
+// lowest index wins ties) -- the reference's two launches compute (b-a)^2 and (a-b)^2, whose
+// bits are equal, so ONE evaluation per pair serves both directions.
 //
-// MI355X design (not the reference's 32x16 blocks of one-thread-per-point):
-//   * the sweep is fp32-VALU bound; every instruction in the pair loop
-//     counts.  The reference spends 9 VALU ops per pair (3 sub, mul, 2 fma, cmp, 2 select).
-//     Here the argmin bookkeeping is taken out of the pair loop: per own point only the
-//     running MIN VALUE over a chunk of CH candidates is kept (v_min3_f32: half an op per
-//     pair), one compare+select per CHUNK remembers which chunk lowered the minimum, and
-//     the winning chunk (CH candidates) is re-scanned once at the end for the first index
-//     whose distance equals the minimum bit-for-bit.  6.5 + 3/CH ops per pair.
-//   * each thread owns R query points in registers; candidates are staged as float4 in LDS
-//     and read with one broadcast ds_read_b128 per candidate per wave (R pairs per read).
-//   * both directions run in ONE launch (no tail between the two sweeps) and the candidate
-//     range is split over workgroups so that >= 4 workgroups per CU exist even for
-//     B=32 x 2048 queries; per-split partial (min, argmin) go to the workspace and a small
-//     merge kernel combines them in split order with strict '<' (deterministic, no atomics).
+// MI355X design.  The sweep is fp32-VALU bound (20*B*(N+M) bytes of HBM traffic against
+// 2*B*N*M directed pairs); measured issue cost on gfx950 is ~2.3 cycles per VOP2
+// wave-instruction and packed-fp32 ops buy nothing (tools/ubench/valu_rate.hip), so the only
+// lever is instructions per pair.  The reference spends 2 x 9 (3 sub, mul, 2 fma, cmp, 2
+// select, per direction).  Here:
+//   * ONE SWEEP: each wave owns 64*R points of the larger set ("own", R per lane, in VGPRs)
+//     and streams the other set ("candidates") through SGPRs with scalar loads -- they are
+//     wave-uniform, so no LDS, no barrier and no VGPR is spent on them, and VALU ops take the
+//     coordinate as their SGPR operand.  d2 is computed once (6 ops) and feeds both minima.
+//   * own-side minimum: running min VALUE only (v_min3_f32, half an op per pair); one
+//     compare+select per 16-candidate CHUNK remembers the chunk that lowered it; the winning
+//     chunk is re-scanned once at the end for the first index whose d2 equals the minimum
+//     bit-for-bit (same instruction sequence => same bits).
+//   * candidate-side minimum: in-lane min3 over the R own points (half an op per pair), then a
+//     wave64 reduce-scatter butterfly over 32 candidates at a time (ds_bpermute + 2 select +
+//     min: ~3 ops per candidate, i.e. 3/R per pair) leaves candidate c's minimum over the
+//     wave's 64*R points in lane 2c.  Lanes own R CONSECUTIVE points, so the lowest matching
+//     index lives in the lowest lane whose in-lane minimum equals the wave minimum: one
+//     v_readlane + one v_cmp_eq (its SGPR mask IS the ballot) + s_ff1 per candidate finds that
+//     lane.  (value, lane) go to a per-(own block) partial array; a resolve kernel takes, per
+//     candidate, the first own block with the smallest value (strict '<' in block order =
+//     lowest index on ties) and re-scans just that lane's R points for the first exact match.
+//   ~7.9 VALU ops per (B*N*M) pair instead of 18.  All merges are order-fixed: no atomics,
+//   deterministic.
 #include "common.hpp"
 
 namespace {
 
-constexpr int TPB = 256;    // threads per workgroup (4 waves: one per SIMD)
-constexpr int R = 4;        // own (query) points per thread
-constexpr int CH = 16;      // candidates per chunk (argmin granularity in the sweep)
-constexpr int TILE = 1024;  // candidates per LDS tile: 16 KiB as float4
+constexpr int TPB = 256;  // 4 independent waves per workgroup
+constexpr int CH = 16;    // candidates per chunk (own-side argmin granularity)
+constexpr int CG = 32;    // candidates per reduce-scatter group (2 chunks)
+constexpr int PADQ = 512; // packed arrays are padded to a multiple of this many points
 
-struct Dir {
-    const float *own;    // (b, nq, 3)
-    const float *other;  // (b, nc, 3)
-    float *out_dist;     // partial or final (see nsplit)
-    int *out_idx;
-    int nq, nc;
-    int qblocks;  // ceil(nq / (TPB*R))
-    int nsplit;   // candidate splits
-    int span;     // candidates per split, multiple of CH
+// Buffers (separate __restrict__ kernel parameters so the candidate loads can be scalar loads):
+//   own      packed (b, no_pad, 3), padded with -inf
+//   cand     packed (b, nc_pad, 3), padded with +inf
+//   row_dist/row_idx  [nsplit][b][no] partial (or the final outputs if nsplit == 1)
+//   colpart  [oblocks][b][nc] minimum over one own block
+struct Sweep {
+    int b, no, nc, no_pad, nc_pad;
+    int oblocks;  // ceil(no / (64*R))
+    int nsplit;   // candidate range splits
+    int span;     // candidates per split (multiple of CG)
 };
 
-struct Args {
-    Dir d[2];
-    int b;
-    int nblk0;  // workgroups of direction 0
-};
-
-__global__ __launch_bounds__(TPB) void nn_sweep_kernel(Args a) {
-    __shared__ float4 tile[TILE];
-    int bid = blockIdx.x;
-    const int which = bid >= a.nblk0;
-    if (which) bid -= a.nblk0;
-    const Dir &D = a.d[which];
-    const int split = bid % D.nsplit;
-    const int qb = (bid / D.nsplit) % D.qblocks;
-    const int bi = bid / (D.nsplit * D.qblocks);
-    const int tid = threadIdx.x;
-
-    const float *own = D.own + (size_t)bi * D.nq * 3;
-    const float *oth = D.other + (size_t)bi * D.nc * 3;
-
-    float ax[R], ay[R], az[R], best[R];
-    int bchunk[R];
-    const int c_begin = split * D.span;
-    const int c_end = min(D.nc, c_begin + D.span);
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        int j = (qb * R + r) * TPB + tid;
-        int jj = min(j, D.nq - 1);
-        ax[r] = own[jj * 3 + 0];
-        ay[r] = own[jj * 3 + 1];
-        az[r] = own[jj * 3 + 2];
-        best[r] = INFINITY;
-        bchunk[r] = c_begin / CH;
+__global__ void pack_kernel(int b, int n, int n_pad, float padval, const float *__restrict__ src,
+                            float *__restrict__ dst) {
+    long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)b * n_pad;
+    if (g >= total) return;
+    long bi = g / n_pad;
+    int j = (int)(g - bi * n_pad);
+    float x = padval, y = 0.f, z = 0.f;
+    if (j < n) {
+        const float *p = src + (bi * n + j) * 3;
+        x = p[0]; y = p[1]; z = p[2];
     }
+    dst[g * 3 + 0] = x;
+    dst[g * 3 + 1] = y;
+    dst[g * 3 + 2] = z;
+}
 
-    for (int t0 = c_begin; t0 < c_end; t0 += TILE) {
-        const int tcount = min(TILE, c_end - t0);
-        const int tpad = (tcount + CH - 1) / CH * CH;
-        __syncthreads();
-        for (int k = tid; k < tpad; k += TPB) {
-            float4 v;
-            if (k < tcount) {
-                const float *p = oth + (size_t)(t0 + k) * 3;
-                v = make_float4(p[0], p[1], p[2], 0.f);
-            } else {
-                v = make_float4(INFINITY, 0.f, 0.f, 0.f);  // d2 = +inf: never the minimum
-            }
-            tile[k] = v;
-        }
-        __syncthreads();
-        for (int c = 0; c < tpad; c += CH) {
-            float cm[R];
-#pragma unroll
-            for (int r = 0; r < R; r++) cm[r] = INFINITY;
-#pragma unroll
-            for (int u = 0; u < CH; u += 2) {
-                const float4 p = tile[c + u];
-                const float4 q = tile[c + u + 1];
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    float d0 = rf::d2_fma(p.x - ax[r], p.y - ay[r], p.z - az[r]);
-                    float d1 = rf::d2_fma(q.x - ax[r], q.y - ay[r], q.z - az[r]);
-                    cm[r] = fminf(fminf(cm[r], d0), d1);
-                }
-            }
-            const int chunk = (t0 + c) / CH;
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                if (cm[r] < best[r]) {
-                    best[r] = cm[r];
-                    bchunk[r] = chunk;
-                }
-            }
-        }
-    }
+// running minimum as ONE v_min3_f32.  Written as asm so that LLVM cannot re-associate the chain
+// of minima over a chunk into a tree evaluated at the end of the chunk (minnum is exactly
+// associative, so it does -- and then keeps all 16 x R distances of the chunk alive: spills).
+__device__ __forceinline__ float min3_acc(float acc, float a, float b) {
+    asm("v_min3_f32 %0, %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
+    return acc;
+}
 
-    // Resolve the argmin: first index inside the winning chunk whose d2 equals the minimum.
-    // (same instruction sequence => same bits.)  If every distance was +inf the chunk is the
-    // first one and index c_begin is returned, like the reference's unconditional k==0.
-    const size_t obase = ((size_t)split * a.b + bi) * D.nq;
+template <int R>
+__device__ __forceinline__ float min_over(const float (&d)[R]) {
+    float m = d[0];
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-        int j = (qb * R + r) * TPB + tid;
-        if (j >= D.nq) continue;
-        int k0 = bchunk[r] * CH;
-        int besti = k0;
+    for (int r = 1; r + 1 < R; r += 2) m = fminf(fminf(m, d[r]), d[r + 1]);
+    if ((R & 1) == 0) m = fminf(m, d[R - 1]);
+    return m;
+}
+
+// reduce-scatter of v[0..31] over the 64 lanes: returns, in lanes 2c and 2c+1, the minimum over
+// all lanes of v[c].  Step (HALF, BIT): lanes with BIT clear keep v[0..HALF) and send
+// v[HALF..2*HALF) to lane^BIT; the others the opposite.  Template recursion keeps every register
+// index a compile-time constant (a runtime-indexed array would go to scratch).
+template <int HALF, int BIT>
+__device__ __forceinline__ void rs_step(float (&v)[CG], int lane) {
+    const bool hi = (lane & BIT) != 0;
 #pragma unroll
-        for (int u = CH - 1; u >= 0; u--) {
-            int k = k0 + u;
-            if (k < c_end) {
-                const float *p = oth + (size_t)k * 3;
-                float d = rf::d2_fma(p[0] - ax[r], p[1] - ay[r], p[2] - az[r]);
-                if (d == best[r]) besti = k;
-            }
-        }
-        float bd = best[r];
-        D.out_dist[obase + j] = bd;
-        D.out_idx[obase + j] = besti;
+    for (int i = 0; i < HALF; i++) {
+        float keep = hi ? v[i + HALF] : v[i];
+        float send = hi ? v[i] : v[i + HALF];
+        float recv = __shfl_xor(send, BIT, 64);
+        v[i] = fminf(keep, recv);
     }
 }
 
-// Combine the per-split partials in split order; strict '<' keeps the lowest index.
-__global__ void nn_merge_kernel(const float *pd, const int *pi, float *dist, int *idx, int nsplit,
-                                long total) {
+__device__ __forceinline__ float reduce_scatter32(float (&v)[CG], int lane) {
+    rs_step<16, 32>(v, lane);
+    rs_step<8, 16>(v, lane);
+    rs_step<4, 8>(v, lane);
+    rs_step<2, 4>(v, lane);
+    rs_step<1, 2>(v, lane);
+    return fminf(v[0], __shfl_xor(v[0], 1, 64));
+}
+
+// For candidate I of the group (its wave minimum sits in lane 2I of `cmin`): the lowest lane whose
+// in-lane minimum orig[I] equals it, written into lane 2I of `wl`.  The minimum is fetched back
+// with ds_bpermute (LDS crossbar, no VALU slot and no VALU->SGPR hazard), compared with
+// v_cmp_eq_f32 -- whose 64-bit result mask IS the ballot -- then s_ff1 + v_writelane.
+// Some lane always matches (the minimum is attained), so the mask is never 0 for finite/inf data.
+template <int I>
+__device__ __forceinline__ void who_has_it(const float (&orig)[CG], float cmin, int &wl) {
+    const float m = __shfl(cmin, 2 * I, 64);
+    const unsigned long long mask = __ballot(orig[I] == m);
+    const int l = __builtin_ctzll(mask);
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(wl) : "s"(l), "n"(2 * I));
+    if constexpr (I + 1 < CG) who_has_it<I + 1>(orig, cmin, wl);
+}
+
+template <int R>
+__global__ __launch_bounds__(TPB) void nn_sweep_kernel(Sweep a, const float *__restrict__ own_all,
+                                                       const float *__restrict__ cand_all,
+                                                       float *__restrict__ row_dist,
+                                                       int *__restrict__ row_idx,
+                                                       float *__restrict__ colpart,
+                                                       unsigned char *__restrict__ collane) {
+    const int lane = threadIdx.x & 63;
+    // wave-uniform work decomposition (readfirstlane => SGPRs => scalar loads of candidates)
+    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * (TPB / 64) + (threadIdx.x >> 6));
+    const int split = w % a.nsplit;
+    const int ob = (w / a.nsplit) % a.oblocks;
+    const int bi = w / (a.nsplit * a.oblocks);
+    if (bi >= a.b) return;
+
+    const float *__restrict__ own = own_all + (size_t)bi * a.no_pad * 3;
+    const float *__restrict__ cand = cand_all + (size_t)bi * a.nc_pad * 3;
+
+    float ax[R], ay[R], az[R], best[R];
+    int bchunk[R];
+    const int c_begin = split * a.span;
+    const int c_end = min(a.nc, c_begin + a.span);  // exclusive, real candidates
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int j = (ob * 64 + lane) * R + r;  // lane-major; < no_pad by construction
+        ax[r] = own[j * 3 + 0];
+        ay[r] = own[j * 3 + 1];
+        az[r] = own[j * 3 + 2];
+        best[r] = INFINITY;
+        bchunk[r] = c_begin / CH;
+    }
+    float *__restrict__ colp = colpart + ((size_t)ob * a.b + bi) * a.nc;
+    unsigned char *__restrict__ collp = collane + ((size_t)ob * a.b + bi) * a.nc;
+
+    // Candidates arrive by scalar loads in sub-chunks of SUB points (3*SUB SGPRs), one sub-chunk
+    // ahead of the arithmetic: the s_load for sub-chunk s+1 is issued before the VALU work on
+    // sub-chunk s, so its latency is covered by ~SUB*7*R instructions.  (The packed arrays carry
+    // one extra group of padding so the last prefetch stays in bounds.)
+    constexpr int SUB = 8;
+    float nb[3 * SUB];
+    {
+        const float *cp = cand + (size_t)c_begin * 3;
+#pragma unroll
+        for (int i = 0; i < 3 * SUB; i++) nb[i] = cp[i];
+    }
+    for (int c0 = c_begin; c0 < c_end; c0 += CG) {
+        float colv[CG];
+        float cm[R];
+#pragma unroll
+        for (int sub = 0; sub < CG / SUB; sub++) {
+            float cb[3 * SUB];
+            // retire the previous prefetch BEFORE issuing the next one: scalar loads return out of
+            // order, so the only wait is lgkmcnt(0), and placed after the new s_load it would
+            // wait for that one too (no overlap).  0xC07F = lgkmcnt(0) only.
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 3 * SUB; i++) cb[i] = nb[i];
+            {
+                const float *cp = cand + (size_t)(c0 + (sub + 1) * SUB) * 3;  // uniform -> s_load
+#pragma unroll
+                for (int i = 0; i < 3 * SUB; i++) nb[i] = cp[i];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if ((sub * SUB) % CH == 0) {
+#pragma unroll
+                for (int r = 0; r < R; r++) cm[r] = INFINITY;
+            }
+#pragma unroll
+            for (int u = 0; u < SUB; u += 2) {
+                const float px = cb[u * 3 + 0], py = cb[u * 3 + 1], pz = cb[u * 3 + 2];
+                const float qx = cb[u * 3 + 3], qy = cb[u * 3 + 4], qz = cb[u * 3 + 5];
+                float d0[R], d1[R];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    d0[r] = rf::d2_fma(px - ax[r], py - ay[r], pz - az[r]);
+                    d1[r] = rf::d2_fma(qx - ax[r], qy - ay[r], qz - az[r]);
+                    cm[r] = min3_acc(cm[r], d0[r], d1[r]);
+                }
+                colv[sub * SUB + u] = min_over<R>(d0);
+                colv[sub * SUB + u + 1] = min_over<R>(d1);
+                // keep the scheduler from interleaving candidate pairs (bounds the live set)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if ((sub * SUB) % CH == CH - SUB) {
+                const int chunk = (c0 + sub * SUB) / CH;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    if (cm[r] < best[r]) {
+                        best[r] = cm[r];
+                        bchunk[r] = chunk;
+                    }
+                }
+            }
+        }
+        float orig[CG];
+#pragma unroll
+        for (int i = 0; i < CG; i++) orig[i] = colv[i];
+        const float cmin = reduce_scatter32(colv, lane);
+        // which lane holds it: the lowest lane whose in-lane minimum equals the wave minimum
+        int wl = 0;
+        who_has_it<0>(orig, cmin, wl);
+        const int c = c0 + (lane >> 1);
+        if ((lane & 1) == 0 && c < c_end) {
+            colp[c] = cmin;
+            collp[c] = (unsigned char)wl;
+        }
+    }
+
+    // own side: first index inside the winning chunk whose d2 equals the minimum.  The loop over
+    // the 16 chunk slots is NOT unrolled (descending, so the lowest matching index is kept):
+    // unrolling it keeps 48 floats x R in flight and spills.
+    const size_t obase = ((size_t)split * a.b + bi) * a.no;
+    int k0[R], besti[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) besti[r] = k0[r] = bchunk[r] * CH;
+#pragma unroll 1
+    for (int u = CH - 1; u >= 0; u--) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int k = k0[r] + u;  // < nc_pad; padded entries give +inf and are excluded below
+            const float *p = cand + (size_t)k * 3;
+            float d = rf::d2_fma(p[0] - ax[r], p[1] - ay[r], p[2] - az[r]);
+            if (k < c_end && d == best[r]) besti[r] = k;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int j = (ob * 64 + lane) * R + r;
+        if (j < a.no) {
+            row_dist[obase + j] = best[r];
+            row_idx[obase + j] = besti[r];
+        }
+    }
+}
+
+// own side: combine the per-split partials in split order; strict '<' keeps the lowest index.
+__global__ void nn_rowmerge_kernel(const float *pd, const int *pi, float *dist, int *idx, int nsplit,
+                                   long total) {
     long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total) return;
     float best = pd[g];
@@ -157,10 +277,49 @@ __global__ void nn_merge_kernel(const float *pd, const int *pi, float *dist, int
     idx[g] = besti;
 }
 
+// candidate side: per candidate (one thread each), the first own block with the smallest partial
+// (strict '<' in block order), then the lowest index among that block's winning lane's R
+// consecutive points with an exactly equal d2.
+template <int R>
+__global__ __launch_bounds__(TPB) void nn_colresolve_kernel(Sweep a, const float *__restrict__ own_all,
+                                                            const float *__restrict__ cand_all,
+                                                            const float *__restrict__ colpart,
+                                                            const unsigned char *__restrict__ collane,
+                                                            float *__restrict__ dist,
+                                                            int *__restrict__ idx) {
+    const int bi = blockIdx.y;
+    const int c = blockIdx.x * TPB + threadIdx.x;
+    if (c >= a.nc) return;
+    const float *own = own_all + (size_t)bi * a.no_pad * 3;
+    const float *cand = cand_all + (size_t)bi * a.nc_pad * 3;
+    const float *cp = colpart + (size_t)bi * a.nc + c;
+    const size_t ostride = (size_t)a.b * a.nc;
+    float best = cp[0];
+    int bblk = 0;
+    for (int o = 1; o < a.oblocks; o++) {
+        float v = cp[(size_t)o * ostride];
+        if (v < best) {
+            best = v;
+            bblk = o;
+        }
+    }
+    const int wl = collane[(size_t)bblk * ostride + (size_t)bi * a.nc + c];
+    const float cx = cand[c * 3 + 0], cy = cand[c * 3 + 1], cz = cand[c * 3 + 2];
+    const int j0 = (bblk * 64 + wl) * R;
+    int found = j0;  // all-inf case: block 0, lane 0 -> index 0
+#pragma unroll
+    for (int r = R - 1; r >= 0; r--) {
+        const int j = j0 + r;
+        float d = rf::d2_fma(cx - own[j * 3 + 0], cy - own[j * 3 + 1], cz - own[j * 3 + 2]);
+        if (j < a.no && d == best) found = j;
+    }
+    dist[(size_t)bi * a.nc + c] = best;
+    idx[(size_t)bi * a.nc + c] = found;
+}
+
 // Backward: one thread per (direction, batch, point).  g = gd+gd; v = (a-b)*g rounded alone;
-// own-side contributions are unique per point (plain adds after the zero fill would also do,
-// but the other direction scatters into the same array, so both use atomics like the reference,
-// tf_nndistance_g.cu:142-147).
+// both directions scatter into both gradient arrays, hence atomics as in the reference
+// (tf_nndistance_g.cu:142-147).
 __global__ void nn_grad_kernel(int b, int n, int m, const float *xyz1, const float *xyz2,
                                const float *gd1, const int *idx1, const float *gd2,
                                const int *idx2, float *g1, float *g2) {
@@ -193,25 +352,44 @@ __global__ void nn_grad_kernel(int b, int n, int m, const float *xyz1, const flo
     }
 }
 
+constexpr int RR = 8;  // own points per lane (16 drops to 2 waves/SIMD and is slower)
+
 struct Plan {
-    int qblocks[2], nsplit[2], span[2];
+    bool swap;  // own = xyz2 (the larger set) when true
+    int no, nc, no_pad, nc_pad, oblocks, nsplit, span;
+    size_t off_own, off_cand, off_rowd, off_rowi, off_col, off_coll, bytes;
 };
+
+int round_up(long v, int q) { return (int)((v + q - 1) / q * q); }
 
 Plan make_plan(int b, int n, int m) {
     Plan p;
-    const int nq[2] = {n, m}, nc[2] = {m, n};
-    for (int d = 0; d < 2; d++) {
-        p.qblocks[d] = rf::ceil_div(nq[d], TPB * R);
-        long base = (long)b * p.qblocks[d];
-        // aim for >= 1024 workgroups per direction (4 per CU), spans of at least 256 candidates
-        int want = (int)((1024 + base - 1) / (base > 0 ? base : 1));
-        int maxs = nc[d] / 256 > 0 ? nc[d] / 256 : 1;
-        int s = want < 1 ? 1 : (want > maxs ? maxs : want);
-        int span = rf::ceil_div(rf::ceil_div(nc[d], s), CH) * CH;
-        if (span < CH) span = CH;
-        p.span[d] = span;
-        p.nsplit[d] = nc[d] > 0 ? rf::ceil_div(nc[d], span) : 1;
-    }
+    p.swap = m > n;
+    p.no = p.swap ? m : n;
+    p.nc = p.swap ? n : m;
+    p.no_pad = round_up(p.no, PADQ);
+    p.nc_pad = round_up(p.nc, PADQ);
+    p.oblocks = rf::ceil_div(p.no, 64 * RR);
+    // aim for >= 8192 waves (8 per SIMD); at least 128 candidates per split
+    long base = (long)b * p.oblocks;
+    int want = (int)((8192 + base - 1) / (base > 0 ? base : 1));
+    int maxs = p.nc / 128 > 0 ? p.nc / 128 : 1;
+    int s = want < 1 ? 1 : (want > maxs ? maxs : want);
+    p.span = round_up(rf::ceil_div(p.nc, s), CG);
+    p.nsplit = rf::ceil_div(p.nc, p.span);
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += (bytes + 255) / 256 * 256;
+        return o;
+    };
+    p.off_own = take(((size_t)b * p.no_pad + CG) * 12);
+    p.off_cand = take(((size_t)b * p.nc_pad + CG) * 12);  // + one group: prefetch overrun
+    p.off_rowd = take(p.nsplit > 1 ? (size_t)p.nsplit * b * p.no * 4 : 0);
+    p.off_rowi = take(p.nsplit > 1 ? (size_t)p.nsplit * b * p.no * 4 : 0);
+    p.off_col = take((size_t)p.oblocks * b * p.nc * 4);
+    p.off_coll = take((size_t)p.oblocks * b * p.nc);
+    p.bytes = off;
     return p;
 }
 
@@ -221,10 +399,7 @@ extern "C" {
 
 size_t rf_nn_distance_workspace_bytes(int b, int n, int m) {
     if (b <= 0 || n <= 0 || m <= 0) return 0;
-    Plan p = make_plan(b, n, m);
-    size_t e0 = p.nsplit[0] > 1 ? (size_t)p.nsplit[0] * b * n : 0;
-    size_t e1 = p.nsplit[1] > 1 ? (size_t)p.nsplit[1] * b * m : 0;
-    return (e0 + e1) * 8;
+    return make_plan(b, n, m).bytes;
 }
 
 int rf_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist1,
@@ -233,35 +408,39 @@ int rf_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2, fl
     if (b < 0 || n < 0 || m < 0) return RF_EINVAL;
     if (b == 0 || (n == 0 && m == 0)) return RF_OK;
     if (n == 0 || m == 0) return RF_EINVAL;  // a nearest neighbour in an empty set is undefined
-    if (!xyz1 || !xyz2 || !dist1 || !idx1 || !dist2 || !idx2) return RF_EINVAL;
-    if (workspace_bytes < rf_nn_distance_workspace_bytes(b, n, m)) return RF_EWORKSPACE;
-    if (workspace_bytes && !workspace) return RF_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
+    if (!xyz1 || !xyz2 || !dist1 || !idx1 || !dist2 || !idx2 || !workspace) return RF_EINVAL;
     Plan p = make_plan(b, n, m);
+    if (workspace_bytes < p.bytes) return RF_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    char *w = (char *)workspace;
+    float *own_p = (float *)(w + p.off_own), *cand_p = (float *)(w + p.off_cand);
+    const float *own_src = p.swap ? xyz2 : xyz1, *cand_src = p.swap ? xyz1 : xyz2;
+    float *own_dist = p.swap ? dist2 : dist1, *cand_dist = p.swap ? dist1 : dist2;
+    int *own_idx = p.swap ? idx2 : idx1, *cand_idx = p.swap ? idx1 : idx2;
 
-    Args a;
-    a.b = b;
-    size_t e0 = p.nsplit[0] > 1 ? (size_t)p.nsplit[0] * b * n : 0;
-    size_t e1 = p.nsplit[1] > 1 ? (size_t)p.nsplit[1] * b * m : 0;
-    float *w = (float *)workspace;
-    float *pd0 = w, *pd1 = w + 2 * e0;
-    int *pi0 = (int *)(w + e0), *pi1 = (int *)(w + 2 * e0 + e1);
+    RF_LAUNCH("nn_pack", pack_kernel, dim3(rf::ceil_div((long)b * p.no_pad, 256)), dim3(256), 0, s, b, p.no,
+              p.no_pad, -INFINITY, own_src, own_p);
+    RF_LAUNCH("nn_pack", pack_kernel, dim3(rf::ceil_div((long)b * p.nc_pad, 256)), dim3(256), 0, s, b, p.nc,
+              p.nc_pad, INFINITY, cand_src, cand_p);
 
-    a.d[0] = Dir{xyz1, xyz2, e0 ? pd0 : dist1, e0 ? pi0 : idx1, n, m, p.qblocks[0], p.nsplit[0], p.span[0]};
-    a.d[1] = Dir{xyz2, xyz1, e1 ? pd1 : dist2, e1 ? pi1 : idx2, m, n, p.qblocks[1], p.nsplit[1], p.span[1]};
-    a.nblk0 = b * p.qblocks[0] * p.nsplit[0];
-    int nblk1 = b * p.qblocks[1] * p.nsplit[1];
-    RF_LAUNCH("nn_sweep", nn_sweep_kernel, dim3(a.nblk0 + nblk1), dim3(TPB), 0, s, a);
-    if (e0) {
-        long tot = (long)b * n;
-        RF_LAUNCH("nn_merge", nn_merge_kernel, dim3(rf::ceil_div(tot, 256)), dim3(256), 0, s, pd0, pi0,
-                  dist1, idx1, p.nsplit[0], tot);
+    Sweep a;
+    float *row_dist = p.nsplit > 1 ? (float *)(w + p.off_rowd) : own_dist;
+    int *row_idx = p.nsplit > 1 ? (int *)(w + p.off_rowi) : own_idx;
+    float *colpart = (float *)(w + p.off_col);
+    unsigned char *collane = (unsigned char *)(w + p.off_coll);
+    a.b = b; a.no = p.no; a.nc = p.nc; a.no_pad = p.no_pad; a.nc_pad = p.nc_pad;
+    a.oblocks = p.oblocks; a.nsplit = p.nsplit; a.span = p.span;
+    long waves = (long)b * p.oblocks * p.nsplit;
+    RF_LAUNCH("nn_sweep", nn_sweep_kernel<RR>, dim3(rf::ceil_div(waves, TPB / 64)), dim3(TPB), 0, s, a,
+              (const float *)own_p, (const float *)cand_p, row_dist, row_idx, colpart, collane);
+    if (p.nsplit > 1) {
+        long tot = (long)b * p.no;
+        RF_LAUNCH("nn_rowmerge", nn_rowmerge_kernel, dim3(rf::ceil_div(tot, 256)), dim3(256), 0, s,
+                  (const float *)row_dist, (const int *)row_idx, own_dist, own_idx, p.nsplit, tot);
     }
-    if (e1) {
-        long tot = (long)b * m;
-        RF_LAUNCH("nn_merge", nn_merge_kernel, dim3(rf::ceil_div(tot, 256)), dim3(256), 0, s, pd1, pi1,
-                  dist2, idx2, p.nsplit[1], tot);
-    }
+    RF_LAUNCH("nn_colresolve", nn_colresolve_kernel<RR>, dim3(rf::ceil_div(p.nc, TPB), b), dim3(TPB), 0, s,
+              a, (const float *)own_p, (const float *)cand_p, (const float *)colpart,
+              (const unsigned char *)collane, cand_dist, cand_idx);
     return RF_OK;
 }
 

@@ -121,11 +121,15 @@ def test_grad_golden_and_oracle(orc, golden, tag):
             g[f"{tag}_gd2"], g[f"{tag}_ref_idx2"])
     g1, g2 = nn_distance_grad(*args)  # numpy in -> numpy out (staged through the GPU)
     assert isinstance(g1, np.ndarray)
-    assert_rel(g1, g[f"{tag}_ref_grad1"], 1e-5, 1e-6, what="grad_xyz1 vs reference CPU op")
-    assert_rel(g2, g[f"{tag}_ref_grad2"], 1e-5, 1e-6, what="grad_xyz2 vs reference CPU op")
+    # fp32 atomics sum the scatter contributions (up to ~50 per point here, of both signs) in
+    # arrival order: the error bar scales with the magnitude of the terms, not of their sum
+    a1 = 1e-5 * np.abs(g[f"{tag}_ref_grad1"]).max()
+    a2 = 1e-5 * np.abs(g[f"{tag}_ref_grad2"]).max()
+    assert_rel(g1, g[f"{tag}_ref_grad1"], 1e-5, a1, what="grad_xyz1 vs reference CPU op")
+    assert_rel(g2, g[f"{tag}_ref_grad2"], 1e-5, a2, what="grad_xyz2 vs reference CPU op")
     o1, o2 = orc.nn_distance_grad(*args)
-    assert_rel(g1, o1, 1e-5, 1e-6)
-    assert_rel(g2, o2, 1e-5, 1e-6)
+    assert_rel(g1, o1, 1e-5, a1)
+    assert_rel(g2, o2, 1e-5, a2)
 
 
 def test_autograd_matches_op_gradient(orc):
@@ -141,8 +145,8 @@ def test_autograd_matches_op_gradient(orc):
     ((d1 * w1).sum() + (d2 * w2).sum()).backward()
     o1, o2 = orc.nn_distance_grad(a, c, w1.cpu().numpy(), i1.cpu().numpy(), w2.cpu().numpy(),
                                   i2.cpu().numpy())
-    assert_rel(ta.grad.cpu().numpy(), o1, 1e-5, 1e-6)
-    assert_rel(tc.grad.cpu().numpy(), o2, 1e-5, 1e-6)
+    assert_rel(ta.grad.cpu().numpy(), o1, 1e-5, 1e-5 * np.abs(o1).max())
+    assert_rel(tc.grad.cpu().numpy(), o2, 1e-5, 1e-5 * np.abs(o2).max())
     # the reference bench's loss (tf_nndistance.py:50): reduce_sum(dist1)+reduce_sum(dist2)
     # has gradient 2*(a - nn(a)) summed with the scatter from the other direction
     assert not i1.requires_grad

@@ -1,0 +1,100 @@
+// valu_rate.hip -- measures the fp32 VALU issue rates that bound the Chamfer / EMD sweeps on
+// gfx950: v_fma_f32, v_pk_fma_f32, v_sub_f32, v_pk_add_f32, v_min3_f32, v_exp_f32 and the
+// Chamfer pair mix, at 1..8 waves per SIMD.  Also reads the shader clock (s_memtime vs
+// s_memrealtime).  Development aid: hipcc --offload-arch=gfx950 -O3 valu_rate.hip -o valu_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+#define REP8(x) x x x x x x x x
+
+template <int MODE>
+__global__ void k(float *out, int iters, unsigned long long *clk) {
+    float a = threadIdx.x * 1e-3f, b = 1.0001f;
+    float c0 = 0, c1 = 1, c2 = 2, c3 = 3, c4 = 4, c5 = 5, c6 = 6, c7 = 7;
+    f2 p0 = {0, 1}, p1 = {2, 3}, p2 = {4, 5}, p3 = {6, 7}, p4 = {1, 1}, p5 = {2, 2}, p6 = {3, 3}, p7 = {4, 4};
+    f2 pa = {a, a}, pb = {b, b};
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; i++) {
+        if (MODE == 0) {  // v_fma_f32, 8 independent chains
+            REP8(asm volatile("v_fma_f32 %0, %8, %9, %0\n v_fma_f32 %1, %8, %9, %1\n v_fma_f32 %2, %8, %9, %2\n v_fma_f32 %3, %8, %9, %3\n"
+                              "v_fma_f32 %4, %8, %9, %4\n v_fma_f32 %5, %8, %9, %5\n v_fma_f32 %6, %8, %9, %6\n v_fma_f32 %7, %8, %9, %7\n"
+                              : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "v"(a), "v"(b));)
+        } else if (MODE == 1) {  // v_pk_fma_f32
+            REP8(asm volatile("v_pk_fma_f32 %0, %8, %9, %0\n v_pk_fma_f32 %1, %8, %9, %1\n v_pk_fma_f32 %2, %8, %9, %2\n v_pk_fma_f32 %3, %8, %9, %3\n"
+                              "v_pk_fma_f32 %4, %8, %9, %4\n v_pk_fma_f32 %5, %8, %9, %5\n v_pk_fma_f32 %6, %8, %9, %6\n v_pk_fma_f32 %7, %8, %9, %7\n"
+                              : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pa), "v"(pb));)
+        } else if (MODE == 2) {  // v_sub_f32 (VOP2)
+            REP8(asm volatile("v_sub_f32 %0, %8, %0\n v_sub_f32 %1, %8, %1\n v_sub_f32 %2, %8, %2\n v_sub_f32 %3, %8, %3\n"
+                              "v_sub_f32 %4, %8, %4\n v_sub_f32 %5, %8, %5\n v_sub_f32 %6, %8, %6\n v_sub_f32 %7, %8, %7\n"
+                              : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "v"(a), "v"(b));)
+        } else if (MODE == 3) {  // v_pk_add_f32
+            REP8(asm volatile("v_pk_add_f32 %0, %8, %0\n v_pk_add_f32 %1, %8, %1\n v_pk_add_f32 %2, %8, %2\n v_pk_add_f32 %3, %8, %3\n"
+                              "v_pk_add_f32 %4, %8, %4\n v_pk_add_f32 %5, %8, %5\n v_pk_add_f32 %6, %8, %6\n v_pk_add_f32 %7, %8, %7\n"
+                              : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pa), "v"(pb));)
+        } else if (MODE == 4) {  // v_min3_f32
+            REP8(asm volatile("v_min3_f32 %0, %8, %9, %0\n v_min3_f32 %1, %8, %9, %1\n v_min3_f32 %2, %8, %9, %2\n v_min3_f32 %3, %8, %9, %3\n"
+                              "v_min3_f32 %4, %8, %9, %4\n v_min3_f32 %5, %8, %9, %5\n v_min3_f32 %6, %8, %9, %6\n v_min3_f32 %7, %8, %9, %7\n"
+                              : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "v"(a), "v"(b));)
+        } else if (MODE == 5) {  // v_exp_f32
+            REP8(asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n"
+                              "v_exp_f32 %4, %4\n v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7\n"
+                              : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "v"(a), "v"(b));)
+        } else if (MODE == 6) {  // Chamfer pair mix: 3 sub, mul, 2 fmac per pair + min3 per 2 pairs (13 instr per 2 pairs) x4
+            REP8(asm volatile(
+                "v_sub_f32 %0, %8, %4\n v_sub_f32 %1, %9, %5\n v_mul_f32 %1, %1, %1\n v_sub_f32 %2, %8, %6\n v_fmac_f32 %1, %0, %0\n v_fmac_f32 %1, %2, %2\n"
+                "v_sub_f32 %0, %9, %4\n v_sub_f32 %3, %8, %5\n v_mul_f32 %3, %3, %3\n v_sub_f32 %2, %9, %6\n v_fmac_f32 %3, %0, %0\n v_fmac_f32 %3, %2, %2\n"
+                "v_min3_f32 %7, %7, %1, %3\n"
+                : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "v"(a), "v"(b));)
+        } else if (MODE == 7) {  // same pair mix with an SGPR candidate operand (scalar-load path)
+            float sa = __builtin_amdgcn_readfirstlane(a), sb = __builtin_amdgcn_readfirstlane(b);
+            REP8(asm volatile(
+                "v_sub_f32 %0, %8, %4\n v_sub_f32 %1, %9, %5\n v_mul_f32 %1, %1, %1\n v_sub_f32 %2, %8, %6\n v_fmac_f32 %1, %0, %0\n v_fmac_f32 %1, %2, %2\n"
+                "v_sub_f32 %0, %9, %4\n v_sub_f32 %3, %8, %5\n v_mul_f32 %3, %3, %3\n v_sub_f32 %2, %9, %6\n v_fmac_f32 %3, %0, %0\n v_fmac_f32 %3, %2, %2\n"
+                "v_min3_f32 %7, %7, %1, %3\n"
+                : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "s"(sa), "s"(sb));)
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.x + p6.x + p7.x;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
+}
+
+template <int MODE>
+void run(const char *name, int instr_per_iter, int waves_per_simd) {
+    const int iters = 2000;
+    int blocks = 256 * waves_per_simd;  // 256 threads = 4 waves = 1 per SIMD per block
+    float *out; unsigned long long *clk;
+    hipMalloc(&out, sizeof(float) * blocks * 256);
+    hipMalloc(&clk, 16);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    k<MODE><<<blocks, 256>>>(out, iters, clk);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int r = 0; r < 5; r++) k<MODE><<<blocks, 256>>>(out, iters, clk);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    unsigned long long h[2]; hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+    double ghz = (double)h[0] / ((double)h[1] / 100e6) / 1e9;
+    double winstr = (double)blocks * 4 * iters * instr_per_iter;  // wave-instructions
+    double per_simd_cyc = ms * 1e-3 * ghz * 1e9 * 1024 / winstr;
+    printf("%-14s waves/SIMD=%d  %.3f ms  clock %.2f GHz  %.2f cycles per wave-instruction per SIMD  (%.1f T wave-lane-ops/s)\n",
+           name, waves_per_simd, ms, ghz, per_simd_cyc, winstr * 64 / (ms * 1e-3) / 1e12);
+    hipFree(out); hipFree(clk);
+}
+
+int main() {
+    for (int w : {1, 2, 4, 8}) {
+        run<0>("v_fma_f32", 64, w);
+        run<1>("v_pk_fma_f32", 64, w);
+        run<2>("v_sub_f32", 64, w);
+        run<3>("v_pk_add_f32", 64, w);
+        run<4>("v_min3_f32", 64, w);
+        run<5>("v_exp_f32", 64, w);
+        run<6>("chamfer mix", 104, w);
+        run<7>("chamfer mix sgpr", 104, w);
+    }
+    return 0;
+}
