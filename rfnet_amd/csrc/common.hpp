@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "../../include/rfops.h"
 

@@ -8,51 +8,94 @@
 // first hit; rows with no hit are not written.
 //
 // MI355X design: the reference gives each query to ONE thread that walks the dataset
-// serially (divergent early exit, uncoalesced AoS loads).  Here one wave64 owns a query:
-// the 64 lanes test 64 consecutive dataset points per step, a 64-bit ballot + popcount
-// prefix gives every hit its output slot in ascending-k order, and the wave stops as soon as
-// nsample hits are found.  Hits are written straight to their final slots; the padding
-// [cnt, nsample) is written once at the end, so no slot is written twice.
+// serially (divergent early exit, uncoalesced AoS loads, one IEEE sqrt per pair).  Here:
+//   * one wave64 owns QPW = 8 queries of one cloud: each step loads 64 consecutive dataset
+//     points ONCE (coalesced) and tests them against the 8 queries, whose coordinates and
+//     hit counters live in SGPRs -- 8x less L1/L2 traffic than one query per wave;
+//   * the per-pair test is ONE compare: max(sqrt_rn(d2),1e-20) < r  <=>  d2 < T, where T is
+//     the smallest float whose correctly-rounded square root reaches r (found on the host by
+//     bisection over the float bit patterns; sqrt_rn is monotone), so no sqrt on the device
+//     and still exactly the reference's distance-domain predicate;
+//   * v_cmp writes the 64-bit hit mask (the ballot) straight to SGPRs; hits are rare
+//     (~0.3 per step), so a scalar branch skips the slot assignment (v_mbcnt prefix) unless
+//     the mask is non-zero; the wave stops when all its queries have nsample hits.
+//   Hits go straight to their final slots; the padding [cnt, nsample) is written once at the
+//   end, so no slot is written twice.
 #include "common.hpp"
 
 namespace {
 
-constexpr int QB_TPB = 256;  // 4 queries per workgroup
+constexpr int QB_TPB = 256;  // 4 waves per workgroup
+constexpr int QPW = 8;       // queries per wave
 
-__global__ __launch_bounds__(QB_TPB) void query_ball_kernel(int n, int m, long nquery, float radius,
-                                                            int nsample,
+__global__ __launch_bounds__(QB_TPB) void query_ball_kernel(int n, int m, int nwaves_per_batch, int b,
+                                                            float thresh, int nsample,
                                                             const float *__restrict__ xyz1,
                                                             const float *__restrict__ xyz2,
                                                             int *__restrict__ idx,
                                                             int *__restrict__ pts_cnt) {
     const int lane = threadIdx.x & 63;
-    const long q = (long)blockIdx.x * (QB_TPB / 64) + (threadIdx.x >> 6);
-    if (q >= nquery) return;  // wave-uniform
-    const long bi = q / m;
-    const float *D = xyz1 + bi * n * 3;
-    const float x2 = xyz2[q * 3 + 0], y2 = xyz2[q * 3 + 1], z2 = xyz2[q * 3 + 2];
-    int *I = idx + q * nsample;
-    int cnt = 0;
-    int first = -1;
-    for (int k0 = 0; k0 < n && cnt < nsample; k0 += 64) {
+    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * (QB_TPB / 64) + (threadIdx.x >> 6));
+    const int bi = w / nwaves_per_batch;
+    if (bi >= b) return;
+    const int q0 = (w - bi * nwaves_per_batch) * QPW;  // first query of this wave (within the cloud)
+    const int nq = min(QPW, m - q0);
+    const float *__restrict__ D = xyz1 + (size_t)bi * n * 3;
+    const float *__restrict__ Q = xyz2 + ((size_t)bi * m + q0) * 3;
+    int *__restrict__ I = idx + ((size_t)bi * m + q0) * nsample;
+
+    float qx[QPW], qy[QPW], qz[QPW];
+    int cnt[QPW], first[QPW];
+#pragma unroll
+    for (int i = 0; i < QPW; i++) {
+        const int ii = i < nq ? i : 0;  // uniform
+        qx[i] = Q[ii * 3 + 0];
+        qy[i] = Q[ii * 3 + 1];
+        qz[i] = Q[ii * 3 + 2];
+        cnt[i] = i < nq ? 0 : nsample;  // absent queries are "done"
+        first[i] = -1;
+    }
+    // dataset points are fetched one step ahead of the tests (the early-exit loop would otherwise
+    // expose the full L2 latency on every step)
+    float nx, ny, nz;
+    {
+        const int kk = min(lane, n - 1);
+        nx = D[kk * 3 + 0]; ny = D[kk * 3 + 1]; nz = D[kk * 3 + 2];
+    }
+    for (int k0 = 0; k0 < n; k0 += 64) {
+        bool all_done = true;
+#pragma unroll
+        for (int i = 0; i < QPW; i++) all_done = all_done && (cnt[i] >= nsample);
+        if (all_done) break;
         const int k = k0 + lane;
-        bool hit = false;
-        if (k < n) {
-            float d2 = rf::d2_fma(x2 - D[k * 3 + 0], y2 - D[k * 3 + 1], z2 - D[k * 3 + 2]);
-            float d = fmaxf(sqrtf(d2), 1e-20f);
-            hit = d < radius;
+        const float x1 = nx, y1 = ny, z1 = nz;
+        {
+            const int kk = min(k + 64, n - 1);
+            nx = D[kk * 3 + 0]; ny = D[kk * 3 + 1]; nz = D[kk * 3 + 2];
         }
-        const unsigned long long mask = __ballot(hit);
-        if (mask) {
-            if (first < 0) first = k0 + __builtin_ctzll(mask);
-            const int pos = cnt + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-            if (hit && pos < nsample) I[pos] = k;
-            cnt = min(nsample, cnt + __builtin_popcountll(mask));
+        const bool valid = k < n;
+#pragma unroll
+        for (int i = 0; i < QPW; i++) {
+            const float d2 = rf::d2_fma(qx[i] - x1, qy[i] - y1, qz[i] - z1);
+            const bool hit = valid && d2 < thresh;
+            unsigned long long mask = __ballot(hit);
+            if (mask != 0ull && cnt[i] < nsample) {  // wave-uniform
+                if (first[i] < 0) first[i] = k0 + __builtin_ctzll(mask);
+                const int pos = cnt[i] + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                             __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                if (hit && pos < nsample) I[(size_t)i * nsample + pos] = k;
+                cnt[i] = min(nsample, cnt[i] + __builtin_popcountll(mask));
+            }
         }
     }
-    if (cnt > 0)
-        for (int l = cnt + lane; l < nsample; l += 64) I[l] = first;
-    if (lane == 0) pts_cnt[q] = cnt;
+#pragma unroll
+    for (int i = 0; i < QPW; i++) {
+        if (i < nq) {
+            if (cnt[i] > 0)
+                for (int l = cnt[i] + lane; l < nsample; l += 64) I[(size_t)i * nsample + l] = first[i];
+            if (lane == 0) pts_cnt[(size_t)bi * m + q0 + i] = cnt[i];
+        }
+    }
 }
 
 __global__ void group_point_kernel(int n, int c, long per_batch /* m*nsample */, long total,
@@ -83,15 +126,39 @@ __global__ void group_point_grad_kernel(int n, int c, long per_batch, long total
 
 extern "C" {
 
+// smallest float T such that max(sqrt_rn(x), 1e-20f) >= radius for every x >= T, i.e.
+// "max(sqrtf(d2),1e-20f) < radius"  <=>  "d2 < T" for d2 >= 0.  Bisection over the (monotone)
+// non-negative float bit patterns with the host's correctly rounded sqrtf.
+static float ball_threshold(float radius) {
+    if (!(radius > 1e-20f)) return 0.0f;  // the clamp alone already reaches the radius: no hit ever
+    unsigned lo = 0u, hi = 0x7F800000u;   // sqrt(+0) = 0 < radius ; sqrt(+inf) = inf >= radius
+    if (!(sqrtf(INFINITY) >= radius)) return INFINITY;  // radius is NaN-like: unreachable (guarded above)
+    while (hi - lo > 1u) {
+        unsigned mid = lo + (hi - lo) / 2u;
+        float x;
+        memcpy(&x, &mid, 4);
+        if (sqrtf(x) >= radius) hi = mid; else lo = mid;
+    }
+    float t;
+    memcpy(&t, &hi, 4);
+    return t;
+}
+
 int rf_queryballpoint(int b, int n, int m, float radius, int nsample, const float *xyz1,
                       const float *xyz2, int *idx, int *pts_cnt, rf_stream_t stream) {
     if (b < 0 || n < 0 || m < 0 || nsample <= 0) return RF_EINVAL;
     long nquery = (long)b * m;
     if (nquery == 0) return RF_OK;
     if (!xyz2 || !idx || !pts_cnt || (n > 0 && !xyz1)) return RF_EINVAL;
-    RF_LAUNCH("query_ball_point", query_ball_kernel, dim3(rf::ceil_div(nquery, QB_TPB / 64)),
-              dim3(QB_TPB), 0, (hipStream_t)stream, n, m, nquery, radius, nsample, xyz1, xyz2, idx,
-              pts_cnt);
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) {  // empty dataset: every ball is empty
+        RF_HIP(hipMemsetAsync(pts_cnt, 0, sizeof(int) * (size_t)nquery, s));
+        return RF_OK;
+    }
+    const int wpb = rf::ceil_div(m, QPW);
+    const long waves = (long)b * wpb;
+    RF_LAUNCH("query_ball_point", query_ball_kernel, dim3(rf::ceil_div(waves, QB_TPB / 64)), dim3(QB_TPB),
+              0, s, n, m, wpb, b, ball_threshold(radius), nsample, xyz1, xyz2, idx, pts_cnt);
     return RF_OK;
 }
 

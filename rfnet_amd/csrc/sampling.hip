@@ -11,9 +11,10 @@
 // memory and re-reads points beyond its 3072-point LDS cache from global every iteration.
 // Here one 1024-thread workgroup holds the WHOLE cloud (up to 16384 points) in registers:
 // 16 points x (x,y,z,running-min) per lane, so an iteration touches no memory except a
-// 16-entry LDS exchange: per-lane scan -> wave64 butterfly arg-max on a packed 64-bit key
-// (distance bits | inverted tie rank) -> one LDS slot per wave (double-buffered: ONE barrier
-// per iteration) -> every wave re-reduces the 16 slots and picks up the winner's xyz.
+// 16-entry LDS exchange and one scalar load: per-lane scan -> wave maximum by DPP row
+// rotations -> the lowest lane holding it publishes (d2,k) in the wave's LDS slot
+// (double-buffered: ONE barrier per iteration) -> every 16-lane row re-reduces the slots by
+// DPP (max d2, then min tie rank) -> the winner's xyz is re-read with a scalar load.
 #include "common.hpp"
 
 namespace {
@@ -44,19 +45,60 @@ struct Slot {
     int k;
 };
 
+// ---- DPP helpers: all-reduce inside a 16-lane row by cyclic rotations (row_ror:8,4,2,1) ----
+template <int N>
+__device__ __forceinline__ float row_ror(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, false));
+}
+template <int N>
+__device__ __forceinline__ unsigned row_ror_u(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + N, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float row_allmax(float v) {
+    v = fmaxf(v, row_ror<8>(v));
+    v = fmaxf(v, row_ror<4>(v));
+    v = fmaxf(v, row_ror<2>(v));
+    v = fmaxf(v, row_ror<1>(v));
+    return v;
+}
+__device__ __forceinline__ unsigned row_allmin_u(unsigned v) {
+    v = min(v, row_ror_u<8>(v));
+    v = min(v, row_ror_u<4>(v));
+    v = min(v, row_ror_u<2>(v));
+    v = min(v, row_ror_u<1>(v));
+    return v;
+}
+// maximum over the wave, uniform (SGPR): row all-reduce, then the four row results
+__device__ __forceinline__ float wave_allmax(float v) {
+    v = row_allmax(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
 // NT threads (multiple of 512), PPT points per thread, all register resident.
 // Thread t owns k = (t & 511) + 512 * (s * (NT/512) + (t >> 9)), s = 0..PPT-1, so all its points
-// share (k mod 512) and ascend with s.
+// share (k mod 512) and ascend with s; inside a wave a lower lane has a lower (k mod 512).
+// One iteration: per-lane scan (10 VALU per point) -> wave maximum by DPP rotations -> the
+// lowest lane holding it (v_cmp mask + s_ff1) publishes (d2, k) in the wave's LDS slot ->
+// ONE barrier -> every 16-lane row re-reduces the <=16 slots by DPP (max d2, then min tie rank)
+// -> the winner's coordinates come back by a scalar load (uniform address, L2-resident cloud).
 template <int NT, int PPT>
 __global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, const float *__restrict__ inp,
                                                      int *__restrict__ out) {
     constexpr int NW = NT / 64;
     constexpr int HALVES = NT / 512;
-    __shared__ Slot slots[2][NW];
+    static_assert(NW <= 16, "slot reduction is one 16-lane DPP row");
+    __shared__ float slot_d[2][16];
+    __shared__ int slot_k[2][16];
     const int bi = blockIdx.x;
     const int t = threadIdx.x;
-    const float *P = inp + (size_t)bi * n * 3;
-    int *O = out + (size_t)bi * m;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const float *__restrict__ P = inp + (size_t)bi * n * 3;
+    int *__restrict__ O = out + (size_t)bi * m;
 
     float px[PPT], py[PPT], pz[PPT], td[PPT];
 #pragma unroll
@@ -72,7 +114,12 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, const float *
             td[s] = -1.0f;  // min(d,-1) = -1 is never '>' the initial best of -1
         }
     }
+    if (t < 32) {  // unused slots never win
+        slot_d[t >> 4][t & 15] = -2.0f;
+        slot_k[t >> 4][t & 15] = 0;
+    }
     if (t == 0) O[0] = 0;
+    __syncthreads();
     float ox = P[0], oy = P[1], oz = P[2];  // old = 0
     for (int j = 1; j < m; j++) {
         float best = -1.0f;
@@ -87,41 +134,27 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, const float *
                 bs = s;
             }
         }
-        float bx = px[0], by = py[0], bz = pz[0];
-#pragma unroll
-        for (int s = 1; s < PPT; s++)
-            if (bs == s) {
-                bx = px[s];
-                by = py[s];
-                bz = pz[s];
-            }
         const int bk = (t & 511) + 512 * (bs * HALVES + (t >> 9));
-        // a thread with no valid point keeps best = -1: give it the lowest possible key
-        const unsigned long long key = best >= 0.f ? make_key(best, bk) : 0ull;
-        const unsigned long long wmax = wave_max_u64(key);
+        const float wm = wave_allmax(best);
+        const unsigned long long mask = __ballot(best == wm);
+        const int wl = mask ? __builtin_ctzll(mask) : 0;
+        const int wk = __builtin_amdgcn_readlane(bk, wl);
         const int buf = j & 1;
-        if (key == wmax && (key != 0ull || (t & 63) == 0)) {
-            Slot sl;
-            sl.key = key;
-            sl.x = bx; sl.y = by; sl.z = bz;
-            sl.k = key != 0ull ? bk : 0;
-            slots[buf][t >> 6] = sl;
+        if (lane == 0) {
+            slot_d[buf][wave] = wm;
+            slot_k[buf][wave] = wm >= 0.f ? wk : 0;
         }
         __syncthreads();
-        unsigned long long gk = slots[buf][0].key;
-        int gw = 0;
-#pragma unroll
-        for (int w = 1; w < NW; w++) {
-            unsigned long long kw = slots[buf][w].key;
-            if (kw > gk) {
-                gk = kw;
-                gw = w;
-            }
-        }
-        ox = slots[buf][gw].x;
-        oy = slots[buf][gw].y;
-        oz = slots[buf][gw].z;
-        if (t == 0) O[j] = slots[buf][gw].k;
+        const float sd = slot_d[buf][lane & 15];
+        const int sk = slot_k[buf][lane & 15];
+        const float gm = row_allmax(sd);
+        const unsigned rank = sd == gm ? tie_rank(sk) : 0xFFFFFFFFu;
+        const unsigned gr = __builtin_amdgcn_readfirstlane(row_allmin_u(rank));
+        const int gk = (int)(((gr & 0x3FFFFFu) << 9) | (gr >> 22));
+        ox = P[gk * 3 + 0];  // uniform address: scalar loads
+        oy = P[gk * 3 + 1];
+        oz = P[gk * 3 + 2];
+        if (t == 0) O[j] = gk;
     }
 }
 
