@@ -29,6 +29,8 @@
 //     lowest index on ties) and re-scans just that lane's R points for the first exact match.
 //   ~7.9 VALU ops per (B*N*M) pair instead of 18.  All merges are order-fixed: no atomics,
 //   deterministic.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
@@ -411,9 +413,15 @@ Plan make_plan(int b, int n, int m) {
     p.no_pad = round_up(p.no, PADQ);
     p.nc_pad = round_up(p.nc, PADQ);
     p.oblocks = rf::ceil_div(p.no, 64 * RR);
-    // aim for >= 8192 waves (8 per SIMD); at least 128 candidates per split
+    // Split the candidate range so that (measured, tools/ab_chamfer.py, one device):
+    //   * at least one residency round exists: 4096 waves (118 VGPRs -> 4 per SIMD x 1024 SIMDs);
+    //   * a wave's span is ~1024 candidates when the set is large (16384 x 16384: 1.28 ms at
+    //     span 1024 vs 1.36 at 4096 and 1.42 at 256), but never below 128.
+    // RF_NN_WAVES overrides the first target for experiments.
     long base = (long)b * p.oblocks;
-    int want = (int)((8192 + base - 1) / (base > 0 ? base : 1));
+    static const long target = getenv("RF_NN_WAVES") ? atol(getenv("RF_NN_WAVES")) : 4096;
+    int want = (int)((target + base - 1) / (base > 0 ? base : 1));
+    if (!getenv("RF_NN_WAVES") && want < rf::ceil_div(p.nc, 1024)) want = rf::ceil_div(p.nc, 1024);
     int maxs = p.nc / 128 > 0 ? p.nc / 128 : 1;
     int s = want < 1 ? 1 : (want > maxs ? maxs : want);
     p.span = round_up(rf::ceil_div(p.nc, s), CG);

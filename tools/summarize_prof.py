@@ -9,7 +9,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for key in ("nn_sweep", "nn_merge", "nn_grad"):
+    for key in ("nn_sweep", "nn_pack", "nn_rowmerge", "nn_colresolve", "nn_grad", "pack_kernel"):
         if key in name:
             return key
     return name[:60]
@@ -22,7 +22,7 @@ def main(out):
             print("  {:40s} calls={:>6s} total_ns={:>12s} avg_ns={:>10s} pct={}".format(
                 short(row.get("Name", "")), row.get("Calls", ""), row.get("TotalDurationNs", ""),
                 row.get("AverageNs", ""), row.get("Percentage", "")))
-    for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
         for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
             acc = defaultdict(lambda: defaultdict(list))
             for row in csv.DictReader(open(f)):
