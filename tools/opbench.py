@@ -55,6 +55,9 @@ def main():
         d1, i1, d2, i2 = R.nn_distance(x1, x2)
         g1, g2 = torch.ones_like(d1), torch.ones_like(d2)
         timeit("C2 nn_distance_grad", lambda: R.nn_distance_grad(x1, x2, g1, i1, g2, i2), a.iters)
+        n1, n2 = x1.cpu().numpy(), x2.cpu().numpy()
+        timeit("C2 fwd, numpy in -> numpy out (PCIe incl.)", lambda: R.nn_distance(n1, n2), a.iters,
+               32 * 2048 * 16384, "pairs")
         x3 = torch.from_numpy(rng.randn(32, 3000, 3).astype(np.float32)).to(dev)
         timeit("nn_distance fwd 32x3000x16384", lambda: R.nn_distance(x3, x2), a.iters,
                32 * 3000 * 16384, "pairs")
