@@ -6,10 +6,14 @@
 // v_exp_f32(d2 * level*log2e) -- the analogue of __expf = ex2.approx(x*log2e)).
 //
 // MI355X design, not the reference's one-block-per-batch-element loop:
-//   * every phase of every level is one launch over (row blocks) x (batch); a row's sweep
-//     over the other set is split over the 4 waves of the workgroup (4 column segments,
-//     combined in segment order), two rows per lane, columns staged as float4
-//     {x,y,z,scalar} in LDS and read with one broadcast ds_read_b128 per column per wave;
+//   * every sweep is one launch over (64-row blocks) x (batch); one row per lane; the row's
+//     sweep over the other set is split over the NSEG waves of the workgroup (column segments,
+//     combined in segment order).  Columns are wave-uniform, so they are STREAMED THROUGH SGPRs
+//     by scalar loads one sub-chunk ahead (no LDS tile, no barrier in the loop; VALU ops take
+//     the SGPR operand directly) -- same scheme as the Chamfer sweep;
+//   * P3 of level v-1 and P1 of level v sweep the same rows over the same columns and P1 only
+//     needs the row's own updated remainL, so they are FUSED: one distance evaluation feeds both
+//     exponentials (20 + 1 launches instead of 30, 6 of 19 ops per pair saved);
 //   * `match` is NOT read-modify-written once per level (the reference moves 21 x 4nm bytes
 //     per sample).  The per-level ratio vectors (10 x (n+m) floats) are kept in the
 //     workspace and match is produced ONCE at the end:
@@ -19,114 +23,172 @@
 //     depend on this restructuring.  HBM traffic for match: one 4nm-byte write.
 //   * row sums are accumulated per column segment and combined in segment order, so they
 //     differ from the reference's strictly sequential order in the last bits (tolerance
-//     stated in tests/test_emd_gpu.py).
+//     stated in tests/test_gpu_emd.py).
 #include "common.hpp"
 
 namespace {
 
 constexpr float kLog2e = 1.44269502f;  // 0x3FB8AA3B, the constant __expf multiplies by
 constexpr int TPB = 256;
-constexpr int RPT = 2;              // rows per lane
-constexpr int ROWS = 64 * RPT;      // rows per workgroup
-constexpr int NSEG = 4;             // column segments = waves per workgroup
-constexpr int CT = 256;             // columns per segment tile
 constexpr int LVG = 16;             // levels per group in the materialisation kernel
 constexpr int MAX_LEVELS = 64;
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-__global__ void am_init_kernel(int n, int m, float multiL, float multiR, float *remainL,
-                               float *remainR, size_t stride) {
-    int bi = blockIdx.y;
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n) remainL[bi * stride + j] = multiL;
-    if (j < m) remainR[bi * stride + j] = multiR;
+constexpr int SUB = 8;     // columns per scalar-load sub-chunk
+constexpr int CPAD = 128;  // column counts are padded to a multiple of this (zero scalars)
+
+// pack xyz (b,npts,3) -> (b,npad,3) zero padded, and initialise remain (padded entries = 0 so
+// that padded columns contribute e*0 = 0 to every sum; e <= 1 is always finite)
+__global__ void am_init_kernel(int npts, int npad, float fill, const float *__restrict__ xyz,
+                               float *__restrict__ xyzp, size_t xyzp_stride,
+                               float *__restrict__ remain, size_t stride) {
+    const int bi = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= npad) return;
+    float x = 0.f, y = 0.f, z = 0.f, r = 0.f;
+    if (j < npts) {
+        const float *p = xyz + ((size_t)bi * npts + j) * 3;
+        x = p[0]; y = p[1]; z = p[2];
+        r = fill;
+    }
+    float *q = xyzp + (size_t)bi * xyzp_stride + (size_t)j * 3;
+    q[0] = x; q[1] = y; q[2] = z;
+    remain[(size_t)bi * stride + j] = r;
 }
 
-// One phase of one level.  rows: the set owning the output vector; cols: the other set.
-//  PHASE 1: rows=xyz1 (k), cols=xyz2 (l) with s=remainR[l];  acc from 1e-9: acc=fma(e,s,acc)
-//           ratioL[k] = remainL[k] / acc
-//  PHASE 2: rows=xyz2 (l), cols=xyz1 (k) with s=ratioL[k];   acc from 0:    acc=fma(e,s,acc)
-//           t=acc*remainR[l]; cons=min(remainR[l]/(t+1e-9),1); ratioR[l]=remainR[l]*cons;
-//           remainR[l]=max(0,remainR[l]-t)
-//  PHASE 3: rows=xyz1 (k), cols=xyz2 (l) with s=ratioR[l];   acc from 0: acc=fma(ratioL[k]*e,s,acc)
-//           remainL[k]=max(0,remainL[k]-acc)
-template <int PHASE>
-__global__ __launch_bounds__(TPB) void am_phase_kernel(int nr, int nc, const float *rows_xyz,
-                                                       const float *cols_xyz, const float *col_s,
-                                                       size_t s_stride, float *remain_row,
-                                                       const float *ratioL_in, float *ratio_out,
-                                                       float c_level) {
-    __shared__ float4 tile[NSEG][CT];
-    __shared__ float part[NSEG][ROWS];
+// Rows = xyz1 points k (one per lane), columns = xyz2 points l streamed through SGPRs.
+//   HAS_P3: acc3 = sum_l fma(ratioL_prev[k]*e(c_prev), ratioR_prev[l], .)   (P3 of the previous level)
+//           remainL[k] = max(0, remainL[k] - acc3)
+//   HAS_P1: acc1 = 1e-9 + sum_l fma(e(c_cur), remainR[l], .)                 (P1 of this level)
+//           ratioL_out[k] = remainL[k] / acc1
+template <bool HAS_P3, bool HAS_P1>
+__global__ __launch_bounds__(1024) void am_rowk_kernel(
+    int n, int seglen, const float *__restrict__ xyz1, const float *__restrict__ xyz2p,
+    size_t xyz2p_stride, const float *__restrict__ ratioR_prev, const float *__restrict__ remainR,
+    const float *__restrict__ ratioL_prev, float *__restrict__ remainL,
+    float *__restrict__ ratioL_out, size_t stride, float c_prev, float c_cur) {
+    __shared__ float part3[16][64], part1[16][64];
     const int bi = blockIdx.y;
     const int lane = threadIdx.x & 63;
-    const int seg = threadIdx.x >> 6;
-    rows_xyz += (size_t)bi * nr * 3;
-    cols_xyz += (size_t)bi * nc * 3;
-    col_s += (size_t)bi * s_stride;
-    remain_row += (size_t)bi * s_stride;
-    ratio_out += (size_t)bi * s_stride;
-    if (PHASE == 3) ratioL_in += (size_t)bi * s_stride;
-
-    float rx[RPT], ry[RPT], rz[RPT], acc[RPT], rl[RPT];
-    int row[RPT];
+    const int seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nseg = blockDim.x >> 6;
+    const int k = blockIdx.x * 64 + lane;
+    const int kk = min(k, n - 1);
+    const float *__restrict__ A = xyz1 + (size_t)bi * n * 3;
+    const float x1 = A[kk * 3], y1 = A[kk * 3 + 1], z1 = A[kk * 3 + 2];
+    const float rl = HAS_P3 ? ratioL_prev[(size_t)bi * stride + kk] : 0.f;
+    const float *__restrict__ C = xyz2p + (size_t)bi * xyz2p_stride;
+    const float *__restrict__ S3 = ratioR_prev + (size_t)bi * stride;
+    const float *__restrict__ S1 = remainR + (size_t)bi * stride;
+    float acc3 = 0.f, acc1 = (seg == 0) ? 1e-9f : 0.f;
+    const int c0 = seg * seglen, c1 = c0 + seglen;  // multiples of SUB, inside the padded range
+    float nb[3 * SUB], n3[SUB], n1[SUB];
 #pragma unroll
-    for (int r = 0; r < RPT; r++) {
-        row[r] = blockIdx.x * ROWS + r * 64 + lane;
-        int rr = min(row[r], nr - 1);
-        rx[r] = rows_xyz[rr * 3 + 0];
-        ry[r] = rows_xyz[rr * 3 + 1];
-        rz[r] = rows_xyz[rr * 3 + 2];
-        acc[r] = (PHASE == 1 && seg == 0) ? 1e-9f : 0.f;
-        rl[r] = (PHASE == 3) ? ratioL_in[rr] : 1.f;
+    for (int i = 0; i < 3 * SUB; i++) nb[i] = C[(size_t)c0 * 3 + i];
+#pragma unroll
+    for (int i = 0; i < SUB; i++) {
+        n3[i] = HAS_P3 ? S3[c0 + i] : 0.f;
+        n1[i] = HAS_P1 ? S1[c0 + i] : 0.f;
     }
-    const int seglen = (nc + NSEG - 1) / NSEG;
-    const int c0 = seg * seglen;
-    const int c1 = min(nc, c0 + seglen);
-    for (int t0 = 0; t0 < seglen; t0 += CT) {
-        const int base = c0 + t0;
-        const int cnt = max(0, min(CT, c1 - base));
-        __syncthreads();
-        for (int k = lane; k < cnt; k += 64) {
-            const float *p = cols_xyz + (size_t)(base + k) * 3;
-            tile[seg][k] = make_float4(p[0], p[1], p[2], col_s[base + k]);
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int k = 0; k < cnt; k++) {
-            const float4 c = tile[seg][k];
+    for (int c = c0; c < c1; c += SUB) {
+        float cb[3 * SUB], s3[SUB], s1[SUB];
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): retire the previous prefetch first
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < RPT; r++) {
-                float d2 = rf::d2_fma(c.x - rx[r], c.y - ry[r], c.z - rz[r]);
-                float e = fast_exp2(d2 * c_level);
-                if (PHASE == 3) e = rl[r] * e;
-                acc[r] = fmaf(e, c.w, acc[r]);
+        for (int i = 0; i < 3 * SUB; i++) cb[i] = nb[i];
+#pragma unroll
+        for (int i = 0; i < SUB; i++) { s3[i] = n3[i]; s1[i] = n1[i]; }
+#pragma unroll
+        for (int i = 0; i < 3 * SUB; i++) nb[i] = C[(size_t)(c + SUB) * 3 + i];
+#pragma unroll
+        for (int i = 0; i < SUB; i++) {
+            n3[i] = HAS_P3 ? S3[c + SUB + i] : 0.f;
+            n1[i] = HAS_P1 ? S1[c + SUB + i] : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < SUB; u++) {
+            const float d2 = rf::d2_fma(cb[u * 3] - x1, cb[u * 3 + 1] - y1, cb[u * 3 + 2] - z1);
+            if (HAS_P3) {
+                const float p = rl * fast_exp2(d2 * c_prev);
+                acc3 = fmaf(p, s3[u], acc3);
             }
+            if (HAS_P1) acc1 = fmaf(fast_exp2(d2 * c_cur), s1[u], acc1);
         }
     }
-#pragma unroll
-    for (int r = 0; r < RPT; r++) part[seg][r * 64 + lane] = acc[r];
+    part3[seg][lane] = acc3;
+    part1[seg][lane] = acc1;
     __syncthreads();
-    if (seg == 0) {
-#pragma unroll
-        for (int r = 0; r < RPT; r++) {
-            if (row[r] >= nr) continue;
-            float s = part[0][r * 64 + lane];
-#pragma unroll
-            for (int g = 1; g < NSEG; g++) s += part[g][r * 64 + lane];
-            if (PHASE == 1) {
-                ratio_out[row[r]] = remain_row[row[r]] / s;
-            } else if (PHASE == 2) {
-                float rem = remain_row[row[r]];
-                float t = s * rem;
-                float cons = fminf(rem / (t + 1e-9f), 1.0f);
-                ratio_out[row[r]] = rem * cons;
-                remain_row[row[r]] = fmaxf(0.0f, rem - t);
-            } else {
-                remain_row[row[r]] = fmaxf(0.0f, remain_row[row[r]] - s);
-            }
+    if (seg == 0 && k < n) {
+        float t3 = part3[0][lane], t1 = part1[0][lane];
+        for (int g = 1; g < nseg; g++) {
+            t3 += part3[g][lane];
+            t1 += part1[g][lane];
         }
+        float rem = remainL[(size_t)bi * stride + k];
+        if (HAS_P3) {
+            rem = fmaxf(0.0f, rem - t3);
+            remainL[(size_t)bi * stride + k] = rem;
+        }
+        if (HAS_P1) ratioL_out[(size_t)bi * stride + k] = rem / t1;
+    }
+}
+
+// P2: rows = xyz2 points l, columns = xyz1 points k with scalar ratioL[k].
+//   sumr = sum_k fma(e, ratioL[k], .);  t = sumr*remainR[l];  cons = min(remainR[l]/(t+1e-9), 1)
+//   ratioR[l] = remainR[l]*cons;  remainR[l] = max(0, remainR[l]-t)
+__global__ __launch_bounds__(1024) void am_rowl_kernel(
+    int m, int seglen, const float *__restrict__ xyz2, const float *__restrict__ xyz1p,
+    size_t xyz1p_stride, const float *__restrict__ ratioL, float *__restrict__ remainR,
+    float *__restrict__ ratioR_out, size_t stride, float c_cur) {
+    __shared__ float part[16][64];
+    const int bi = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nseg = blockDim.x >> 6;
+    const int l = blockIdx.x * 64 + lane;
+    const int ll = min(l, m - 1);
+    const float *__restrict__ B = xyz2 + (size_t)bi * m * 3;
+    const float x2 = B[ll * 3], y2 = B[ll * 3 + 1], z2 = B[ll * 3 + 2];
+    const float *__restrict__ C = xyz1p + (size_t)bi * xyz1p_stride;
+    const float *__restrict__ S = ratioL + (size_t)bi * stride;
+    float acc = 0.f;
+    const int c0 = seg * seglen, c1 = c0 + seglen;
+    float nb[3 * SUB], ns[SUB];
+#pragma unroll
+    for (int i = 0; i < 3 * SUB; i++) nb[i] = C[(size_t)c0 * 3 + i];
+#pragma unroll
+    for (int i = 0; i < SUB; i++) ns[i] = S[c0 + i];
+    for (int c = c0; c < c1; c += SUB) {
+        float cb[3 * SUB], sc[SUB];
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 3 * SUB; i++) cb[i] = nb[i];
+#pragma unroll
+        for (int i = 0; i < SUB; i++) sc[i] = ns[i];
+#pragma unroll
+        for (int i = 0; i < 3 * SUB; i++) nb[i] = C[(size_t)(c + SUB) * 3 + i];
+#pragma unroll
+        for (int i = 0; i < SUB; i++) ns[i] = S[c + SUB + i];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < SUB; u++) {
+            const float d2 = rf::d2_fma(x2 - cb[u * 3], y2 - cb[u * 3 + 1], z2 - cb[u * 3 + 2]);
+            acc = fmaf(fast_exp2(d2 * c_cur), sc[u], acc);
+        }
+    }
+    part[seg][lane] = acc;
+    __syncthreads();
+    if (seg == 0 && l < m) {
+        float sumr = part[0][lane];
+        for (int g = 1; g < nseg; g++) sumr += part[g][lane];
+        const float rem = remainR[(size_t)bi * stride + l];
+        const float t = sumr * rem;
+        const float cons = fminf(rem / (t + 1e-9f), 1.0f);
+        ratioR_out[(size_t)bi * stride + l] = rem * cons;
+        remainR[(size_t)bi * stride + l] = fmaxf(0.0f, rem - t);
     }
 }
 
@@ -139,10 +201,10 @@ struct LevelConsts {
 
 __global__ __launch_bounds__(TPB) void am_match_kernel(int n, int m, const float *xyz1,
                                                        const float *xyz2, const float *ratios,
-                                                       size_t lv_stride, size_t b_stride,
+                                                       size_t lv_stride, size_t b_stride, int roff,
                                                        int lv0, int nlv, LevelConsts lc,
                                                        float *match) {
-    // ratios: [b][level][ (ratioL: n) (ratioR: m) ]
+    // ratios: [b][level][ (ratioL: npad) (ratioR: mpad) ]; roff = npad
     __shared__ float cxyz[LSEG][4];
     __shared__ float crr[LSEG][LVG];
     const int bi = blockIdx.z;
@@ -155,7 +217,7 @@ __global__ __launch_bounds__(TPB) void am_match_kernel(int n, int m, const float
     match += (size_t)bi * n * m;
     for (int i = threadIdx.x; i < lcnt * LVG; i += TPB) {
         int l = i / LVG, v = i % LVG;
-        crr[l][v] = v < nlv ? ratios[(size_t)v * lv_stride + n + l0 + l] : 0.f;
+        crr[l][v] = v < nlv ? ratios[(size_t)v * lv_stride + roff + l0 + l] : 0.f;
     }
     for (int i = threadIdx.x; i < lcnt; i += TPB) {
         cxyz[i][0] = xyz2[(size_t)(l0 + i) * 3 + 0];
@@ -305,9 +367,37 @@ int default_levels(float *lv) {
     return c;
 }
 
-size_t am_ws_floats(int b, int n, int m, int nlevels) {
-    // per batch element: remainL[n] remainR[m], then per level ratioL[n] ratioR[m]
-    return (size_t)b * (size_t)(n + m) * (size_t)(1 + nlevels);
+struct AmLayout {
+    int npad, mpad;
+    size_t V;        // floats per vector pair [L: npad | R: mpad]
+    size_t bstride;  // floats per batch element in the vector region: (1 + nlevels) * V
+    size_t off_x1, off_x2, total;  // in floats
+};
+
+int round_up_i(int v, int q) { return (v + q - 1) / q * q; }
+
+AmLayout am_layout(int b, int n, int m, int nlevels) {
+    AmLayout L;
+    L.npad = round_up_i(n, CPAD);
+    L.mpad = round_up_i(m, CPAD);
+    L.V = (size_t)L.npad + L.mpad;
+    L.bstride = L.V * (size_t)(1 + nlevels);
+    size_t off = (size_t)b * L.bstride + 64;  // + slack: scalar prefetch runs SUB entries ahead
+    L.off_x1 = off;
+    off += (size_t)b * L.npad * 3 + 64;
+    L.off_x2 = off;
+    off += (size_t)b * L.mpad * 3 + 64;
+    L.total = off;
+    return L;
+}
+
+// waves per workgroup (= column segments): the smallest power of two that gives >= 4096 waves,
+// keeping >= 64 columns per segment
+int pick_nseg(int b, int rows, int cols_pad) {
+    long base = (long)b * rf::ceil_div(rows, 64);
+    int nseg = 1;
+    while (nseg < 16 && base * nseg < 4096 && cols_pad / (nseg * 2) >= 64) nseg *= 2;
+    return nseg;
 }
 
 }  // namespace
@@ -317,7 +407,7 @@ extern "C" {
 size_t rf_approxmatch_workspace_bytes(int b, int n, int m, int nlevels) {
     if (b <= 0 || n <= 0 || m <= 0) return 0;
     if (nlevels <= 0) nlevels = 10;
-    return am_ws_floats(b, n, m, nlevels) * sizeof(float);
+    return am_layout(b, n, m, nlevels).total * sizeof(float);
 }
 
 int rf_approxmatch_levels(int b, int n, int m, const float *xyz1, const float *xyz2, float *match,
@@ -334,34 +424,45 @@ int rf_approxmatch_levels(int b, int n, int m, const float *xyz1, const float *x
     if (n >= m) { multiL = 1.f; multiR = (float)(n / m); }
     else        { multiL = (float)(m / n); multiR = 1.f; }
 
-    const size_t S = (size_t)(n + m);            // floats per vector pair
-    const size_t bstride = S * (size_t)(1 + nlevels);
+    const AmLayout L = am_layout(b, n, m, nlevels);
     float *w = (float *)workspace;
-    float *remainL = w, *remainR = w + n;       // + bi*bstride
-    float *ratios = w + S;                       // [level][ratioL n | ratioR m]
-    {
-        int mx = n > m ? n : m;
-        RF_LAUNCH("am_init", am_init_kernel, dim3(rf::ceil_div(mx, 256), b), dim3(256), 0, s, n, m,
-                  multiL, multiR, remainL, remainR, bstride);
-    }
+    float *remainL = w, *remainR = w + L.npad;          // slot 0 of the vector region
+    float *ratios = w + L.V;                            // slot 1+v: [ratioL npad | ratioR mpad]
+    float *x1p = w + L.off_x1, *x2p = w + L.off_x2;
+    // padded entries of every vector must read 0 (they are column scalars of padded columns)
+    RF_HIP(hipMemsetAsync(w, 0, sizeof(float) * ((size_t)b * L.bstride + 64), s));
+    RF_LAUNCH("am_init", am_init_kernel, dim3(rf::ceil_div(L.npad, 256), b), dim3(256), 0, s, n, L.npad,
+              multiL, xyz1, x1p, (size_t)L.npad * 3, remainL, L.bstride);
+    RF_LAUNCH("am_init", am_init_kernel, dim3(rf::ceil_div(L.mpad, 256), b), dim3(256), 0, s, m, L.mpad,
+              multiR, xyz2, x2p, (size_t)L.mpad * 3, remainR, L.bstride);
+
     LevelConsts lc;
     for (int v = 0; v < MAX_LEVELS; v++) lc.c[v] = v < nlevels ? levels_host[v] * kLog2e : 0.f;
-    const dim3 g1(rf::ceil_div(n, ROWS), b), g2(rf::ceil_div(m, ROWS), b);
+    const int segk = pick_nseg(b, n, L.mpad), segl = pick_nseg(b, m, L.npad);
+    const dim3 gk(rf::ceil_div(n, 64), b), gl(rf::ceil_div(m, 64), b);
     for (int v = 0; v < nlevels; v++) {
-        float *ratioL = ratios + (size_t)v * S, *ratioR = ratioL + n;
-        RF_LAUNCH("am_phase1", am_phase_kernel<1>, g1, dim3(TPB), 0, s, n, m, xyz1, xyz2,
-                  (const float *)remainR, bstride, remainL, (const float *)nullptr, ratioL, lc.c[v]);
-        RF_LAUNCH("am_phase2", am_phase_kernel<2>, g2, dim3(TPB), 0, s, m, n, xyz2, xyz1,
-                  (const float *)ratioL, bstride, remainR, (const float *)nullptr, ratioR, lc.c[v]);
-        RF_LAUNCH("am_phase3", am_phase_kernel<3>, g1, dim3(TPB), 0, s, n, m, xyz1, xyz2,
-                  (const float *)ratioR, bstride, remainL, (const float *)ratioL, ratioL /*unused*/,
-                  lc.c[v]);
+        float *ratioL = ratios + (size_t)v * L.V, *ratioR = ratioL + L.npad;
+        if (v == 0) {
+            RF_LAUNCH("am_p1", (am_rowk_kernel<false, true>), gk, dim3(64 * segk), 0, s, n, L.mpad / segk,
+                      xyz1, (const float *)x2p, (size_t)L.mpad * 3, (const float *)remainR,
+                      (const float *)remainR, (const float *)remainL, remainL, ratioL, L.bstride, 0.f,
+                      lc.c[0]);
+        } else {
+            const float *pL = ratios + (size_t)(v - 1) * L.V, *pR = pL + L.npad;
+            RF_LAUNCH("am_p3p1", (am_rowk_kernel<true, true>), gk, dim3(64 * segk), 0, s, n,
+                      L.mpad / segk, xyz1, (const float *)x2p, (size_t)L.mpad * 3, pR,
+                      (const float *)remainR, pL, remainL, ratioL, L.bstride, lc.c[v - 1], lc.c[v]);
+        }
+        RF_LAUNCH("am_p2", am_rowl_kernel, gl, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
+                  (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR,
+                  L.bstride, lc.c[v]);
     }
+    // P3 of the last level only updates remainL, which nothing reads afterwards: not launched.
     const dim3 gm(rf::ceil_div(n, TPB), rf::ceil_div(m, LSEG), b);
     for (int lv0 = 0; lv0 < nlevels; lv0 += LVG) {
         int nlv = nlevels - lv0 < LVG ? nlevels - lv0 : LVG;
         RF_LAUNCH("am_match", am_match_kernel, gm, dim3(TPB), 0, s, n, m, xyz1, xyz2,
-                  (const float *)ratios, S, bstride, lv0, nlv, lc, match);
+                  (const float *)ratios, L.V, L.bstride, L.npad, lv0, nlv, lc, match);
     }
     return RF_OK;
 }
