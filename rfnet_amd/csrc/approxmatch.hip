@@ -298,66 +298,96 @@ __global__ void mc_final_kernel(const float *partial, int per_batch, float *cost
     if (threadIdx.x == 0) cost[bi] = red[0];
 }
 
-// ---- match_cost_grad, one pass over match for both gradients.
+// ---- match_cost_grad: ONE pass over match (HBM-bound: 4*B*n*m bytes) for both gradients.
 //  grad1[k] = sum_l match[l][k] (x1_k - x2_l) * rsqrt(max(d2,1e-20))     (tf_approxmatch.cu:270-291)
 //  grad2[l] = sum_k match[l][k] (x2_l - x1_k) * rsqrt(max(d2,1e-20))     (:229-269)
-// workgroup = 256 k x MG_L l.  grad1 partial per thread -> atomicAdd; grad2 partial per l via
-// wave reduction -> atomicAdd.  Outputs are zero-filled first.
-constexpr int MG_L = 64;
-__global__ __launch_bounds__(TPB) void mcg_kernel(int n, int m, const float *xyz1,
-                                                  const float *xyz2, const float *match,
-                                                  float *grad1, float *grad2) {
-    __shared__ float cxyz[MG_L][4];
-    __shared__ float g2[MG_L][3];
+// The reference reads match twice and tree-reduces 256 threads per l.  Here a workgroup owns
+// 256 k x an l-range and walks it in tiles of 32 l:
+//   phase A (thread <-> k): 32 coalesced row loads of match, q = match*rsq kept in an LDS tile
+//            [32][257] (stride 257: conflict-free by rows and by columns), grad1 accumulated in
+//            registers over the whole l-range (x2_l comes by scalar loads: it is wave-uniform);
+//   phase B (thread <-> (l, 32-k slice)): re-reads q column-wise from LDS, accumulates
+//            (x2_l - x1_k)*q, 8 slices summed through LDS, one coalesced atomicAdd per (l, c).
+// grad1: 3 atomics per thread at the end (LSPLIT-way contention only).  Outputs zero-filled first.
+constexpr int MG_TL = 32;
+constexpr int MG_LSPLIT = 4;
+__global__ __launch_bounds__(TPB) void mcg_kernel(int n, int m, int lspan,
+                                                  const float *__restrict__ xyz1,
+                                                  const float *__restrict__ xyz2,
+                                                  const float *__restrict__ match,
+                                                  float *__restrict__ grad1,
+                                                  float *__restrict__ grad2) {
+    __shared__ float qs[MG_TL][TPB + 1];
+    __shared__ float4 sx1[TPB];
+    __shared__ float ps[TPB / MG_TL][MG_TL][3];
     const int bi = blockIdx.z;
-    const int k = blockIdx.x * TPB + threadIdx.x;
-    const int l0 = blockIdx.y * MG_L;
-    const int lcnt = min(MG_L, m - l0);
-    xyz1 += (size_t)bi * n * 3;
-    xyz2 += (size_t)bi * m * 3;
-    match += (size_t)bi * n * m;
-    grad1 += (size_t)bi * n * 3;
-    grad2 += (size_t)bi * m * 3;
-    if (threadIdx.x < lcnt) {
-        cxyz[threadIdx.x][0] = xyz2[(size_t)(l0 + threadIdx.x) * 3 + 0];
-        cxyz[threadIdx.x][1] = xyz2[(size_t)(l0 + threadIdx.x) * 3 + 1];
-        cxyz[threadIdx.x][2] = xyz2[(size_t)(l0 + threadIdx.x) * 3 + 2];
-    }
-    if (threadIdx.x < MG_L * 3) (&g2[0][0])[threadIdx.x] = 0.f;
-    __syncthreads();
+    const int t = threadIdx.x;
+    const int k0 = blockIdx.x * TPB;
+    const int k = k0 + t;
     const bool live = k < n;
     const int kk = live ? k : n - 1;
-    const float x1 = xyz1[kk * 3], y1 = xyz1[kk * 3 + 1], z1 = xyz1[kk * 3 + 2];
+    const float *__restrict__ A = xyz1 + (size_t)bi * n * 3;
+    const float *__restrict__ B = xyz2 + (size_t)bi * m * 3;
+    const float *__restrict__ M = match + (size_t)bi * n * m;
+    const float x1 = A[kk * 3], y1 = A[kk * 3 + 1], z1 = A[kk * 3 + 2];
+    sx1[t] = make_float4(x1, y1, z1, 0.f);
     float ax = 0.f, ay = 0.f, az = 0.f;
-    for (int l = 0; l < lcnt; l++) {
-        float dx = x1 - cxyz[l][0], dy = y1 - cxyz[l][1], dz = z1 - cxyz[l][2];
-        float mt = live ? match[(size_t)(l0 + l) * n + kk] : 0.f;
-        float q = mt * __builtin_amdgcn_rsqf(fmaxf(rf::d2_fma(dx, dy, dz), 1e-20f));
-        float vx = dx * q, vy = dy * q, vz = dz * q;
-        ax += vx; ay += vy; az += vz;
-        // grad2 wants (x2-x1)*q = -v summed over k: wave-reduce, one LDS atomic per wave
-        float sx = -vx, sy = -vy, sz = -vz;
+    const int lbeg = blockIdx.y * lspan;
+    const int lend = min(m, lbeg + lspan);
+    const int bl = t & (MG_TL - 1);  // phase-B row (l) of this thread
+    const int br = t / MG_TL;        // phase-B k slice: [br*32, br*32+32)
+    for (int l0 = lbeg; l0 < lend; l0 += MG_TL) {
+        const int lc = min(MG_TL, lend - l0);
+        float mv[MG_TL];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            sx += __shfl_down(sx, o, 64);
-            sy += __shfl_down(sy, o, 64);
-            sz += __shfl_down(sz, o, 64);
+        for (int l = 0; l < MG_TL; l++)
+            mv[l] = (live && l < lc) ? M[(size_t)(l0 + l) * n + kk] : 0.f;
+#pragma unroll
+        for (int l = 0; l < MG_TL; l++) {
+            const int ll = min(l0 + l, m - 1);  // uniform -> scalar loads
+            const float dx = x1 - B[ll * 3], dy = y1 - B[ll * 3 + 1], dz = z1 - B[ll * 3 + 2];
+            const float q = mv[l] * __builtin_amdgcn_rsqf(fmaxf(rf::d2_fma(dx, dy, dz), 1e-20f));
+            ax = fmaf(dx, q, ax);
+            ay = fmaf(dy, q, ay);
+            az = fmaf(dz, q, az);
+            qs[l][t] = q;
         }
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&g2[l][0], sx);
-            atomicAdd(&g2[l][1], sy);
-            atomicAdd(&g2[l][2], sz);
+        __syncthreads();
+        {
+            const int ll = min(l0 + bl, m - 1);
+            const float x2 = B[ll * 3], y2 = B[ll * 3 + 1], z2 = B[ll * 3 + 2];
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll 8
+            for (int j = 0; j < MG_TL; j++) {
+                const int kq = br * MG_TL + j;
+                const float q = qs[bl][kq];
+                const float4 p = sx1[kq];
+                sx = fmaf(x2 - p.x, q, sx);
+                sy = fmaf(y2 - p.y, q, sy);
+                sz = fmaf(z2 - p.z, q, sz);
+            }
+            ps[br][bl][0] = sx;
+            ps[br][bl][1] = sy;
+            ps[br][bl][2] = sz;
         }
+        __syncthreads();
+        if (t < MG_TL * 3) {
+            const int l = t / 3, c = t - l * 3;
+            if (l < lc) {
+                float v = 0.f;
+#pragma unroll
+                for (int r = 0; r < TPB / MG_TL; r++) v += ps[r][l][c];
+                atomicAdd(&grad2[((size_t)bi * m + l0 + l) * 3 + c], v);
+            }
+        }
+        // qs / ps are rewritten only after the next tile's first barrier-separated phase
+        __syncthreads();
     }
     if (live) {
-        atomicAdd(&grad1[k * 3 + 0], ax);
-        atomicAdd(&grad1[k * 3 + 1], ay);
-        atomicAdd(&grad1[k * 3 + 2], az);
-    }
-    __syncthreads();
-    if (threadIdx.x < lcnt * 3) {
-        int l = threadIdx.x / 3, c = threadIdx.x % 3;
-        atomicAdd(&grad2[(size_t)(l0 + l) * 3 + c], g2[l][c]);
+        float *g = grad1 + ((size_t)bi * n + k) * 3;
+        atomicAdd(g + 0, ax);
+        atomicAdd(g + 1, ay);
+        atomicAdd(g + 2, az);
     }
 }
 
@@ -506,8 +536,11 @@ int rf_matchcost_grad(int b, int n, int m, const float *xyz1, const float *xyz2,
     if ((size_t)b * n) RF_HIP(hipMemsetAsync(grad1, 0, sizeof(float) * 3 * (size_t)b * n, s));
     if ((size_t)b * m) RF_HIP(hipMemsetAsync(grad2, 0, sizeof(float) * 3 * (size_t)b * m, s));
     if (b == 0 || n == 0 || m == 0) return RF_OK;
-    dim3 g(rf::ceil_div(n, TPB), rf::ceil_div(m, MG_L), b);
-    RF_LAUNCH("mc_grad", mcg_kernel, g, dim3(TPB), 0, s, n, m, xyz1, xyz2, match, grad1, grad2);
+    int lsplit = MG_LSPLIT;
+    while (lsplit > 1 && m / lsplit < MG_TL) lsplit /= 2;
+    const int lspan = rf::ceil_div(rf::ceil_div(m, lsplit), MG_TL) * MG_TL;
+    dim3 g(rf::ceil_div(n, TPB), rf::ceil_div(m, lspan), b);
+    RF_LAUNCH("mc_grad", mcg_kernel, g, dim3(TPB), 0, s, n, m, lspan, xyz1, xyz2, match, grad1, grad2);
     return RF_OK;
 }
 
