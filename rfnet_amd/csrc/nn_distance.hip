@@ -52,9 +52,17 @@ struct Sweep {
     int span;     // candidates per split (multiple of CG)
 };
 
-__global__ void pack_kernel(int b, int n, int n_pad, float padval, const float *__restrict__ src,
-                            float *__restrict__ dst) {
-    long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// Re-pack both clouds in ONE launch: blocks [0, nblk_own) pack the own set (padded with -inf),
+// the rest the candidate set (padded with +inf).
+__global__ void pack_kernel(int b, int n_own, int n_own_pad, const float *__restrict__ src_own,
+                            float *__restrict__ dst_own, int nblk_own, int n_cand, int n_cand_pad,
+                            const float *__restrict__ src_cand, float *__restrict__ dst_cand) {
+    const bool is_cand = (int)blockIdx.x >= nblk_own;
+    const int n = is_cand ? n_cand : n_own, n_pad = is_cand ? n_cand_pad : n_own_pad;
+    const float *__restrict__ src = is_cand ? src_cand : src_own;
+    float *__restrict__ dst = is_cand ? dst_cand : dst_own;
+    const float padval = is_cand ? INFINITY : -INFINITY;
+    long g = (long)(blockIdx.x - (is_cand ? nblk_own : 0)) * blockDim.x + threadIdx.x;
     long total = (long)b * n_pad;
     if (g >= total) return;
     long bi = g / n_pad;
@@ -262,9 +270,9 @@ __global__ __launch_bounds__(TPB) void nn_sweep_kernel(Sweep a, const float *__r
 }
 
 // own side: combine the per-split partials in split order; strict '<' keeps the lowest index.
-__global__ void nn_rowmerge_kernel(const float *pd, const int *pi, float *dist, int *idx, int nsplit,
-                                   long total) {
-    long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void rowmerge_body(long g, const float *__restrict__ pd,
+                                              const int *__restrict__ pi, float *__restrict__ dist,
+                                              int *__restrict__ idx, int nsplit, long total) {
     if (g >= total) return;
     float best = pd[g];
     int besti = pi[g];
@@ -282,15 +290,25 @@ __global__ void nn_rowmerge_kernel(const float *pd, const int *pi, float *dist, 
 // candidate side: per candidate (one thread each), the first own block with the smallest partial
 // (strict '<' in block order), then the lowest index among that block's winning lane's R
 // consecutive points with an exactly equal d2.
+// The same launch also finishes the own side: blocks beyond the candidate blocks run rowmerge.
 template <int R>
-__global__ __launch_bounds__(TPB) void nn_colresolve_kernel(Sweep a, const float *__restrict__ own_all,
-                                                            const float *__restrict__ cand_all,
-                                                            const float *__restrict__ colpart,
-                                                            const unsigned char *__restrict__ collane,
-                                                            float *__restrict__ dist,
-                                                            int *__restrict__ idx) {
-    const int bi = blockIdx.y;
-    const int c = blockIdx.x * TPB + threadIdx.x;
+__global__ __launch_bounds__(TPB) void nn_resolve_kernel(Sweep a, const float *__restrict__ own_all,
+                                                         const float *__restrict__ cand_all,
+                                                         const float *__restrict__ colpart,
+                                                         const unsigned char *__restrict__ collane,
+                                                         float *__restrict__ dist, int *__restrict__ idx,
+                                                         int nblk_col, const float *__restrict__ row_pd,
+                                                         const int *__restrict__ row_pi,
+                                                         float *__restrict__ row_dist,
+                                                         int *__restrict__ row_idx) {
+    if ((int)blockIdx.x >= nblk_col) {
+        rowmerge_body((long)(blockIdx.x - nblk_col) * TPB + threadIdx.x, row_pd, row_pi, row_dist, row_idx,
+                      a.nsplit, (long)a.b * a.no);
+        return;
+    }
+    const int cblocks = nblk_col / a.b;
+    const int bi = blockIdx.x / cblocks;
+    const int c = (blockIdx.x - bi * cblocks) * TPB + threadIdx.x;
     if (c >= a.nc) return;
     const float *own = own_all + (size_t)bi * a.no_pad * 3;
     const float *cand = cand_all + (size_t)bi * a.nc_pad * 3;
@@ -467,10 +485,11 @@ int rf_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2, fl
     float *own_dist = p.swap ? dist2 : dist1, *cand_dist = p.swap ? dist1 : dist2;
     int *own_idx = p.swap ? idx2 : idx1, *cand_idx = p.swap ? idx1 : idx2;
 
-    RF_LAUNCH("nn_pack", pack_kernel, dim3(rf::ceil_div((long)b * p.no_pad, 256)), dim3(256), 0, s, b, p.no,
-              p.no_pad, -INFINITY, own_src, own_p);
-    RF_LAUNCH("nn_pack", pack_kernel, dim3(rf::ceil_div((long)b * p.nc_pad, 256)), dim3(256), 0, s, b, p.nc,
-              p.nc_pad, INFINITY, cand_src, cand_p);
+    {
+        const int nb_own = rf::ceil_div((long)b * p.no_pad, 256), nb_cand = rf::ceil_div((long)b * p.nc_pad, 256);
+        RF_LAUNCH("nn_pack", pack_kernel, dim3(nb_own + nb_cand), dim3(256), 0, s, b, p.no, p.no_pad, own_src,
+                  own_p, nb_own, p.nc, p.nc_pad, cand_src, cand_p);
+    }
 
     Sweep a;
     float *row_dist = p.nsplit > 1 ? (float *)(w + p.off_rowd) : own_dist;
@@ -482,14 +501,15 @@ int rf_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2, fl
     long waves = (long)b * p.oblocks * p.nsplit;
     RF_LAUNCH("nn_sweep", nn_sweep_kernel<RR>, dim3(rf::ceil_div(waves, TPB / 64)), dim3(TPB), 0, s, a,
               (const float *)own_p, (const float *)cand_p, row_dist, row_idx, colpart, collane);
-    if (p.nsplit > 1) {
-        long tot = (long)b * p.no;
-        RF_LAUNCH("nn_rowmerge", nn_rowmerge_kernel, dim3(rf::ceil_div(tot, 256)), dim3(256), 0, s,
-                  (const float *)row_dist, (const int *)row_idx, own_dist, own_idx, p.nsplit, tot);
+    {
+        const int cblocks = rf::ceil_div(p.nc, TPB);
+        const int nblk_col = cblocks * b;
+        const int nblk_row = p.nsplit > 1 ? rf::ceil_div((long)b * p.no, TPB) : 0;
+        RF_LAUNCH("nn_resolve", nn_resolve_kernel<RR>, dim3(nblk_col + nblk_row), dim3(TPB), 0, s, a,
+                  (const float *)own_p, (const float *)cand_p, (const float *)colpart,
+                  (const unsigned char *)collane, cand_dist, cand_idx, nblk_col, (const float *)row_dist,
+                  (const int *)row_idx, own_dist, own_idx);
     }
-    RF_LAUNCH("nn_colresolve", nn_colresolve_kernel<RR>, dim3(rf::ceil_div(p.nc, TPB), b), dim3(TPB), 0, s,
-              a, (const float *)own_p, (const float *)cand_p, (const float *)colpart,
-              (const unsigned char *)collane, cand_dist, cand_idx);
     return RF_OK;
 }
 
