@@ -1,0 +1,94 @@
+"""GPU: the C ABI called directly through ctypes (no Python wrappers): status codes, workspace
+contract, empty shapes, stream argument -- the behaviour a non-Python host binds to."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def test_status_codes_and_workspace_contract(orc):
+    from rfnet_amd._lib import lib
+    dev = "cuda"
+    b, n, m = 2, 100, 300
+    rng = np.random.RandomState(0)
+    a = torch.from_numpy(rng.randn(b, n, 3).astype(np.float32)).to(dev)
+    c = torch.from_numpy(rng.randn(b, m, 3).astype(np.float32)).to(dev)
+    d1 = torch.empty(b, n, device=dev); i1 = torch.empty(b, n, dtype=torch.int32, device=dev)
+    d2 = torch.empty(b, m, device=dev); i2 = torch.empty(b, m, dtype=torch.int32, device=dev)
+    need = lib.rf_nn_distance_workspace_bytes(b, n, m)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.Stream()
+    args = (b, n, m, p(a), p(c), p(d1), p(i1), p(d2), p(i2))
+    assert lib.rf_nn_distance(*args, p(ws), need - 1, stream.cuda_stream) == -2  # RF_EWORKSPACE
+    assert lib.rf_nn_distance(-1, n, m, *args[3:], p(ws), need, stream.cuda_stream) == -1  # RF_EINVAL
+    assert lib.rf_nn_distance(b, n, m, None, p(c), p(d1), p(i1), p(d2), p(i2), p(ws), need,
+                              stream.cuda_stream) == -1
+    assert lib.rf_nn_distance(b, 0, m, *args[3:], p(ws), need, stream.cuda_stream) == -1
+    assert lib.rf_nn_distance(0, n, m, *args[3:], p(ws), need, stream.cuda_stream) == 0  # empty batch
+    # a real call on a non-default stream; the library never synchronises
+    assert lib.rf_nn_distance(*args, p(ws), need, stream.cuda_stream) == 0
+    stream.synchronize()
+    e = orc.nn_distance(a.cpu().numpy(), c.cpu().numpy())
+    assert np.array_equal(d1.cpu().numpy(), e[0]) and np.array_equal(i2.cpu().numpy(), e[3])
+    # bad attributes of the other entry points
+    assert lib.rf_queryballpoint(b, n, m, C.c_float(0.1), 0, p(a), p(c), p(i1), p(i1), None) == -1
+    assert lib.rf_farthestpointsampling(b, 0, 4, p(a), None, p(i1), None) == -1
+    assert lib.rf_farthestpointsampling(b, n, 0, p(a), None, p(i1), None) == 0
+    lv = (C.c_float * 65)()
+    assert lib.rf_approxmatch_levels(b, n, m, p(a), p(c), p(d1), lv, 65, p(ws), need, None) == -1
+    assert lib.rf_status_string(-1) == b"invalid argument"
+
+
+def test_empty_sets_and_degenerate_sizes(orc):
+    from rfnet_amd import _raw as R
+    dev = "cuda"
+    z = torch.zeros(0, 5, 3, device=dev)
+    out = R.nn_distance(z, torch.zeros(0, 7, 3, device=dev))
+    assert [tuple(t.shape) for t in out] == [(0, 5), (0, 5), (0, 7), (0, 7)]
+    pts = torch.rand(2, 50, 3, device=dev)
+    idx = torch.zeros(2, 0, dtype=torch.int32, device=dev)
+    assert tuple(R.gather_point(pts, idx).shape) == (2, 0, 3)
+    g = R.gather_point_grad(pts, idx, torch.zeros(2, 0, 3, device=dev))
+    assert tuple(g.shape) == (2, 50, 3) and float(g.abs().sum()) == 0.0
+    gi = torch.zeros(2, 4, 0, dtype=torch.int32, device=dev)
+    assert tuple(R.group_point(pts, gi).shape) == (2, 4, 0, 3)
+    # empty dataset: every ball empty, pts_cnt = 0, idx untouched (wrapper zero-fills)
+    qi, cnt = R.query_ball_point(0.5, 3, torch.zeros(2, 0, 3, device=dev), pts[:, :4])
+    assert int(cnt.sum()) == 0 and int(qi.abs().sum()) == 0
+    # three_nn against an empty known set: dist = +inf, idx = 0 (reference: 1e40 cast, tf_interpolate.cpp:66)
+    d, i = R.three_nn(pts, torch.zeros(2, 0, 3, device=dev))
+    assert torch.isinf(d).all() and int(i.abs().sum()) == 0
+    # EMD with a single point on each side: all the mass goes to the one pair
+    a = torch.rand(3, 1, 3, device=dev)
+    c = torch.rand(3, 1, 3, device=dev)
+    mt = R.approx_match(a, c)
+    assert np.allclose(mt.cpu().numpy(), orc.approx_match(a.cpu().numpy(), c.cpu().numpy()), rtol=1e-5)
+    cost = R.match_cost(a, c, mt)
+    assert np.allclose(cost.cpu().numpy(), (mt[:, 0, 0] * (a - c).norm(dim=-1)[:, 0]).cpu().numpy(), rtol=1e-5)
+
+
+def test_calls_are_independent_of_workspace_contents(orc):
+    """The workspace carries no state between calls: poison it and results do not change."""
+    from rfnet_amd import _host, _raw as R
+    rng = np.random.RandomState(3)
+    a = torch.from_numpy(rng.randn(2, 700, 3).astype(np.float32)).cuda()
+    c = torch.from_numpy(rng.randn(2, 1300, 3).astype(np.float32)).cuda()
+    first = [t.clone() for t in R.nn_distance(a, c)]
+    for buf in _host._ws_cache.values():
+        buf.fill_(0xFF)
+    second = R.nn_distance(a, c)
+    for x, y in zip(first, second):
+        assert torch.equal(x, y)
+    u = torch.from_numpy((rng.rand(2, 300, 3) - .5).astype(np.float32)).cuda()
+    v = torch.from_numpy((rng.rand(2, 200, 3) - .5).astype(np.float32)).cuda()
+    m1 = R.approx_match(u, v).clone()
+    for buf in _host._ws_cache.values():
+        buf.fill_(0xFF)
+    assert torch.equal(m1, R.approx_match(u, v))
