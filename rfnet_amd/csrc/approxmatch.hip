@@ -24,6 +24,8 @@
 //   * row sums are accumulated per column segment and combined in segment order, so they
 //     differ from the reference's strictly sequential order in the last bits (tolerance
 //     stated in tests/test_gpu_emd.py).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
@@ -62,26 +64,30 @@ __global__ void am_init_kernel(int npts, int npad, float fill, const float *__re
 //           remainL[k] = max(0, remainL[k] - acc3)
 //   HAS_P1: acc1 = 1e-9 + sum_l fma(e(c_cur), remainR[l], .)                 (P1 of this level)
 //           ratioL_out[k] = remainL[k] / acc1
-template <bool HAS_P3, bool HAS_P1>
+template <bool HAS_P3, bool HAS_P1, int RPT>
 __global__ __launch_bounds__(1024) void am_rowk_kernel(
     int n, int seglen, const float *__restrict__ xyz1, const float *__restrict__ xyz2p,
     size_t xyz2p_stride, const float *__restrict__ ratioR_prev, const float *__restrict__ remainR,
     const float *__restrict__ ratioL_prev, float *__restrict__ remainL,
     float *__restrict__ ratioL_out, size_t stride, float c_prev, float c_cur) {
-    __shared__ float part3[16][64], part1[16][64];
+    __shared__ float part3[16][64 * RPT], part1[16][64 * RPT];
     const int bi = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nseg = blockDim.x >> 6;
-    const int k = blockIdx.x * 64 + lane;
-    const int kk = min(k, n - 1);
     const float *__restrict__ A = xyz1 + (size_t)bi * n * 3;
-    const float x1 = A[kk * 3], y1 = A[kk * 3 + 1], z1 = A[kk * 3 + 2];
-    const float rl = HAS_P3 ? ratioL_prev[(size_t)bi * stride + kk] : 0.f;
+    float x1[RPT], y1[RPT], z1[RPT], rl[RPT], acc3[RPT], acc1[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; r++) {
+        const int kk = min((int)blockIdx.x * 64 * RPT + r * 64 + lane, n - 1);
+        x1[r] = A[kk * 3]; y1[r] = A[kk * 3 + 1]; z1[r] = A[kk * 3 + 2];
+        rl[r] = HAS_P3 ? ratioL_prev[(size_t)bi * stride + kk] : 0.f;
+        acc3[r] = 0.f;
+        acc1[r] = (seg == 0) ? 1e-9f : 0.f;
+    }
     const float *__restrict__ C = xyz2p + (size_t)bi * xyz2p_stride;
     const float *__restrict__ S3 = ratioR_prev + (size_t)bi * stride;
     const float *__restrict__ S1 = remainR + (size_t)bi * stride;
-    float acc3 = 0.f, acc1 = (seg == 0) ? 1e-9f : 0.f;
     const int c0 = seg * seglen, c1 = c0 + seglen;  // multiples of SUB, inside the padded range
     float nb[3 * SUB], n3[SUB], n1[SUB];
 #pragma unroll
@@ -109,51 +115,66 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < SUB; u++) {
-            const float d2 = rf::d2_fma(cb[u * 3] - x1, cb[u * 3 + 1] - y1, cb[u * 3 + 2] - z1);
-            if (HAS_P3) {
-                const float p = rl * fast_exp2(d2 * c_prev);
-                acc3 = fmaf(p, s3[u], acc3);
+#pragma unroll
+            for (int r = 0; r < RPT; r++) {
+                const float d2 = rf::d2_fma(cb[u * 3] - x1[r], cb[u * 3 + 1] - y1[r], cb[u * 3 + 2] - z1[r]);
+                if (HAS_P3) {
+                    const float p = rl[r] * fast_exp2(d2 * c_prev);
+                    acc3[r] = fmaf(p, s3[u], acc3[r]);
+                }
+                if (HAS_P1) acc1[r] = fmaf(fast_exp2(d2 * c_cur), s1[u], acc1[r]);
             }
-            if (HAS_P1) acc1 = fmaf(fast_exp2(d2 * c_cur), s1[u], acc1);
         }
     }
-    part3[seg][lane] = acc3;
-    part1[seg][lane] = acc1;
+#pragma unroll
+    for (int r = 0; r < RPT; r++) {
+        part3[seg][r * 64 + lane] = acc3[r];
+        part1[seg][r * 64 + lane] = acc1[r];
+    }
     __syncthreads();
-    if (seg == 0 && k < n) {
-        float t3 = part3[0][lane], t1 = part1[0][lane];
-        for (int g = 1; g < nseg; g++) {
-            t3 += part3[g][lane];
-            t1 += part1[g][lane];
+    if (seg == 0) {
+#pragma unroll
+        for (int r = 0; r < RPT; r++) {
+            const int k = blockIdx.x * 64 * RPT + r * 64 + lane;
+            if (k >= n) continue;
+            float t3 = part3[0][r * 64 + lane], t1 = part1[0][r * 64 + lane];
+            for (int g = 1; g < nseg; g++) {
+                t3 += part3[g][r * 64 + lane];
+                t1 += part1[g][r * 64 + lane];
+            }
+            float rem = remainL[(size_t)bi * stride + k];
+            if (HAS_P3) {
+                rem = fmaxf(0.0f, rem - t3);
+                remainL[(size_t)bi * stride + k] = rem;
+            }
+            if (HAS_P1) ratioL_out[(size_t)bi * stride + k] = rem / t1;
         }
-        float rem = remainL[(size_t)bi * stride + k];
-        if (HAS_P3) {
-            rem = fmaxf(0.0f, rem - t3);
-            remainL[(size_t)bi * stride + k] = rem;
-        }
-        if (HAS_P1) ratioL_out[(size_t)bi * stride + k] = rem / t1;
     }
 }
 
 // P2: rows = xyz2 points l, columns = xyz1 points k with scalar ratioL[k].
 //   sumr = sum_k fma(e, ratioL[k], .);  t = sumr*remainR[l];  cons = min(remainR[l]/(t+1e-9), 1)
 //   ratioR[l] = remainR[l]*cons;  remainR[l] = max(0, remainR[l]-t)
+template <int RPT>
 __global__ __launch_bounds__(1024) void am_rowl_kernel(
     int m, int seglen, const float *__restrict__ xyz2, const float *__restrict__ xyz1p,
     size_t xyz1p_stride, const float *__restrict__ ratioL, float *__restrict__ remainR,
     float *__restrict__ ratioR_out, size_t stride, float c_cur) {
-    __shared__ float part[16][64];
+    __shared__ float part[16][64 * RPT];
     const int bi = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nseg = blockDim.x >> 6;
-    const int l = blockIdx.x * 64 + lane;
-    const int ll = min(l, m - 1);
     const float *__restrict__ B = xyz2 + (size_t)bi * m * 3;
-    const float x2 = B[ll * 3], y2 = B[ll * 3 + 1], z2 = B[ll * 3 + 2];
+    float x2[RPT], y2[RPT], z2[RPT], acc[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; r++) {
+        const int ll = min((int)blockIdx.x * 64 * RPT + r * 64 + lane, m - 1);
+        x2[r] = B[ll * 3]; y2[r] = B[ll * 3 + 1]; z2[r] = B[ll * 3 + 2];
+        acc[r] = 0.f;
+    }
     const float *__restrict__ C = xyz1p + (size_t)bi * xyz1p_stride;
     const float *__restrict__ S = ratioL + (size_t)bi * stride;
-    float acc = 0.f;
     const int c0 = seg * seglen, c1 = c0 + seglen;
     float nb[3 * SUB], ns[SUB];
 #pragma unroll
@@ -175,20 +196,29 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < SUB; u++) {
-            const float d2 = rf::d2_fma(x2 - cb[u * 3], y2 - cb[u * 3 + 1], z2 - cb[u * 3 + 2]);
-            acc = fmaf(fast_exp2(d2 * c_cur), sc[u], acc);
+#pragma unroll
+            for (int r = 0; r < RPT; r++) {
+                const float d2 = rf::d2_fma(x2[r] - cb[u * 3], y2[r] - cb[u * 3 + 1], z2[r] - cb[u * 3 + 2]);
+                acc[r] = fmaf(fast_exp2(d2 * c_cur), sc[u], acc[r]);
+            }
         }
     }
-    part[seg][lane] = acc;
+#pragma unroll
+    for (int r = 0; r < RPT; r++) part[seg][r * 64 + lane] = acc[r];
     __syncthreads();
-    if (seg == 0 && l < m) {
-        float sumr = part[0][lane];
-        for (int g = 1; g < nseg; g++) sumr += part[g][lane];
-        const float rem = remainR[(size_t)bi * stride + l];
-        const float t = sumr * rem;
-        const float cons = fminf(rem / (t + 1e-9f), 1.0f);
-        ratioR_out[(size_t)bi * stride + l] = rem * cons;
-        remainR[(size_t)bi * stride + l] = fmaxf(0.0f, rem - t);
+    if (seg == 0) {
+#pragma unroll
+        for (int r = 0; r < RPT; r++) {
+            const int l = blockIdx.x * 64 * RPT + r * 64 + lane;
+            if (l >= m) continue;
+            float sumr = part[0][r * 64 + lane];
+            for (int g = 1; g < nseg; g++) sumr += part[g][r * 64 + lane];
+            const float rem = remainR[(size_t)bi * stride + l];
+            const float t = sumr * rem;
+            const float cons = fminf(rem / (t + 1e-9f), 1.0f);
+            ratioR_out[(size_t)bi * stride + l] = rem * cons;
+            remainR[(size_t)bi * stride + l] = fmaxf(0.0f, rem - t);
+        }
     }
 }
 
@@ -423,8 +453,8 @@ AmLayout am_layout(int b, int n, int m, int nlevels) {
 
 // waves per workgroup (= column segments): the smallest power of two that gives >= 4096 waves,
 // keeping >= 64 columns per segment
-int pick_nseg(int b, int rows, int cols_pad) {
-    long base = (long)b * rf::ceil_div(rows, 64);
+int pick_nseg(int b, int rows, int cols_pad, int rpt) {
+    long base = (long)b * rf::ceil_div(rows, 64 * rpt);
     int nseg = 1;
     while (nseg < 16 && base * nseg < 4096 && cols_pad / (nseg * 2) >= 64) nseg *= 2;
     return nseg;
@@ -468,25 +498,37 @@ int rf_approxmatch_levels(int b, int n, int m, const float *xyz1, const float *x
 
     LevelConsts lc;
     for (int v = 0; v < MAX_LEVELS; v++) lc.c[v] = v < nlevels ? levels_host[v] * kLog2e : 0.f;
-    const int segk = pick_nseg(b, n, L.mpad), segl = pick_nseg(b, m, L.npad);
-    const dim3 gk(rf::ceil_div(n, 64), b), gl(rf::ceil_div(m, 64), b);
+    // rows per lane: 2 when there are enough rows to keep >= 2048 waves (longer compute per scalar
+    // prefetch covers the L2 latency of the s_loads); RF_AM_RPT overrides for experiments
+    static const int rpt_env = getenv("RF_AM_RPT") ? atoi(getenv("RF_AM_RPT")) : 0;
+    const int rpt = rpt_env ? rpt_env : 2;
+    const int segk = pick_nseg(b, n, L.mpad, rpt), segl = pick_nseg(b, m, L.npad, rpt);
+    const dim3 gk(rf::ceil_div(n, 64 * rpt), b), gl(rf::ceil_div(m, 64 * rpt), b);
+#define AM_ROWK(P3, P1, NAME, ...)                                                                   \
+    if (rpt == 2) { RF_LAUNCH(NAME, (am_rowk_kernel<P3, P1, 2>), gk, dim3(64 * segk), 0, s, __VA_ARGS__); } \
+    else          { RF_LAUNCH(NAME, (am_rowk_kernel<P3, P1, 1>), gk, dim3(64 * segk), 0, s, __VA_ARGS__); }
     for (int v = 0; v < nlevels; v++) {
         float *ratioL = ratios + (size_t)v * L.V, *ratioR = ratioL + L.npad;
         if (v == 0) {
-            RF_LAUNCH("am_p1", (am_rowk_kernel<false, true>), gk, dim3(64 * segk), 0, s, n, L.mpad / segk,
-                      xyz1, (const float *)x2p, (size_t)L.mpad * 3, (const float *)remainR,
-                      (const float *)remainR, (const float *)remainL, remainL, ratioL, L.bstride, 0.f,
-                      lc.c[0]);
+            AM_ROWK(false, true, "am_p1", n, L.mpad / segk, xyz1, (const float *)x2p, (size_t)L.mpad * 3,
+                    (const float *)remainR, (const float *)remainR, (const float *)remainL, remainL, ratioL,
+                    L.bstride, 0.f, lc.c[0]);
         } else {
             const float *pL = ratios + (size_t)(v - 1) * L.V, *pR = pL + L.npad;
-            RF_LAUNCH("am_p3p1", (am_rowk_kernel<true, true>), gk, dim3(64 * segk), 0, s, n,
-                      L.mpad / segk, xyz1, (const float *)x2p, (size_t)L.mpad * 3, pR,
-                      (const float *)remainR, pL, remainL, ratioL, L.bstride, lc.c[v - 1], lc.c[v]);
+            AM_ROWK(true, true, "am_p3p1", n, L.mpad / segk, xyz1, (const float *)x2p, (size_t)L.mpad * 3, pR,
+                    (const float *)remainR, pL, remainL, ratioL, L.bstride, lc.c[v - 1], lc.c[v]);
         }
-        RF_LAUNCH("am_p2", am_rowl_kernel, gl, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
-                  (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR,
-                  L.bstride, lc.c[v]);
+        if (rpt == 2) {
+            RF_LAUNCH("am_p2", am_rowl_kernel<2>, gl, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
+                      (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR,
+                      L.bstride, lc.c[v]);
+        } else {
+            RF_LAUNCH("am_p2", am_rowl_kernel<1>, gl, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
+                      (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR,
+                      L.bstride, lc.c[v]);
+        }
     }
+#undef AM_ROWK
     // P3 of the last level only updates remainL, which nothing reads afterwards: not launched.
     const dim3 gm(rf::ceil_div(n, TPB), rf::ceil_div(m, LSEG), b);
     for (int lv0 = 0; lv0 < nlevels; lv0 += LVG) {

@@ -16,6 +16,7 @@ __global__ void k(float *out, int iters, unsigned long long *clk) {
     float c0 = 0, c1 = 1, c2 = 2, c3 = 3, c4 = 4, c5 = 5, c6 = 6, c7 = 7;
     f2 p0 = {0, 1}, p1 = {2, 3}, p2 = {4, 5}, p3 = {6, 7}, p4 = {1, 1}, p5 = {2, 2}, p6 = {3, 3}, p7 = {4, 4};
     f2 pa = {a, a}, pb = {b, b};
+    const float sa2 = __builtin_amdgcn_readfirstlane(a), sb2 = __builtin_amdgcn_readfirstlane(b);
     unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int i = 0; i < iters; i++) {
         if (MODE == 0) {  // v_fma_f32, 8 independent chains
@@ -55,6 +56,18 @@ __global__ void k(float *out, int iters, unsigned long long *clk) {
                 "v_sub_f32 %0, %9, %4\n v_sub_f32 %3, %8, %5\n v_mul_f32 %3, %3, %3\n v_sub_f32 %2, %9, %6\n v_fmac_f32 %3, %0, %0\n v_fmac_f32 %3, %2, %2\n"
                 "v_min3_f32 %7, %7, %1, %3\n"
                 : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "s"(sa), "s"(sb));)
+        } else if (MODE == 8) {  // EMD column: 3 sub, mul, 2 fmac, mul, exp, fmac -- ONE accumulator (x8 columns)
+            REP8(asm volatile(
+                "v_sub_f32 %0, %8, %4\n v_sub_f32 %1, %9, %5\n v_mul_f32 %1, %1, %1\n v_sub_f32 %2, %8, %6\n v_fmac_f32 %1, %0, %0\n v_fmac_f32 %1, %2, %2\n"
+                "v_mul_f32 %1, %9, %1\n v_exp_f32 %1, %1\n v_fmac_f32 %7, %8, %1\n"
+                : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "s"(sa2), "s"(sb2));)
+        } else if (MODE == 9) {  // same, two columns interleaved with two accumulators (x4)
+            REP8(asm volatile(
+                "v_sub_f32 %0, %8, %4\n v_sub_f32 %1, %9, %5\n v_sub_f32 %2, %8, %6\n v_mul_f32 %1, %1, %1\n v_fmac_f32 %1, %0, %0\n v_fmac_f32 %1, %2, %2\n"
+                "v_mul_f32 %1, %9, %1\n v_exp_f32 %1, %1\n"
+                "v_sub_f32 %0, %9, %4\n v_sub_f32 %2, %8, %5\n v_mul_f32 %2, %2, %2\n v_fmac_f32 %2, %0, %0\n v_sub_f32 %0, %9, %6\n v_fmac_f32 %2, %0, %0\n"
+                "v_mul_f32 %2, %9, %2\n v_exp_f32 %2, %2\n v_fmac_f32 %7, %8, %1\n v_fmac_f32 %3, %8, %2\n"
+                : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "s"(sa2), "s"(sb2));)
         }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -95,6 +108,8 @@ int main() {
         run<5>("v_exp_f32", 64, w);
         run<6>("chamfer mix", 104, w);
         run<7>("chamfer mix sgpr", 104, w);
+        run<8>("emd col 1acc", 72, w);
+        run<9>("emd col 2acc", 144, w);
     }
     return 0;
 }
