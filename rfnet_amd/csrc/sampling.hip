@@ -45,46 +45,62 @@ struct Slot {
     int k;
 };
 
-// ---- DPP helpers: all-reduce inside a 16-lane row by cyclic rotations (row_ror:8,4,2,1) ----
-template <int N>
-__device__ __forceinline__ float row_ror(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, false));
+// ---- single-instruction helpers.  hipcc wraps fminf/fmaxf in canonicalising v_max x,x and
+// expands a float DPP reduction step into mov/nop/mov_dpp/max/max; on the serial path of FPS
+// every instruction counts, so these are written as the one instruction they are.  (Inputs are
+// never NaN here: distances of finite points, or the -1 / 1e38 sentinels.)
+__device__ __forceinline__ float vmin(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
-template <int N>
-__device__ __forceinline__ unsigned row_ror_u(unsigned v) {
-    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + N, 0xf, 0xf, false);
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
+// v = max(v, v rotated by N lanes inside each 16-lane row).  The s_nop covers the
+// VALU-write -> DPP-read hazard (the assembler/hazard recogniser does not look inside asm).
+#define RF_DPP_STEP(OP, N)                                                                          \
+    asm volatile("s_nop 1\n\t" OP " %0, %0, %0 row_ror:" #N " row_mask:0xf bank_mask:0xf" : "+v"(v))
 __device__ __forceinline__ float row_allmax(float v) {
-    v = fmaxf(v, row_ror<8>(v));
-    v = fmaxf(v, row_ror<4>(v));
-    v = fmaxf(v, row_ror<2>(v));
-    v = fmaxf(v, row_ror<1>(v));
+    RF_DPP_STEP("v_max_f32_dpp", 8);
+    RF_DPP_STEP("v_max_f32_dpp", 4);
+    RF_DPP_STEP("v_max_f32_dpp", 2);
+    RF_DPP_STEP("v_max_f32_dpp", 1);
     return v;
 }
 __device__ __forceinline__ unsigned row_allmin_u(unsigned v) {
-    v = min(v, row_ror_u<8>(v));
-    v = min(v, row_ror_u<4>(v));
-    v = min(v, row_ror_u<2>(v));
-    v = min(v, row_ror_u<1>(v));
+    RF_DPP_STEP("v_min_u32_dpp", 8);
+    RF_DPP_STEP("v_min_u32_dpp", 4);
+    RF_DPP_STEP("v_min_u32_dpp", 2);
+    RF_DPP_STEP("v_min_u32_dpp", 1);
     return v;
 }
-// maximum over the wave, uniform (SGPR): row all-reduce, then the four row results
+#undef RF_DPP_STEP
+// maximum over the wave, uniform: row all-reduce, then the four row results
 __device__ __forceinline__ float wave_allmax(float v) {
     v = row_allmax(v);
     const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
     const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
     const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
     const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+    return vmax3(vmax3(r0, r1, r2), r3, r3);
 }
 
 // NT threads (multiple of 512), PPT points per thread, all register resident.
 // Thread t owns k = (t & 511) + 512 * (s * (NT/512) + (t >> 9)), s = 0..PPT-1, so all its points
 // share (k mod 512) and ascend with s; inside a wave a lower lane has a lower (k mod 512).
-// One iteration: per-lane scan (10 VALU per point) -> wave maximum by DPP rotations -> the
-// lowest lane holding it (v_cmp mask + s_ff1) publishes (d2, k) in the wave's LDS slot ->
-// ONE barrier -> every 16-lane row re-reduces the <=16 slots by DPP (max d2, then min tie rank)
-// -> the winner's coordinates come back by a scalar load (uniform address, L2-resident cloud).
+// One iteration:
+//   scan      7 VALU per point (3 sub, mul, 2 fma, min) + half a v_max3 for the per-lane maximum
+//             VALUE -- no per-point compare/select for the arg-max;
+//   wave max  DPP row rotations + 4 v_readlane -> wm (uniform);
+//   arg-max   16 x v_cmp_eq(td[s], wm): each writes its 64-bit lane mask to SGPRs; the lowest
+//             lane of the OR of the masks, then the lowest s whose mask has that lane, is the
+//             wave's winner under the reference's tie order -- scalar ALU only;
+//   exchange  lane 0 publishes (wm, k) in the wave's LDS slot (double-buffered: ONE barrier per
+//             iteration); every 16-lane row re-reduces the <=16 slots by DPP (max d2, then
+//             min tie rank); the winner's coordinates come back by a scalar load.
 template <int NT, int PPT>
 __global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, const float *__restrict__ inp,
                                                      int *__restrict__ out) {
@@ -111,7 +127,7 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, const float *
             td[s] = 1e38f;
         } else {
             px[s] = py[s] = pz[s] = 0.f;
-            td[s] = -1.0f;  // min(d,-1) = -1 is never '>' the initial best of -1
+            td[s] = -1.0f;  // min(d,-1) = -1: below every real distance, like the reference's best=-1
         }
     }
     if (t < 32) {  // unused slots never win
@@ -122,23 +138,31 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, const float *
     __syncthreads();
     float ox = P[0], oy = P[1], oz = P[2];  // old = 0
     for (int j = 1; j < m; j++) {
-        float best = -1.0f;
-        int bs = 0;
+        float mx = -1.0f;
 #pragma unroll
         for (int s = 0; s < PPT; s++) {
-            float d = rf::d2_fma(px[s] - ox, py[s] - oy, pz[s] - oz);
-            float d2 = fminf(d, td[s]);
-            td[s] = d2;
-            if (d2 > best) {
-                best = d2;
-                bs = s;
+            td[s] = vmin(rf::d2_fma(px[s] - ox, py[s] - oy, pz[s] - oz), td[s]);
+            if (PPT == 1) {
+                mx = td[0];
+            } else if (s & 1) {
+                mx = vmax3(mx, td[s - 1], td[s]);
             }
         }
-        const int bk = (t & 511) + 512 * (bs * HALVES + (t >> 9));
-        const float wm = wave_allmax(best);
-        const unsigned long long mask = __ballot(best == wm);
-        const int wl = mask ? __builtin_ctzll(mask) : 0;
-        const int wk = __builtin_amdgcn_readlane(bk, wl);
+        const float wm = wave_allmax(mx);
+        // the wave's arg-max under the tie order: lowest lane, then lowest s
+        unsigned long long hit[PPT], any = 0ull;
+#pragma unroll
+        for (int s = 0; s < PPT; s++) {
+            hit[s] = __ballot(td[s] == wm);
+            any |= hit[s];
+        }
+        const int wl = any ? __builtin_ctzll(any) : 0;
+        int bs = 0;
+#pragma unroll
+        for (int s = PPT - 1; s >= 0; s--)
+            if ((hit[s] >> wl) & 1ull) bs = s;
+        const int wt = wave * 64 + wl;
+        const int wk = (wt & 511) + 512 * (bs * HALVES + (wt >> 9));
         const int buf = j & 1;
         if (lane == 0) {
             slot_d[buf][wave] = wm;
