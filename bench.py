@@ -142,10 +142,26 @@ def main():
     dt_emd = time.perf_counter() - t2
     emd_checksum = float(cost.double().sum().item())
 
-    tmax = torch.tensor([dt, dt_emd], dtype=torch.float64, device=dev)
+    # north_star's own target shape, reported as an extra field: B=32 x 16384 vs 16384 forward
+    ns_n = 16384
+    nrng = np.random.RandomState(200 + rank)
+    y1 = torch.from_numpy(nrng.randn(B, ns_n, 3).astype(np.float32)).to(dev)
+    y2 = torch.from_numpy(nrng.randn(B, ns_n, 3).astype(np.float32)).to(dev)
+    ns_steps = max(3, min(10, args.steps))
+    for _ in range(2):
+        nso = nn_distance(y1, y2)
+    fence()
+    t3 = time.perf_counter()
+    for _ in range(ns_steps):
+        nso = nn_distance(y1, y2)
+    fence()
+    dt_ns = time.perf_counter() - t3
+    del y1, y2
+
+    tmax = torch.tensor([dt, dt_emd, dt_ns], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-    dt, dt_emd = float(tmax[0].item()), float(tmax[1].item())
+    dt, dt_emd, dt_ns = float(tmax[0].item()), float(tmax[1].item()), float(tmax[2].item())
     checksum = float(out[0].double().sum().item())
 
     if rank == 0:
@@ -215,8 +231,15 @@ def main():
                 "checksum": emd_checksum,
             },
         }
+        line["north_star_16384sq"] = {
+            "workload": f"nn_distance forward, B={B} per GPU, {ns_n} vs {ns_n} (north_star target shape)",
+            "value": world * B * ns_n * ns_n * ns_steps / dt_ns, "unit": "pairs/s",
+            "ms_per_call": dt_ns / ns_steps * 1e3, "steps": ns_steps,
+        }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(B, N, M, 100)
+            line["north_star_16384sq"]["vs_cpu_baseline"] = (
+                line["north_star_16384sq"]["value"] / line["cpu_baseline"]["value"])
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

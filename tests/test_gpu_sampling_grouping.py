@@ -197,3 +197,69 @@ def test_numpy_and_cpu_tensor_inputs_round_trip(orc):
     assert isinstance(i_cpu, torch.Tensor) and not i_cpu.is_cuda
     assert np.array_equal(i_np, i_cpu.numpy()) and np.array_equal(i_np, orc.farthest_point_sample(16, p))
     assert np.array_equal(gather_point(p, i_np), orc.gather_point(p, i_np))
+
+
+# ------------------------------------------------------------------ the reference's own tests
+def _numeric_grad(f, x, eps=1e-2):
+    """central differences of sum(f(x) * w) wrt x, like tf.test.compute_gradient_error does per
+    element (float64 accumulation on the host)."""
+    g = np.zeros_like(x, dtype=np.float64)
+    it = np.nditer(x, flags=["multi_index"])
+    while not it.finished:
+        i = it.multi_index
+        old = x[i]
+        x[i] = old + eps
+        hi = f(x)
+        x[i] = old - eps
+        lo = f(x)
+        x[i] = old
+        g[i] = (hi - lo) / (2 * eps)
+        it.iternext()
+    return g
+
+
+def test_reference_group_point_gradient_test():
+    """tf_ops/grouping/tf_grouping_op_test.py:9-25: points (1,128,16), xyz1 (1,128,3), xyz2 (1,8,3),
+    radius 0.3, nsample 32; gradient error of group_point wrt points must be < 1e-4."""
+    from tf_ops.grouping.tf_grouping import group_point, query_ball_point
+    rng = np.random.RandomState(0)
+    points = rng.random_sample((1, 128, 16)).astype(np.float32)
+    xyz1 = rng.random_sample((1, 128, 3)).astype(np.float32)
+    xyz2 = rng.random_sample((1, 8, 3)).astype(np.float32)
+    idx, _ = query_ball_point(0.3, 32, cu(xyz1), cu(xyz2))
+    w = rng.random_sample((1, 8, 32, 16))
+    tp = cu(points).requires_grad_(True)
+    (group_point(tp, idx) * cu(w.astype(np.float32))).sum().backward()
+    analytic = tp.grad.cpu().numpy().astype(np.float64)
+
+    def f(p):
+        return float((group_point(cu(p), idx).cpu().numpy().astype(np.float64) * w).sum())
+    sub = points[:, :6].copy()  # finite differences on a slice of the points (every channel)
+
+    def f_sub(ps):
+        p = points.copy()
+        p[:, :6] = ps
+        return f(p)
+    numeric = _numeric_grad(f_sub, sub)
+    assert np.abs(numeric - analytic[:, :6]).max() < 1e-4 * max(1.0, np.abs(analytic).max())
+
+
+def test_reference_three_interpolate_gradient_test():
+    """tf_ops/interpolation/tf_interpolate_op_test.py:9-21: points (1,8,16), xyz1 (1,128,3),
+    xyz2 (1,8,3), weights 1/3; gradient error of three_interpolate wrt points < 1e-4."""
+    from tf_ops.interpolation.tf_interpolate import three_interpolate, three_nn
+    rng = np.random.RandomState(0)
+    points = rng.random_sample((1, 8, 16)).astype(np.float32)
+    xyz1 = rng.random_sample((1, 128, 3)).astype(np.float32)
+    xyz2 = rng.random_sample((1, 8, 3)).astype(np.float32)
+    _, idx = three_nn(cu(xyz1), cu(xyz2))
+    weight = cu(np.full((1, 128, 3), 1.0 / 3.0, np.float32))
+    w = rng.random_sample((1, 128, 16))
+    tp = cu(points).requires_grad_(True)
+    (three_interpolate(tp, idx, weight) * cu(w.astype(np.float32))).sum().backward()
+    analytic = tp.grad.cpu().numpy().astype(np.float64)
+
+    def f(p):
+        return float((three_interpolate(cu(p), idx, weight).cpu().numpy().astype(np.float64) * w).sum())
+    numeric = _numeric_grad(f, points.copy())
+    assert np.abs(numeric - analytic).max() < 1e-4 * max(1.0, np.abs(analytic).max())
