@@ -274,6 +274,92 @@ __global__ __launch_bounds__(TPB) void am_match_kernel(int n, int m, const float
     }
 }
 
+// ---- small clouds (max(n,m) <= AM_SMALL, e.g. the 64 x 64 EMD term of the training loss,
+// vv_recon.py:489): the multi-launch pipeline above is launch-bound there (21 launches for a few
+// thousand pairs), so ONE workgroup per batch element runs the whole schedule out of LDS, like
+// the reference's block (tf_approxmatch.cu:13-178) -- and, summing each row strictly in index
+// order, with exactly the reference's summation order.
+constexpr int AM_SMALL = 256;
+__global__ __launch_bounds__(AM_SMALL) void am_small_kernel(int n, int m, int nlevels, LevelConsts lc,
+                                                            float multiL, float multiR,
+                                                            const float *__restrict__ xyz1,
+                                                            const float *__restrict__ xyz2,
+                                                            float *__restrict__ match) {
+    // columns are float4 {x,y,z,scalar}: one broadcast ds_read_b128 per column; the scalar slot is
+    // rewritten by the owning thread before each phase (remainR / ratioL / ratioR of the level)
+    __shared__ float4 c1[AM_SMALL], c2[AM_SMALL];
+    __shared__ float ratL[MAX_LEVELS][AM_SMALL], ratR[MAX_LEVELS][AM_SMALL];  // 128 KiB
+    const int bi = blockIdx.x, t = threadIdx.x;
+    float x1 = 0.f, y1 = 0.f, z1 = 0.f, x2 = 0.f, y2 = 0.f, z2 = 0.f;
+    float remL = multiL, remR = multiR;
+    if (t < n) {
+        const float *p = xyz1 + ((size_t)bi * n + t) * 3;
+        x1 = p[0]; y1 = p[1]; z1 = p[2];
+        c1[t] = make_float4(x1, y1, z1, 0.f);
+    }
+    if (t < m) {
+        const float *p = xyz2 + ((size_t)bi * m + t) * 3;
+        x2 = p[0]; y2 = p[1]; z2 = p[2];
+        c2[t] = make_float4(x2, y2, z2, remR);
+    }
+    __syncthreads();
+    for (int v = 0; v < nlevels; v++) {
+        const float c = lc.c[v];
+        float rl = 0.f;
+        if (t < n) {  // P1: columns l carry remainR
+            float suml = 1e-9f;
+#pragma unroll 4
+            for (int l = 0; l < m; l++) {
+                const float4 q = c2[l];
+                suml = fmaf(fast_exp2(rf::d2_fma(q.x - x1, q.y - y1, q.z - z1) * c), q.w, suml);
+            }
+            rl = remL / suml;
+            ratL[v][t] = rl;
+            c1[t].w = rl;
+        }
+        __syncthreads();
+        if (t < m) {  // P2: columns k carry ratioL
+            float sumr = 0.f;
+#pragma unroll 4
+            for (int k = 0; k < n; k++) {
+                const float4 q = c1[k];
+                sumr = fmaf(fast_exp2(rf::d2_fma(x2 - q.x, y2 - q.y, z2 - q.z) * c), q.w, sumr);
+            }
+            const float tt = sumr * remR;
+            const float cons = fminf(remR / (tt + 1e-9f), 1.0f);
+            const float rr = remR * cons;
+            ratR[v][t] = rr;
+            c2[t].w = rr;
+            remR = fmaxf(0.0f, remR - tt);
+        }
+        __syncthreads();
+        if (v + 1 < nlevels) {  // P3 (its only effect is remainL, unused after the last level)
+            if (t < n) {
+                float suml = 0.f;
+#pragma unroll 4
+                for (int l = 0; l < m; l++) {
+                    const float4 q = c2[l];
+                    suml = fmaf(rl * fast_exp2(rf::d2_fma(q.x - x1, q.y - y1, q.z - z1) * c), q.w, suml);
+                }
+                remL = fmaxf(0.0f, remL - suml);
+            }
+            __syncthreads();
+            if (t < m) c2[t].w = remR;  // next level's P1 scalar
+            __syncthreads();
+        }
+    }
+    if (t < n) {  // match[l][k] = level-ordered fma chain, as am_match_kernel
+        float *M = match + (size_t)bi * n * m;
+        for (int l = 0; l < m; l++) {
+            const float4 q = c2[l];
+            const float d2 = rf::d2_fma(q.x - x1, q.y - y1, q.z - z1);
+            float acc = 0.f;
+            for (int v = 0; v < nlevels; v++) acc = fmaf(ratL[v][t] * fast_exp2(d2 * lc.c[v]), ratR[v][l], acc);
+            M[(size_t)l * n + t] = acc;
+        }
+    }
+}
+
 // ---- match_cost: cost[i] = sum_{l,k} match[l][k] * sqrt(d2(k,l)); HBM-bound stream of match.
 // workgroup = 256 k x MC_L l; per-workgroup partial -> workspace; fixed-order final sum.
 constexpr int MC_L = 32;
@@ -484,6 +570,13 @@ int rf_approxmatch_levels(int b, int n, int m, const float *xyz1, const float *x
     if (n >= m) { multiL = 1.f; multiR = (float)(n / m); }
     else        { multiL = (float)(m / n); multiR = 1.f; }
 
+    if (n <= AM_SMALL && m <= AM_SMALL) {
+        LevelConsts lcs;
+        for (int v = 0; v < MAX_LEVELS; v++) lcs.c[v] = v < nlevels ? levels_host[v] * kLog2e : 0.f;
+        RF_LAUNCH("am_small", am_small_kernel, dim3(b), dim3(AM_SMALL), 0, s, n, m, nlevels, lcs, multiL,
+                  multiR, xyz1, xyz2, match);
+        return RF_OK;
+    }
     const AmLayout L = am_layout(b, n, m, nlevels);
     float *w = (float *)workspace;
     float *remainL = w, *remainR = w + L.npad;          // slot 0 of the vector region
@@ -505,8 +598,9 @@ int rf_approxmatch_levels(int b, int n, int m, const float *xyz1, const float *x
     const int segk = pick_nseg(b, n, L.mpad, rpt), segl = pick_nseg(b, m, L.npad, rpt);
     const dim3 gk(rf::ceil_div(n, 64 * rpt), b), gl(rf::ceil_div(m, 64 * rpt), b);
 #define AM_ROWK(P3, P1, NAME, ...)                                                                   \
-    if (rpt == 2) { RF_LAUNCH(NAME, (am_rowk_kernel<P3, P1, 2>), gk, dim3(64 * segk), 0, s, __VA_ARGS__); } \
-    else          { RF_LAUNCH(NAME, (am_rowk_kernel<P3, P1, 1>), gk, dim3(64 * segk), 0, s, __VA_ARGS__); }
+    if (rpt == 4)      { RF_LAUNCH(NAME, (am_rowk_kernel<P3, P1, 4>), gk, dim3(64 * segk), 0, s, __VA_ARGS__); } \
+    else if (rpt == 2) { RF_LAUNCH(NAME, (am_rowk_kernel<P3, P1, 2>), gk, dim3(64 * segk), 0, s, __VA_ARGS__); } \
+    else               { RF_LAUNCH(NAME, (am_rowk_kernel<P3, P1, 1>), gk, dim3(64 * segk), 0, s, __VA_ARGS__); }
     for (int v = 0; v < nlevels; v++) {
         float *ratioL = ratios + (size_t)v * L.V, *ratioR = ratioL + L.npad;
         if (v == 0) {
@@ -518,7 +612,11 @@ int rf_approxmatch_levels(int b, int n, int m, const float *xyz1, const float *x
             AM_ROWK(true, true, "am_p3p1", n, L.mpad / segk, xyz1, (const float *)x2p, (size_t)L.mpad * 3, pR,
                     (const float *)remainR, pL, remainL, ratioL, L.bstride, lc.c[v - 1], lc.c[v]);
         }
-        if (rpt == 2) {
+        if (rpt == 4) {
+            RF_LAUNCH("am_p2", am_rowl_kernel<4>, gl, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
+                      (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR,
+                      L.bstride, lc.c[v]);
+        } else if (rpt == 2) {
             RF_LAUNCH("am_p2", am_rowl_kernel<2>, gl, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
                       (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR,
                       L.bstride, lc.c[v]);
