@@ -161,3 +161,17 @@ def test_pc_distance_alias_and_errors():
         nn_distance(x, torch.zeros(2, 5, 2, device="cuda"))
     with pytest.raises(ValueError, match="same batch size"):
         nn_distance(x, torch.zeros(3, 5, 3, device="cuda"))
+
+
+def test_large_clouds_65536(orc):
+    """Beyond any config size: 65536 vs 32768 points (oracle on slices, mutual-consistency property)."""
+    rng = np.random.RandomState(11)
+    a = rng.randn(1, 65536, 3).astype(np.float32)
+    c = rng.randn(1, 32768, 3).astype(np.float32)
+    d1, i1, d2, i2 = _run(a, c)
+    e = orc.nn_distance(a[:, 60000:60300], c)
+    assert np.array_equal(d1[0, 60000:60300], e[0][0]) and np.array_equal(i1[0, 60000:60300], e[1][0])
+    e = orc.nn_distance(a, c[:, 100:300])
+    assert np.array_equal(d2[0, 100:300], e[2][0]) and np.array_equal(i2[0, 100:300], e[3][0])
+    assert (np.take_along_axis(d2, i1.astype(np.int64), 1) <= d1).all()
+    assert (np.take_along_axis(d1, i2.astype(np.int64), 1) <= d2).all()

@@ -115,3 +115,26 @@ def test_match_cost_autograd(orc):
     s = scale.cpu().numpy()[:, None, None]
     assert_rel(ta.grad.cpu().numpy(), o1 * s, 1e-4, 1e-5)
     assert_rel(tc.grad.cpu().numpy(), o2 * s, 1e-4, 1e-5)
+
+
+def test_eval_size_16384_sq_single_sample():
+    """The evaluation shape of the reference (vv_recon.py:485: earth_mover at 16384 x 16384, match =
+    1 GiB per sample): one sample, size-independent properties only (the oracle would need 8e9 exp)."""
+    from pc_distance.tf_approxmatch import approx_match, match_cost, match_cost_grad
+    rng = np.random.RandomState(16384)
+    a = cu((rng.random_sample((1, 16384, 3)) - 0.5).astype(np.float32))
+    c = cu((rng.random_sample((1, 16384, 3)) - 0.5).astype(np.float32))
+    match = approx_match(a, c)
+    assert tuple(match.shape) == (1, 16384, 16384)
+    rows, cols = match.sum(1).cpu().numpy(), match.sum(2).cpu().numpy()
+    assert_rel(rows, np.ones_like(rows), 2e-3)
+    assert_rel(cols, np.ones_like(cols), 2e-3)
+    cost = float(match_cost(a, c, match)[0])
+    assert 0.01 < cost / 16384 < 0.1  # EMD per point of two uniform clouds, O(n^-1/3)
+    # linearity of match_cost in match, and consistency of the gradient with the cost
+    half = float(match_cost(a, c, match * 0.5)[0])
+    assert abs(half - 0.5 * cost) < 1e-5 * cost
+    g1, g2 = match_cost_grad(a, c, match)
+    # sum_k grad1[k] = -sum_l grad2[l] (every pair contributes +v to one and -v to the other)
+    s1, s2 = g1.sum(1).cpu().numpy(), g2.sum(1).cpu().numpy()
+    assert np.allclose(s1, -s2, atol=1e-2)

@@ -61,6 +61,12 @@ def main():
         x3 = torch.from_numpy(rng.randn(32, 3000, 3).astype(np.float32)).to(dev)
         timeit("nn_distance fwd 32x3000x16384", lambda: R.nn_distance(x3, x2), a.iters,
                32 * 3000 * 16384, "pairs")
+    if w in ("model", "all"):
+        # the shapes one RFNet training step calls, B=32
+        for (n_, m_) in ((3000, 64), (3000, 1024), (3000, 16384), (2048, 2048), (64, 1024), (1024, 16384)):
+            a_ = torch.from_numpy(rng.randn(32, n_, 3).astype(np.float32)).to(dev)
+            c_ = torch.from_numpy(rng.randn(32, m_, 3).astype(np.float32)).to(dev)
+            timeit(f"nn_distance fwd 32x{n_}x{m_}", lambda: R.nn_distance(a_, c_), a.iters, 32 * n_ * m_, "pairs")
     if w in ("ns", "all"):
         y1 = torch.from_numpy(rng.randn(32, 16384, 3).astype(np.float32)).to(dev)
         y2 = torch.from_numpy(rng.randn(32, 16384, 3).astype(np.float32)).to(dev)
