@@ -80,3 +80,22 @@ def test_world_size_2_gloo(tmp_path, B):
     c = rng.randn(B, 90, 3).astype(np.float32)
     d1, _, d2, _ = Oracle().nn_distance(a, c)
     assert np.array_equal(l0, ((np.sqrt(d1).mean(1) + np.sqrt(d2).mean(1)) / 2).astype(np.float32))
+
+
+def test_bench_multi_rank_plumbing_dry_run():
+    """bench.py under torch.distributed.run with 2 ranks (gloo, CPU): the launch line the driver
+    uses for N>1, in the script's dry-run mode (tiny shapes, oracle stand-in, no metric).  Checks
+    that exactly one JSON line comes out of rank 0 and that both ranks rendezvous and exit cleanly."""
+    import json
+    import subprocess
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run-cpu"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == 2
