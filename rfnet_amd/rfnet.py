@@ -1,0 +1,206 @@
+"""RFNet generator graph (`full_process`, vv_recon.py:194-244 and the cells it calls, :84-160,
+246-364) on PyTorch-ROCm -- the second "next" row.
+
+Every layer of the reference is a 1x1 convolution over points, i.e. a dense layer on the channel
+axis, so tensors are kept as (batch, points, channels) and the GEMMs go to the library
+(rocBLAS/hipBLASLt through torch) -- "plain library GEMMs".  The point-cloud operators inside the
+graph (FPS + gather in `sampling`, Chamfer + group_point in `merge_layer`) are the HIP ops of this
+repository.
+
+What is pinned: the PARAMETER INVENTORY.  `tests/golden/rfnet_variables.json` is the list of
+variable names and shapes read out of the reference's checkpoint index
+(bestrecord/model-229999.index, with tools/read_tf_index.py -- data only); `RFNet.tf_variables()`
+must reproduce it entry for entry, which checks every layer's existence, name, fan-in and fan-out,
+and the reference's sharing quirk: `encode_cell` ('cell') is applied three times and `decode_cell`
+twice with SHARED kernels (tf.get_variable under reuse=True) but FRESH biases per application
+(tf.Variable: `cell/...`, `cell_1/...`, `cell_2/...`, `decode_cell_1/...`).  The checkpoint's weight
+blob is absent and TensorFlow cannot run here, so numerical parity of the forward pass with the
+reference is NOT established; initialisation follows the reference (Xavier-uniform
+kernels, zero biases).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import glue
+
+_MLP3 = [("ini_layer0", 3, 64), ("ini_layer1", 64, 128), ("ini_layer2", 128, 256)]
+_RECOVER = [("recover20", 259, 256), ("recover21", 256, 256), ("recover2out1", 256, 256)]
+_REFINE = [("ini_layer0", 259, 128), ("ini_layer1", 128, 128), ("refine_layers0", 131, 128),
+           ("refine_layers1", 128, 64), ("refine_layers2", 64, 64), ("refine_layer_final", 64, 3),
+           ("feat_refine0", 387, 128), ("feat_refine1", 128, 128), ("feat_refine_final", 128, 128)]
+_DECODE = ([("mlp_mask0", 259, 128), ("mlp_mask1", 128, 128), ("mask_tensor", 128, 256),
+            ("input_trans", 256, 256), ("state_trans", 128, 128), ("basic_state0", 384, 256),
+            ("basic_state1", 256, 256), ("points0", 256, 128), ("points1", 128, 64),
+            ("points_out", 64, 48), ("state0", 512, 128), ("state1", 128, 128)]
+           + [x for i in range(16) for x in ((f"state_expand{i}_0", 128, 128), (f"state_expand{i}", 128, 128))])
+
+# (variable scope, layers (name, fan_in, fan_out), number of applications)
+LAYERS = [
+    ("init_mlp", _MLP3, 1),
+    ("cell", [("state0", 259, 256), ("state1", 256, 384), ("state_end", 384, 256),
+              ("codemlp0", 256, 256), ("codemlp1", 256, 256)], 3),
+    ("recover1", _RECOVER, 1), ("recover2", _RECOVER, 1), ("recover3", _RECOVER, 1),
+    ("", [("ini_layer0", 259, 256), ("ini_layer1", 256, 256), ("ini_layer2", 256, 256),
+          ("ini_featout0", 515, 256), ("ini_featout1", 256, 128), ("inimove_featout", 128, 128),
+          ("ini_ptsout0", 515, 256), ("ini_ptsout1", 256, 128), ("ini_ptsout2", 128, 64),
+          ("inimove_ptsout", 64, 3), ("partfeat0", 512, 256), ("partfeat1", 256, 256)], 1),
+    ("part_mlp", _MLP3, 1),
+    ("init_cell", [("input_trans", 256, 256), ("basic_state0", 256, 256), ("basic_state1", 256, 256),
+                   ("points_out", 256, 108), ("state_out", 256, 512), ("state0", 272, 256),
+                   ("state1", 256, 256), ("state_outo", 256, 128)], 1),
+    ("refine_layer1", _REFINE, 1), ("refine_layer2", _REFINE, 1), ("refine_layer_final", _REFINE, 1),
+    ("decode_cell", _DECODE, 2),
+]
+
+
+def _key(name):
+    return name.replace("/", "__")
+
+
+class RFNet(nn.Module):
+    """points (B, 3000, 3) -> (points1 (B,64,3), points2 (B,1024,3), points3 (B,16384,3),
+    points_final (B,16384,3)), as `full_process`."""
+
+    def __init__(self):
+        super().__init__()
+        self.weights = nn.ParameterDict()
+        self.biases = nn.ParameterDict()
+        self._tf_names = {}
+        for scope, layers, ncall in LAYERS:
+            for name, cin, cout in layers:
+                base = f"{scope}/{name}" if scope else name
+                w = nn.Parameter(torch.empty(cin, cout))
+                nn.init.xavier_uniform_(w)  # tf.contrib.layers.xavier_initializer on [1,1,cin,cout]
+                self.weights[_key(base)] = w
+                self._tf_names[f"{base}/weights"] = [1, 1, cin, cout]
+                for c in range(ncall):
+                    # tf.Variable under a re-entered scope lands in a uniquified NAME scope
+                    sc = scope if c == 0 else f"{scope}_{c}"
+                    bname = f"{sc}/{name}" if sc else name
+                    self.biases[_key(bname)] = nn.Parameter(torch.zeros(cout))
+                    self._tf_names[f"{bname}/Variable"] = [cout]
+        for dn in ("decline_factor0", "decline_factor1", "decline_factor"):
+            p = nn.Parameter(torch.empty(1))
+            nn.init.uniform_(p, -math.sqrt(3.0), math.sqrt(3.0))  # xavier on shape [1]
+            setattr(self, dn, p)
+            self._tf_names[dn] = [1]
+
+    def tf_variables(self):
+        """{TensorFlow variable name: shape} of this module (checked against the checkpoint index)."""
+        return dict(self._tf_names)
+
+    # -- one 1x1 convolution = dense layer on the channel axis -------------------------------
+    def d(self, scope, name, x, act="relu", call=0):
+        base = f"{scope}/{name}" if scope else name
+        sc = scope if call == 0 else f"{scope}_{call}"
+        bname = f"{sc}/{name}" if sc else name
+        y = F.linear(x, self.weights[_key(base)].t(), self.biases[_key(bname)])
+        if act == "relu":
+            return F.relu(y)
+        if act == "tanh":
+            return torch.tanh(y)
+        if act == "leaky_relu":
+            return F.leaky_relu(y, 0.2)
+        return y
+
+    def mlp(self, scope, prefix, n, x, call=0):
+        for i in range(n):
+            x = self.d(scope, f"{prefix}{i}", x, call=call)
+        return x
+
+    # -- cells ---------------------------------------------------------------------------------
+    def global_mlp(self, scope, xyz):  # vv_recon.py:84-91
+        return self.mlp(scope, "ini_layer", 3, xyz).max(1, keepdim=True).values
+
+    def encode_cell(self, x, state, call):  # :93-112
+        s = torch.cat([x, state.expand(-1, x.shape[1], -1)], -1)
+        s = self.mlp("cell", "state", 2, s, call)
+        new_state = self.d("cell", "state_end", s, call=call).max(1, keepdim=True).values
+        return self.mlp("cell", "codemlp", 2, new_state, call), new_state
+
+    def recover_cell(self, scope, code, con):  # :124-131
+        t = torch.cat([code.expand(-1, con.shape[1], -1), con], -1)
+        t = self.mlp(scope, "recover2", 2, t).max(1, keepdim=True).values
+        return self.d(scope, "recover2out1", t, act=None)
+
+    def init_move_layer(self, startpts, codeword):  # :140-159
+        t1 = torch.cat([startpts, codeword.expand(-1, startpts.shape[1], -1)], -1)
+        t = self.mlp("", "ini_layer", 3, t1)
+        t = torch.cat([t1, t.max(1, keepdim=True).values.expand(-1, t1.shape[1], -1)], -1)
+        feats = self.d("", "inimove_featout", self.mlp("", "ini_featout", 2, t))
+        pts = self.d("", "inimove_ptsout", self.mlp("", "ini_ptsout", 3, t), act="tanh")
+        return startpts + pts, feats
+
+    def init_decode_layer(self, x, ptnum=32):  # :246-272 with state_tensor=None
+        ns = self.d("init_cell", "input_trans", x)
+        ns = self.mlp("init_cell", "basic_state", 2, ns)
+        po = self.d("init_cell", "points_out", ns, act=None)  # (B,1,3*ptnum+12)
+        transmat = po[..., -12:-3].reshape(-1, 3, 3)
+        movemat = po[..., -3:].reshape(-1, 1, 3)
+        pts = torch.tanh(po[..., :-12]).reshape(-1, ptnum, 3) @ transmat + movemat
+        so = self.d("init_cell", "state_out", ns).reshape(-1, ptnum, 16)
+        so = torch.cat([so, ns.expand(-1, ptnum, -1)], -1)
+        so = self.mlp("init_cell", "state", 2, so)
+        return pts, self.d("init_cell", "state_outo", so)
+
+    def refine_layer(self, scope, ptcoor, feat, feat2):  # :273-308
+        n = ptcoor.shape[1]
+        t = torch.cat([ptcoor, feat.expand(-1, n, -1)], -1)
+        t = self.mlp(scope, "ini_layer", 2, t)
+        t = torch.cat([ptcoor, t.max(1, keepdim=True).values.expand(-1, n, -1)], -1)
+        t = self.mlp(scope, "refine_layers", 3, t)
+        newcoor = ptcoor + self.d(scope, "refine_layer_final", t, act="tanh")
+        t = torch.cat([newcoor, feat2, feat.expand(-1, feat2.shape[1], -1)], -1)
+        t = self.mlp(scope, "feat_refine", 2, t)
+        return newcoor, self.d(scope, "feat_refine_final", t, act="tanh") + feat2
+
+    def decode_cell(self, code, center, state, call, up_ratio=16):  # :310-364
+        n = state.shape[1]
+        sc = "decode_cell"
+        mask = torch.cat([center, code.expand(-1, n, -1)], -1)
+        mask = self.d(sc, "mask_tensor", self.mlp(sc, "mlp_mask", 2, mask, call), call=call)
+        info = self.d(sc, "input_trans", mask * code, call=call)
+        ns = torch.cat([info, self.d(sc, "state_trans", state, call=call)], -1)
+        ns = self.mlp(sc, "basic_state", 2, ns, call)
+        move = self.d(sc, "points_out", self.mlp(sc, "points", 2, ns, call), act="tanh", call=call)
+        pts = (center.unsqueeze(2) + move.reshape(-1, n, up_ratio, 3)).reshape(-1, n * up_ratio, 3)
+        ns = torch.cat([ns, code.expand(-1, n, -1)], -1)
+        ns = self.mlp(sc, "state", 2, ns, call)
+        parts, cur = [], ns
+        for i in range(up_ratio):  # a CHAIN: expansion i feeds expansion i+1
+            cur = self.d(sc, f"state_expand{i}_0", cur, call=call)
+            cur = self.d(sc, f"state_expand{i}", cur, act="leaky_relu", call=call)
+            parts.append(cur)
+        move_state = torch.stack(parts, 2)  # (B, n, up_ratio, 128)
+        return pts, (state.unsqueeze(2) + move_state).reshape(-1, n * up_ratio, state.shape[-1])
+
+    # -- the graph -------------------------------------------------------------------------------
+    def forward(self, pointcloud):
+        x = pointcloud
+        state0 = self.global_mlp("init_mlp", x)
+        code1, state = self.encode_cell(x, state0, 0)
+        code1 = self.recover_cell("recover1", code1, x)
+        start = glue.sampling(32, pointcloud, use_type="f")[1]
+        points1, dstate = self.init_move_layer(start, code1)
+        partfeat = self.global_mlp("part_mlp", torch.cat([pointcloud, points1], 1))
+        ft = self.mlp("", "partfeat", 2, torch.cat([partfeat, code1], -1))
+        points0, dstate0 = self.init_decode_layer(ft)
+        points1, dstate = torch.cat([points0, points1], 1), torch.cat([dstate0, dstate], 1)
+        points1 = glue.merge_layer(pointcloud, points1.contiguous(), self.decline_factor0, knum=1)
+        points1, dstate = self.refine_layer("refine_layer1", points1, code1, dstate)
+
+        code2, state = self.encode_cell(torch.cat([pointcloud, points1], 1), state, 1)
+        code2 = code1 + self.recover_cell("recover2", code2, torch.cat([pointcloud, points1], 1))
+        points2, dstate = self.decode_cell(code2, points1, dstate, 0)
+        points2 = glue.merge_layer(pointcloud, points2.contiguous(), self.decline_factor1, knum=1)
+        points2, dstate = self.refine_layer("refine_layer2", points2, code2, dstate)
+
+        code3, state = self.encode_cell(torch.cat([pointcloud, points2], 1), state, 2)
+        code3 = code2 + self.recover_cell("recover3", code3, torch.cat([pointcloud, points2], 1))
+        points3, dstate = self.decode_cell(code3, points2, dstate, 1)
+        final = glue.merge_layer(pointcloud, points3.contiguous(), self.decline_factor, knum=1)
+        final, _ = self.refine_layer("refine_layer_final", final, code3, dstate)
+        return points1, points2, points3, final

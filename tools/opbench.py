@@ -67,6 +67,30 @@ def main():
             a_ = torch.from_numpy(rng.randn(32, n_, 3).astype(np.float32)).to(dev)
             c_ = torch.from_numpy(rng.randn(32, m_, 3).astype(np.float32)).to(dev)
             timeit(f"nn_distance fwd 32x{n_}x{m_}", lambda: R.nn_distance(a_, c_), a.iters, 32 * n_ * m_, "pairs")
+    if w in ("c5",):
+        # BASELINE.json configs[4], one GPU's share: full RFNet recurrent forward (3 steps to 16384
+        # points) + CD/EMD loss at B=32 (= B=256 over 8 GPUs); random weights, synthetic clouds
+        from rfnet_amd import glue
+        from rfnet_amd.rfnet import RFNet
+        net = RFNet().cuda()
+        partial = torch.from_numpy((rng.rand(32, 3000, 3) - 0.5).astype(np.float32)).to(dev)
+        gt = torch.from_numpy((rng.rand(32, 16384, 3) - 0.5).astype(np.float32)).to(dev)
+
+        def fwd_loss():
+            with torch.no_grad():
+                p1, p2, p3, pf = net(partial)
+                gt64, gt1024 = glue.sampling(64, gt)[1], glue.sampling(1024, gt)[1]
+                return glue.chamfer_big(pf, gt)[0] + glue.earth_mover(p1, gt64) + glue.earth_mover(p2, gt1024)
+
+        def fwd_bwd():
+            net.zero_grad(set_to_none=True)
+            p1, p2, p3, pf = net(partial)
+            gt64, gt1024 = glue.sampling(64, gt)[1], glue.sampling(1024, gt)[1]
+            (glue.chamfer_big(pf, gt)[0] + glue.earth_mover(p1, gt64) + glue.earth_mover(p2, gt1024)).backward()
+        ms = timeit("C5 RFNet forward + CD/EMD loss, B=32", fwd_loss, max(3, a.iters // 4))
+        print(f"      -> {32 / ms * 1e3:.1f} samples/s per GPU (forward + loss)")
+        ms = timeit("C5 RFNet forward+backward (training step w/o optimizer), B=32", fwd_bwd, max(3, a.iters // 4))
+        print(f"      -> {32 / ms * 1e3:.1f} samples/s per GPU (forward + backward)")
     if w in ("ns", "all"):
         y1 = torch.from_numpy(rng.randn(32, 16384, 3).astype(np.float32)).to(dev)
         y2 = torch.from_numpy(rng.randn(32, 16384, 3).astype(np.float32)).to(dev)
