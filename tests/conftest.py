@@ -16,6 +16,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built artefacts (*.so is git-ignored): build them once, here
+    # (hipcc cross-compiles gfx950 without a GPU; the oracle is plain gcc)
+    from rfnet_amd.build import LIB, build_library
+    if not os.path.exists(LIB):
+        build_library()
 
 
 def pytest_collection_modifyitems(config, items):
