@@ -24,12 +24,26 @@ def main(out):
             print("  {:40s} calls={:>6s} total_ns={:>12s} avg_ns={:>10s} pct={}".format(
                 short(row.get("Name", "")), row.get("Calls", ""), row.get("TotalDurationNs", ""),
                 row.get("AverageNs", ""), row.get("Percentage", "")))
+    # per-dispatch trace: split each kernel by launch shape (bench.py also runs the kernel at the
+    # north-star 16384^2 shape as an extra, so the per-name average of --stats mixes two workloads)
+    for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_trace.csv"), recursive=True):
+        acc = defaultdict(list)
+        for row in csv.DictReader(open(f)):
+            key = (short(row["Kernel_Name"]), int(row["Grid_Size_X"]), int(row["Workgroup_Size_X"]))
+            acc[key].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+        print("== kernel trace by launch shape:", os.path.relpath(f, out))
+        for (k, grid, wg), v in sorted(acc.items()):
+            if "at::native" in k or "rocclr" in k:
+                continue
+            print(f"  {k:30s} grid_x={grid:>9d} wg={wg:>5d} calls={len(v):>5d} avg_ns={sum(v) / len(v):12.1f}")
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
         for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
             acc = defaultdict(lambda: defaultdict(list))
             for row in csv.DictReader(open(f)):
-                acc[short(row.get("Kernel_Name", ""))][row.get("Counter_Name", "")].append(
-                    float(row.get("Counter_Value", 0)))
+                nm = short(row.get("Kernel_Name", ""))
+                if nm == "nn_sweep":
+                    nm = "nn_sweep grid_x=%s" % row.get("Grid_Size", row.get("Grid_Size_X", "?"))
+                acc[nm][row.get("Counter_Name", "")].append(float(row.get("Counter_Value", 0)))
             print("== counters:", os.path.relpath(f, out))
             for k, cs in sorted(acc.items()):
                 for c, vals in sorted(cs.items()):
