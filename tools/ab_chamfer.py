@@ -24,9 +24,10 @@ x2 = torch.from_numpy(rng.randn(32, 16384, 3).astype(np.float32)).cuda()
 y1 = torch.from_numpy(rng.randn(32, 16384, 3).astype(np.float32)).cuda()
 print("C2 %%.4f ms   NS %%.4f ms" %% (t(lambda: R.nn_distance(x1, x2), 50), t(lambda: R.nn_distance(y1, x2), 15)))
 ''' % ROOT
+ENVNAME = os.environ.get("AB_ENV", "RF_NN_WAVES")
 variants = sys.argv[1:] or ["2048", "4096", "8192", "16384"]
 for rnd in range(2):
     for v in variants:
-        env = dict(os.environ, RF_NN_WAVES=v)
+        env = dict(os.environ, **{ENVNAME: v})
         out = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True)
-        print(f"round {rnd} RF_NN_WAVES={v:>6s}: {out.stdout.strip()} {out.stderr.strip()[-200:] if out.returncode else ''}")
+        print(f"round {rnd} {ENVNAME}={v:>6s}: {out.stdout.strip()} {out.stderr.strip()[-200:] if out.returncode else ''}")
