@@ -126,6 +126,23 @@ int rf_threeinterpolate(int b, int m, int c, int n, const float *points, const i
 int rf_threeinterpolate_grad(int b, int n, int c, int m, const float *grad_out, const int *idx,
                              const float *weight, float *grad_points, rf_stream_t stream);
 
+/* ------------------------------------------- rest of the import surface ("next" row f3) --- */
+/* Replaces AuctionMatchLauncher(b,n,xyz1,xyz2,matchl,matchr,cost) (tf_ops/emd/tf_auctionmatch.cpp:25,
+ * tf_auctionmatch_g.cu:292-294).  xyz1, xyz2 (b,n,3); matchl, matchr (b,n) int32: matchr[j] = the
+ * xyz1 point assigned to xyz2 point j, matchl its inverse.  `workspace` is the reference's temp
+ * cost matrix (b,n,n) floats.  Defined for n < 1024 or n in {1024, 2048, 4096}
+ * (rf_auctionmatch_supported); the reference additionally caps n at 4096. */
+int rf_auctionmatch_supported(int n);
+size_t rf_auctionmatch_workspace_bytes(int b, int n);
+int rf_auctionmatch(int b, int n, const float *xyz1, const float *xyz2, int *matchl, int *matchr,
+                    void *workspace, size_t workspace_bytes, rf_stream_t stream);
+
+/* Replaces selectionSortLauncher(b,n,m,k,dist,outi,out) (tf_ops/grouping/tf_grouping.cpp:112,
+ * tf_grouping_g.cu:129-132).  dist (b,m,n); outi (b,m,n) int32, out (b,m,n): per row a partial
+ * selection sort, the first k entries are the k smallest in ascending order.  n <= 16384. */
+int rf_selectionsort(int b, int n, int m, int k, const float *dist, int *outi, float *out,
+                     rf_stream_t stream);
+
 /* ------------------------------------------------------------------ measurement hooks --- */
 /* When enabled, every kernel launch made by this library is bracketed by hipEvents recorded
  * on the launch stream.  rf_profile_collect() waits for them and returns the per-kernel sums

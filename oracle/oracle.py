@@ -182,6 +182,27 @@ class Oracle:
         return g
 
 
+def _orc_auction(self, xyz1, xyz2):
+    xyz1, xyz2 = _f32(xyz1), _f32(xyz2)
+    b, n, _ = xyz1.shape
+    assert self.lib.orc_auction_match_supported(n), "n must be < 1024 or one of 1024, 2048, 4096"
+    ml, mr = np.empty((b, n), np.int32), np.empty((b, n), np.int32)
+    self.lib.orc_auction_match(b, n, _f(xyz1), _f(xyz2), _i(ml), _i(mr))
+    return ml, mr
+
+
+def _orc_select_top_k(self, k, dist):
+    dist = _f32(dist)
+    b, m, n = dist.shape
+    idx, val = np.empty((b, m, n), np.int32), np.empty((b, m, n), np.float32)
+    self.lib.orc_selection_sort(b, n, m, int(k), _f(dist), _i(idx), _f(val))
+    return idx, val
+
+
+Oracle.auction_match = _orc_auction
+Oracle.select_top_k = _orc_select_top_k
+
+
 def ref_available():
     return os.path.exists(os.path.join(_HERE, "_ref", "libref.so"))
 

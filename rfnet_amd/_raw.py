@@ -330,3 +330,47 @@ def three_interpolate_grad(points, idx, weight, grad_out):
     check(lib.rf_threeinterpolate_grad(b, n, c, m, H.ptr(go), H.ptr(ix), H.ptr(w), H.ptr(g),
                                        H.stream(dev)), "rf_threeinterpolate_grad")
     return st.give(g)
+
+
+# ------------------------------------------------------------------ import surface (f3) -----
+def auction_match(xyz1, xyz2):
+    """AuctionMatchGpuOp, tf_ops/emd/tf_auctionmatch.cpp:27-58 -> matchl (b,n), matchr (b,n) int32."""
+    st = H.Staged()
+    a, b_ = st.take(xyz1, F32), st.take(xyz2, F32)
+    if not _shape3(a, 3):
+        raise H.invalid("ApproxMatch expects (batch_size,num_points,3) xyz1 shape")  # sic (reference wording)
+    b, n = a.shape[0], a.shape[1]
+    if n > 4096:
+        raise H.invalid("AuctionMatch handles at most 4096 dataset points")
+    if not (_shape3(b_, 3) and b_.shape[0] == b and b_.shape[1] == n):
+        raise H.invalid("AuctionMatch expects (batch_size,num_points,3) xyz2 shape, and shape must match with xyz1")
+    if n and not lib.rf_auctionmatch_supported(n):
+        raise H.invalid("AuctionMatch is defined for n < 1024 or n in {1024, 2048, 4096}: for other n "
+                        "the reference kernel reads out of bounds (tf_auctionmatch_g.cu:148,185)")
+    dev = st.device_()
+    a, b_ = st.up(a, b_)
+    ml, mr = H.empty((b, n), I32, dev), H.empty((b, n), I32, dev)
+    ws, wsz = H.workspace(lib.rf_auctionmatch_workspace_bytes(b, n), dev, "auction")
+    check(lib.rf_auctionmatch(b, n, H.ptr(a), H.ptr(b_), H.ptr(ml), H.ptr(mr), H.ptr(ws), wsz,
+                              H.stream(dev)), "rf_auctionmatch")
+    return st.give(ml), st.give(mr)
+
+
+def select_top_k(k, dist):
+    """SelectionSortGpuOp, tf_ops/grouping/tf_grouping.cpp:113-143 -> idx (b,m,n) int32, dist_out (b,m,n)."""
+    k = int(k)
+    if k <= 0:
+        raise H.invalid("SelectionSort expects positive k")
+    st = H.Staged()
+    d = st.take(dist, F32)
+    if d.dim() != 3:
+        raise H.invalid("SelectionSort expects (b,m,n) dist shape.")
+    b, m, n = d.shape
+    if n > 16384:
+        raise H.invalid("select_top_k handles rows of at most 16384 entries")
+    dev = st.device_()
+    d, = st.up(d)
+    idx, out = H.empty((b, m, n), I32, dev), H.empty((b, m, n), F32, dev)
+    check(lib.rf_selectionsort(b, n, m, k, H.ptr(d), H.ptr(idx), H.ptr(out), H.stream(dev)),
+          "rf_selectionsort")
+    return st.give(idx), st.give(out)

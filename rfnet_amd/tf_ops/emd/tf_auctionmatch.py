@@ -1,8 +1,15 @@
-"""Import surface of the reference module tf_ops/emd/tf_auctionmatch.py.  vv_recon.py:8 imports
-it, but only dead code (emd_func, vv_recon.py:365-380) calls auction_match; the kernel is a
-'next' row."""
+"""Drop-in for the reference module tf_ops/emd/tf_auctionmatch.py (auction_match :11-20,
+ops.NoGradient :21).  vv_recon.py:8 imports it; only dead code (emd_func, :365-380) calls it."""
+from ... import _raw
 
 
 def auction_match(xyz1, xyz2):
-    raise NotImplementedError("auction_match is a 'next' row: SURVEY.md 8(f3); the RFNet losses "
-                              "use pc_distance.tf_approxmatch instead")
+    '''
+input:
+    xyz1 : batch_size * #points * 3
+    xyz2 : batch_size * #points * 3
+returns:
+    matchl : batch_size * #npoints   (for each xyz1 point, the xyz2 point it is matched to)
+    matchr : batch_size * #npoints   (for each xyz2 point, the xyz1 point it is matched to)
+    '''
+    return _raw.auction_match(xyz1, xyz2)

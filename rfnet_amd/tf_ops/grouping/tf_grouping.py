@@ -1,6 +1,6 @@
 """Ball query and grouping: drop-in for the reference module tf_ops/grouping/tf_grouping.py
 (query_ball_point :8-20, group_point :33-41 + gradient :42-46, knn_point :48-73;
-select_top_k is a "next" row)."""
+select_top_k :22-31)."""
 import torch
 
 from ... import _raw
@@ -69,5 +69,12 @@ def knn_point(k, xyz1, xyz2):
 
 
 def select_top_k(k, dist):
-    raise NotImplementedError("select_top_k (SelectionSort) is a 'next' row: SURVEY.md 8(f3); "
-                              "unused by the RFNet model")
+    '''
+    Input:
+        k: int32, number of k SMALLEST elements selected
+        dist: (b,m,n) float32 array, distance matrix, m query points, n dataset points
+    Output:
+        idx: (b,m,n) int32 array, first k in n are indices to the top k
+        dist_out: (b,m,n) float32 array, first k in n are the top k
+    '''
+    return _raw.select_top_k(k, dist)
