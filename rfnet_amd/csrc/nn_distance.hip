@@ -192,7 +192,9 @@ __global__ __launch_bounds__(TPB) void nn_sweep_kernel(Sweep a, const float *__r
 #pragma unroll
             for (int i = 0; i < 3 * SUB; i++) cb[i] = nb[i];
             {
-                const float *cp = cand + (size_t)(c0 + (sub + 1) * SUB) * 3;  // uniform -> s_load
+                // (clamped: the prefetch issued by the last sub-chunk is never used and must not
+                // run past the array when the clouds are read in place, without the padded copy)
+                const float *cp = cand + (size_t)min(c0 + (sub + 1) * SUB, a.nc_pad - SUB) * 3;  // uniform -> s_load
 #pragma unroll
                 for (int i = 0; i < 3 * SUB; i++) nb[i] = cp[i];
             }
@@ -485,7 +487,16 @@ int rf_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2, fl
     float *own_dist = p.swap ? dist2 : dist1, *cand_dist = p.swap ? dist1 : dist2;
     int *own_idx = p.swap ? idx2 : idx1, *cand_idx = p.swap ? idx1 : idx2;
 
-    {
+    // Clouds whose sizes already fit the tiling (own a multiple of 64*R, candidates a multiple of
+    // the 32-candidate group) are swept in place; otherwise both are re-packed with -inf / +inf
+    // padding (pack_kernel).  BASELINE's shapes (2048, 16384) take the in-place path.
+    const bool in_place = (p.no % (64 * RR) == 0) && (p.nc % CG == 0);
+    if (in_place) {
+        own_p = const_cast<float *>(own_src);
+        cand_p = const_cast<float *>(cand_src);
+        p.no_pad = p.no;
+        p.nc_pad = p.nc;
+    } else {
         const int nb_own = rf::ceil_div((long)b * p.no_pad, 256), nb_cand = rf::ceil_div((long)b * p.nc_pad, 256);
         RF_LAUNCH("nn_pack", pack_kernel, dim3(nb_own + nb_cand), dim3(256), 0, s, b, p.no, p.no_pad, own_src,
                   own_p, nb_own, p.nc, p.nc_pad, cand_src, cand_p);
