@@ -73,11 +73,12 @@ _ws_cache = {}
 
 
 def workspace(nbytes, dev, tag):
-    """A cached per-(device, op) scratch buffer, grown on demand (caller-owned scratch, like
-    the reference's allocate_temp)."""
+    """A cached per-(device, stream, op) scratch buffer, grown on demand (caller-owned scratch,
+    like the reference's allocate_temp).  Keyed by the current stream as well: two streams running
+    the same op concurrently must not share scratch."""
     if nbytes == 0:
         return None, 0
-    key = (dev.index, tag)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)

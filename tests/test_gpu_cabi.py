@@ -92,3 +92,27 @@ def test_calls_are_independent_of_workspace_contents(orc):
     for buf in _host._ws_cache.values():
         buf.fill_(0xFF)
     assert torch.equal(m1, R.approx_match(u, v))
+
+
+def test_two_streams_do_not_share_scratch(orc):
+    """The same op on two streams at once: each stream gets its own cached workspace."""
+    from rfnet_amd import _raw as R
+    rng = np.random.RandomState(5)
+    a1 = torch.from_numpy(rng.randn(4, 3000, 3).astype(np.float32)).cuda()
+    c1 = torch.from_numpy(rng.randn(4, 5000, 3).astype(np.float32)).cuda()
+    a2 = torch.from_numpy(rng.randn(4, 3000, 3).astype(np.float32)).cuda()
+    c2 = torch.from_numpy(rng.randn(4, 5000, 3).astype(np.float32)).cuda()
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for _ in range(5):  # interleave launches on the two streams
+        with torch.cuda.stream(s1):
+            o1 = R.nn_distance(a1, c1)
+        with torch.cuda.stream(s2):
+            o2 = R.nn_distance(a2, c2)
+        outs.append((o1, o2))
+    torch.cuda.synchronize()
+    e1, e2 = orc.nn_distance(a1.cpu().numpy(), c1.cpu().numpy()), orc.nn_distance(a2.cpu().numpy(), c2.cpu().numpy())
+    for o1, o2 in outs:
+        assert all(np.array_equal(x.cpu().numpy(), y) for x, y in zip(o1, e1))
+        assert all(np.array_equal(x.cpu().numpy(), y) for x, y in zip(o2, e2))
