@@ -229,6 +229,9 @@ struct LevelConsts {
     float c[MAX_LEVELS];  // level * log2e
 };
 
+// NLV > 0: exactly NLV levels starting at level 0, fully unrolled with no per-level branch (the
+// reference schedule is NLV = 10); NLV = 0: generic group of up to LVG levels, predicated.
+template <int NLV>
 __global__ __launch_bounds__(TPB) void am_match_kernel(int n, int m, const float *xyz1,
                                                        const float *xyz2, const float *ratios,
                                                        size_t lv_stride, size_t b_stride, int roff,
@@ -257,6 +260,22 @@ __global__ __launch_bounds__(TPB) void am_match_kernel(int n, int m, const float
     __syncthreads();
     if (k >= n) return;
     const float x1 = xyz1[k * 3], y1 = xyz1[k * 3 + 1], z1 = xyz1[k * 3 + 2];
+    if (NLV > 0) {
+        float rl[NLV > 0 ? NLV : 1], cl[NLV > 0 ? NLV : 1];
+#pragma unroll
+        for (int v = 0; v < NLV; v++) {
+            rl[v] = ratios[(size_t)v * lv_stride + k];
+            cl[v] = lc.c[v];
+        }
+        for (int l = 0; l < lcnt; l++) {
+            const float d2 = rf::d2_fma(cxyz[l][0] - x1, cxyz[l][1] - y1, cxyz[l][2] - z1);
+            float acc = 0.f;
+#pragma unroll
+            for (int v = 0; v < NLV; v++) acc = fmaf(rl[v] * fast_exp2(d2 * cl[v]), crr[l][v], acc);
+            match[(size_t)(l0 + l) * n + k] = acc;
+        }
+        return;
+    }
     float rl[LVG];
 #pragma unroll
     for (int v = 0; v < LVG; v++) rl[v] = v < nlv ? ratios[(size_t)v * lv_stride + k] : 0.f;
@@ -629,10 +648,15 @@ int rf_approxmatch_levels(int b, int n, int m, const float *xyz1, const float *x
 #undef AM_ROWK
     // P3 of the last level only updates remainL, which nothing reads afterwards: not launched.
     const dim3 gm(rf::ceil_div(n, TPB), rf::ceil_div(m, LSEG), b);
-    for (int lv0 = 0; lv0 < nlevels; lv0 += LVG) {
-        int nlv = nlevels - lv0 < LVG ? nlevels - lv0 : LVG;
-        RF_LAUNCH("am_match", am_match_kernel, gm, dim3(TPB), 0, s, n, m, xyz1, xyz2,
-                  (const float *)ratios, L.V, L.bstride, L.npad, lv0, nlv, lc, match);
+    if (nlevels == 10) {
+        RF_LAUNCH("am_match", am_match_kernel<10>, gm, dim3(TPB), 0, s, n, m, xyz1, xyz2,
+                  (const float *)ratios, L.V, L.bstride, L.npad, 0, 10, lc, match);
+    } else {
+        for (int lv0 = 0; lv0 < nlevels; lv0 += LVG) {
+            int nlv = nlevels - lv0 < LVG ? nlevels - lv0 : LVG;
+            RF_LAUNCH("am_match", am_match_kernel<0>, gm, dim3(TPB), 0, s, n, m, xyz1, xyz2,
+                      (const float *)ratios, L.V, L.bstride, L.npad, lv0, nlv, lc, match);
+        }
     }
     return RF_OK;
 }
