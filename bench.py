@@ -135,9 +135,11 @@ def main():
         g1, g2 = nn_distance_grad(xyz1, xyz2, gd1, i1, gd2, i2)
         return d1, g1, g2
 
+    use_pg = torch.distributed.is_available() and torch.distributed.is_initialized()
+
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_pg:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -198,7 +200,7 @@ def main():
     del y1, y2
 
     tmax = torch.tensor([dt, dt_emd, dt_ns], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_pg:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt, dt_emd, dt_ns = float(tmax[0].item()), float(tmax[1].item()), float(tmax[2].item())
     checksum = float(out[0].double().sum().item())
@@ -280,7 +282,7 @@ def main():
             line["north_star_16384sq"]["vs_cpu_baseline"] = (
                 line["north_star_16384sq"]["value"] / line["cpu_baseline"]["value"])
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_pg:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

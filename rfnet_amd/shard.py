@@ -22,7 +22,8 @@ def init_from_env(backend=None):
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     if torch.cuda.is_available():
         torch.cuda.set_device(local % torch.cuda.device_count())
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("RF_FORCE_PG") == "1"  # testing: exercise the RCCL path on one GPU
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
