@@ -143,6 +143,12 @@ int rf_auctionmatch(int b, int n, const float *xyz1, const float *xyz2, int *mat
 int rf_selectionsort(int b, int n, int m, int k, const float *dist, int *outi, float *out,
                      rf_stream_t stream);
 
+/* Replaces probsampleLauncher(b,n,m,inp_p,inp_r,temp,out) (tf_ops/sampling/tf_sampling.cpp:65,
+ * tf_sampling_g.cu:198-201): inp_p (b,n) weights, inp_r (b,m) uniforms in [0,1), temp (b,n) floats
+ * (receives the cumulative sums), out (b,m) int32 inverse-CDF indices. */
+int rf_probsample(int b, int n, int m, const float *inp_p, const float *inp_r, float *temp, int *out,
+                  rf_stream_t stream);
+
 /* ------------------------------------------------------------------ measurement hooks --- */
 /* When enabled, every kernel launch made by this library is bracketed by hipEvents recorded
  * on the launch stream.  rf_profile_collect() waits for them and returns the per-kernel sums

@@ -199,6 +199,16 @@ def _orc_select_top_k(self, k, dist):
     return idx, val
 
 
+def _orc_prob_sample(self, inp_p, inp_r):
+    inp_p, inp_r = _f32(inp_p), _f32(inp_r)
+    b, n = inp_p.shape
+    m = inp_r.shape[1]
+    temp, out = np.empty((b, n), np.float32), np.empty((b, m), np.int32)
+    self.lib.orc_prob_sample(b, n, m, _f(inp_p), _f(inp_r), _f(temp), _i(out))
+    return out, temp
+
+
+Oracle.prob_sample = _orc_prob_sample
 Oracle.auction_match = _orc_auction
 Oracle.select_top_k = _orc_select_top_k
 

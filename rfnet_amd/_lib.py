@@ -38,6 +38,7 @@ SIGNATURES = {
     "rf_auctionmatch_workspace_bytes": (_sz, [_i, _i]),
     "rf_auctionmatch": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rf_selectionsort": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "rf_probsample": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "rf_profile_enable": (None, [_i]),
     "rf_profile_collect": (_i, [C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_long), _i]),
 }

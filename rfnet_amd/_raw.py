@@ -374,3 +374,20 @@ def select_top_k(k, dist):
     check(lib.rf_selectionsort(b, n, m, k, H.ptr(d), H.ptr(idx), H.ptr(out), H.stream(dev)),
           "rf_selectionsort")
     return st.give(idx), st.give(out)
+
+
+def prob_sample(inp, inpr):
+    """ProbSampleGpuOp, tf_ops/sampling/tf_sampling.cpp:66-92 -> (b,m) int32."""
+    st = H.Staged()
+    p, r = st.take(inp, F32), st.take(inpr, F32)
+    if p.dim() != 2:
+        raise H.invalid("ProbSample expects (batch_size,num_choices) inp shape")
+    if not (r.dim() == 2 and r.shape[0] == p.shape[0]):
+        raise H.invalid("ProbSample expects (batch_size,num_points) inpr shape")
+    b, n, m = p.shape[0], p.shape[1], r.shape[1]
+    dev = st.device_()
+    p, r = st.up(p, r)
+    temp, out = H.empty((b, n), F32, dev), H.empty((b, m), I32, dev)
+    check(lib.rf_probsample(b, n, m, H.ptr(p), H.ptr(r), H.ptr(temp), H.ptr(out), H.stream(dev)),
+          "rf_probsample")
+    return st.give(out)

@@ -260,6 +260,85 @@ __global__ void scatteradd_kernel(int n, int m, long total, const float *__restr
     atomicAdd(p + 2, out_g[g * 3 + 2]);
 }
 
+// ---- prob_sample (ProbSample op): cumsumKernel + binarysearchKernel, tf_sampling_g.cu:7-104.
+// One workgroup per row; the scan keeps the reference's association order exactly (groups of
+// 4, up-sweep / down-sweep over the group totals with the (i + i>>5) padded index, compensated
+// carry between 8192-element chunks), so the cumulative sums -- and therefore the sampled
+// indices -- are bit-exact with oracle/rfops_oracle.c::orc_cumsum.  Adds only: no FMA question.
+constexpr int CS_BS = 2048;
+__device__ __forceinline__ int pad5(int i) { return i + (i >> 5); }
+
+__global__ __launch_bounds__(512) void cumsum_kernel(int n, const float *__restrict__ inp,
+                                                     float *__restrict__ out) {
+    __shared__ float buffer4[CS_BS * 4];
+    __shared__ float buffer[CS_BS + (CS_BS >> 5) + 1];
+    const int i = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+    float runningsum = 0.f, runningsum2 = 0.f;
+    for (int j = 0; j < n; j += CS_BS * 4) {
+        const float *in = inp + (size_t)i * n + j;
+        const int n24_i = min(n - j, CS_BS * 4);
+        const int n24 = (n24_i + 3) & ~3, n2 = n24 >> 2;
+        for (int k = t * 4; k < n24_i; k += nt * 4) {
+            if (k + 3 < n24_i) {
+                float v1 = in[k], v2 = in[k + 1];
+                v2 += v1;
+                float v3 = in[k + 2], v4 = in[k + 3];
+                v4 += v3;
+                v3 += v2;
+                v4 += v2;
+                buffer4[k] = v1; buffer4[k + 1] = v2; buffer4[k + 2] = v3; buffer4[k + 3] = v4;
+                buffer[pad5(k >> 2)] = v4;
+            } else {
+                float v = 0.f;
+                for (int k2 = k; k2 < n24_i; k2++) { v += in[k2]; buffer4[k2] = v; }
+                for (int k2 = n24_i; k2 < n24; k2++) buffer4[k2] = v;
+                buffer[pad5(k >> 2)] = v;
+            }
+        }
+        int u = 0;
+        for (; (2 << u) <= n2; u++) {
+            __syncthreads();
+            for (int k = t; k < (n2 >> (u + 1)); k += nt)
+                buffer[pad5((((k << 1) + 2) << u) - 1)] += buffer[pad5((((k << 1) + 1) << u) - 1)];
+        }
+        u--;
+        for (; u >= 0; u--) {
+            __syncthreads();
+            for (int k = t; k < ((n2 - (1 << u)) >> (u + 1)); k += nt)
+                buffer[pad5((((k << 1) + 3) << u) - 1)] += buffer[pad5((((k << 1) + 2) << u) - 1)];
+        }
+        __syncthreads();
+        for (int k = t * 4; k < n24; k += nt * 4) {
+            if (k != 0) {
+                const float add = buffer[pad5((k >> 2) - 1)];
+                buffer4[k] += add; buffer4[k + 1] += add; buffer4[k + 2] += add; buffer4[k + 3] += add;
+            }
+        }
+        __syncthreads();
+        for (int k = t; k < n24_i; k += nt) out[(size_t)i * n + j + k] = buffer4[k] + runningsum;
+        const float tt = buffer[pad5(n2 - 1)] + runningsum2;
+        const float r2 = runningsum + tt;
+        runningsum2 = tt - (r2 - runningsum);
+        runningsum = r2;
+        __syncthreads();
+    }
+}
+
+__global__ void binarysearch_kernel(int n, int m, long total, const float *__restrict__ dataset,
+                                    const float *__restrict__ query, int *__restrict__ result) {
+    long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const long i = g / m;
+    const float *ds = dataset + i * n;
+    int base = 1;
+    while (base < n) base <<= 1;
+    const float q = query[g] * ds[n - 1];
+    int r = n - 1;
+    for (int k = base; k >= 1; k >>= 1)
+        if (r >= k && ds[r - k] >= q) r -= k;
+    result[g] = r;
+}
+
 }  // namespace
 
 extern "C" {
@@ -314,6 +393,20 @@ int rf_scatteraddpoint(int b, int n, int m, const float *out_g, const int *idx, 
     if (!out_g || !idx) return RF_EINVAL;
     RF_LAUNCH("scatteradd_point", scatteradd_kernel, dim3(rf::ceil_div(total, 256)), dim3(256), 0, s, n,
               m, total, out_g, idx, inp_g);
+    return RF_OK;
+}
+
+int rf_probsample(int b, int n, int m, const float *inp_p, const float *inp_r, float *temp, int *out,
+                  rf_stream_t stream) {
+    if (b < 0 || n < 0 || m < 0) return RF_EINVAL;
+    if (b == 0 || m == 0) return RF_OK;
+    if (n == 0) return RF_EINVAL;
+    if (!inp_p || !inp_r || !temp || !out) return RF_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    RF_LAUNCH("cumsum", cumsum_kernel, dim3(b), dim3(512), 0, s, n, inp_p, temp);
+    const long total = (long)b * m;
+    RF_LAUNCH("binarysearch", binarysearch_kernel, dim3(rf::ceil_div(total, 256)), dim3(256), 0, s, n, m,
+              total, (const float *)temp, inp_r, out);
     return RF_OK;
 }
 

@@ -46,3 +46,16 @@ returns:
 (no gradient, like ops.NoGradient('FarthestPointSample'))
     '''
     return _raw.farthest_point_sample(npoint, inp)
+
+
+def prob_sample(inp, inpr):
+    '''
+input:
+    batch_size * ncategory float32   (unnormalised weights)
+    batch_size * npoints   float32   (uniform numbers in [0,1))
+returns:
+    batch_size * npoints   int32     (inverse-CDF sample of a category per number)
+The ProbSample op exists in the reference's library (tf_sampling.cpp:14-27,66-92); its Python
+wrapper is commented out there (tf_sampling.py:13-22).
+    '''
+    return _raw.prob_sample(inp, inpr)

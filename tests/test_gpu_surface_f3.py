@@ -66,3 +66,16 @@ def test_select_top_k_vs_oracle(orc, b, m, n, k):
     # element past another), so indices are checked through the values they point at
     assert np.array_equal(np.take_along_axis(d, oi.astype(np.int64), -1), ov)
     assert (np.sort(oi, -1) == np.arange(n)).all()  # every row of idx is a permutation
+
+
+@pytest.mark.parametrize("b,n,m", [(1, 1, 5), (2, 3, 7), (3, 40, 100), (2, 8192, 300), (2, 8193, 300), (2, 50001, 1000)])
+def test_prob_sample_vs_oracle(orc, b, n, m):
+    from tf_ops.sampling.tf_sampling import prob_sample
+    rng = np.random.RandomState(n)
+    p = rng.rand(b, n).astype(np.float32)
+    r = rng.rand(b, m).astype(np.float32)
+    got = prob_sample(cu(p), cu(r)).cpu().numpy()
+    exp, cs = orc.prob_sample(p, r)
+    assert np.array_equal(got, exp)
+    # inverse CDF: index i is drawn with probability p[i] / sum(p)
+    assert (got >= 0).all() and (got < n).all()
