@@ -21,7 +21,8 @@ u1, v1 = u[:, :1024].contiguous(), v[:, :1024].contiguous()
 u0, v0 = u[:, :64].contiguous(), v[:, :64].contiguous()
 print("C4 2048^2 %%.4f ms   1024^2 %%.4f ms   64^2 %%.4f ms" %% (t(lambda: R.approx_match(u, v), 10), t(lambda: R.approx_match(u1, v1), 20), t(lambda: R.approx_match(u0, v0), 20)))
 ''' % ROOT
+ENVNAME = os.environ.get("AB_ENV", "RF_AM_RPT")
 for rnd in range(2):
     for v in (sys.argv[1:] or ["1", "2"]):
-        out = subprocess.run([sys.executable, "-c", CODE], env=dict(os.environ, RF_AM_RPT=v), capture_output=True, text=True)
-        print(f"round {rnd} RF_AM_RPT={v}: {out.stdout.strip()} {out.stderr.strip()[-300:] if out.returncode else ''}")
+        out = subprocess.run([sys.executable, "-c", CODE], env=dict(os.environ, **{ENVNAME: v}), capture_output=True, text=True)
+        print(f"round {rnd} {ENVNAME}={v}: {out.stdout.strip()} {out.stderr.strip()[-300:] if out.returncode else ''}")
