@@ -149,6 +149,20 @@ int rf_selectionsort(int b, int n, int m, int k, const float *dist, int *outi, f
 int rf_probsample(int b, int n, int m, const float *inp_p, const float *inp_r, float *temp, int *out,
                   rf_stream_t stream);
 
+/* ------------------------------------------------------- loss glue as a fused op (row f1) --- */
+/* The reference's `earth_mover` (vv_recon.py:392-399) is approx_match -> match_cost, with
+ * MatchCostGrad behind it (pc_distance/tf_approxmatch.py:44-50; ApproxMatch itself is NoGradient,
+ * so match is a constant in the backward).  rf_earth_mover computes the same cost (b) -- and,
+ * when grad1/grad2 are non-NULL (both or neither), the same MatchCostGrad outputs grad1 (b,n,3),
+ * grad2 (b,m,3) -- straight from the per-level ratio vectors, without materialising the
+ * (b,m,n) match tensor (512 MiB at 32x2048x2048; 1 GiB per sample at 16384^2).  No reference
+ * launcher corresponds to it: a TF-side maintainer would register it as one new op replacing
+ * the three-op chain.  Reference 10-level schedule only. */
+size_t rf_earth_mover_workspace_bytes(int b, int n, int m);
+int rf_earth_mover(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost,
+                   float *grad1, float *grad2, void *workspace, size_t workspace_bytes,
+                   rf_stream_t stream);
+
 /* ------------------------------------------------------------------ measurement hooks --- */
 /* When enabled, every kernel launch made by this library is bracketed by hipEvents recorded
  * on the launch stream.  rf_profile_collect() waits for them and returns the per-kernel sums

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "librfops.so")
+# RFOPS_LIB: load another build of the same library (A/B of kernel variants, tools/ab_chamfer.py)
+LIB_PATH = os.environ.get("RFOPS_LIB") or os.path.join(_PKG, "librfops.so")
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -39,6 +40,8 @@ SIGNATURES = {
     "rf_auctionmatch": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rf_selectionsort": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "rf_probsample": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rf_earth_mover_workspace_bytes": (_sz, [_i, _i, _i]),
+    "rf_earth_mover": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rf_profile_enable": (None, [_i]),
     "rf_profile_collect": (_i, [C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_long), _i]),
 }

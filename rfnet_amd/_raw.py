@@ -149,6 +149,27 @@ def match_cost_grad(xyz1, xyz2, match):
     return st.give(g1), st.give(g2)
 
 
+def earth_mover(xyz1, xyz2, with_grad=False):
+    """Row f1: the fused form of `earth_mover`'s op chain (vv_recon.py:392-399):
+    approx_match -> match_cost [-> MatchCostGrad], without materialising match.
+    -> cost (b)  or  (cost, grad1 (b,n,3), grad2 (b,m,3)) with `with_grad`."""
+    st = H.Staged()
+    a, b_ = _emd_inputs(st, xyz1, xyz2, "ApproxMatch")
+    b, n, m = a.shape[0], a.shape[1], b_.shape[1]
+    dev = st.device_()
+    a, b_ = st.up(a, b_)
+    cost = H.empty((b,), F32, dev)
+    g1 = H.empty((b, n, 3), F32, dev) if with_grad else None
+    g2 = H.empty((b, m, 3), F32, dev) if with_grad else None
+    ws, wsz = H.workspace(lib.rf_earth_mover_workspace_bytes(b, n, m), dev, "emd")
+    check(lib.rf_earth_mover(b, n, m, H.ptr(a), H.ptr(b_), H.ptr(cost),
+                             H.ptr(g1) if with_grad else None, H.ptr(g2) if with_grad else None,
+                             H.ptr(ws), wsz, H.stream(dev)), "rf_earth_mover")
+    if with_grad:
+        return st.give(cost), st.give(g1), st.give(g2)
+    return st.give(cost)
+
+
 # ------------------------------------------------------------------ sampling ---------------
 def farthest_point_sample(npoint, inp):
     """FarthestPointSampleGpuOp, tf_ops/sampling/tf_sampling.cpp:95-123 -> (b,npoint) int32."""

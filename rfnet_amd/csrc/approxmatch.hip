@@ -526,6 +526,135 @@ __global__ __launch_bounds__(TPB) void mcg_kernel(int n, int m, int lspan,
     }
 }
 
+// ---- earth_mover fused (row f1): cost and its gradients straight from the per-level ratio vectors;
+// `match` (4*B*n*m bytes: 512 MiB at C4, 1 GiB per sample at 16384^2) is never materialised.
+// The match entry is recomputed in registers with the same level-ordered fma chain as
+// am_match_kernel, then used at once the way matchcost / matchcostgrad1/2 use it
+// (tf_approxmatch.cu:183-295): cost += sqrt(d2)*match, q = match*rsq(max(d2,1e-20)),
+// grad1[k] += (x1-x2)q, grad2[l] += (x2-x1)q.  Compute-bound (10 exp per pair) instead of three
+// HBM passes over match.  Layout as mcg_kernel: thread <-> k, the l-range walked in tiles of 32;
+// the column operands (x2_l and the 10 ratioR values of l) are wave-uniform and come from one
+// 64-byte record per l by scalar loads.
+constexpr int EF_REC = 16;  // floats per column record: x y z 0 | ratioR[0..NLV) | 0 ..
+__global__ void emd_pack_cols_kernel(int m, int mpad, int nlv, const float *__restrict__ xyz2,
+                                     const float *__restrict__ ratios, size_t lv_stride,
+                                     size_t b_stride, int roff, float *__restrict__ rec) {
+    const int bi = blockIdx.y;
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= mpad) return;
+    float r[EF_REC];
+#pragma unroll
+    for (int i = 0; i < EF_REC; i++) r[i] = 0.f;
+    if (l < m) {
+        const float *p = xyz2 + ((size_t)bi * m + l) * 3;
+        r[0] = p[0]; r[1] = p[1]; r[2] = p[2];
+        for (int v = 0; v < nlv; v++) r[4 + v] = ratios[(size_t)bi * b_stride + (size_t)v * lv_stride + roff + l];
+    }
+    float4 *q = (float4 *)(rec + ((size_t)bi * mpad + l) * EF_REC);
+#pragma unroll
+    for (int i = 0; i < EF_REC / 4; i++) q[i] = make_float4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
+}
+
+template <int NLV, bool GRAD>
+__global__ __launch_bounds__(TPB) void emd_fused_kernel(int n, int m, int mpad, int lspan,
+                                                        const float *__restrict__ xyz1,
+                                                        const float *__restrict__ rec,
+                                                        const float *__restrict__ ratios,
+                                                        size_t lv_stride, size_t b_stride,
+                                                        LevelConsts lc, float *__restrict__ partial,
+                                                        float *__restrict__ grad1,
+                                                        float *__restrict__ grad2) {
+    static_assert(NLV + 4 <= EF_REC, "column record too small");
+    __shared__ float qs[GRAD ? MG_TL : 1][TPB + 1];
+    __shared__ float4 sx1[GRAD ? TPB : 1];
+    __shared__ float ps[GRAD ? TPB / MG_TL : 1][MG_TL][3];
+    __shared__ float wsum[TPB / 64];
+    const int bi = blockIdx.z;
+    const int t = threadIdx.x;
+    const int k = blockIdx.x * TPB + t;
+    const bool live = k < n;
+    const int kk = live ? k : n - 1;
+    const float *__restrict__ A = xyz1 + (size_t)bi * n * 3;
+    const float *__restrict__ R = rec + (size_t)bi * mpad * EF_REC;
+    const float x1 = A[kk * 3], y1 = A[kk * 3 + 1], z1 = A[kk * 3 + 2];
+    float rl[NLV], cl[NLV];
+#pragma unroll
+    for (int v = 0; v < NLV; v++) {
+        rl[v] = live ? ratios[(size_t)bi * b_stride + (size_t)v * lv_stride + kk] : 0.f;
+        cl[v] = lc.c[v];
+    }
+    if (GRAD) sx1[t] = make_float4(x1, y1, z1, 0.f);
+    float ax = 0.f, ay = 0.f, az = 0.f, csum = 0.f;
+    const int lbeg = blockIdx.y * lspan;
+    const int lend = min(mpad, lbeg + lspan);  // multiples of MG_TL; records beyond m are zero
+    const int bl = t & (MG_TL - 1);
+    const int br = t / MG_TL;
+    for (int l0 = lbeg; l0 < lend; l0 += MG_TL) {
+#pragma unroll 4
+        for (int l = 0; l < MG_TL; l++) {
+            const float4 *__restrict__ c = (const float4 *)(R + (size_t)(l0 + l) * EF_REC);  // uniform
+            const float4 cx = c[0], r0 = c[1], r1 = c[2], r2 = c[3];
+            const float rr[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+            const float dx = cx.x - x1, dy = cx.y - y1, dz = cx.z - z1;  // xyz2 - xyz1, as :207
+            const float d2 = rf::d2_fma(dx, dy, dz);
+            float acc = 0.f;
+#pragma unroll
+            for (int v = 0; v < NLV; v++) acc = fmaf(rl[v] * fast_exp2(d2 * cl[v]), rr[v], acc);
+            csum = fmaf(sqrtf(d2), acc, csum);
+            if (GRAD) {
+                const float q = acc * __builtin_amdgcn_rsqf(fmaxf(d2, 1e-20f));
+                ax = fmaf(-dx, q, ax);  // (x1 - x2) q: negation is exact
+                ay = fmaf(-dy, q, ay);
+                az = fmaf(-dz, q, az);
+                qs[l][t] = q;
+            }
+        }
+        if (GRAD) {
+            __syncthreads();
+            {
+                const float4 cx = *(const float4 *)(R + (size_t)(l0 + bl) * EF_REC);
+                float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll 8
+                for (int j = 0; j < MG_TL; j++) {
+                    const int kq = br * MG_TL + j;
+                    const float q = qs[bl][kq];
+                    const float4 p = sx1[kq];
+                    sx = fmaf(cx.x - p.x, q, sx);
+                    sy = fmaf(cx.y - p.y, q, sy);
+                    sz = fmaf(cx.z - p.z, q, sz);
+                }
+                ps[br][bl][0] = sx;
+                ps[br][bl][1] = sy;
+                ps[br][bl][2] = sz;
+            }
+            __syncthreads();
+            if (t < MG_TL * 3) {
+                const int l = t / 3, c = t - l * 3;
+                if (l0 + l < m) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int r = 0; r < TPB / MG_TL; r++) v += ps[r][l][c];
+                    atomicAdd(&grad2[((size_t)bi * m + l0 + l) * 3 + c], v);
+                }
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) csum += __shfl_down(csum, o, 64);
+    if ((t & 63) == 0) wsum[t >> 6] = csum;
+    __syncthreads();
+    if (t == 0)
+        partial[((size_t)bi * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] =
+            (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    if (GRAD && live) {
+        float *g = grad1 + ((size_t)bi * n + k) * 3;
+        atomicAdd(g + 0, ax);
+        atomicAdd(g + 1, ay);
+        atomicAdd(g + 2, az);
+    }
+}
+
 int default_levels(float *lv) {
     int c = 0;
     for (int j = 7; j >= -2; j--) lv[c++] = (j == -2) ? 0.0f : -ldexpf(1.0f, 2 * j);
@@ -566,37 +695,17 @@ int pick_nseg(int b, int rows, int cols_pad, int rpt) {
     return nseg;
 }
 
-}  // namespace
-
-extern "C" {
-
-size_t rf_approxmatch_workspace_bytes(int b, int n, int m, int nlevels) {
-    if (b <= 0 || n <= 0 || m <= 0) return 0;
-    if (nlevels <= 0) nlevels = 10;
-    return am_layout(b, n, m, nlevels).total * sizeof(float);
-}
-
-int rf_approxmatch_levels(int b, int n, int m, const float *xyz1, const float *xyz2, float *match,
-                          const float *levels_host, int nlevels, void *workspace,
-                          size_t workspace_bytes, rf_stream_t stream) {
-    if (b < 0 || n < 0 || m < 0 || nlevels <= 0 || nlevels > MAX_LEVELS || !levels_host)
-        return RF_EINVAL;
-    if (b == 0 || n == 0 || m == 0) return RF_OK;
-    if (!xyz1 || !xyz2 || !match || !workspace) return RF_EINVAL;
-    if (workspace_bytes < rf_approxmatch_workspace_bytes(b, n, m, nlevels)) return RF_EWORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
-    // multiL / multiR: integer division as in tf_approxmatch.cu:4-10
-    float multiL, multiR;
+// multiL / multiR: integer division as in tf_approxmatch.cu:4-10
+void am_multipliers(int n, int m, float &multiL, float &multiR) {
     if (n >= m) { multiL = 1.f; multiR = (float)(n / m); }
     else        { multiL = (float)(m / n); multiR = 1.f; }
+}
 
-    if (n <= AM_SMALL && m <= AM_SMALL) {
-        LevelConsts lcs;
-        for (int v = 0; v < MAX_LEVELS; v++) lcs.c[v] = v < nlevels ? levels_host[v] * kLog2e : 0.f;
-        RF_LAUNCH("am_small", am_small_kernel, dim3(b), dim3(AM_SMALL), 0, s, n, m, nlevels, lcs, multiL,
-                  multiR, xyz1, xyz2, match);
-        return RF_OK;
-    }
+// The level pipeline (P1 / P2 / fused P3+P1 launches) of the large-cloud path: fills the
+// workspace's per-level ratio vectors.  Shared by rf_approxmatch_levels (which then materialises
+// match) and rf_earth_mover (which does not).
+int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int nlevels,
+                  const LevelConsts &lc, float multiL, float multiR, void *workspace, hipStream_t s) {
     const AmLayout L = am_layout(b, n, m, nlevels);
     float *w = (float *)workspace;
     float *remainL = w, *remainR = w + L.npad;          // slot 0 of the vector region
@@ -609,8 +718,6 @@ int rf_approxmatch_levels(int b, int n, int m, const float *xyz1, const float *x
     RF_LAUNCH("am_init", am_init_kernel, dim3(rf::ceil_div(L.mpad, 256), b), dim3(256), 0, s, m, L.mpad,
               multiR, xyz2, x2p, (size_t)L.mpad * 3, remainR, L.bstride);
 
-    LevelConsts lc;
-    for (int v = 0; v < MAX_LEVELS; v++) lc.c[v] = v < nlevels ? levels_host[v] * kLog2e : 0.f;
     // rows per lane: 2 when there are enough rows to keep >= 2048 waves (longer compute per scalar
     // prefetch covers the L2 latency of the s_loads); RF_AM_RPT overrides for experiments
     static const int rpt_env = getenv("RF_AM_RPT") ? atoi(getenv("RF_AM_RPT")) : 0;
@@ -647,6 +754,46 @@ int rf_approxmatch_levels(int b, int n, int m, const float *xyz1, const float *x
         }
     }
 #undef AM_ROWK
+    return RF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t rf_approxmatch_workspace_bytes(int b, int n, int m, int nlevels) {
+    if (b <= 0 || n <= 0 || m <= 0) return 0;
+    if (nlevels <= 0) nlevels = 10;
+    return am_layout(b, n, m, nlevels).total * sizeof(float);
+}
+
+int rf_approxmatch_levels(int b, int n, int m, const float *xyz1, const float *xyz2, float *match,
+                          const float *levels_host, int nlevels, void *workspace,
+                          size_t workspace_bytes, rf_stream_t stream) {
+    if (b < 0 || n < 0 || m < 0 || nlevels <= 0 || nlevels > MAX_LEVELS || !levels_host)
+        return RF_EINVAL;
+    if (b == 0 || n == 0 || m == 0) return RF_OK;
+    if (!xyz1 || !xyz2 || !match || !workspace) return RF_EINVAL;
+    if (workspace_bytes < rf_approxmatch_workspace_bytes(b, n, m, nlevels)) return RF_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    float multiL, multiR;
+    am_multipliers(n, m, multiL, multiR);
+
+    if (n <= AM_SMALL && m <= AM_SMALL) {
+        LevelConsts lcs;
+        for (int v = 0; v < MAX_LEVELS; v++) lcs.c[v] = v < nlevels ? levels_host[v] * kLog2e : 0.f;
+        RF_LAUNCH("am_small", am_small_kernel, dim3(b), dim3(AM_SMALL), 0, s, n, m, nlevels, lcs, multiL,
+                  multiR, xyz1, xyz2, match);
+        return RF_OK;
+    }
+    LevelConsts lc;
+    for (int v = 0; v < MAX_LEVELS; v++) lc.c[v] = v < nlevels ? levels_host[v] * kLog2e : 0.f;
+    {
+        const int st = am_run_levels(b, n, m, xyz1, xyz2, nlevels, lc, multiL, multiR, workspace, s);
+        if (st != RF_OK) return st;
+    }
+    const AmLayout L = am_layout(b, n, m, nlevels);
+    const float *ratios = (const float *)workspace + L.V;
     // P3 of the last level only updates remainL, which nothing reads afterwards: not launched.
     const dim3 gm(rf::ceil_div(n, TPB), rf::ceil_div(m, LSEG), b);
     if (nlevels == 10) {
@@ -706,6 +853,112 @@ int rf_matchcost_grad(int b, int n, int m, const float *xyz1, const float *xyz2,
     const int lspan = rf::ceil_div(rf::ceil_div(m, lsplit), MG_TL) * MG_TL;
     dim3 g(rf::ceil_div(n, TPB), rf::ceil_div(m, lspan), b);
     RF_LAUNCH("mc_grad", mcg_kernel, g, dim3(TPB), 0, s, n, m, lspan, xyz1, xyz2, match, grad1, grad2);
+    return RF_OK;
+}
+
+// ---- row f1: earth_mover fused ------------------------------------------------------------
+namespace {
+struct EmdLayout {
+    bool small;
+    size_t off_rec, off_partial, off_match, off_mc, total;  // floats
+    int lsplit, lspan;
+};
+EmdLayout emd_layout(int b, int n, int m) {
+    EmdLayout E;
+    E.small = n <= AM_SMALL && m <= AM_SMALL;
+    E.lsplit = 1; E.lspan = 0;
+    if (E.small) {
+        E.off_match = 0;
+        E.off_mc = (size_t)b * n * m;
+        E.total = E.off_mc + rf_matchcost_workspace_bytes(b, n, m) / sizeof(float);
+        E.off_rec = E.off_partial = 0;
+        return E;
+    }
+    const AmLayout L = am_layout(b, n, m, 10);
+    // enough workgroups to fill the chip: >= 4096 of 4 waves, l-spans of whole 32-column tiles
+    const long base = (long)b * rf::ceil_div(n, TPB);
+    int lsplit = 1;
+    while (lsplit < 64 && base * lsplit < 4096 && L.mpad / (lsplit * 2) >= 2 * MG_TL) lsplit *= 2;
+    E.lspan = round_up_i(rf::ceil_div(L.mpad, lsplit), MG_TL);
+    E.lsplit = rf::ceil_div(L.mpad, E.lspan);
+    E.off_rec = L.total;
+    E.off_partial = E.off_rec + (size_t)b * L.mpad * EF_REC + 64;
+    E.total = E.off_partial + (size_t)b * rf::ceil_div(n, TPB) * E.lsplit;
+    E.off_match = E.off_mc = 0;
+    return E;
+}
+}  // namespace
+
+size_t rf_earth_mover_workspace_bytes(int b, int n, int m) {
+    if (b <= 0 || n <= 0 || m <= 0) return 0;
+    return emd_layout(b, n, m).total * sizeof(float);
+}
+
+int rf_earth_mover(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost,
+                   float *grad1, float *grad2, void *workspace, size_t workspace_bytes,
+                   rf_stream_t stream) {
+    if (b < 0 || n < 0 || m < 0) return RF_EINVAL;
+    if ((grad1 == nullptr) != (grad2 == nullptr)) return RF_EINVAL;
+    if (b == 0) return RF_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const bool want_grad = grad1 != nullptr;
+    if (!cost) return RF_EINVAL;
+    if (want_grad) {
+        if ((size_t)b * n) RF_HIP(hipMemsetAsync(grad1, 0, sizeof(float) * 3 * (size_t)b * n, s));
+        if ((size_t)b * m) RF_HIP(hipMemsetAsync(grad2, 0, sizeof(float) * 3 * (size_t)b * m, s));
+    }
+    if (n == 0 || m == 0) {
+        RF_HIP(hipMemsetAsync(cost, 0, sizeof(float) * b, s));
+        return RF_OK;
+    }
+    if (!xyz1 || !xyz2 || !workspace) return RF_EINVAL;
+    if (workspace_bytes < rf_earth_mover_workspace_bytes(b, n, m)) return RF_EWORKSPACE;
+    const EmdLayout E = emd_layout(b, n, m);
+    float *w = (float *)workspace;
+    float lv[16];
+    const int nl = default_levels(lv);
+    LevelConsts lc;
+    for (int v = 0; v < MAX_LEVELS; v++) lc.c[v] = v < nl ? lv[v] * kLog2e : 0.f;
+    float multiL, multiR;
+    am_multipliers(n, m, multiL, multiR);
+    if (E.small) {
+        // launch-bound sizes: one workgroup per sample builds match (<= 256 KiB) in the workspace,
+        // then the ordinary match_cost(+grad) kernels read it back out of L2
+        float *match = w + E.off_match;
+        RF_LAUNCH("am_small", am_small_kernel, dim3(b), dim3(AM_SMALL), 0, s, n, m, nl, lc, multiL, multiR,
+                  xyz1, xyz2, match);
+        int st = rf_matchcost(b, n, m, xyz1, xyz2, match, cost, w + E.off_mc,
+                              rf_matchcost_workspace_bytes(b, n, m), stream);
+        if (st != RF_OK) return st;
+        if (want_grad) {
+            int lsplit = MG_LSPLIT;
+            while (lsplit > 1 && m / lsplit < MG_TL) lsplit /= 2;
+            const int lspan = rf::ceil_div(rf::ceil_div(m, lsplit), MG_TL) * MG_TL;
+            dim3 g(rf::ceil_div(n, TPB), rf::ceil_div(m, lspan), b);
+            RF_LAUNCH("mc_grad", mcg_kernel, g, dim3(TPB), 0, s, n, m, lspan, xyz1, xyz2,
+                      (const float *)match, grad1, grad2);
+        }
+        return RF_OK;
+    }
+    {
+        const int st = am_run_levels(b, n, m, xyz1, xyz2, nl, lc, multiL, multiR, workspace, s);
+        if (st != RF_OK) return st;
+    }
+    const AmLayout L = am_layout(b, n, m, nl);
+    const float *ratios = w + L.V;
+    float *rec = w + E.off_rec, *partial = w + E.off_partial;
+    RF_LAUNCH("emd_pack_cols", emd_pack_cols_kernel, dim3(rf::ceil_div(L.mpad, 256), b), dim3(256), 0, s, m,
+              L.mpad, nl, xyz2, ratios, L.V, L.bstride, L.npad, rec);
+    const dim3 g(rf::ceil_div(n, TPB), E.lsplit, b);
+    if (want_grad) {
+        RF_LAUNCH("emd_fused_grad", (emd_fused_kernel<10, true>), g, dim3(TPB), 0, s, n, m, L.mpad, E.lspan,
+                  xyz1, (const float *)rec, ratios, L.V, L.bstride, lc, partial, grad1, grad2);
+    } else {
+        RF_LAUNCH("emd_fused", (emd_fused_kernel<10, false>), g, dim3(TPB), 0, s, n, m, L.mpad, E.lspan, xyz1,
+                  (const float *)rec, ratios, L.V, L.bstride, lc, partial, grad1, grad2);
+    }
+    RF_LAUNCH("mc_final", mc_final_kernel, dim3(b), dim3(256), 0, s, (const float *)partial,
+              (int)(g.x * g.y), cost);
     return RF_OK;
 }
 

@@ -110,13 +110,24 @@ __device__ __forceinline__ void rs_step(float (&v)[CG], int lane) {
     }
 }
 
-__device__ __forceinline__ float reduce_scatter32(float (&v)[CG], int lane) {
-    rs_step<16, 32>(v, lane);
-    rs_step<8, 16>(v, lane);
-    rs_step<4, 8>(v, lane);
-    rs_step<2, 4>(v, lane);
-    rs_step<1, 2>(v, lane);
-    return fminf(v[0], __shfl_xor(v[0], 1, 64));
+// The first step writes into a fresh half-size array, so the caller's v[] (the in-lane minima
+// that the winning-lane pass compares against) survives without a 32-register copy.
+__device__ __forceinline__ float reduce_scatter32(const float (&v)[CG], int lane) {
+    float w[CG];
+    {
+        const bool hi = (lane & 32) != 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            float keep = hi ? v[i + 16] : v[i];
+            float send = hi ? v[i] : v[i + 16];
+            w[i] = fminf(keep, __shfl_xor(send, 32, 64));
+        }
+    }
+    rs_step<8, 16>(w, lane);
+    rs_step<4, 8>(w, lane);
+    rs_step<2, 4>(w, lane);
+    rs_step<1, 2>(w, lane);
+    return fminf(w[0], __shfl_xor(w[0], 1, 64));
 }
 
 // For candidate I of the group (its wave minimum sits in lane 2I of `cmin`): the lowest lane whose
@@ -230,13 +241,10 @@ __global__ __launch_bounds__(TPB) void nn_sweep_kernel(Sweep a, const float *__r
                 }
             }
         }
-        float orig[CG];
-#pragma unroll
-        for (int i = 0; i < CG; i++) orig[i] = colv[i];
         const float cmin = reduce_scatter32(colv, lane);
         // which lane holds it: the lowest lane whose in-lane minimum equals the wave minimum
         int wl = 0;
-        who_has_it<0>(orig, cmin, wl);
+        who_has_it<0>(colv, cmin, wl);
         const int c = c0 + (lane >> 1);
         if ((lane & 1) == 0 && c < c_end) {
             colp[c] = cmin;

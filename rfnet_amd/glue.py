@@ -10,7 +10,7 @@ are small elementwise / reduction tensor ops that autograd differentiates.
 """
 import torch
 
-from .pc_distance.tf_approxmatch import approx_match, match_cost
+from .pc_distance.tf_approxmatch import earth_mover_cost
 from .tf_ops.CD.tf_nndistance import nn_distance
 from .tf_ops.grouping.tf_grouping import group_point
 from .tf_ops.sampling.tf_sampling import farthest_point_sample, gather_point
@@ -55,8 +55,7 @@ def fidelity_loss(pcd1, pcd2):
 
 def earth_mover(pcd1, pcd2):
     assert pcd1.shape[1] == pcd2.shape[1]
-    match = approx_match(pcd1, pcd2)
-    cost = match_cost(pcd1, pcd2, match)
+    cost = earth_mover_cost(pcd1, pcd2)  # approx_match -> match_cost fused: match never hits HBM
     return (cost / float(pcd1.shape[1])).mean()
 
 

@@ -56,3 +56,29 @@ returns:
 def match_cost_grad(xyz1, xyz2, match):
     """The reference's MatchCostGrad op (tf_approxmatch.cpp:16-21): (grad1, grad2)."""
     return _raw.match_cost_grad(xyz1, xyz2, match)
+
+
+class _EarthMoverCost(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz1, xyz2):
+        # one launch sequence yields the cost and MatchCostGrad's outputs; the backward only scales
+        cost, g1, g2 = _raw.earth_mover(xyz1, xyz2, with_grad=True)
+        ctx.save_for_backward(g1, g2)
+        return cost
+
+    @staticmethod
+    def backward(ctx, grad_cost):
+        g1, g2 = ctx.saved_tensors
+        s = grad_cost.reshape(-1, 1, 1)
+        return g1 * s, g2 * s
+
+
+def earth_mover_cost(xyz1, xyz2):
+    """match_cost(xyz1, xyz2, approx_match(xyz1, xyz2)) as ONE fused op: cost (batch_size), with the
+    reference's gradient (MatchCostGrad scaled by grad_cost, match held constant) -- but the
+    (batch, #query, #dataset) match tensor is never written.  Extension for the loss glue
+    (`earth_mover`, vv_recon.py:392-399); the two-op chain above stays available unchanged."""
+    if all(isinstance(t, torch.Tensor) for t in (xyz1, xyz2)) and (
+            xyz1.requires_grad or xyz2.requires_grad):
+        return _EarthMoverCost.apply(xyz1, xyz2)
+    return _raw.earth_mover(xyz1, xyz2)

@@ -109,6 +109,5 @@ def chamfer_per_sample(xyz1, xyz2):
 
 def emd_per_sample(xyz1, xyz2):
     """Per-sample EMD as `earth_mover` (vv_recon.py:392-399): match_cost / num_points."""
-    from .pc_distance.tf_approxmatch import approx_match, match_cost
-    match = approx_match(xyz1, xyz2)
-    return match_cost(xyz1, xyz2, match) / float(xyz1.shape[1])
+    from .pc_distance.tf_approxmatch import earth_mover_cost
+    return earth_mover_cost(xyz1, xyz2) / float(xyz1.shape[1])

@@ -138,3 +138,77 @@ def test_eval_size_16384_sq_single_sample():
     # sum_k grad1[k] = -sum_l grad2[l] (every pair contributes +v to one and -v to the other)
     s1, s2 = g1.sum(1).cpu().numpy(), g2.sum(1).cpu().numpy()
     assert np.allclose(s1, -s2, atol=1e-2)
+
+
+# ---- row f1: earth_mover fused (cost + MatchCostGrad without materialising match) -------------
+@pytest.mark.parametrize("b,n,m", [(2, 5, 3), (2, 64, 64), (2, 256, 256), (3, 100, 1000), (2, 1024, 1024),
+                                   (2, 777, 130), (1, 130, 777), (1, 2048, 2048), (2, 300, 257)])
+def test_earth_mover_fused_vs_oracle(orc, b, n, m):
+    """The fused op against the oracle's three-op chain approx_match -> match_cost / match_cost_grad."""
+    from rfnet_amd import _raw
+    rng = np.random.RandomState(7 * n + m)
+    a = (rng.random_sample((b, n, 3)) - 0.5).astype(np.float32)
+    c = (rng.random_sample((b, m, 3)) - 0.5).astype(np.float32)
+    om = orc.approx_match(a, c)
+    ocost = orc.match_cost(a, c, om)
+    o1, o2 = orc.match_cost_grad(a, c, om)
+    cost = _raw.earth_mover(cu(a), cu(c))
+    assert_rel(cost.cpu().numpy(), ocost, 1e-5, what="fused cost")
+    cost_g, g1, g2 = _raw.earth_mover(cu(a), cu(c), with_grad=True)
+    assert_rel(cost_g.cpu().numpy(), ocost, 1e-5, what="fused cost (grad variant)")
+    # The fused gradients are built on the GPU's own match entries (hardware exp2: each within
+    # rel 1e-4 of the oracle's, the `match` tolerance above), not on the oracle's match as in
+    # test_emd_random_shapes.  A row's entries sum to its mass (multiL for grad1 rows, multiR for
+    # grad2 rows) and multiply unit vectors, so the inherited error bound is 1e-4 * mass.
+    massL, massR = max(1, m // n), max(1, n // m)
+    assert_rel(g1.cpu().numpy(), o1, 1e-4, 1e-4 * massL, what="fused grad1")
+    assert_rel(g2.cpu().numpy(), o2, 1e-4, 1e-4 * massR, what="fused grad2")
+
+
+def test_earth_mover_fused_equals_chain_full_size():
+    """C4 size: fused op == this library's own approx_match -> match_cost -> match_cost_grad chain
+    on all 32 samples (both compute match entries with the same fma chain; only summation order
+    differs)."""
+    from rfnet_amd import _raw
+    from pc_distance.tf_approxmatch import approx_match, match_cost, match_cost_grad
+    rng = np.random.RandomState(100)
+    a = cu((rng.random_sample((32, 2048, 3)) - 0.5).astype(np.float32))
+    c = cu((rng.random_sample((32, 2048, 3)) - 0.5).astype(np.float32))
+    match = approx_match(a, c)
+    cost = match_cost(a, c, match)
+    r1, r2 = match_cost_grad(a, c, match)
+    del match
+    fcost, g1, g2 = _raw.earth_mover(a, c, with_grad=True)
+    assert_rel(fcost.cpu().numpy(), cost.cpu().numpy(), 1e-5, what="cost")
+    assert_rel(g1.cpu().numpy(), r1.cpu().numpy(), 1e-4, 1e-5, what="grad1")
+    assert_rel(g2.cpu().numpy(), r2.cpu().numpy(), 1e-4, 1e-5, what="grad2")
+
+
+def test_earth_mover_cost_autograd_matches_chain():
+    from pc_distance.tf_approxmatch import approx_match, match_cost, earth_mover_cost
+    rng = np.random.RandomState(3)
+    a0 = (rng.random_sample((2, 512, 3)) - 0.5).astype(np.float32)
+    c0 = (rng.random_sample((2, 512, 3)) - 0.5).astype(np.float32)
+    w = cu(np.array([0.5, 2.0], np.float32))
+    a, c = cu(a0).requires_grad_(), cu(c0).requires_grad_()
+    (match_cost(a, c, approx_match(a, c)) * w).sum().backward()
+    a2, c2 = cu(a0).requires_grad_(), cu(c0).requires_grad_()
+    (earth_mover_cost(a2, c2) * w).sum().backward()
+    assert_rel(a2.grad.cpu().numpy(), a.grad.cpu().numpy(), 1e-4, 1e-5)
+    assert_rel(c2.grad.cpu().numpy(), c.grad.cpu().numpy(), 1e-4, 1e-5)
+
+
+def test_earth_mover_abi_errors():
+    from rfnet_amd import _lib
+    import ctypes as C
+    lib = _lib.lib
+    x = torch.zeros(1, 300, 3, device="cuda")
+    cost = torch.zeros(1, device="cuda")
+    g = torch.zeros(1, 300, 3, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    need = lib.rf_earth_mover_workspace_bytes(1, 300, 300)
+    ws = torch.zeros(need, dtype=torch.uint8, device="cuda")
+    assert lib.rf_earth_mover(1, 300, 300, p(x), p(x), p(cost), None, None, p(ws), need - 4, None) == -2
+    assert lib.rf_earth_mover(1, 300, 300, p(x), p(x), p(cost), p(g), None, p(ws), need, None) == -1
+    assert lib.rf_earth_mover(-1, 300, 300, p(x), p(x), p(cost), None, None, p(ws), need, None) == -1
+    assert lib.rf_earth_mover(0, 300, 300, None, None, None, None, None, None, 0, None) == 0

@@ -118,6 +118,10 @@ def main():
         timeit("C4 match_cost", lambda: R.match_cost(u, v, mt), a.iters, 32 * 2048 * 2048 * 4, "B")
         timeit("C4 match_cost_grad", lambda: R.match_cost_grad(u, v, mt), a.iters,
                32 * 2048 * 2048 * 4, "B")
+        del mt
+        timeit("C4 earth_mover fused (cost only)", lambda: R.earth_mover(u, v), max(3, a.iters // 4))
+        timeit("C4 earth_mover fused (cost + grads)", lambda: R.earth_mover(u, v, with_grad=True),
+               max(3, a.iters // 4))
         u1 = u[:, :1024].contiguous()
         v1 = v[:, :1024].contiguous()
         timeit("approx_match 32x1024x1024 (training)", lambda: R.approx_match(u1, v1), a.iters)
