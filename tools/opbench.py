@@ -124,6 +124,9 @@ def main():
                max(3, a.iters // 4))
         u1 = u[:, :1024].contiguous()
         v1 = v[:, :1024].contiguous()
+        ue = torch.from_numpy((rng.random_sample((4, 16384, 3)) - 0.5).astype(np.float32)).to(dev)
+        ve = torch.from_numpy((rng.random_sample((4, 16384, 3)) - 0.5).astype(np.float32)).to(dev)
+        timeit("eval-size earth_mover fused 4x16384x16384", lambda: R.earth_mover(ue, ve), 3)
         timeit("approx_match 32x1024x1024 (training)", lambda: R.approx_match(u1, v1), a.iters)
 
 
