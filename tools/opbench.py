@@ -119,6 +119,11 @@ def main():
         timeit("C4 match_cost_grad", lambda: R.match_cost_grad(u, v, mt), a.iters,
                32 * 2048 * 2048 * 4, "B")
         del mt
+        # BASELINE.json configs[3] says "50 Sinkhorn iters": no reference counterpart;
+        # reported as the reference's 10 levels each repeated 5x through rf_approxmatch_levels
+        lv50 = [float(x) for x in np.repeat([-4.0 ** j for j in range(7, -2, -1)] + [0.0], 5)]
+        timeit("C4 approx_match, 50-level schedule", lambda: R.approx_match(u, v, levels=lv50),
+               max(3, a.iters // 8), 150 * 32 * 2048 * 2048, "exp")
         timeit("C4 earth_mover fused (cost only)", lambda: R.earth_mover(u, v), max(3, a.iters // 4))
         timeit("C4 earth_mover fused (cost + grads)", lambda: R.earth_mover(u, v, with_grad=True),
                max(3, a.iters // 4))
