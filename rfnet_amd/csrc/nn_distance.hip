@@ -370,7 +370,7 @@ struct GradDir {
     const float *gd_src;    // (b, ns)
     const int *idx_src;     // (b, ns) nn of each src point in dst
     float *grad;            // (b, nd, 3)
-    int nd, ns, tiles, slices;
+    int nd, ns, gt, tiles, slices;  // gt = destination points per tile (<= GT)
 };
 struct GradArgs {
     GradDir d[2];
@@ -386,39 +386,78 @@ __global__ __launch_bounds__(GTPB) void nn_grad_kernel(GradArgs a) {
     const int slice = bid % D.slices;
     const int tile = (bid / D.slices) % D.tiles;
     const int bi = bid / (D.slices * D.tiles);
-    const int j0 = tile * GT;
-    const int jn = min(GT, D.nd - j0);
-    const float *dxyz = D.dst_xyz + (size_t)bi * D.nd * 3;
-    const float *sxyz = D.src_xyz + (size_t)bi * D.ns * 3;
+    const int j0 = tile * D.gt;
+    const int jn = min(D.gt, D.nd - j0);
+    const float *__restrict__ dxyz = D.dst_xyz + (size_t)bi * D.nd * 3;
+    const float *__restrict__ sxyz = D.src_xyz + (size_t)bi * D.ns * 3;
     for (int i = threadIdx.x; i < jn * 3; i += GTPB) acc[i] = 0.f;
-    __syncthreads();
-    const int *is = D.idx_src + (size_t)bi * D.ns;
-    const float *gs = D.gd_src + (size_t)bi * D.ns;
-    const int per = (D.ns + D.slices - 1) / D.slices;
-    const int k_end = min(D.ns, (slice + 1) * per);
-    for (int k = slice * per + threadIdx.x; k < k_end; k += GTPB) {
-        const int j = is[k] - j0;
-        if (j >= 0 && j < jn) {
-            const float g = gs[k] + gs[k];
-            const float *ps = sxyz + (size_t)k * 3;
-            const float *pd = dxyz + (size_t)(j0 + j) * 3;
+    // own term first: its idx -> gather chain is independent of the scatter scan below, so the two
+    // dependent-load chains overlap instead of running back to back (the kernel is latency-bound)
+    constexpr int OWN = GT * 3 / GTPB;
+    float own[OWN];
+    {
+        const int *__restrict__ id = D.idx_dst + (size_t)bi * D.nd;
+        const float *__restrict__ gdd = D.gd_dst + (size_t)bi * D.nd;
 #pragma unroll
-            for (int c = 0; c < 3; c++) atomicAdd(&acc[j * 3 + c], -((ps[c] - pd[c]) * g));
+        for (int u = 0; u < OWN; u++) {
+            const int i = threadIdx.x + u * GTPB;
+            own[u] = 0.f;
+            if (i < jn * 3) {
+                const int j = i / 3, c = i - j * 3;
+                const int k = id[j0 + j];
+                const float g = gdd[j0 + j] + gdd[j0 + j];
+                own[u] = (dxyz[(size_t)(j0 + j) * 3 + c] - sxyz[(size_t)k * 3 + c]) * g;
+            }
         }
     }
+    const int *__restrict__ is = D.idx_src + (size_t)bi * D.ns;
+    const float *__restrict__ gs = D.gd_src + (size_t)bi * D.ns;
+    const int per = (D.ns + D.slices - 1) / D.slices;
+    const int k_end = min(D.ns, (slice + 1) * per);
+    constexpr int SU = 4;  // sources per thread in flight
+    int jj[SU];
+    int kb = slice * per + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < SU; u++) {  // first batch of source indices: issued before the barrier
+        const int k = kb + u * GTPB;
+        jj[u] = k < k_end ? is[k] - j0 : -1;
+    }
     __syncthreads();
-    const int *id = D.idx_dst + (size_t)bi * D.nd;
-    const float *gdd = D.gd_dst + (size_t)bi * D.nd;
+    while (kb < k_end) {
+        int nj[SU];
+        const int kn = kb + GTPB * SU;
+#pragma unroll
+        for (int u = 0; u < SU; u++) {  // next batch, in flight while this one scatters
+            const int k = kn + u * GTPB;
+            nj[u] = k < k_end ? is[k] - j0 : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < SU; u++) {
+            const int k = kb + u * GTPB;
+            const int j = jj[u];
+            if (j >= 0 && j < jn) {
+                const float g = gs[k] + gs[k];
+                const float *ps = sxyz + (size_t)k * 3;
+                const float *pd = dxyz + (size_t)(j0 + j) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; c++) atomicAdd(&acc[j * 3 + c], -((ps[c] - pd[c]) * g));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SU; u++) jj[u] = nj[u];
+        kb = kn;
+    }
+    __syncthreads();
     float *out = D.grad + ((size_t)bi * D.nd + j0) * 3;
-    for (int i = threadIdx.x; i < jn * 3; i += GTPB) {
-        const int j = i / 3, c = i - j * 3;
-        const int k = id[j0 + j];
-        const float g = gdd[j0 + j] + gdd[j0 + j];
-        const float own = (dxyz[(size_t)(j0 + j) * 3 + c] - sxyz[(size_t)k * 3 + c]) * g;
-        if (D.slices == 1) {
-            out[i] = own + acc[i];
-        } else {
-            atomicAdd(&out[i], slice == 0 ? own + acc[i] : acc[i]);
+#pragma unroll
+    for (int u = 0; u < OWN; u++) {
+        const int i = threadIdx.x + u * GTPB;
+        if (i < jn * 3) {
+            if (D.slices == 1) {
+                out[i] = own[u] + acc[i];
+            } else {
+                atomicAdd(&out[i], slice == 0 ? own[u] + acc[i] : acc[i]);
+            }
         }
     }
 }
@@ -547,8 +586,17 @@ int rf_nn_distance_grad(int b, int n, int m, const float *xyz1, const float *xyz
         return RF_EINVAL;
     GradArgs a;
     a.b = b;
-    const int t0 = rf::ceil_div(n, GT), t1 = rf::ceil_div(m, GT);
-    // >= ~256 workgroups per direction, at least 1024 sources per slice
+    // Tile size per direction: small enough that b * tiles >= 256 workgroups with every workgroup
+    // sweeping ALL sources (no slices: plain stores, no memset, no global atomics), down to 64
+    // destination points; only when even that leaves the chip empty (tiny batches) are the sources
+    // sliced, at least 1024 per slice.
+    auto tile_for = [&](int nd) {
+        long want = ((long)nd * b + 255) / 256;
+        int gt = (int)((want + 63) / 64 * 64);
+        return gt < 64 ? 64 : (gt > GT ? GT : gt);
+    };
+    const int g0 = tile_for(n), g1 = tile_for(m);
+    const int t0 = rf::ceil_div(n, g0), t1 = rf::ceil_div(m, g1);
     auto slices_for = [&](int tiles, int ns) {
         int want = rf::ceil_div(256, (long)b * tiles);
         int maxs = ns / 1024 > 0 ? ns / 1024 : 1;
@@ -557,8 +605,8 @@ int rf_nn_distance_grad(int b, int n, int m, const float *xyz1, const float *xyz
     const int s0 = slices_for(t0, m), s1 = slices_for(t1, n);
     if (s0 > 1) RF_HIP(hipMemsetAsync(grad_xyz1, 0, sizeof(float) * 3 * (size_t)b * n, s));
     if (s1 > 1) RF_HIP(hipMemsetAsync(grad_xyz2, 0, sizeof(float) * 3 * (size_t)b * m, s));
-    a.d[0] = GradDir{xyz1, xyz2, grad_dist1, idx1, grad_dist2, idx2, grad_xyz1, n, m, t0, s0};
-    a.d[1] = GradDir{xyz2, xyz1, grad_dist2, idx2, grad_dist1, idx1, grad_xyz2, m, n, t1, s1};
+    a.d[0] = GradDir{xyz1, xyz2, grad_dist1, idx1, grad_dist2, idx2, grad_xyz1, n, m, g0, t0, s0};
+    a.d[1] = GradDir{xyz2, xyz1, grad_dist2, idx2, grad_dist1, idx1, grad_xyz2, m, n, g1, t1, s1};
     a.nblk0 = b * t0 * s0;
     const int nblk1 = b * t1 * s1;
     RF_LAUNCH("nn_grad", nn_grad_kernel, dim3(a.nblk0 + nblk1), dim3(GTPB), 0, s, a);
