@@ -354,12 +354,13 @@ __global__ __launch_bounds__(TPB) void nn_resolve_kernel(Sweep a, const float *_
 // rate on MI355X (one lane per row), so here the scatter is privatised in LDS: one workgroup
 // owns a TILE of destination points of one batch element, sweeps ALL sources of the other set
 // (coalesced idx/gd/xyz reads), accumulates the hits with ds_add_f32, adds the own term and
-// writes the tile with plain coalesced stores: no memset, no global atomics.  When that gives
-// too few workgroups (few destination tiles, many sources: B=32 x 2048 <- 16384) the sources
-// are split over `slices` workgroups per tile, which then flush their tiles with coalesced
-// global atomics (256 B per wave-instruction: the full atomic rate) onto a zero-filled output.
+// writes the tile with plain coalesced stores: no memset, no global atomics.  The tile size is
+// chosen per direction (64..2048 destination points) so that b * tiles >= 256 workgroups; only
+// when even 64-point tiles leave the chip empty (tiny batches) are the sources split over
+// `slices` workgroups per tile, which then flush their tiles with coalesced global atomics
+// (256 B per wave-instruction: the full atomic rate) onto a zero-filled output.
 // Arithmetic as the reference: g = gd+gd; v = (a-b)*g rounded on its own; plain adds.
-constexpr int GT = 2048;    // destination points per tile (24 KiB of LDS)
+constexpr int GT = 2048;    // max destination points per tile (24 KiB of LDS)
 constexpr int GTPB = 1024;
 
 struct GradDir {
