@@ -64,7 +64,10 @@ __global__ void am_init_kernel(int npts, int npad, float fill, const float *__re
 //           remainL[k] = max(0, remainL[k] - acc3)
 //   HAS_P1: acc1 = 1e-9 + sum_l fma(e(c_cur), remainR[l], .)                 (P1 of this level)
 //           ratioL_out[k] = remainL[k] / acc1
-template <bool HAS_P3, bool HAS_P1, int RPT>
+// P1: 0 = absent, 1 = present, 2 = present at a level whose multiplier is 0 (the reference's last
+// level): e = exp2(d2*0) = 1.0 exactly, so the exponential (and, without P3, the distance) is not
+// evaluated; fma(1.0, s, acc) rounds exactly as before -> the same bits for fewer instructions.
+template <bool HAS_P3, int P1, int RPT>
 __global__ __launch_bounds__(1024) void am_rowk_kernel(
     int n, int seglen, const float *__restrict__ xyz1, const float *__restrict__ xyz2p,
     size_t xyz2p_stride, const float *__restrict__ ratioR_prev, const float *__restrict__ remainR,
@@ -74,6 +77,7 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
     const int bi = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr bool HAS_P1 = P1 != 0;
     const int nseg = blockDim.x >> 6;
     const float *__restrict__ A = xyz1 + (size_t)bi * n * 3;
     float x1[RPT], y1[RPT], z1[RPT], rl[RPT], acc3[RPT], acc1[RPT];
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
                     const float p = rl[r] * fast_exp2(d2 * c_prev);
                     acc3[r] = fmaf(p, s3[u], acc3[r]);
                 }
-                if (HAS_P1) acc1[r] = fmaf(fast_exp2(d2 * c_cur), s1[u], acc1[r]);
+                if (HAS_P1) acc1[r] = fmaf(P1 == 2 ? 1.0f : fast_exp2(d2 * c_cur), s1[u], acc1[r]);
             }
         }
     }
@@ -155,7 +159,8 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
 // P2: rows = xyz2 points l, columns = xyz1 points k with scalar ratioL[k].
 //   sumr = sum_k fma(e, ratioL[k], .);  t = sumr*remainR[l];  cons = min(remainR[l]/(t+1e-9), 1)
 //   ratioR[l] = remainR[l]*cons;  remainR[l] = max(0, remainR[l]-t)
-template <int RPT>
+// ZERO: the level's multiplier is 0 -> e = 1.0 exactly, no distance and no exponential (see am_rowk).
+template <int RPT, bool ZERO>
 __global__ __launch_bounds__(1024) void am_rowl_kernel(
     int m, int seglen, const float *__restrict__ xyz2, const float *__restrict__ xyz1p,
     size_t xyz1p_stride, const float *__restrict__ ratioL, float *__restrict__ remainR,
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
 #pragma unroll
             for (int r = 0; r < RPT; r++) {
                 const float d2 = rf::d2_fma(x2[r] - cb[u * 3], y2[r] - cb[u * 3 + 1], z2[r] - cb[u * 3 + 2]);
-                acc[r] = fmaf(fast_exp2(d2 * c_cur), sc[u], acc[r]);
+                acc[r] = fmaf(ZERO ? 1.0f : fast_exp2(d2 * c_cur), sc[u], acc[r]);
             }
         }
     }
@@ -231,7 +236,8 @@ struct LevelConsts {
 
 // NLV > 0: exactly NLV levels starting at level 0, fully unrolled with no per-level branch (the
 // reference schedule is NLV = 10); NLV = 0: generic group of up to LVG levels, predicated.
-template <int NLV>
+// LASTZERO: level NLV-1 has multiplier 0 (e = 1.0 exactly): its exponential is not evaluated.
+template <int NLV, bool LASTZERO = false>
 __global__ __launch_bounds__(TPB) void am_match_kernel(int n, int m, const float *xyz1,
                                                        const float *xyz2, const float *ratios,
                                                        size_t lv_stride, size_t b_stride, int roff,
@@ -271,7 +277,10 @@ __global__ __launch_bounds__(TPB) void am_match_kernel(int n, int m, const float
             const float d2 = rf::d2_fma(cxyz[l][0] - x1, cxyz[l][1] - y1, cxyz[l][2] - z1);
             float acc = 0.f;
 #pragma unroll
-            for (int v = 0; v < NLV; v++) acc = fmaf(rl[v] * fast_exp2(d2 * cl[v]), crr[l][v], acc);
+            for (int v = 0; v < NLV; v++) {
+                const float e = (LASTZERO && v == NLV - 1) ? 1.0f : fast_exp2(d2 * cl[v]);
+                acc = fmaf(rl[v] * e, crr[l][v], acc);
+            }
             match[(size_t)(l0 + l) * n + k] = acc;
         }
         return;
@@ -555,7 +564,7 @@ __global__ void emd_pack_cols_kernel(int m, int mpad, int nlv, const float *__re
     for (int i = 0; i < EF_REC / 4; i++) q[i] = make_float4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
 }
 
-template <int NLV, bool GRAD>
+template <int NLV, bool GRAD, bool LASTZERO>
 __global__ __launch_bounds__(TPB) void emd_fused_kernel(int n, int m, int mpad, int lspan,
                                                         const float *__restrict__ xyz1,
                                                         const float *__restrict__ rec,
@@ -599,7 +608,10 @@ __global__ __launch_bounds__(TPB) void emd_fused_kernel(int n, int m, int mpad, 
             const float d2 = rf::d2_fma(dx, dy, dz);
             float acc = 0.f;
 #pragma unroll
-            for (int v = 0; v < NLV; v++) acc = fmaf(rl[v] * fast_exp2(d2 * cl[v]), rr[v], acc);
+            for (int v = 0; v < NLV; v++) {
+                const float e = (LASTZERO && v == NLV - 1) ? 1.0f : fast_exp2(d2 * cl[v]);
+                acc = fmaf(rl[v] * e, rr[v], acc);
+            }
             csum = fmaf(sqrtf(d2), acc, csum);
             if (GRAD) {
                 const float q = acc * __builtin_amdgcn_rsqf(fmaxf(d2, 1e-20f));
@@ -718,42 +730,46 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
     RF_LAUNCH("am_init", am_init_kernel, dim3(rf::ceil_div(L.mpad, 256), b), dim3(256), 0, s, m, L.mpad,
               multiR, xyz2, x2p, (size_t)L.mpad * 3, remainR, L.bstride);
 
-    // rows per lane: 2 when there are enough rows to keep >= 2048 waves (longer compute per scalar
-    // prefetch covers the L2 latency of the s_loads); RF_AM_RPT overrides for experiments
-    static const int rpt_env = getenv("RF_AM_RPT") ? atoi(getenv("RF_AM_RPT")) : 0;
-    const int rpt = rpt_env ? rpt_env : 2;
-    const int segk = pick_nseg(b, n, L.mpad, rpt), segl = pick_nseg(b, m, L.npad, rpt);
-    const dim3 gk(rf::ceil_div(n, 64 * rpt), b), gl(rf::ceil_div(m, 64 * rpt), b);
-#define AM_ROWK(P3, P1, NAME, ...)                                                                   \
-    if (rpt == 4)      { RF_LAUNCH(NAME, (am_rowk_kernel<P3, P1, 4>), gk, dim3(64 * segk), 0, s, __VA_ARGS__); } \
-    else if (rpt == 2) { RF_LAUNCH(NAME, (am_rowk_kernel<P3, P1, 2>), gk, dim3(64 * segk), 0, s, __VA_ARGS__); } \
-    else               { RF_LAUNCH(NAME, (am_rowk_kernel<P3, P1, 1>), gk, dim3(64 * segk), 0, s, __VA_ARGS__); }
+    // 2 rows per lane (measured best of 1 / 2 / 4: longer compute per scalar prefetch covers the L2
+    // latency of the s_loads without dropping below 4 waves per SIMD)
+    constexpr int RPT = 2;
+    const int segk = pick_nseg(b, n, L.mpad, RPT), segl = pick_nseg(b, m, L.npad, RPT);
+    const dim3 gk(rf::ceil_div(n, 64 * RPT), b), gl(rf::ceil_div(m, 64 * RPT), b);
     for (int v = 0; v < nlevels; v++) {
         float *ratioL = ratios + (size_t)v * L.V, *ratioR = ratioL + L.npad;
+        const bool zero = lc.c[v] == 0.0f;  // e = exp2(d2 * 0) = 1 exactly: no exponential needed
+#define AM_ROWK_ARGS(pR_, pL_, cprev)                                                                 \
+    n, L.mpad / segk, xyz1, (const float *)x2p, (size_t)L.mpad * 3, pR_, (const float *)remainR, pL_,  \
+        remainL, ratioL, L.bstride, cprev, lc.c[v]
         if (v == 0) {
-            AM_ROWK(false, true, "am_p1", n, L.mpad / segk, xyz1, (const float *)x2p, (size_t)L.mpad * 3,
-                    (const float *)remainR, (const float *)remainR, (const float *)remainL, remainL, ratioL,
-                    L.bstride, 0.f, lc.c[0]);
+            if (zero) {
+                RF_LAUNCH("am_p1", (am_rowk_kernel<false, 2, RPT>), gk, dim3(64 * segk), 0, s,
+                          AM_ROWK_ARGS((const float *)remainR, (const float *)remainL, 0.f));
+            } else {
+                RF_LAUNCH("am_p1", (am_rowk_kernel<false, 1, RPT>), gk, dim3(64 * segk), 0, s,
+                          AM_ROWK_ARGS((const float *)remainR, (const float *)remainL, 0.f));
+            }
         } else {
             const float *pL = ratios + (size_t)(v - 1) * L.V, *pR = pL + L.npad;
-            AM_ROWK(true, true, "am_p3p1", n, L.mpad / segk, xyz1, (const float *)x2p, (size_t)L.mpad * 3, pR,
-                    (const float *)remainR, pL, remainL, ratioL, L.bstride, lc.c[v - 1], lc.c[v]);
+            if (zero) {
+                RF_LAUNCH("am_p3p1", (am_rowk_kernel<true, 2, RPT>), gk, dim3(64 * segk), 0, s,
+                          AM_ROWK_ARGS(pR, pL, lc.c[v - 1]));
+            } else {
+                RF_LAUNCH("am_p3p1", (am_rowk_kernel<true, 1, RPT>), gk, dim3(64 * segk), 0, s,
+                          AM_ROWK_ARGS(pR, pL, lc.c[v - 1]));
+            }
         }
-        if (rpt == 4) {
-            RF_LAUNCH("am_p2", am_rowl_kernel<4>, gl, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
-                      (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR,
-                      L.bstride, lc.c[v]);
-        } else if (rpt == 2) {
-            RF_LAUNCH("am_p2", am_rowl_kernel<2>, gl, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
+#undef AM_ROWK_ARGS
+        if (zero) {
+            RF_LAUNCH("am_p2", (am_rowl_kernel<RPT, true>), gl, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
                       (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR,
                       L.bstride, lc.c[v]);
         } else {
-            RF_LAUNCH("am_p2", am_rowl_kernel<1>, gl, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
+            RF_LAUNCH("am_p2", (am_rowl_kernel<RPT, false>), gl, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
                       (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR,
                       L.bstride, lc.c[v]);
         }
     }
-#undef AM_ROWK
     return RF_OK;
 }
 
@@ -796,13 +812,16 @@ int rf_approxmatch_levels(int b, int n, int m, const float *xyz1, const float *x
     const float *ratios = (const float *)workspace + L.V;
     // P3 of the last level only updates remainL, which nothing reads afterwards: not launched.
     const dim3 gm(rf::ceil_div(n, TPB), rf::ceil_div(m, LSEG), b);
-    if (nlevels == 10) {
-        RF_LAUNCH("am_match", am_match_kernel<10>, gm, dim3(TPB), 0, s, n, m, xyz1, xyz2,
+    if (nlevels == 10 && lc.c[9] == 0.0f) {  // the reference schedule
+        RF_LAUNCH("am_match", (am_match_kernel<10, true>), gm, dim3(TPB), 0, s, n, m, xyz1, xyz2,
+                  (const float *)ratios, L.V, L.bstride, L.npad, 0, 10, lc, match);
+    } else if (nlevels == 10) {
+        RF_LAUNCH("am_match", (am_match_kernel<10, false>), gm, dim3(TPB), 0, s, n, m, xyz1, xyz2,
                   (const float *)ratios, L.V, L.bstride, L.npad, 0, 10, lc, match);
     } else {
         for (int lv0 = 0; lv0 < nlevels; lv0 += LVG) {
             int nlv = nlevels - lv0 < LVG ? nlevels - lv0 : LVG;
-            RF_LAUNCH("am_match", am_match_kernel<0>, gm, dim3(TPB), 0, s, n, m, xyz1, xyz2,
+            RF_LAUNCH("am_match", (am_match_kernel<0, false>), gm, dim3(TPB), 0, s, n, m, xyz1, xyz2,
                       (const float *)ratios, L.V, L.bstride, L.npad, lv0, nlv, lc, match);
         }
     }
@@ -951,10 +970,10 @@ int rf_earth_mover(int b, int n, int m, const float *xyz1, const float *xyz2, fl
               L.mpad, nl, xyz2, ratios, L.V, L.bstride, L.npad, rec);
     const dim3 g(rf::ceil_div(n, TPB), E.lsplit, b);
     if (want_grad) {
-        RF_LAUNCH("emd_fused_grad", (emd_fused_kernel<10, true>), g, dim3(TPB), 0, s, n, m, L.mpad, E.lspan,
+        RF_LAUNCH("emd_fused_grad", (emd_fused_kernel<10, true, true>), g, dim3(TPB), 0, s, n, m, L.mpad, E.lspan,
                   xyz1, (const float *)rec, ratios, L.V, L.bstride, lc, partial, grad1, grad2);
     } else {
-        RF_LAUNCH("emd_fused", (emd_fused_kernel<10, false>), g, dim3(TPB), 0, s, n, m, L.mpad, E.lspan, xyz1,
+        RF_LAUNCH("emd_fused", (emd_fused_kernel<10, false, true>), g, dim3(TPB), 0, s, n, m, L.mpad, E.lspan, xyz1,
                   (const float *)rec, ratios, L.V, L.bstride, lc, partial, grad1, grad2);
     }
     RF_LAUNCH("mc_final", mc_final_kernel, dim3(b), dim3(256), 0, s, (const float *)partial,

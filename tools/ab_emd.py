@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Same-device A/B of approx_match under RF_AM_RPT (rows per lane)."""
+"""Same-device A/B of approx_match under an env knob (default RF_AM_WAVES; AB_ENV=RFOPS_LIB compares two builds of the library)."""
 import os, subprocess, sys
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 CODE = r'''
@@ -21,7 +21,7 @@ u1, v1 = u[:, :1024].contiguous(), v[:, :1024].contiguous()
 u0, v0 = u[:, :64].contiguous(), v[:, :64].contiguous()
 print("C4 2048^2 %%.4f ms   1024^2 %%.4f ms   64^2 %%.4f ms" %% (t(lambda: R.approx_match(u, v), 10), t(lambda: R.approx_match(u1, v1), 20), t(lambda: R.approx_match(u0, v0), 20)))
 ''' % ROOT
-ENVNAME = os.environ.get("AB_ENV", "RF_AM_RPT")
+ENVNAME = os.environ.get("AB_ENV", "RF_AM_WAVES")
 for rnd in range(2):
     for v in (sys.argv[1:] or ["1", "2"]):
         out = subprocess.run([sys.executable, "-c", CODE], env=dict(os.environ, **{ENVNAME: v}), capture_output=True, text=True)
