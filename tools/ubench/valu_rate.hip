@@ -68,6 +68,48 @@ __global__ void k(float *out, int iters, unsigned long long *clk) {
                 "v_sub_f32 %0, %9, %4\n v_sub_f32 %2, %8, %5\n v_mul_f32 %2, %2, %2\n v_fmac_f32 %2, %0, %0\n v_sub_f32 %0, %9, %6\n v_fmac_f32 %2, %0, %0\n"
                 "v_mul_f32 %2, %9, %2\n v_exp_f32 %2, %2\n v_fmac_f32 %7, %8, %1\n v_fmac_f32 %3, %8, %2\n"
                 : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "s"(sa2), "s"(sb2));)
+        } else if (MODE == 10) {  // mode 8 + 2 SALU moves per column: is scalar issue free next to VALU?
+            REP8(asm volatile(
+                "v_sub_f32 %0, %8, %4\n v_sub_f32 %1, %9, %5\n s_mov_b32 s20, s21\n v_mul_f32 %1, %1, %1\n v_sub_f32 %2, %8, %6\n v_fmac_f32 %1, %0, %0\n s_mov_b32 s22, s23\n v_fmac_f32 %1, %2, %2\n"
+                "v_mul_f32 %1, %9, %1\n v_exp_f32 %1, %1\n v_fmac_f32 %7, %8, %1\n"
+                : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "s"(sa2), "s"(sb2) : "s20", "s22");)
+        } else if (MODE == 11) {  // chamfer pair mix with an SGPR operand + 1 SALU move per pair
+            float sa = __builtin_amdgcn_readfirstlane(a), sb = __builtin_amdgcn_readfirstlane(b);
+            REP8(asm volatile(
+                "v_sub_f32 %0, %8, %4\n v_sub_f32 %1, %9, %5\n s_mov_b32 s20, s21\n v_mul_f32 %1, %1, %1\n v_sub_f32 %2, %8, %6\n v_fmac_f32 %1, %0, %0\n v_fmac_f32 %1, %2, %2\n"
+                "v_sub_f32 %0, %9, %4\n v_sub_f32 %3, %8, %5\n s_mov_b32 s22, s23\n v_mul_f32 %3, %3, %3\n v_sub_f32 %2, %9, %6\n v_fmac_f32 %3, %0, %0\n v_fmac_f32 %3, %2, %2\n"
+                "v_min3_f32 %7, %7, %1, %3\n"
+                : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "s"(sa), "s"(sb) : "s20", "s22");)
+        } else if (MODE == 12) {  // v_permlane32_swap (VOP1), 4 independent register pairs
+            REP8(asm volatile("v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7\n"
+                              "v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7\n"
+                              : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7));)
+        } else if (MODE == 13) {  // v_permlane16_swap
+            REP8(asm volatile("v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3\n v_permlane16_swap_b32 %4, %5\n v_permlane16_swap_b32 %6, %7\n"
+                              "v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3\n v_permlane16_swap_b32 %4, %5\n v_permlane16_swap_b32 %6, %7\n"
+                              : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7));)
+        } else if (MODE == 14) {  // v_min_f32_dpp row_ror:8, 8 independent chains (sources never just-written)
+            REP8(asm volatile("v_min_f32_dpp %0, %8, %9 row_ror:8 row_mask:0xf bank_mask:0xf\n v_min_f32_dpp %1, %8, %9 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+                              "v_min_f32_dpp %2, %8, %9 row_ror:8 row_mask:0xf bank_mask:0xf\n v_min_f32_dpp %3, %8, %9 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+                              "v_min_f32_dpp %4, %8, %9 row_ror:8 row_mask:0xf bank_mask:0xf\n v_min_f32_dpp %5, %8, %9 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+                              "v_min_f32_dpp %6, %8, %9 row_ror:8 row_mask:0xf bank_mask:0xf\n v_min_f32_dpp %7, %8, %9 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+                              : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "v"(a), "v"(b));)
+        } else if (MODE == 15) {  // v_cndmask_b32_e64 with an SGPR-pair mask
+            REP8(asm volatile("v_cndmask_b32_e64 %0, %8, %9, s[20:21]\n v_cndmask_b32_e64 %1, %8, %9, s[20:21]\n v_cndmask_b32_e64 %2, %8, %9, s[20:21]\n v_cndmask_b32_e64 %3, %8, %9, s[20:21]\n"
+                              "v_cndmask_b32_e64 %4, %8, %9, s[20:21]\n v_cndmask_b32_e64 %5, %8, %9, s[20:21]\n v_cndmask_b32_e64 %6, %8, %9, s[20:21]\n v_cndmask_b32_e64 %7, %8, %9, s[20:21]\n"
+                              : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "v"(a), "v"(b) : "s20", "s21");)
+        } else if (MODE == 16) {  // ds_bpermute_b32, 8 in flight
+            REP8(asm volatile("ds_bpermute_b32 %0, %8, %0\n ds_bpermute_b32 %1, %8, %1\n ds_bpermute_b32 %2, %8, %2\n ds_bpermute_b32 %3, %8, %3\n"
+                              "ds_bpermute_b32 %4, %8, %4\n ds_bpermute_b32 %5, %8, %5\n ds_bpermute_b32 %6, %8, %6\n ds_bpermute_b32 %7, %8, %7\n s_waitcnt lgkmcnt(0)\n"
+                              : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "v"(a), "v"(b));)
+        } else if (MODE == 17) {  // v_cndmask_b32_e32 (VCC mask)
+            REP8(asm volatile("v_cndmask_b32_e32 %0, %8, %9, vcc\n v_cndmask_b32_e32 %1, %8, %9, vcc\n v_cndmask_b32_e32 %2, %8, %9, vcc\n v_cndmask_b32_e32 %3, %8, %9, vcc\n"
+                              "v_cndmask_b32_e32 %4, %8, %9, vcc\n v_cndmask_b32_e32 %5, %8, %9, vcc\n v_cndmask_b32_e32 %6, %8, %9, vcc\n v_cndmask_b32_e32 %7, %8, %9, vcc\n"
+                              : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "v"(a), "v"(b) : "vcc");)
+        } else if (MODE == 18) {  // v_readlane_b32 + v_writelane_b32 pairs
+            REP8(asm volatile("v_readlane_b32 s20, %0, 3\n v_writelane_b32 %1, s22, 5\n v_readlane_b32 s21, %2, 3\n v_writelane_b32 %3, s22, 5\n"
+                              "v_readlane_b32 s20, %4, 3\n v_writelane_b32 %5, s22, 5\n v_readlane_b32 s21, %6, 3\n v_writelane_b32 %7, s22, 5\n"
+                              : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : : "s20", "s21");)
         }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -99,7 +141,7 @@ void run(const char *name, int instr_per_iter, int waves_per_simd) {
 }
 
 int main() {
-    for (int w : {1, 2, 4, 8}) {
+    for (int w : {4, 8}) {
         run<0>("v_fma_f32", 64, w);
         run<1>("v_pk_fma_f32", 64, w);
         run<2>("v_sub_f32", 64, w);
@@ -110,6 +152,15 @@ int main() {
         run<7>("chamfer mix sgpr", 104, w);
         run<8>("emd col 1acc", 72, w);
         run<9>("emd col 2acc", 144, w);
+        run<10>("emd col +2salu", 72, w);   // cycles per VALU instruction (the 16 SALU not counted)
+        run<11>("chamfer +salu", 104, w);
+        run<12>("permlane32_swap", 64, w);
+        run<13>("permlane16_swap", 64, w);
+        run<14>("v_min_f32_dpp", 64, w);
+        run<15>("cndmask_e64 sgpr", 64, w);
+        run<16>("ds_bpermute", 64, w);
+        run<17>("cndmask_e32 vcc", 64, w);
+        run<18>("readlane/writelane", 64, w);
     }
     return 0;
 }
