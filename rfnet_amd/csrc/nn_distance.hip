@@ -50,6 +50,8 @@ struct Sweep {
     int oblocks;  // ceil(no / (64*R))
     int nsplit;   // candidate range splits
     int span;     // candidates per split (multiple of CG)
+    int wgm;      // 1: the 4 waves of a workgroup are 4 consecutive splits of one own block and merge
+                  //    their own-side results in LDS (row partial slots = nsplit / 4)
 };
 
 // Re-pack both clouds in ONE launch: blocks [0, nblk_own) pack the own set (padded with -inf),
@@ -269,6 +271,39 @@ __global__ __launch_bounds__(TPB) void nn_sweep_kernel(Sweep a, const float *__r
             if (k < c_end && d == best[r]) besti[r] = k;
         }
     }
+    if (a.wgm) {
+        // The workgroup's 4 waves hold the same 64*R own points against 4 consecutive candidate
+        // spans: merge them here, in span order with strict '<' (lowest index wins ties), and write
+        // ONE result per point instead of four partials (C2: the own side is final after this).
+        static_assert(R % 4 == 0, "float4 staging");
+        __shared__ float md[TPB / 64][64 * R];
+        __shared__ int mi[TPB / 64][64 * R];
+        const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+        for (int r = 0; r < R; r += 4) {
+            *(float4 *)&md[wib][lane * R + r] = make_float4(best[r], best[r + 1], best[r + 2], best[r + 3]);
+            *(int4 *)&mi[wib][lane * R + r] = make_int4(besti[r], besti[r + 1], besti[r + 2], besti[r + 3]);
+        }
+        __syncthreads();
+        const size_t mbase = ((size_t)(split / (TPB / 64)) * a.b + bi) * a.no + (size_t)ob * 64 * R;
+        for (int pnt = threadIdx.x; pnt < 64 * R; pnt += TPB) {
+            float bd = md[0][pnt];
+            int bk = mi[0][pnt];
+#pragma unroll
+            for (int sp = 1; sp < TPB / 64; sp++) {
+                const float d = md[sp][pnt];
+                if (d < bd) {
+                    bd = d;
+                    bk = mi[sp][pnt];
+                }
+            }
+            if (ob * 64 * R + pnt < a.no) {
+                row_dist[mbase + pnt] = bd;
+                row_idx[mbase + pnt] = bk;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int j = (ob * 64 + lane) * R + r;
@@ -310,10 +345,10 @@ __global__ __launch_bounds__(TPB) void nn_resolve_kernel(Sweep a, const float *_
                                                          int nblk_col, const float *__restrict__ row_pd,
                                                          const int *__restrict__ row_pi,
                                                          float *__restrict__ row_dist,
-                                                         int *__restrict__ row_idx) {
+                                                         int *__restrict__ row_idx, int rslots) {
     if ((int)blockIdx.x >= nblk_col) {
         rowmerge_body((long)(blockIdx.x - nblk_col) * TPB + threadIdx.x, row_pd, row_pi, row_dist, row_idx,
-                      a.nsplit, (long)a.b * a.no);
+                      rslots, (long)a.b * a.no);
         return;
     }
     const int cblocks = nblk_col / a.b;
@@ -468,6 +503,7 @@ constexpr int RR = 8;  // own points per lane (16 drops to 2 waves/SIMD and is s
 struct Plan {
     bool swap;  // own = xyz2 (the larger set) when true
     int no, nc, no_pad, nc_pad, oblocks, nsplit, span;
+    int wgm, rslots;  // in-workgroup merge of 4 splits; own-side partial slots left for nn_resolve
     size_t off_own, off_cand, off_rowd, off_rowi, off_col, off_coll, bytes;
 };
 
@@ -494,6 +530,8 @@ Plan make_plan(int b, int n, int m) {
     int s = want < 1 ? 1 : (want > maxs ? maxs : want);
     p.span = round_up(rf::ceil_div(p.nc, s), CG);
     p.nsplit = rf::ceil_div(p.nc, p.span);
+    p.wgm = (p.nsplit % (TPB / 64) == 0) ? 1 : 0;
+    p.rslots = p.wgm ? p.nsplit / (TPB / 64) : p.nsplit;
     size_t off = 0;
     auto take = [&](size_t bytes) {
         size_t o = off;
@@ -502,8 +540,8 @@ Plan make_plan(int b, int n, int m) {
     };
     p.off_own = take(((size_t)b * p.no_pad + CG) * 12);
     p.off_cand = take(((size_t)b * p.nc_pad + CG) * 12);  // + one group: prefetch overrun
-    p.off_rowd = take(p.nsplit > 1 ? (size_t)p.nsplit * b * p.no * 4 : 0);
-    p.off_rowi = take(p.nsplit > 1 ? (size_t)p.nsplit * b * p.no * 4 : 0);
+    p.off_rowd = take(p.rslots > 1 ? (size_t)p.rslots * b * p.no * 4 : 0);
+    p.off_rowi = take(p.rslots > 1 ? (size_t)p.rslots * b * p.no * 4 : 0);
     p.off_col = take((size_t)p.oblocks * b * p.nc * 4);
     p.off_coll = take((size_t)p.oblocks * b * p.nc);
     p.bytes = off;
@@ -551,23 +589,23 @@ int rf_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2, fl
     }
 
     Sweep a;
-    float *row_dist = p.nsplit > 1 ? (float *)(w + p.off_rowd) : own_dist;
-    int *row_idx = p.nsplit > 1 ? (int *)(w + p.off_rowi) : own_idx;
+    float *row_dist = p.rslots > 1 ? (float *)(w + p.off_rowd) : own_dist;
+    int *row_idx = p.rslots > 1 ? (int *)(w + p.off_rowi) : own_idx;
     float *colpart = (float *)(w + p.off_col);
     unsigned char *collane = (unsigned char *)(w + p.off_coll);
     a.b = b; a.no = p.no; a.nc = p.nc; a.no_pad = p.no_pad; a.nc_pad = p.nc_pad;
-    a.oblocks = p.oblocks; a.nsplit = p.nsplit; a.span = p.span;
+    a.oblocks = p.oblocks; a.nsplit = p.nsplit; a.span = p.span; a.wgm = p.wgm;
     long waves = (long)b * p.oblocks * p.nsplit;
     RF_LAUNCH("nn_sweep", nn_sweep_kernel<RR>, dim3(rf::ceil_div(waves, TPB / 64)), dim3(TPB), 0, s, a,
               (const float *)own_p, (const float *)cand_p, row_dist, row_idx, colpart, collane);
     {
         const int cblocks = rf::ceil_div(p.nc, TPB);
         const int nblk_col = cblocks * b;
-        const int nblk_row = p.nsplit > 1 ? rf::ceil_div((long)b * p.no, TPB) : 0;
+        const int nblk_row = p.rslots > 1 ? rf::ceil_div((long)b * p.no, TPB) : 0;
         RF_LAUNCH("nn_resolve", nn_resolve_kernel<RR>, dim3(nblk_col + nblk_row), dim3(TPB), 0, s, a,
                   (const float *)own_p, (const float *)cand_p, (const float *)colpart,
                   (const unsigned char *)collane, cand_dist, cand_idx, nblk_col, (const float *)row_dist,
-                  (const int *)row_idx, own_dist, own_idx);
+                  (const int *)row_idx, own_dist, own_idx, p.rslots);
     }
     return RF_OK;
 }
