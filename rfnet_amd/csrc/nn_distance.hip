@@ -332,8 +332,8 @@ __device__ __forceinline__ void rowmerge_body(long g, const float *__restrict__ 
     idx[g] = besti;
 }
 
-// candidate side: per candidate (one thread each), the first own block with the smallest partial
-// (strict '<' in block order), then the lowest index among that block's winning lane's R
+// candidate side: per candidate (one quad of lanes each), the first own block with the smallest
+// partial (strict '<' in block order), then the lowest index among that block's winning lane's R
 // consecutive points with an exactly equal d2.
 // The same launch also finishes the own side: blocks beyond the candidate blocks run rowmerge.
 template <int R>
@@ -351,35 +351,60 @@ __global__ __launch_bounds__(TPB) void nn_resolve_kernel(Sweep a, const float *_
                       rslots, (long)a.b * a.no);
         return;
     }
+    // 4 lanes (a quad) per candidate: lane q scans the own blocks o = q, q+4, ... (its loads are
+    // independent and all in flight), the quad combines (value, block) lexicographically -- the
+    // first block with the smallest partial -- and shares the R-point re-scan.  One thread per
+    // candidate left the kernel latency-bound on a chain of `oblocks` dependent compares.
+    constexpr int CPB = TPB / 4;  // candidates per workgroup
     const int cblocks = nblk_col / a.b;
     const int bi = blockIdx.x / cblocks;
-    const int c = (blockIdx.x - bi * cblocks) * TPB + threadIdx.x;
-    if (c >= a.nc) return;
+    const int q = threadIdx.x & 3;
+    const int c = min((int)(blockIdx.x - bi * cblocks) * CPB + (int)(threadIdx.x >> 2), a.nc - 1);
+    const bool writer = q == 0 && (int)(blockIdx.x - bi * cblocks) * CPB + (int)(threadIdx.x >> 2) < a.nc;
     const float *own = own_all + (size_t)bi * a.no_pad * 3;
     const float *cand = cand_all + (size_t)bi * a.nc_pad * 3;
     const float *cp = colpart + (size_t)bi * a.nc + c;
     const size_t ostride = (size_t)a.b * a.nc;
-    float best = cp[0];
-    int bblk = 0;
-    for (int o = 1; o < a.oblocks; o++) {
-        float v = cp[(size_t)o * ostride];
-        if (v < best) {
+    float best = INFINITY;
+    int bblk = 0x7fffffff;
+    for (int o = q; o < a.oblocks; o += 4) {
+        const float v = cp[(size_t)o * ostride];
+        if (v < best || bblk == 0x7fffffff) {  // strict '<' in block order; the first one always taken
             best = v;
             bblk = o;
         }
     }
+#pragma unroll
+    for (int x = 1; x <= 2; x <<= 1) {
+        const float ov = __shfl_xor(best, x, 64);
+        const int ob = __shfl_xor(bblk, x, 64);
+        if (ob != 0x7fffffff && (bblk == 0x7fffffff || ov < best || (ov == best && ob < bblk))) {
+            best = ov;
+            bblk = ob;
+        }
+    }
+    // lane 0 of the quad holds exactly what the sequential scan would (NaN partials included);
+    // the whole quad re-scans for ITS result
+    best = __shfl(best, threadIdx.x & ~3, 64);
+    bblk = __shfl(bblk, threadIdx.x & ~3, 64);
     const int wl = collane[(size_t)bblk * ostride + (size_t)bi * a.nc + c];
     const float cx = cand[c * 3 + 0], cy = cand[c * 3 + 1], cz = cand[c * 3 + 2];
     const int j0 = (bblk * 64 + wl) * R;
-    int found = j0;  // all-inf case: block 0, lane 0 -> index 0
+    static_assert(R % 4 == 0, "the quad shares the re-scan");
+    int found = 0x7fffffff;
 #pragma unroll
-    for (int r = R - 1; r >= 0; r--) {
-        const int j = j0 + r;
+    for (int r = R / 4 - 1; r >= 0; r--) {
+        const int j = j0 + q * (R / 4) + r;
         float d = rf::d2_fma(cx - own[j * 3 + 0], cy - own[j * 3 + 1], cz - own[j * 3 + 2]);
         if (j < a.no && d == best) found = j;
     }
-    dist[(size_t)bi * a.nc + c] = best;
-    idx[(size_t)bi * a.nc + c] = found;
+    found = min(found, __shfl_xor(found, 1, 64));
+    found = min(found, __shfl_xor(found, 2, 64));
+    if (found == 0x7fffffff) found = j0;  // all-inf case: block 0, lane 0 -> index 0
+    if (writer) {
+        dist[(size_t)bi * a.nc + c] = best;
+        idx[(size_t)bi * a.nc + c] = found;
+    }
 }
 
 // Backward.  grad_own[j] = 2*gd_own[j]*(own_j - other_{idx_own[j]})            (own term)
@@ -599,7 +624,7 @@ int rf_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2, fl
     RF_LAUNCH("nn_sweep", nn_sweep_kernel<RR>, dim3(rf::ceil_div(waves, TPB / 64)), dim3(TPB), 0, s, a,
               (const float *)own_p, (const float *)cand_p, row_dist, row_idx, colpart, collane);
     {
-        const int cblocks = rf::ceil_div(p.nc, TPB);
+        const int cblocks = rf::ceil_div(p.nc, TPB / 4);  // 4 lanes per candidate
         const int nblk_col = cblocks * b;
         const int nblk_row = p.rslots > 1 ? rf::ceil_div((long)b * p.no, TPB) : 0;
         RF_LAUNCH("nn_resolve", nn_resolve_kernel<RR>, dim3(nblk_col + nblk_row), dim3(TPB), 0, s, a,
