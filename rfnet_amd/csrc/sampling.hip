@@ -95,9 +95,10 @@ __device__ __forceinline__ float wave_allmax(float v) {
 //   scan      7 VALU per point (3 sub, mul, 2 fma, min) + half a v_max3 for the per-lane maximum
 //             VALUE -- no per-point compare/select for the arg-max;
 //   wave max  DPP row rotations + 4 v_readlane -> wm (uniform);
-//   arg-max   16 x v_cmp_eq(td[s], wm): each writes its 64-bit lane mask to SGPRs; the lowest
-//             lane of the OR of the masks, then the lowest s whose mask has that lane, is the
-//             wave's winner under the reference's tie order -- scalar ALU only;
+//   arg-max   per lane the lowest s with td[s] == the lane's maximum (compare + select per
+//             point, overlapping the wave reduction); one v_cmp_eq(mx, wm) gives the lanes
+//             holding the wave maximum, the lowest of them is the winner under the reference's
+//             tie order and a v_readlane fetches its s;
 //   exchange  lane 0 publishes (wm, k) in the wave's LDS slot (double-buffered: ONE barrier per
 //             iteration); every 16-lane row re-reduces the <=16 slots by DPP (max d2, then
 //             min tie rank); the winner's coordinates come back by a scalar load.
@@ -148,19 +149,19 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, const float *
                 mx = vmax3(mx, td[s - 1], td[s]);
             }
         }
+        // The wave's arg-max under the tie order (lowest lane, then lowest s).  Per lane, the lowest
+        // s attaining the lane's OWN maximum: 2 VALU per point, independent of the wave reduction
+        // (so it overlaps the DPP latency); then ONE compare finds the lanes holding the wave
+        // maximum and a v_readlane fetches the winner's s.  (16 v_cmp_eq + a 48-deep scalar
+        // select chain per iteration cost 25 % of the kernel: ablation in DESIGN.md 5.3.)
+        int sidx = 0;
+#pragma unroll
+        for (int s = PPT - 1; s >= 1; s--) sidx = (td[s] == mx) ? s : sidx;
+        if (PPT > 1) sidx = (td[0] == mx) ? 0 : sidx;
         const float wm = wave_allmax(mx);
-        // the wave's arg-max under the tie order: lowest lane, then lowest s
-        unsigned long long hit[PPT], any = 0ull;
-#pragma unroll
-        for (int s = 0; s < PPT; s++) {
-            hit[s] = __ballot(td[s] == wm);
-            any |= hit[s];
-        }
-        const int wl = any ? __builtin_ctzll(any) : 0;
-        int bs = 0;
-#pragma unroll
-        for (int s = PPT - 1; s >= 0; s--)
-            if ((hit[s] >> wl) & 1ull) bs = s;
+        const unsigned long long hl = __ballot(mx == wm);
+        const int wl = hl ? __builtin_ctzll(hl) : 0;
+        const int bs = __builtin_amdgcn_readlane(sidx, wl);
         const int wt = wave * 64 + wl;
         const int wk = (wt & 511) + 512 * (bs * HALVES + (wt >> 9));
         const int buf = j & 1;
