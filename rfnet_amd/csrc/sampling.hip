@@ -363,7 +363,7 @@ int rf_farthestpointsampling(int b, int n, int m, const float *inp, float *temp,
     if (n <= 2048) { FPS_CASE(1024, 2); }
     if (n <= 4096) { FPS_CASE(1024, 4); }
     if (n <= 8192) { FPS_CASE(1024, 8); }
-    if (n <= 16384) { FPS_CASE(1024, 16); }
+    if (n <= 16384) { FPS_CASE(512, 32); }
 #undef FPS_CASE
     if (!temp) return RF_EINVAL;
     RF_LAUNCH("fps_mem", fps_mem_kernel, dim3(b), dim3(1024), 0, s, n, m, inp, temp, out);
