@@ -59,7 +59,8 @@ int rf_nn_distance_grad(int b, int n, int m, const float *xyz1, const float *xyz
 
 /* ----------------------------------------------------------- EMD (pc_distance) ---------- */
 /* Replaces approxmatchLauncher(b,n,m,xyz1,xyz2,match,temp) (pc_distance/tf_approxmatch.cpp:141,
- * tf_approxmatch.cu:180-182).  xyz1 (b,n,3) "dataset", xyz2 (b,m,3) "query"; match is
+ * tf_approxmatch.cu:180-182).  xyz1 (b,n,3) "dataset", xyz2 (b,m,3) "query" (b <= 65535 for
+ * every entry point of this section: the batch is a grid dimension); match is
  * (b,m,n) (tf_approxmatch.cpp:164).  The reference's `temp` (b,2(n+m)) becomes `workspace`
  * (larger: it keeps the per-level ratio vectors so that match is written once). */
 size_t rf_approxmatch_workspace_bytes(int b, int n, int m, int nlevels /* 0 = reference's 10 */);

@@ -34,6 +34,7 @@ constexpr float kLog2e = 1.44269502f;  // 0x3FB8AA3B, the constant __expf multip
 constexpr int TPB = 256;
 constexpr int LVG = 16;             // levels per group in the materialisation kernel
 constexpr int MAX_LEVELS = 64;
+constexpr int MAX_BATCH = 65535;  // the batch index is a grid y/z dimension (the reference: 32 blocks)
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
@@ -786,7 +787,7 @@ size_t rf_approxmatch_workspace_bytes(int b, int n, int m, int nlevels) {
 int rf_approxmatch_levels(int b, int n, int m, const float *xyz1, const float *xyz2, float *match,
                           const float *levels_host, int nlevels, void *workspace,
                           size_t workspace_bytes, rf_stream_t stream) {
-    if (b < 0 || n < 0 || m < 0 || nlevels <= 0 || nlevels > MAX_LEVELS || !levels_host)
+    if (b < 0 || b > MAX_BATCH || n < 0 || m < 0 || nlevels <= 0 || nlevels > MAX_LEVELS || !levels_host)
         return RF_EINVAL;
     if (b == 0 || n == 0 || m == 0) return RF_OK;
     if (!xyz1 || !xyz2 || !match || !workspace) return RF_EINVAL;
@@ -843,7 +844,7 @@ size_t rf_matchcost_workspace_bytes(int b, int n, int m) {
 
 int rf_matchcost(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match,
                  float *cost, void *workspace, size_t workspace_bytes, rf_stream_t stream) {
-    if (b < 0 || n < 0 || m < 0) return RF_EINVAL;
+    if (b < 0 || b > MAX_BATCH || n < 0 || m < 0) return RF_EINVAL;
     if (b == 0) return RF_OK;
     hipStream_t s = (hipStream_t)stream;
     if (n == 0 || m == 0) {
@@ -862,7 +863,7 @@ int rf_matchcost(int b, int n, int m, const float *xyz1, const float *xyz2, cons
 
 int rf_matchcost_grad(int b, int n, int m, const float *xyz1, const float *xyz2,
                       const float *match, float *grad1, float *grad2, rf_stream_t stream) {
-    if (b < 0 || n < 0 || m < 0) return RF_EINVAL;
+    if (b < 0 || b > MAX_BATCH || n < 0 || m < 0) return RF_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if ((size_t)b * n) RF_HIP(hipMemsetAsync(grad1, 0, sizeof(float) * 3 * (size_t)b * n, s));
     if ((size_t)b * m) RF_HIP(hipMemsetAsync(grad2, 0, sizeof(float) * 3 * (size_t)b * m, s));
@@ -916,7 +917,7 @@ size_t rf_earth_mover_workspace_bytes(int b, int n, int m) {
 int rf_earth_mover(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost,
                    float *grad1, float *grad2, void *workspace, size_t workspace_bytes,
                    rf_stream_t stream) {
-    if (b < 0 || n < 0 || m < 0) return RF_EINVAL;
+    if (b < 0 || b > MAX_BATCH || n < 0 || m < 0) return RF_EINVAL;
     if ((grad1 == nullptr) != (grad2 == nullptr)) return RF_EINVAL;
     if (b == 0) return RF_OK;
     hipStream_t s = (hipStream_t)stream;
