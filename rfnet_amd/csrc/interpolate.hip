@@ -102,7 +102,7 @@ extern "C" {
 
 int rf_threenn(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist, int *idx,
                rf_stream_t stream) {
-    if (b < 0 || n < 0 || m < 0) return RF_EINVAL;
+    if (b < 0 || b > 65535 || n < 0 || m < 0) return RF_EINVAL;  // the batch is grid.y
     if (b == 0 || n == 0) return RF_OK;
     if (!xyz1 || !dist || !idx || (m > 0 && !xyz2)) return RF_EINVAL;
     RF_LAUNCH("three_nn", three_nn_kernel, dim3(rf::ceil_div(n, TN_TPB), b), dim3(TN_TPB), 0,
