@@ -32,6 +32,35 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib.rf_status_string(-2) == b"workspace too small"
 
 
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/rfops.h is the boundary for non-C++ hosts (cgo, JNI, ctypes): it must compile as
+    strict C, and a C program must link against librfops.so and call the host-only entry points."""
+    import shutil
+    import subprocess
+    from rfnet_amd import _lib
+    if not shutil.which("gcc"):
+        pytest.skip("gcc not available")
+    src = tmp_path / "use_rfops.c"
+    src.write_text(
+        '#include <stdio.h>\n#include "rfops.h"\n'
+        "int main(void) {\n"
+        "  size_t w = rf_nn_distance_workspace_bytes(32, 2048, 16384);\n"
+        "  if (w == 0 || rf_earth_mover_workspace_bytes(2, 300, 300) == 0) return 2;\n"
+        "  if (rf_auctionmatch_supported(1024) != 1 || rf_auctionmatch_supported(1500) != 0) return 3;\n"
+        '  printf("%s|%s\\n", rf_version(), rf_status_string(RF_EWORKSPACE));\n'
+        "  return rf_nn_distance(-1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0) == RF_EINVAL ? 0 : 4;\n"
+        "}\n")
+    exe = tmp_path / "use_rfops"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        str(src), "-o", str(exe), "-L", libdir, "-lrfops", f"-Wl,-rpath,{libdir}"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "gfx950" in r.stdout and "workspace too small" in r.stdout
+
+
 def test_workspace_queries_are_pure_host_functions():
     from rfnet_amd._lib import lib
     assert lib.rf_nn_distance_workspace_bytes(0, 10, 10) == 0
