@@ -21,6 +21,8 @@
 //     the mask is non-zero; the wave stops when all its queries have nsample hits.
 //   Hits go straight to their final slots; the padding [cnt, nsample) is written once at the
 //   end, so no slot is written twice.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
@@ -125,6 +127,118 @@ __global__ __launch_bounds__(QB_TPB) void query_ball_kernel(int n, int m, int nw
     }
 }
 
+// ---- query_ball_point, lanes <-> queries -------------------------------------------------------
+// The kernel above keeps QPW queries in SGPRs and tests 64 dataset points per step: every step pays
+// ~6 scalar instructions per query for mask bookkeeping (PMC: 49 SALU next to 74 VALU per step).
+// Here the roles are swapped, as in the Chamfer sweep: a wave owns 64 QUERIES (one per lane) and the
+// dataset is streamed through SGPRs by scalar loads; a test is 6 VALU + 1 compare, and the hit
+// path (append k to the lane's list) runs under the exec mask only when some lane hit (~20 % of the
+// points at C3).  To fill the chip the dataset is cut into QS segments scanned by the QS waves of a
+// workgroup for the same 64 queries; each keeps the first `nsample` hits of its segment in LDS and
+// the workgroup concatenates the segments in order at the end (no global scratch, no second launch).
+constexpr int QL_SUB = 8;  // dataset points per scalar-load sub-chunk
+template <int QS, int NSMAX>
+__global__ __launch_bounds__(64 * QS) void query_ball_lanes_kernel(int n, int m, int n_pad, int seg,
+                                                                   float thresh, int nsample,
+                                                                   const float *__restrict__ xyz1,
+                                                                   const float *__restrict__ xyz2,
+                                                                   int *__restrict__ idx,
+                                                                   int *__restrict__ pts_cnt) {
+    __shared__ int list[QS][NSMAX][64];  // [segment][slot][query lane]
+    __shared__ int segcnt[QS][64];
+    const int lane = threadIdx.x & 63;
+    const int sg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bi = blockIdx.y;
+    const int q = blockIdx.x * 64 + lane;
+    const int qq = min(q, m - 1);
+    const float *__restrict__ D = xyz1 + (size_t)bi * n * 3;
+    const float *__restrict__ Q = xyz2 + ((size_t)bi * m + qq) * 3;
+    const float qx = Q[0], qy = Q[1], qz = Q[2];
+    int cnt = 0;
+    const int k_begin = sg * seg, k_end = min(n, k_begin + seg);
+    // Whole sub-chunks of 8 points: scalar prefetch one sub-chunk ahead, no per-point range test.
+    // The hit path sits behind a wave-uniform branch on the compare mask (without it the compiler
+    // predicates the 5 append instructions and issues them for every point).
+    const int k_full = k_begin + (max(k_end - k_begin, 0) / QL_SUB) * QL_SUB;
+    // Two register sets, ping-pong: "wait for everything outstanding, issue the load of the OTHER
+    // set, compute on this set".  (Scalar loads return out of order, so the only usable wait is
+    // lgkmcnt(0); placed right before the next s_load it costs no overlap -- and unlike a
+    // load-then-copy double buffer it needs no s_mov per operand: 3 SALU per 7 VALU here.)
+    float pa[3 * QL_SUB], pb[3 * QL_SUB];
+    auto fetch = [&](float (&dst)[3 * QL_SUB], int k) {
+        const float *cp = D + (size_t)min(k, n_pad) * 3;  // uniform -> s_load; clamped in bounds
+#pragma unroll
+        for (int i = 0; i < 3 * QL_SUB; i++) dst[i] = cp[i];
+    };
+    auto scan8 = [&](const float (&c)[3 * QL_SUB], int k0) {
+#pragma unroll
+        for (int u = 0; u < QL_SUB; u++) {
+            const float d2 = rf::d2_fma(qx - c[u * 3], qy - c[u * 3 + 1], qz - c[u * 3 + 2]);
+            const bool hit = d2 < thresh;
+            if (__ballot(hit) != 0ull) {  // wave-uniform
+                // (the empty volatile asm keeps this a real s_cbranch: without it the two
+                // conditions are merged and the append is predicated instead of skipped)
+                asm volatile("; some lane hit");
+                if (hit && cnt < nsample) {
+                    list[sg][cnt][lane] = k0 + u;
+                    cnt++;
+                }
+            }
+        }
+    };
+    fetch(pa, k_begin);
+    for (int k0 = k_begin; k0 < k_full; k0 += 2 * QL_SUB) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): pa has arrived
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(pb, k0 + QL_SUB);
+        __builtin_amdgcn_sched_barrier(0);
+        scan8(pa, k0);
+        if (k0 + QL_SUB >= k_full) break;
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // pb has arrived
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(pa, k0 + 2 * QL_SUB);
+        __builtin_amdgcn_sched_barrier(0);
+        scan8(pb, k0 + QL_SUB);
+        if (__ballot(cnt < nsample) == 0ull) break;  // all 64 queries full
+    }
+    // ragged tail of the cloud (n not a multiple of 8): the last 8 points, those below k_full skipped
+    if (k_full < k_end) {
+        const int ks = n - QL_SUB;
+#pragma unroll 1
+        for (int u = 0; u < QL_SUB; u++) {
+            const int k = ks + u;
+            const float d2 = rf::d2_fma(qx - D[k * 3], qy - D[k * 3 + 1], qz - D[k * 3 + 2]);
+            if (d2 < thresh && k >= k_full && k < k_end && cnt < nsample) {
+                list[sg][cnt][lane] = k;
+                cnt++;
+            }
+        }
+    }
+    segcnt[sg][lane] = cnt;
+    __syncthreads();
+    // concatenate: query `ql`, output slot j <- the j-th hit over the segments in order
+    int *__restrict__ I = idx + ((size_t)bi * m + (size_t)blockIdx.x * 64) * nsample;
+    const int nq = min(64, m - (int)blockIdx.x * 64);
+    for (int e = threadIdx.x; e < nq * nsample; e += 64 * QS) {
+        const int ql = e / nsample, j = e - ql * nsample;
+        int total = 0, val = -1, first = -1;
+#pragma unroll
+        for (int s2 = 0; s2 < QS; s2++) {
+            const int c = segcnt[s2][ql];
+            if (first < 0 && c > 0) first = list[s2][0][ql];
+            if (val < 0 && j < total + c) val = list[s2][j - total][ql];
+            total += c;
+        }
+        if (total > 0) I[e] = val >= 0 ? val : first;  // empty balls are left untouched
+    }
+    if (threadIdx.x < nq) {
+        int total = 0;
+#pragma unroll
+        for (int s2 = 0; s2 < QS; s2++) total += segcnt[s2][threadIdx.x];
+        pts_cnt[(size_t)bi * m + (size_t)blockIdx.x * 64 + threadIdx.x] = min(total, nsample);
+    }
+}
+
 __global__ void group_point_kernel(int n, int c, long per_batch /* m*nsample */, long total,
                                    const float *__restrict__ points, const int *__restrict__ idx,
                                    float *__restrict__ out) {
@@ -184,6 +298,23 @@ int rf_queryballpoint(int b, int n, int m, float radius, int nsample, const floa
     }
     const int wpb = rf::ceil_div(m, QPW);
     const long waves = (long)b * wpb;
+    // lanes <-> queries form: needs n >= 8 (scalar prefetch of whole sub-chunks) and b <= 65535
+    if (n >= QL_SUB && b <= 65535 && nsample <= 64 && getenv("RF_QB_OLD") == nullptr) {
+        const int n_pad = n - QL_SUB;  // last sub-chunk start that stays in bounds
+        const dim3 g(rf::ceil_div(m, 64), b);
+        if (nsample <= 32) {
+            constexpr int QS = 8;
+            const int seg = rf::ceil_div(rf::ceil_div(n, QS), QL_SUB) * QL_SUB;
+            RF_LAUNCH("query_ball_point", (query_ball_lanes_kernel<QS, 32>), g, dim3(64 * QS), 0, s, n, m, n_pad,
+                      seg, ball_threshold(radius), nsample, xyz1, xyz2, idx, pts_cnt);
+        } else {
+            constexpr int QS = 4;
+            const int seg = rf::ceil_div(rf::ceil_div(n, QS), QL_SUB) * QL_SUB;
+            RF_LAUNCH("query_ball_point", (query_ball_lanes_kernel<QS, 64>), g, dim3(64 * QS), 0, s, n, m, n_pad,
+                      seg, ball_threshold(radius), nsample, xyz1, xyz2, idx, pts_cnt);
+        }
+        return RF_OK;
+    }
     if (nsample <= QB_NS) {
         RF_LAUNCH("query_ball_point", query_ball_kernel<true>, dim3(rf::ceil_div(waves, QB_TPB / 64)),
                   dim3(QB_TPB), 0, s, n, m, wpb, b, ball_threshold(radius), nsample, xyz1, xyz2, idx, pts_cnt);
