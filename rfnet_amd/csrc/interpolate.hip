@@ -7,56 +7,84 @@
 // rounded.  This file is compiled with -ffp-contract=off and uses no fmaf(), so dist / idx /
 // out are bit-exact with oracle/rfops_oracle.c (and with the reference CPU bodies).
 //
-// three_nn: one lane per unknown point; the known set is staged through LDS in tiles and
-// broadcast-read, so each known point is fetched from HBM once per workgroup.
+// three_nn: one lane per unknown point; the known set is wave-uniform, so it is streamed through
+// SGPRs by scalar loads (two register sets used alternately, as query_ball_lanes_kernel) and the
+// VALU ops take the SGPR operands directly -- no LDS tile, no barrier.  A candidate enters the
+// lane's sorted triple only if d < b3; that test is one compare, and the insertion chain sits
+// behind a wave-uniform branch (taken for ~half of the candidates at m = 1024, ever more rarely as
+// m grows), instead of being predicated over every pair.
 #include "common.hpp"
 
 namespace {
 
 constexpr int TN_TPB = 256;
-constexpr int TN_TILE = 1024;
+constexpr int TN_SUB = 8;  // known points per scalar-load sub-chunk
 
 __global__ __launch_bounds__(TN_TPB) void three_nn_kernel(int n, int m,
                                                           const float *__restrict__ xyz1,
                                                           const float *__restrict__ xyz2,
                                                           float *__restrict__ dist,
                                                           int *__restrict__ idx) {
-    __shared__ float4 tile[TN_TILE];
     const int bi = blockIdx.y;
     const int j = blockIdx.x * TN_TPB + threadIdx.x;
-    const float *U = xyz1 + (size_t)bi * n * 3;
-    const float *K = xyz2 + (size_t)bi * m * 3;
+    const float *__restrict__ U = xyz1 + (size_t)bi * n * 3;
+    const float *__restrict__ K = xyz2 + (size_t)bi * m * 3;
     const int jj = min(j, n - 1);
     const float x1 = U[jj * 3], y1 = U[jj * 3 + 1], z1 = U[jj * 3 + 2];
     float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
     int i1 = 0, i2 = 0, i3 = 0;
-    for (int t0 = 0; t0 < m; t0 += TN_TILE) {
-        const int cnt = min(TN_TILE, m - t0);
-        __syncthreads();
-        for (int k = threadIdx.x; k < cnt; k += TN_TPB) {
-            const float *p = K + (size_t)(t0 + k) * 3;
-            tile[k] = make_float4(p[0], p[1], p[2], 0.f);
-        }
-        __syncthreads();
-        for (int k = 0; k < cnt; k++) {
-            const float4 c = tile[k];
-            float dx = c.x - x1, dy = c.y - y1, dz = c.z - z1;
-            float xx = dx * dx, yy = dy * dy, zz = dz * dz;
-            float d = (xx + yy) + zz;
-            int kk = t0 + k;
-            // strict '<' insertion: an earlier index keeps its place on ties
-            if (d < b1) {
-                b3 = b2; i3 = i2;
-                b2 = b1; i2 = i1;
-                b1 = d;  i1 = kk;
-            } else if (d < b2) {
-                b3 = b2; i3 = i2;
-                b2 = d;  i2 = kk;
-            } else if (d < b3) {
-                b3 = d;  i3 = kk;
-            }
+    // One candidate.  A macro, not a lambda: with the triple captured by reference the compiler
+    // kept the indices in scratch memory.  The insertion is select-only (2 compares, 10 selects):
+    // strict '<' everywhere, so an earlier index keeps its place on ties, exactly the reference's
+    // if / else-if chain (tf_interpolate.cpp:78-93).
+#define TN_CONSIDER(cx, cy, cz, kk)                                                           \
+    {                                                                                         \
+        const float dx_ = (cx) - x1, dy_ = (cy) - y1, dz_ = (cz) - z1;                         \
+        const float xx_ = dx_ * dx_, yy_ = dy_ * dy_, zz_ = dz_ * dz_;                         \
+        const float d_ = (xx_ + yy_) + zz_;                                                    \
+        const bool in_ = d_ < b3;                                                              \
+        if (__ballot(in_) != 0ull) { /* wave-uniform */                                        \
+            asm volatile("; some lane inserts"); /* keeps this a real branch (grouping.hip) */ \
+            if (in_) {                                                                         \
+                const bool c1_ = d_ < b1, c2_ = d_ < b2;                                       \
+                b3 = c2_ ? b2 : d_;                                                            \
+                i3 = c2_ ? i2 : (kk);                                                          \
+                b2 = c1_ ? b1 : (c2_ ? d_ : b2);                                               \
+                i2 = c1_ ? i1 : (c2_ ? (kk) : i2);                                             \
+                b1 = c1_ ? d_ : b1;                                                            \
+                i1 = c1_ ? (kk) : i1;                                                          \
+            }                                                                                  \
+        }                                                                                      \
+    }
+    const int m_full = (m / TN_SUB) * TN_SUB;
+    if (m_full > 0) {
+        float pa[3 * TN_SUB], pb[3 * TN_SUB];
+        auto fetch = [&](float (&dst)[3 * TN_SUB], int k) {
+            const float *cp = K + (size_t)min(k, m - TN_SUB) * 3;  // uniform -> s_load; clamped in bounds
+#pragma unroll
+            for (int i = 0; i < 3 * TN_SUB; i++) dst[i] = cp[i];
+        };
+#define TN_SCAN8(c, k0)                  \
+    _Pragma("unroll") for (int u = 0; u < TN_SUB; u++) TN_CONSIDER(c[u * 3], c[u * 3 + 1], c[u * 3 + 2], (k0) + u)
+        fetch(pa, 0);
+        for (int k0 = 0; k0 < m_full; k0 += 2 * TN_SUB) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): pa has arrived
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(pb, k0 + TN_SUB);
+            __builtin_amdgcn_sched_barrier(0);
+            TN_SCAN8(pa, k0);
+            if (k0 + TN_SUB >= m_full) break;
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // pb has arrived
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(pa, k0 + 2 * TN_SUB);
+            __builtin_amdgcn_sched_barrier(0);
+            TN_SCAN8(pb, k0 + TN_SUB);
         }
     }
+#pragma unroll 1
+    for (int k = m_full; k < m; k++) TN_CONSIDER(K[k * 3], K[k * 3 + 1], K[k * 3 + 2], k);
+#undef TN_SCAN8
+#undef TN_CONSIDER
     if (j < n) {
         size_t o = ((size_t)bi * n + j) * 3;
         dist[o] = b1; dist[o + 1] = b2; dist[o + 2] = b3;
