@@ -483,19 +483,26 @@ __global__ __launch_bounds__(TPB) void mcg_kernel(int n, int m, int lspan,
     const int br = t / MG_TL;        // phase-B k slice: [br*32, br*32+32)
     for (int l0 = lbeg; l0 < lend; l0 += MG_TL) {
         const int lc = min(MG_TL, lend - l0);
-        float mv[MG_TL];
+        // 8 rows at a time (the group loop is NOT unrolled): with all 32 rows of the tile in flight
+        // the kernel needed 177 VGPRs = 2 waves per SIMD, and with three barriers per tile it is
+        // occupancy that hides the latencies
+        constexpr int MG_G = 8;
+#pragma unroll 1
+        for (int g = 0; g < MG_TL; g += MG_G) {
+            float mv[MG_G];
 #pragma unroll
-        for (int l = 0; l < MG_TL; l++)
-            mv[l] = (live && l < lc) ? M[(size_t)(l0 + l) * n + kk] : 0.f;
+            for (int l = 0; l < MG_G; l++)
+                mv[l] = (live && g + l < lc) ? M[(size_t)(l0 + g + l) * n + kk] : 0.f;
 #pragma unroll
-        for (int l = 0; l < MG_TL; l++) {
-            const int ll = min(l0 + l, m - 1);  // uniform -> scalar loads
-            const float dx = x1 - B[ll * 3], dy = y1 - B[ll * 3 + 1], dz = z1 - B[ll * 3 + 2];
-            const float q = mv[l] * __builtin_amdgcn_rsqf(fmaxf(rf::d2_fma(dx, dy, dz), 1e-20f));
-            ax = fmaf(dx, q, ax);
-            ay = fmaf(dy, q, ay);
-            az = fmaf(dz, q, az);
-            qs[l][t] = q;
+            for (int l = 0; l < MG_G; l++) {
+                const int ll = min(l0 + g + l, m - 1);  // uniform -> scalar loads
+                const float dx = x1 - B[ll * 3], dy = y1 - B[ll * 3 + 1], dz = z1 - B[ll * 3 + 2];
+                const float q = mv[l] * __builtin_amdgcn_rsqf(fmaxf(rf::d2_fma(dx, dy, dz), 1e-20f));
+                ax = fmaf(dx, q, ax);
+                ay = fmaf(dy, q, ay);
+                az = fmaf(dz, q, az);
+                qs[g + l][t] = q;
+            }
         }
         __syncthreads();
         {
