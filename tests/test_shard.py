@@ -84,7 +84,7 @@ def test_world_size_2_gloo(tmp_path, B):
 
 def test_bench_multi_rank_plumbing_dry_run():
     """bench.py under torch.distributed.run with 2 ranks (gloo, CPU): the launch line the driver
-    uses for N>1, in the script's dry-run mode (tiny shapes, oracle stand-in, no metric).  Checks
+    uses for N>1, in the script's dry-run mode (placeholder work, no operator, no metric).  Checks
     that exactly one JSON line comes out of rank 0 and that both ranks rendezvous and exit cleanly."""
     import json
     import subprocess
