@@ -51,6 +51,19 @@ int rf_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2, fl
                    int *idx1, float *dist2, int *idx2, void *workspace, size_t workspace_bytes,
                    rf_stream_t stream);
 
+/* Same call with the sweep pinned: RF_NN_DENSE evaluates all b*n*m pairs (nn_distance.hip),
+ * RF_NN_CULLED sorts both clouds along a space-filling curve and skips blocks of candidates whose
+ * bounding box is strictly farther than every query's current minimum (nn_pruned.hip; n, m <=
+ * 65536) -- identical outputs, bit for bit, ties included.  RF_NN_AUTO (what rf_nn_distance
+ * uses) picks by size.  `stats` (host pointer, 8 counters, or NULL): per direction {waves,
+ * superblock steps, block tests, block scans} of the culled sweep; non-NULL synchronises. */
+#define RF_NN_AUTO 0
+#define RF_NN_DENSE 1
+#define RF_NN_CULLED 2
+int rf_nn_distance_mode(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist1,
+                        int *idx1, float *dist2, int *idx2, void *workspace, size_t workspace_bytes,
+                        rf_stream_t stream, int mode, unsigned long long *stats);
+
 /* Replaces NmDistanceGradKernelLauncher (tf_nndistance.cpp:208, tf_nndistance_g.cu:151-156).
  * grad_xyz1 (b,n,3) and grad_xyz2 (b,m,3) are zero-filled here, then accumulated. */
 int rf_nn_distance_grad(int b, int n, int m, const float *xyz1, const float *xyz2,

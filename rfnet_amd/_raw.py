@@ -21,8 +21,14 @@ def _shape3(t, last=None):
 
 
 # ------------------------------------------------------------------ Chamfer ----------------
-def nn_distance(xyz1, xyz2):
-    """NnDistanceGpuOp::Compute, tf_ops/CD/tf_nndistance.cpp:172-204."""
+NN_MODES = {"auto": 0, "dense": 1, "culled": 2}
+
+
+def nn_distance(xyz1, xyz2, mode="auto", stats=None):
+    """NnDistanceGpuOp::Compute, tf_ops/CD/tf_nndistance.cpp:172-204.
+
+    `mode` pins the sweep ("dense": every pair; "culled": nn_pruned.hip) -- same outputs; `stats`
+    (a list) receives the culled sweep's 8 counters (rfops.h)."""
     st = H.Staged()
     a, b_ = st.take(xyz1, F32), st.take(xyz2, F32)
     if a.dim() != 3:
@@ -41,8 +47,12 @@ def nn_distance(xyz1, xyz2):
     d1, i1 = H.empty((b, n), F32, dev), H.empty((b, n), I32, dev)
     d2, i2 = H.empty((b, m), F32, dev), H.empty((b, m), I32, dev)
     ws, wsz = H.workspace(lib.rf_nn_distance_workspace_bytes(b, n, m), dev, "nn")
-    check(lib.rf_nn_distance(b, n, m, H.ptr(a), H.ptr(b_), H.ptr(d1), H.ptr(i1), H.ptr(d2),
-                             H.ptr(i2), H.ptr(ws), wsz, H.stream(dev)), "rf_nn_distance")
+    cnt = (C.c_ulonglong * 8)() if stats is not None else None
+    check(lib.rf_nn_distance_mode(b, n, m, H.ptr(a), H.ptr(b_), H.ptr(d1), H.ptr(i1), H.ptr(d2),
+                                  H.ptr(i2), H.ptr(ws), wsz, H.stream(dev), NN_MODES[mode],
+                                  C.cast(cnt, C.c_void_p) if cnt is not None else None), "rf_nn_distance")
+    if stats is not None:
+        stats[:] = list(cnt)
     return tuple(st.give(t) for t in (d1, i1, d2, i2))
 
 

@@ -32,6 +32,7 @@
 #include <stdlib.h>
 
 #include "common.hpp"
+#include "nn_pruned.hpp"
 
 namespace {
 
@@ -573,25 +574,54 @@ Plan make_plan(int b, int n, int m) {
     return p;
 }
 
+// When the culled sweep (nn_pruned.hip) beats the dense one: its cost grows with n + m (times a
+// few hundred instructions per point) plus a fixed sort, the dense sweep's with n * m.
+bool culled_pays(int b, int n, int m) {
+    const int lo = n < m ? n : m;
+    return rfp::pruned_supported(b, n, m) && lo >= 512 && (long)n * m >= (1L << 24);
+}
+
 }  // namespace
 
 extern "C" {
 
 size_t rf_nn_distance_workspace_bytes(int b, int n, int m) {
     if (b <= 0 || n <= 0 || m <= 0) return 0;
-    return make_plan(b, n, m).bytes;
+    const size_t dense = make_plan(b, n, m).bytes, pruned = rfp::pruned_workspace_bytes(b, n, m);
+    return dense > pruned ? dense : pruned;  // either path may be taken (rf_nn_distance_mode)
 }
 
 int rf_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist1,
                    int *idx1, float *dist2, int *idx2, void *workspace, size_t workspace_bytes,
                    rf_stream_t stream) {
+    return rf_nn_distance_mode(b, n, m, xyz1, xyz2, dist1, idx1, dist2, idx2, workspace, workspace_bytes,
+                               stream, RF_NN_AUTO, nullptr);
+}
+
+int rf_nn_distance_mode(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist1,
+                        int *idx1, float *dist2, int *idx2, void *workspace, size_t workspace_bytes,
+                        rf_stream_t stream, int mode, unsigned long long *stats) {
     if (b < 0 || n < 0 || m < 0) return RF_EINVAL;
+    if (mode != RF_NN_AUTO && mode != RF_NN_DENSE && mode != RF_NN_CULLED) return RF_EINVAL;
     if (b == 0 || (n == 0 && m == 0)) return RF_OK;
     if (n == 0 || m == 0) return RF_EINVAL;  // a nearest neighbour in an empty set is undefined
     if (!xyz1 || !xyz2 || !dist1 || !idx1 || !dist2 || !idx2 || !workspace) return RF_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == RF_NN_AUTO) {
+        // RF_NN_MODE=dense|culled pins the choice for experiments (tools/ab_chamfer.py)
+        static const char *env = getenv("RF_NN_MODE");
+        if (env && env[0] == 'd') mode = RF_NN_DENSE;
+        else if (env && env[0] == 'c') mode = RF_NN_CULLED;
+        else mode = culled_pays(b, n, m) ? RF_NN_CULLED : RF_NN_DENSE;
+        if (mode == RF_NN_CULLED && !rfp::pruned_supported(b, n, m)) mode = RF_NN_DENSE;
+    }
+    if (mode == RF_NN_CULLED) {
+        if (!rfp::pruned_supported(b, n, m)) return RF_EINVAL;
+        return rfp::pruned_nn_distance(b, n, m, xyz1, xyz2, dist1, idx1, dist2, idx2, workspace,
+                                       workspace_bytes, s, stats);
+    }
     Plan p = make_plan(b, n, m);
     if (workspace_bytes < p.bytes) return RF_EWORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
     char *w = (char *)workspace;
     float *own_p = (float *)(w + p.off_own), *cand_p = (float *)(w + p.off_cand);
     const float *own_src = p.swap ? xyz2 : xyz1, *cand_src = p.swap ? xyz1 : xyz2;

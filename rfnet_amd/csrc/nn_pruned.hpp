@@ -1,0 +1,19 @@
+// nn_pruned.hpp -- internal interface between nn_distance.hip (the C ABI entry points) and
+// nn_pruned.hip (the culled exact nearest-neighbour sweep).  Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace rfp {
+
+constexpr int kMaxPoints = 65536;  // per cloud: superblock ids must fit 10 bits
+
+bool pruned_supported(int b, int n, int m);
+size_t pruned_workspace_bytes(int b, int n, int m);
+// stats_out (host, 8 counters, may be NULL): per direction {waves, superblock steps, block
+// tests, block scans}; asking for them synchronises the stream.
+int pruned_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist1, int *idx1,
+                       float *dist2, int *idx2, void *workspace, size_t workspace_bytes, hipStream_t s,
+                       unsigned long long *stats_out);
+
+}  // namespace rfp

@@ -1,0 +1,143 @@
+"""GPU parity of the culled Chamfer sweep (rfnet_amd/csrc/nn_pruned.hip, RF_NN_CULLED).
+
+The culled sweep must return exactly what the dense sweep and the oracle return -- distances
+bit for bit, and the LOWEST ORIGINAL INDEX on ties although candidates are visited in Hilbert
+order -- on every input: it only skips pairs whose bounding-box lower bound is strictly above
+the running minimum.  Small cases are checked against the oracle (NmDistanceKernel restated,
+oracle/rfops_oracle.c); large ones against the dense sweep (itself oracle-checked in
+test_gpu_chamfer.py) plus oracle slices.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ("dist1", "idx1", "dist2", "idx2")
+
+
+def _run(xyz1, xyz2, mode, stats=None):
+    from rfnet_amd import _raw
+    out = _raw.nn_distance(torch.from_numpy(xyz1).cuda(), torch.from_numpy(xyz2).cuda(), mode=mode, stats=stats)
+    return [t.cpu().numpy() for t in out]
+
+
+def _same(got, exp, what):
+    for g, e, name in zip(got, exp, NAMES):
+        assert g.dtype == e.dtype and g.shape == e.shape
+        assert np.array_equal(g, e), f"{what} {name}: {np.sum(g != e)} mismatches of {g.size}"
+
+
+def _check_vs_oracle(orc, a, c):
+    got = _run(a, c, "culled")
+    _same(got, orc.nn_distance(a, c), "culled vs oracle")
+    return got
+
+
+@pytest.mark.parametrize("b,n,m", [(1, 1, 1), (2, 7, 5), (3, 1, 300), (2, 300, 1), (3, 256, 1024),
+                                   (2, 1025, 4097), (1, 5000, 300), (5, 64, 3000), (33, 100, 17),
+                                   (2, 63, 65), (1, 64, 64), (70, 130, 129)])
+def test_random_shapes_vs_oracle(orc, b, n, m):
+    rng = np.random.RandomState(b * 1000 + n + m)
+    _check_vs_oracle(orc, rng.randn(b, n, 3).astype(np.float32), rng.randn(b, m, 3).astype(np.float32))
+
+
+def test_golden_ragged_and_dup(orc, golden):
+    g = golden("nn_distance_ragged")
+    for tag in ("a", "b", "dup"):
+        got = _check_vs_oracle(orc, g[f"{tag}_xyz1"], g[f"{tag}_xyz2"])
+        assert np.array_equal(got[1], g[f"{tag}_ref_idx1"]) and np.array_equal(got[3], g[f"{tag}_ref_idx2"])
+    g = golden("nn_distance_c1")
+    got = _check_vs_oracle(orc, g["xyz1"], g["xyz2"])
+    assert np.array_equal(got[1], g["ref_idx1"]) and np.array_equal(got[3], g["ref_idx2"])
+
+
+def test_many_exact_ties_vs_oracle(orc):
+    rng = np.random.RandomState(1)
+    grid = rng.randint(0, 4, size=(2, 2000, 3)).astype(np.float32)  # lattice: masses of ties across blocks
+    _check_vs_oracle(orc, grid[:, :900], grid[:, 900:])
+    same = np.ones((1, 700, 3), np.float32)  # all distances 0: every idx must be 0
+    got = _check_vs_oracle(orc, same, same[:, :333])
+    assert (got[1] == 0).all() and (got[3] == 0).all()
+    # duplicated points as resample_pcd (data_util.py:8-13) makes them: draws with replacement
+    base = rng.randn(3, 500, 3).astype(np.float32)
+    dup = np.take_along_axis(base, rng.randint(0, 500, size=(3, 3000, 1)), 1)
+    _check_vs_oracle(orc, dup, base)
+    _check_vs_oracle(orc, base, dup)
+    _check_vs_oracle(orc, dup, dup[:, ::-1].copy())
+
+
+def test_degenerate_geometry_vs_oracle(orc):
+    rng = np.random.RandomState(2)
+    line = np.zeros((2, 1500, 3), np.float32)
+    line[..., 0] = rng.randn(2, 1500)  # collinear: two axes have zero extent
+    _check_vs_oracle(orc, line[:, :700], line[:, 700:])
+    out = rng.randn(1, 3000, 3).astype(np.float32)
+    out[0, :3] *= 1e6  # far outliers stretch the bounding box
+    _check_vs_oracle(orc, out[:, :1000], out[:, 1000:])
+    big = (rng.randn(1, 500, 3) * 1e18).astype(np.float32)
+    big[0, :5] = 3e38
+    c = (rng.randn(1, 300, 3) * 1e18).astype(np.float32)
+    c[0, :3] = -3e38  # d2 overflows to +inf for these pairs
+    _check_vs_oracle(orc, big, c)
+    tiny = (rng.randn(1, 400, 3) * 1e-30).astype(np.float32)  # d2 underflows: everything ties at 0 or denormals
+    _check_vs_oracle(orc, tiny[:, :150], tiny[:, 150:])
+
+
+@pytest.mark.parametrize("kind", ["randn", "uniform", "sphere", "lattice", "dup"])
+@pytest.mark.parametrize("b,n,m", [(4, 2048, 16384), (2, 16384, 16384), (40, 1000, 3000)])
+def test_culled_equals_dense(orc, kind, b, n, m):
+    """All four outputs identical to the dense sweep's, plus an oracle slice."""
+    rng = np.random.RandomState(len(kind) * 100 + b + n)
+
+    def cloud(k):
+        if kind == "randn":
+            return rng.randn(b, k, 3).astype(np.float32)
+        if kind == "uniform":
+            return rng.random_sample((b, k, 3)).astype(np.float32)
+        if kind == "sphere":
+            x = rng.randn(b, k, 3)
+            return (x / np.linalg.norm(x, axis=-1, keepdims=True)).astype(np.float32)
+        if kind == "lattice":
+            return rng.randint(0, 12, size=(b, k, 3)).astype(np.float32)
+        base = rng.randn(b, max(k // 5, 1), 3).astype(np.float32)
+        return np.take_along_axis(base, rng.randint(0, base.shape[1], size=(b, k, 1)), 1)
+
+    a, c = cloud(n), cloud(m)
+    stats = []
+    got = _run(a, c, "culled", stats)
+    _same(got, _run(a, c, "dense"), f"{kind} culled vs dense")
+    e = orc.nn_distance(a[:1, :200], c[:1])
+    assert np.array_equal(got[0][0, :200], e[0][0]) and np.array_equal(got[1][0, :200], e[1][0])
+    # the sweep did cull: fewer pairs evaluated than b*n*m in each direction (not for the lattice /
+    # duplicate clouds, where most boxes overlap most queries)
+    if kind in ("randn", "uniform", "sphere"):
+        pairs = [stats[3] * 16 * 64, stats[7] * 16 * 64]
+        assert pairs[0] < 0.6 * b * n * m and pairs[1] < 0.6 * b * n * m, (stats, b * n * m)
+
+
+def test_c2_and_auto_mode(orc):
+    """BASELINE.json configs[1] through the public op (auto mode picks the culled sweep at this size)."""
+    from tf_ops.CD.tf_nndistance import nn_distance
+    rng = np.random.RandomState(100)
+    a = rng.randn(32, 2048, 3).astype(np.float32)
+    c = rng.randn(32, 16384, 3).astype(np.float32)
+    auto = [t.cpu().numpy() for t in nn_distance(torch.from_numpy(a).cuda(), torch.from_numpy(c).cuda())]
+    _same(auto, _run(a, c, "dense"), "auto vs dense")
+    _same(auto, _run(a, c, "culled"), "auto vs culled")
+    for bi in (0, 31):
+        e = orc.nn_distance(a[bi:bi + 1], c[bi:bi + 1])
+        for k in range(4):
+            assert np.array_equal(auto[k][bi], e[k][0])
+
+
+def test_large_clouds_65536(orc):
+    rng = np.random.RandomState(11)
+    a = rng.randn(1, 65536, 3).astype(np.float32)
+    c = rng.randn(1, 32768, 3).astype(np.float32)
+    got = _run(a, c, "culled")
+    _same(got, _run(a, c, "dense"), "65536 culled vs dense")
+    from rfnet_amd._lib import RfopsError
+    with pytest.raises(RfopsError):
+        _run(np.zeros((1, 65537, 3), np.float32), c, "culled")  # beyond the culled sweep's limit: explicit error
+    _run(np.zeros((1, 65537, 3), np.float32), c[:, :100], "auto")  # auto falls back to the dense sweep
