@@ -10,9 +10,11 @@
 //   nnp_sort_kernel   one workgroup per cloud.  Per-axis histogram equalisation (256 bins ->
 //                     32 cells of equal marginal population: far outliers cannot flatten the
 //                     grid), a 15-bit Hilbert key per point, counting sort in LDS (32768 bins =
-//                     128 KiB of the CU's 160 KiB).  Output: the cloud as float4 records
-//                     (x, y, z, original index) in key order, padded to a multiple of 64, and the
-//                     axis-aligned boxes of every 16-record block and 64-record superblock.
+//                     128 KiB of the CU's 160 KiB), clouds of up to 16384 points held in registers
+//                     throughout.  Output: the cloud's coordinates (x, y, z packed: a 16-record
+//                     block is three aligned 64-byte scalar loads) and original indices in key
+//                     order, padded to a multiple of 64, and the axis-aligned boxes of every
+//                     16-record block and 64-record superblock.
 //                     The ORDER only steers how much gets culled; any permutation is correct.
 //   nnp_sweep_kernel  one wave per 64 consecutive sorted queries (one per lane).  Candidate
 //                     superblocks are visited in ascending order of the box-to-box lower bound
@@ -51,17 +53,26 @@ constexpr int SB = BS * SBB;       // 64 records: one superblock = one query gro
 constexpr int KEYBITS = 15;        // 5 bits per axis
 constexpr int NBINS = 1 << KEYBITS;
 constexpr int STPB = 1024;         // sort kernel threads
+constexpr int RPT = 16;            // points per thread of the register-resident sort (n <= 16384)
 constexpr int HB = 256;            // equalisation histogram bins per axis
 constexpr int MAXSB = rfp::kMaxPoints / SB;  // 1024: superblock id fits the key's low 10 bits
 constexpr unsigned IDMASK = 0x3FFu;
+constexpr int B16F = SBB * 6;      // floats per superblock in box16: 4 x (lo.xyz, hi.xyz)
+constexpr int B64F = 8;            // floats per superblock in box64: lo.xyz, -, hi.xyz, -
 
+// Sorted cloud, per batch element and set:
+//   xyz   (npad, 3)      coordinates in key order, padding = +inf
+//   orig  (npad)         original index of each record, padding = -1
+//   box16 (npad/64, 24)  per superblock, for each of its 4 blocks: lo.xyz, hi.xyz
+//   box64 (npad/64, 8)   lo.xyz, 0, hi.xyz, 0
 struct SortArgs {
     int b;
     int n[2], npad[2];
     const float *src[2];  // (b, n, 3)
-    float4 *sorted[2];    // (b, npad)
-    float4 *box16[2];     // (b, npad/16, 2): lo, hi
-    float4 *box64[2];     // (b, npad/64, 2)
+    float *xyz[2];
+    int *orig[2];
+    float *box16[2];
+    float *box64[2];
 };
 
 // Skilling's axes-to-transpose Hilbert mapping, 5 bits per axis -> 15-bit index.
@@ -104,8 +115,311 @@ __device__ __forceinline__ int axis_bin(float v, float lo, float scale) {
     return (int)f;  // NaN products (inf * 0) fall through fmaxf as 0
 }
 
+// The same curve as hilbert15() as a state machine, one octant (3 bits) per level: entry
+// [state * 8 + octant] = next state << 3 | digit; 24 orientations (derived from, and verified
+// against, Skilling's mapping over all 32768 cells).  ~6 ALU ops + one LDS byte per level
+// instead of ~30.
+__constant__ unsigned char kHilbertLut[192] = {32, 9, 147, 2, 103, 118, 44, 5, 40, 1, 111, 126, 155, 10, 36, 13, 8, 163, 33, 18, 119, 28, 102, 21, 0, 171, 127, 20, 41, 26, 110, 29, 24, 135, 17, 142, 179, 12, 34, 37, 16, 143, 187, 4, 25, 134, 42, 45, 50, 153, 59, 176, 53, 94, 132, 79, 58, 145, 61, 86, 51, 184, 140, 71, 66, 83, 177, 152, 69, 108, 78, 95, 74, 91, 77, 100, 185, 144, 70, 87, 82, 85, 161, 62, 67, 124, 168, 55, 90, 93, 75, 116, 169, 54, 160, 63, 76, 115, 101, 98, 167, 56, 22, 137, 68, 123, 175, 48, 109, 106, 30, 129, 92, 117, 99, 114, 151, 6, 80, 121, 84, 125, 159, 14, 107, 122, 88, 113, 52, 191, 139, 64, 133, 46, 130, 105, 60, 183, 141, 38, 131, 72, 138, 97, 166, 57, 149, 146, 23, 136, 188, 3, 174, 49, 31, 128, 157, 154, 180, 11, 150, 165, 81, 162, 7, 172, 120, 19, 158, 173, 15, 164, 89, 170, 112, 27, 190, 47, 65, 104, 181, 156, 178, 35, 182, 39, 189, 148, 73, 96, 186, 43};
+
+__device__ __forceinline__ unsigned spread5(unsigned v) {  // bit b -> bit 3b
+    v = (v | (v << 8)) & 0x100Fu;
+    v = (v | (v << 4)) & 0x10C3u;
+    v = (v | (v << 2)) & 0x1249u;
+    return v;
+}
+
+// inclusive prefix sum over the wave in 6 DPP steps (row shifts, then the two row broadcasts)
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+#define RFP_ROW(OP, N) asm volatile("s_nop 1\n\t" OP " %0, %0, %0 row_ror:" #N " row_mask:0xf bank_mask:0xf" : "+v"(v))
+__device__ __forceinline__ float wave_min_f32(float v) {  // uniform result; inputs not NaN
+    RFP_ROW("v_min_f32_dpp", 8);
+    RFP_ROW("v_min_f32_dpp", 4);
+    RFP_ROW("v_min_f32_dpp", 2);
+    RFP_ROW("v_min_f32_dpp", 1);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fminf(fminf(r0, r1), fminf(r2, r3));
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+    RFP_ROW("v_max_f32_dpp", 8);
+    RFP_ROW("v_max_f32_dpp", 4);
+    RFP_ROW("v_max_f32_dpp", 2);
+    RFP_ROW("v_max_f32_dpp", 1);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+#undef RFP_ROW
+
+constexpr int HALF = 8192;  // records staged in LDS at a time (4 arrays x 32 KiB over the dead histogram)
+
+// Clouds of up to RPT * STPB = 16384 points: the points are loaded ONCE into registers; every
+// later phase is LDS and ALU work.  The sorted records are staged in LDS (over the histogram,
+// dead once every point has its position), 8192 at a time, so that the boxes come from LDS and
+// the arrays leave the CU as coalesced stores (a direct scatter is 4 x 16384 single-dword stores).
+__global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned hist[NBINS];
+    __shared__ unsigned ahist[3][HB];
+    __shared__ unsigned short cellmap[3][HB];  // equalised cell, already bit-spread and shifted per axis
+    __shared__ unsigned char hlut[192];
+    __shared__ float red[STPB / 64][6];
+    __shared__ unsigned wsum[STPB / 64];
+    __shared__ float frame[6];  // lo[3], scale[3]
+
+    const int set = (int)blockIdx.x >= a.b;
+    const int bi = blockIdx.x - (set ? a.b : 0);
+    const int n = a.n[set], npad = a.npad[set];
+    const float *__restrict__ src = a.src[set] + (size_t)bi * n * 3;
+    float *__restrict__ oxyz = a.xyz[set] + (size_t)bi * npad * 3;
+    int *__restrict__ oorig = a.orig[set] + (size_t)bi * npad;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    float px[RPT], py[RPT], pz[RPT];
+    unsigned pk[RPT];  // key, then position
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+        const int i = tid + k * STPB;
+        px[k] = py[k] = pz[k] = 0.f;
+        if (i < n) {
+            px[k] = src[(size_t)i * 3 + 0];
+            py[k] = src[(size_t)i * 3 + 1];
+            pz[k] = src[(size_t)i * 3 + 2];
+        }
+    }
+    {
+        uint4 *h4 = (uint4 *)hist;
+#pragma unroll
+        for (int k = 0; k < NBINS / 4 / STPB; k++) h4[tid + k * STPB] = make_uint4(0, 0, 0, 0);
+    }
+    if (tid < 3 * HB) (&ahist[0][0])[tid] = 0;
+    if (tid < 192) hlut[tid] = kHilbertLut[tid];
+
+    // 1. bounding box of the finite coordinates
+    {
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+            if (tid + k * STPB < n) {
+                const float v[3] = {px[k], py[k], pz[k]};
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    if (isfinite(v[c])) {
+                        lo[c] = fminf(lo[c], v[c]);
+                        hi[c] = fmaxf(hi[c], v[c]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            lo[c] = wave_min_f32(lo[c]);
+            hi[c] = wave_max_f32(hi[c]);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                red[wave][c] = lo[c];
+                red[wave][3 + c] = hi[c];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 3) {
+        float l = INFINITY, h = -INFINITY;
+        for (int w = 0; w < STPB / 64; w++) {
+            l = fminf(l, red[w][tid]);
+            h = fmaxf(h, red[w][3 + tid]);
+        }
+        const float ext = h - l;
+        const bool ok = isfinite(ext) && ext > 0.f;
+        frame[tid] = ok ? l : 0.f;
+        frame[3 + tid] = ok ? (float)HB / ext : 0.f;
+    }
+    __syncthreads();
+    const float fl[3] = {frame[0], frame[1], frame[2]};
+    const float fs[3] = {frame[3], frame[4], frame[5]};
+
+    // 2. per-axis histograms of a quarter of the points (every 4th, staggered over the threads:
+    // the cells only need approximate quantiles, and same-address LDS atomics serialise)
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+        if (tid + k * STPB < n && ((k + tid) & 3) == 0) {
+            atomicAdd(&ahist[0][axis_bin(px[k], fl[0], fs[0])], 1u);
+            atomicAdd(&ahist[1][axis_bin(py[k], fl[1], fs[1])], 1u);
+            atomicAdd(&ahist[2][axis_bin(pz[k], fl[2], fs[2])], 1u);
+        }
+    }
+    __syncthreads();
+    if (wave < 3) {
+        unsigned c4[4], s = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            c4[k] = ahist[wave][lane * 4 + k];
+            s += c4[k];
+        }
+        const unsigned incl = wave_incl_scan(s);
+        const unsigned total = max((unsigned)__builtin_amdgcn_readlane((int)incl, 63), 1u);
+        unsigned run = incl - s;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            // cell of a bin = the 1/32-quantile its first sample falls into
+            unsigned cell = (unsigned)(((unsigned long long)run * 32u) / total);
+            cell = cell > 31u ? 31u : cell;
+            cellmap[wave][lane * 4 + k] = (unsigned short)(spread5(cell) << (2 - wave));
+            run += c4[k];
+        }
+    }
+    __syncthreads();
+
+    // 3. keys and their histogram
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+        if (tid + k * STPB < n) {
+            const unsigned m = (unsigned)cellmap[0][axis_bin(px[k], fl[0], fs[0])] |
+                               (unsigned)cellmap[1][axis_bin(py[k], fl[1], fs[1])] |
+                               (unsigned)cellmap[2][axis_bin(pz[k], fl[2], fs[2])];
+            unsigned st = 0, key = 0;
+#pragma unroll
+            for (int l = 4; l >= 0; l--) {
+                const unsigned e = hlut[st * 8 + ((m >> (3 * l)) & 7u)];
+                key = (key << 3) | (e & 7u);
+                st = e >> 3;
+            }
+            pk[k] = key;
+            atomicAdd(&hist[key], 1u);
+        }
+    }
+    __syncthreads();
+
+    // 4. exclusive scan of the 32768 bins: each wave owns 2048 consecutive bins, 8 steps of 256
+    // (4 per lane, one ds_read_b128: consecutive lanes on consecutive banks)
+    {
+        constexpr int STEPS = NBINS / (STPB / 64) / 256;  // 8
+        uint4 *h4 = (uint4 *)hist + (size_t)wave * (NBINS / (STPB / 64) / 4);
+        uint4 v[STEPS];
+        unsigned tot = 0;
+#pragma unroll
+        for (int it = 0; it < STEPS; it++) {
+            v[it] = h4[it * 64 + lane];
+            tot += v[it].x + v[it].y + v[it].z + v[it].w;
+        }
+        tot = wave_incl_scan(tot);
+        if (lane == 63) wsum[wave] = tot;
+        __syncthreads();
+        unsigned carry = 0;
+        for (int w = 0; w < wave; w++) carry += wsum[w];
+#pragma unroll
+        for (int it = 0; it < STEPS; it++) {
+            const unsigned sm = v[it].x + v[it].y + v[it].z + v[it].w;
+            const unsigned incl = wave_incl_scan(sm);
+            uint4 out;
+            out.x = carry + incl - sm;
+            out.y = out.x + v[it].x;
+            out.z = out.y + v[it].y;
+            out.w = out.z + v[it].z;
+            h4[it * 64 + lane] = out;
+            carry += (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+    }
+    __syncthreads();
+
+    // 5. positions (the order inside a key is whatever the atomics give: results do not depend on it)
+#pragma unroll
+    for (int k = 0; k < RPT; k++)
+        if (tid + k * STPB < n) pk[k] = atomicAdd(&hist[pk[k]], 1u);
+    __syncthreads();  // the histogram is dead from here on
+
+    // 6. per half of 8192 records: stage in LDS, boxes from LDS, coalesced write-out
+    float *sx = (float *)hist, *sy = sx + HALF, *sz = sy + HALF;
+    int *so = (int *)(sz + HALF);
+    float *__restrict__ b16 = a.box16[set] + (size_t)bi * (npad / SB) * B16F;
+    float *__restrict__ b64 = a.box64[set] + (size_t)bi * (npad / SB) * B64F;
+    for (int h0 = 0; h0 < npad; h0 += HALF) {
+        const int cnt = min(HALF, npad - h0);  // multiple of 64
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+            const int i = tid + k * STPB;
+            const int p = (int)pk[k] - h0;
+            if (i < n && p >= 0 && p < HALF) {
+                sx[p] = px[k];
+                sy[p] = py[k];
+                sz[p] = pz[k];
+                so[p] = i;
+            }
+        }
+        for (int p = n - h0 + tid; p < cnt; p += STPB) {  // padding records live at positions >= n
+            if (p >= 0) {
+                sx[p] = sy[p] = sz[p] = INFINITY;
+                so[p] = -1;
+            }
+        }
+        __syncthreads();
+        // boxes: one thread per 16-record block, a quad of lanes per superblock (cnt/16 is a
+        // multiple of 4: quads are complete and inside one wave).  Record (u + t) % 16 at step u:
+        // lanes t and t+16 share a bank, 4-way instead of 64-way conflicts.
+        if (tid < cnt / BS) {
+            float l[3] = {INFINITY, INFINITY, INFINITY}, hh[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll 4
+            for (int u = 0; u < BS; u++) {
+                const int r = tid * BS + ((u + tid) & (BS - 1));
+                if (h0 + r < n) {  // padding excluded; NaN coordinates drop out of fminf/fmaxf
+                    l[0] = fminf(l[0], sx[r]); hh[0] = fmaxf(hh[0], sx[r]);
+                    l[1] = fminf(l[1], sy[r]); hh[1] = fmaxf(hh[1], sy[r]);
+                    l[2] = fminf(l[2], sz[r]); hh[2] = fmaxf(hh[2], sz[r]);
+                }
+            }
+            const int gblk = h0 / BS + tid;
+            float *o = b16 + (size_t)(gblk >> 2) * B16F + (gblk & 3) * 6;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                o[c] = l[c];
+                o[3 + c] = hh[c];
+            }
+#pragma unroll
+            for (int x = 1; x <= 2; x <<= 1) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    l[c] = fminf(l[c], __shfl_xor(l[c], x, 64));
+                    hh[c] = fmaxf(hh[c], __shfl_xor(hh[c], x, 64));
+                }
+            }
+            if ((gblk & 3) == 0) {
+                float *o64 = b64 + (size_t)(gblk >> 2) * B64F;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    o64[c] = l[c];
+                    o64[4 + c] = hh[c];
+                }
+                o64[3] = o64[7] = 0.f;
+            }
+        }
+        for (int j = tid; j < cnt * 3; j += STPB) {
+            const int r = j / 3, c = j - r * 3;
+            oxyz[(size_t)h0 * 3 + j] = c == 0 ? sx[r] : (c == 1 ? sy[r] : sz[r]);
+        }
+        for (int j = tid; j < cnt; j += STPB) oorig[h0 + j] = so[j];
+        __syncthreads();
+    }
+}
+
+// REG: the cloud (n <= RPT * STPB points) is loaded once into registers -- every later phase is
+// LDS and ALU work only; otherwise each phase re-reads the points (L2-resident) from `src`.
+template <bool REG>
 __global__ __launch_bounds__(STPB) void nnp_sort_kernel(SortArgs a) {
-    __shared__ unsigned hist[NBINS];
+    __shared__ __attribute__((aligned(16))) unsigned hist[NBINS];
     __shared__ unsigned ahist[3][HB];
     __shared__ unsigned char cellmap[3][HB];
     __shared__ float red[STPB / 64][6];
@@ -116,24 +430,52 @@ __global__ __launch_bounds__(STPB) void nnp_sort_kernel(SortArgs a) {
     const int bi = blockIdx.x - (set ? a.b : 0);
     const int n = a.n[set], npad = a.npad[set];
     const float *__restrict__ src = a.src[set] + (size_t)bi * n * 3;
-    float4 *__restrict__ out = a.sorted[set] + (size_t)bi * npad;
+    float *__restrict__ oxyz = a.xyz[set] + (size_t)bi * npad * 3;
+    int *__restrict__ oorig = a.orig[set] + (size_t)bi * npad;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    float px[REG ? RPT : 1], py[REG ? RPT : 1], pz[REG ? RPT : 1];
+    unsigned pkey[REG ? RPT : 1];
+    if constexpr (REG) {
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+            const int i = tid + k * STPB;
+            px[k] = py[k] = pz[k] = 0.f;
+            if (i < n) {
+                px[k] = src[(size_t)i * 3 + 0];
+                py[k] = src[(size_t)i * 3 + 1];
+                pz[k] = src[(size_t)i * 3 + 2];
+            }
+        }
+    }
+    // f(k, i, x, y, z) for every point of this thread; k indexes the register copy (REG only)
+    auto for_points = [&](auto f) {
+        if constexpr (REG) {
+#pragma unroll
+            for (int k = 0; k < RPT; k++) {
+                const int i = tid + k * STPB;
+                if (i < n) f(k, i, px[k], py[k], pz[k]);
+            }
+        } else {
+            for (int i = tid; i < n; i += STPB) f(0, i, src[(size_t)i * 3 + 0], src[(size_t)i * 3 + 1], src[(size_t)i * 3 + 2]);
+        }
+    };
 
     for (int i = tid; i < NBINS; i += STPB) hist[i] = 0;
     if (tid < 3 * HB) (&ahist[0][0])[tid] = 0;
 
     // 1. bounding box of the finite coordinates
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = tid; i < n; i += STPB) {
+    for_points([&](int, int, float x, float y, float z) {
+        const float v[3] = {x, y, z};
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const float v = src[(size_t)i * 3 + c];
-            if (isfinite(v)) {
-                lo[c] = fminf(lo[c], v);
-                hi[c] = fmaxf(hi[c], v);
+            if (isfinite(v[c])) {
+                lo[c] = fminf(lo[c], v[c]);
+                hi[c] = fmaxf(hi[c], v[c]);
             }
         }
-    }
+    });
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
 #pragma unroll
@@ -165,11 +507,14 @@ __global__ __launch_bounds__(STPB) void nnp_sort_kernel(SortArgs a) {
     const float fl[3] = {frame[0], frame[1], frame[2]};
     const float fs[3] = {frame[3], frame[4], frame[5]};
 
-    // 2. per-axis histograms -> equal-population cells
-    for (int i = tid; i < n; i += STPB) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) atomicAdd(&ahist[c][axis_bin(src[(size_t)i * 3 + c], fl[c], fs[c])], 1u);
-    }
+    // 2. per-axis histograms of a quarter of the points (every 4th, staggered over the threads:
+    // the cells only need approximate quantiles, and same-address LDS atomics serialise)
+    for_points([&](int, int i, float x, float y, float z) {
+        if ((((unsigned)i >> 10) + (unsigned)i) & 3u) return;
+        atomicAdd(&ahist[0][axis_bin(x, fl[0], fs[0])], 1u);
+        atomicAdd(&ahist[1][axis_bin(y, fl[1], fs[1])], 1u);
+        atomicAdd(&ahist[2][axis_bin(z, fl[2], fs[2])], 1u);
+    });
     __syncthreads();
     if (wave < 3) {
         unsigned c4[4], s = 0;
@@ -184,93 +529,133 @@ __global__ __launch_bounds__(STPB) void nnp_sort_kernel(SortArgs a) {
             const unsigned v = __shfl_up(incl, o, 64);
             if (lane >= o) incl += v;
         }
+        const unsigned total = max(__shfl(incl, 63, 64), 1u);
         unsigned run = incl - s;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            // cell of a bin = the 1/32-quantile its first point falls into
-            const unsigned cell = (unsigned)(((unsigned long long)run * 32u) / (unsigned)n);
+            // cell of a bin = the 1/32-quantile its first sample falls into
+            const unsigned cell = (unsigned)(((unsigned long long)run * 32u) / total);
             cellmap[wave][lane * 4 + k] = (unsigned char)(cell > 31u ? 31u : cell);
             run += c4[k];
         }
     }
     __syncthreads();
 
-    auto key_of = [&](int i) {
-        const unsigned cx = cellmap[0][axis_bin(src[(size_t)i * 3 + 0], fl[0], fs[0])];
-        const unsigned cy = cellmap[1][axis_bin(src[(size_t)i * 3 + 1], fl[1], fs[1])];
-        const unsigned cz = cellmap[2][axis_bin(src[(size_t)i * 3 + 2], fl[2], fs[2])];
+    auto key_of = [&](float x, float y, float z) {
+        const unsigned cx = cellmap[0][axis_bin(x, fl[0], fs[0])];
+        const unsigned cy = cellmap[1][axis_bin(y, fl[1], fs[1])];
+        const unsigned cz = cellmap[2][axis_bin(z, fl[2], fs[2])];
         return hilbert15(cx, cy, cz);
     };
 
     // 3. key histogram
-    for (int i = tid; i < n; i += STPB) atomicAdd(&hist[key_of(i)], 1u);
+    for_points([&](int k, int, float x, float y, float z) {
+        const unsigned key = key_of(x, y, z);
+        if constexpr (REG) pkey[k] = key;
+        atomicAdd(&hist[key], 1u);
+    });
     __syncthreads();
 
-    // 4. exclusive scan of the 32768 bins: 32 consecutive bins per thread
+    // 4. exclusive scan of the 32768 bins.  Each wave owns 2048 consecutive bins and walks them in
+    // 8 steps of 256 (4 per lane, one ds_read_b128: consecutive lanes, consecutive banks -- a
+    // thread-per-32-bins layout would put all 64 lanes on two banks).
     {
-        constexpr int PER = NBINS / STPB;
-        unsigned s = 0;
-#pragma unroll 8
-        for (int k = 0; k < PER; k++) s += hist[tid * PER + k];
-        unsigned incl = s;
+        constexpr int STEPS = NBINS / STPB / 4 * 0 + (NBINS / (STPB / 64) / 256);  // 8
+        uint4 *h4 = (uint4 *)hist + (size_t)wave * (NBINS / (STPB / 64) / 4);
+        unsigned tot = 0;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned v = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += v;
+        for (int it = 0; it < STEPS; it++) {
+            const uint4 v = h4[it * 64 + lane];
+            tot += v.x + v.y + v.z + v.w;
         }
-        if (lane == 63) wsum[wave] = incl;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+        if (lane == 0) wsum[wave] = tot;
         __syncthreads();
-        unsigned base = 0;
-        for (int w = 0; w < wave; w++) base += wsum[w];
-        unsigned run = base + incl - s;
-#pragma unroll 8
-        for (int k = 0; k < PER; k++) {
-            const unsigned c = hist[tid * PER + k];
-            hist[tid * PER + k] = run;
-            run += c;
+        unsigned carry = 0;
+        for (int w = 0; w < wave; w++) carry += wsum[w];
+#pragma unroll
+        for (int it = 0; it < STEPS; it++) {
+            const uint4 v = h4[it * 64 + lane];
+            const unsigned sm = v.x + v.y + v.z + v.w;
+            unsigned incl = sm;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned t = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            uint4 out;
+            out.x = carry + incl - sm;
+            out.y = out.x + v.x;
+            out.z = out.y + v.y;
+            out.w = out.z + v.z;
+            h4[it * 64 + lane] = out;
+            carry += __shfl(incl, 63, 64);
         }
     }
     __syncthreads();
 
     // 5. scatter (the order inside a key is whatever the atomics give: results do not depend on it)
-    for (int i = tid; i < n; i += STPB) {
-        const unsigned pos = atomicAdd(&hist[key_of(i)], 1u);
-        out[pos] = make_float4(src[(size_t)i * 3 + 0], src[(size_t)i * 3 + 1], src[(size_t)i * 3 + 2],
-                               __int_as_float(i));
+    for_points([&](int k, int i, float x, float y, float z) {
+        unsigned key;
+        if constexpr (REG) key = pkey[k];
+        else key = key_of(x, y, z);
+        const unsigned pos = atomicAdd(&hist[key], 1u);
+        oxyz[(size_t)pos * 3 + 0] = x;
+        oxyz[(size_t)pos * 3 + 1] = y;
+        oxyz[(size_t)pos * 3 + 2] = z;
+        oorig[pos] = i;
+    });
+    for (int i = n + tid; i < npad; i += STPB) {
+        oxyz[(size_t)i * 3 + 0] = INFINITY;
+        oxyz[(size_t)i * 3 + 1] = INFINITY;
+        oxyz[(size_t)i * 3 + 2] = INFINITY;
+        oorig[i] = -1;
     }
-    for (int i = n + tid; i < npad; i += STPB) out[i] = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(-1));
-    __threadfence();
+    // (the barrier's workgroup-scope release/acquire is enough: the records are re-read by this
+    // workgroup only; an agent-scope __threadfence() here writes back the whole L2 -- 40 us)
     __syncthreads();
 
-    // 6. boxes of the 16-record blocks and the 64-record superblocks (padding and NaN excluded)
-    float4 *__restrict__ b16 = a.box16[set] + (size_t)bi * (npad / BS) * 2;
-    float4 *__restrict__ b64 = a.box64[set] + (size_t)bi * (npad / SB) * 2;
-    // a quad of lanes per superblock, one block each; quads stay inside a wave
+    // 6. boxes of the 16-record blocks and the 64-record superblocks (padding and NaN excluded):
+    // a quad of lanes per superblock, one block each (npad/16 and STPB are multiples of 4, so a
+    // quad is always complete and inside one wave)
+    float *__restrict__ b16 = a.box16[set] + (size_t)bi * (npad / SB) * B16F;
+    float *__restrict__ b64 = a.box64[set] + (size_t)bi * (npad / SB) * B64F;
     for (int blk = tid; blk < npad / BS; blk += STPB) {
         float l[3] = {INFINITY, INFINITY, INFINITY}, h[3] = {-INFINITY, -INFINITY, -INFINITY};
-        const float4 *p = out + (size_t)blk * BS;
+        const float *p = oxyz + (size_t)blk * BS * 3;
+        const int *po = oorig + (size_t)blk * BS;
         for (int u = 0; u < BS; u++) {
-            const float4 r = p[u];
-            if (__float_as_int(r.w) >= 0) {
-                l[0] = fminf(l[0], r.x); h[0] = fmaxf(h[0], r.x);
-                l[1] = fminf(l[1], r.y); h[1] = fmaxf(h[1], r.y);
-                l[2] = fminf(l[2], r.z); h[2] = fmaxf(h[2], r.z);
+            if (po[u] >= 0) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    l[c] = fminf(l[c], p[u * 3 + c]);
+                    h[c] = fmaxf(h[c], p[u * 3 + c]);
+                }
             }
         }
-        b16[(size_t)blk * 2 + 0] = make_float4(l[0], l[1], l[2], 0.f);
-        b16[(size_t)blk * 2 + 1] = make_float4(h[0], h[1], h[2], 0.f);
-        // npad/BS is a multiple of 4 and STPB too, so all 4 lanes of a quad are in this iteration
+        float *o = b16 + (size_t)(blk >> 2) * B16F + (blk & 3) * 6;
 #pragma unroll
-        for (int o = 1; o <= 2; o <<= 1) {
+        for (int c = 0; c < 3; c++) {
+            o[c] = l[c];
+            o[3 + c] = h[c];
+        }
+#pragma unroll
+        for (int x = 1; x <= 2; x <<= 1) {
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                l[c] = fminf(l[c], __shfl_xor(l[c], o, 64));
-                h[c] = fmaxf(h[c], __shfl_xor(h[c], o, 64));
+                l[c] = fminf(l[c], __shfl_xor(l[c], x, 64));
+                h[c] = fmaxf(h[c], __shfl_xor(h[c], x, 64));
             }
         }
         if ((blk & 3) == 0) {
-            b64[(size_t)(blk >> 2) * 2 + 0] = make_float4(l[0], l[1], l[2], 0.f);
-            b64[(size_t)(blk >> 2) * 2 + 1] = make_float4(h[0], h[1], h[2], 0.f);
+            float *o64 = b64 + (size_t)(blk >> 2) * B64F;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                o64[c] = l[c];
+                o64[4 + c] = h[c];
+            }
+            o64[3] = o64[7] = 0.f;
         }
     }
 }
@@ -318,29 +703,41 @@ __device__ __forceinline__ float wave_max_nonneg(float f) {
 }
 #undef RFP_DPP
 
-// lower bound of d2 between point (qx,qy,qz) and the box [lo,hi], same instruction sequence as d2
-__device__ __forceinline__ float box_bound(float qx, float qy, float qz, const float4 lo, const float4 hi) {
-    const float gx = fmaxf(fmaxf(lo.x - qx, qx - hi.x), 0.f);
-    const float gy = fmaxf(fmaxf(lo.y - qy, qy - hi.y), 0.f);
-    const float gz = fmaxf(fmaxf(lo.z - qz, qz - hi.z), 0.f);
+// lower bound of d2 between point q and the box [lo,hi], same instruction sequence as d2
+__device__ __forceinline__ float box_bound(float qx, float qy, float qz, float lx, float ly, float lz, float hx,
+                                           float hy, float hz) {
+    const float gx = fmaxf(fmaxf(lx - qx, qx - hx), 0.f);
+    const float gy = fmaxf(fmaxf(ly - qy, qy - hy), 0.f);
+    const float gz = fmaxf(fmaxf(lz - qz, qz - hz), 0.f);
     return rf::d2_fma(gx, gy, gz);
 }
 // box to box: gap per axis between [alo,ahi] and [blo,bhi]
-__device__ __forceinline__ float boxbox_bound(const float4 alo, const float4 ahi, const float4 blo,
-                                              const float4 bhi) {
-    const float gx = fmaxf(fmaxf(blo.x - ahi.x, alo.x - bhi.x), 0.f);
-    const float gy = fmaxf(fmaxf(blo.y - ahi.y, alo.y - bhi.y), 0.f);
-    const float gz = fmaxf(fmaxf(blo.z - ahi.z, alo.z - bhi.z), 0.f);
+__device__ __forceinline__ float boxbox_bound(const float *alo, const float *ahi, const float4 blo, const float4 bhi) {
+    const float gx = fmaxf(fmaxf(blo.x - ahi[0], alo[0] - bhi.x), 0.f);
+    const float gy = fmaxf(fmaxf(blo.y - ahi[1], alo[1] - bhi.y), 0.f);
+    const float gz = fmaxf(fmaxf(blo.z - ahi[2], alo[2] - bhi.z), 0.f);
     return rf::d2_fma(gx, gy, gz);
+}
+
+// minimum of d2 over the 8 records r[0..23] (x,y,z packed), folded into cm
+__device__ __forceinline__ float scan8(const float (&r)[24], float qx, float qy, float qz, float cm) {
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+        const float d0 = rf::d2_fma(r[u * 3 + 0] - qx, r[u * 3 + 1] - qy, r[u * 3 + 2] - qz);
+        const float d1 = rf::d2_fma(r[u * 3 + 3] - qx, r[u * 3 + 4] - qy, r[u * 3 + 5] - qz);
+        cm = min3_acc(cm, d0, d1);
+    }
+    return cm;
 }
 
 // direction d: nearest neighbour of every point of set d among set 1-d -> dist_d, idx_d (b, n[d]).
 // stats (optional): [dir][4] = waves, superblock steps, block tests, block scans.
 __global__ __launch_bounds__(256) void nnp_sweep_kernel(
-    SweepArgs a, const float4 *__restrict__ sorted0, const float4 *__restrict__ sorted1,
-    const float4 *__restrict__ b16_0, const float4 *__restrict__ b16_1, const float4 *__restrict__ b64_0,
-    const float4 *__restrict__ b64_1, float *__restrict__ dist0, float *__restrict__ dist1,
-    int *__restrict__ idx0, int *__restrict__ idx1, unsigned long long *__restrict__ stats) {
+    SweepArgs a, const float *__restrict__ xyz0, const float *__restrict__ xyz1, const int *__restrict__ orig0,
+    const int *__restrict__ orig1, const float *__restrict__ b16_0, const float *__restrict__ b16_1,
+    const float *__restrict__ b64_0, const float *__restrict__ b64_1, float *__restrict__ dist0,
+    float *__restrict__ dist1, int *__restrict__ idx0, int *__restrict__ idx1,
+    unsigned long long *__restrict__ stats) {
     __shared__ unsigned keys[4][MAXSB];
     __shared__ int shbest[64];
     __shared__ float md[4][64];
@@ -359,17 +756,21 @@ __global__ __launch_bounds__(256) void nnp_sweep_kernel(
     if (gid >= a.b * G) return;  // only in the 1-wave-per-group shape (no barriers there)
     const int bi = gid / G, g = gid - bi * G;
 
-    const float4 *__restrict__ Q = (dir ? sorted1 : sorted0) + (size_t)bi * a.npad[dir];
-    const float4 *__restrict__ C = (dir ? sorted0 : sorted1) + (size_t)bi * a.npad[cd];
-    const float4 *__restrict__ CB16 = (dir ? b16_0 : b16_1) + (size_t)bi * (a.npad[cd] / BS) * 2;
-    const float4 *__restrict__ CB64 = (dir ? b64_0 : b64_1) + (size_t)bi * (a.npad[cd] / SB) * 2;
+    const float *__restrict__ Q = (dir ? xyz1 : xyz0) + (size_t)bi * a.npad[dir] * 3;
+    const int *__restrict__ Qo = (dir ? orig1 : orig0) + (size_t)bi * a.npad[dir];
+    const float *__restrict__ C = (dir ? xyz0 : xyz1) + (size_t)bi * a.npad[cd] * 3;
+    const int *__restrict__ Co = (dir ? orig0 : orig1) + (size_t)bi * a.npad[cd];
     const int nsb = a.npad[cd] / SB;
+    const float *__restrict__ CB16 = (dir ? b16_0 : b16_1) + (size_t)bi * nsb * B16F;
+    const float *__restrict__ CB64 = (dir ? b64_0 : b64_1) + (size_t)bi * nsb * B64F;
 
-    const float4 q = Q[(size_t)g * SB + lane];
-    const int qorig = __float_as_int(q.w);
+    const float qx = Q[(size_t)(g * SB + lane) * 3 + 0];
+    const float qy = Q[(size_t)(g * SB + lane) * 3 + 1];
+    const float qz = Q[(size_t)(g * SB + lane) * 3 + 2];
+    const int qorig = Qo[g * SB + lane];
     const bool valid = qorig >= 0;
-    const float4 *gb = (dir ? b64_1 : b64_0) + ((size_t)bi * G + g) * 2;  // uniform
-    const float4 glo = gb[0], ghi = gb[1];
+    const float *gb = (dir ? b64_1 : b64_0) + ((size_t)bi * G + g) * B64F;  // uniform
+    const float glo[3] = {gb[0], gb[1], gb[2]}, ghi[3] = {gb[4], gb[5], gb[6]};
 
     // lower bound group box <-> candidate superblock, truncated (downwards) into the high 22 bits
     // of a key whose low 10 bits are the superblock id: the wave minimum of the keys is the next
@@ -380,7 +781,8 @@ __global__ __launch_bounds__(256) void nnp_sweep_kernel(
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
     for (int e = lane; e < nmine; e += 64) {
         const int s = sub + nsub * e;
-        const float lb = boxbox_bound(glo, ghi, CB64[(size_t)s * 2], CB64[(size_t)s * 2 + 1]);
+        const float4 *cb = (const float4 *)(CB64 + (size_t)s * B64F);
+        const float lb = boxbox_bound(glo, ghi, cb[0], cb[1]);
         const unsigned key = (__float_as_uint(lb) & ~IDMASK) | (unsigned)s;
         keys[wib][e] = key;
         lmin = min(lmin, key);
@@ -394,7 +796,7 @@ __global__ __launch_bounds__(256) void nnp_sweep_kernel(
     int bblk = 0;
     bool tie = false;
     float cull = INFINITY;  // <= best: also what the other waves of the group have found
-    unsigned n_step = 0, n_test = 0, n_scan = 0;
+    unsigned n_step = 0, n_scan = 0;
 
     for (;;) {
         const unsigned kmin = wave_min_u32(lmin);
@@ -405,6 +807,13 @@ __global__ __launch_bounds__(256) void nnp_sweep_kernel(
         if (bound > worst) break;  // every remaining superblock is strictly farther than every lane's minimum
         const int s = (int)(kmin & IDMASK);
         const int e = (s - sub) / nsub;
+        // the 4 block boxes of this superblock: 24 SGPRs, in flight during the key-list upkeep
+        float bx[B16F];
+        {
+            const float *bp = CB16 + (size_t)s * B16F;  // uniform
+#pragma unroll
+            for (int i = 0; i < B16F; i++) bx[i] = bp[i];
+        }
         if (lane == (e & 63)) {
             keys[wib][e] = 0xFFFFFFFFu;
             lmin = 0xFFFFFFFFu;
@@ -412,22 +821,51 @@ __global__ __launch_bounds__(256) void nnp_sweep_kernel(
             for (int ee = lane; ee < nmine; ee += 64) lmin = min(lmin, keys[wib][ee]);
         }
         n_step++;
-#pragma unroll 1
-        for (int j = 0; j < SBB; j++) {
-            const int blk = s * SBB + j;
-            const float lb = box_bound(q.x, q.y, q.z, CB16[(size_t)blk * 2], CB16[(size_t)blk * 2 + 1]);
-            n_test++;
-            if (__ballot(valid && lb <= cull) == 0ull) continue;
-            n_scan++;
-            const float4 *cp = C + (size_t)blk * BS;  // uniform: scalar loads
-            float cm = INFINITY;
+        unsigned need = 0;
 #pragma unroll
-            for (int u = 0; u < BS; u += 2) {
-                const float4 c0 = cp[u], c1 = cp[u + 1];
-                const float d0 = rf::d2_fma(c0.x - q.x, c0.y - q.y, c0.z - q.z);
-                const float d1 = rf::d2_fma(c1.x - q.x, c1.y - q.y, c1.z - q.z);
-                cm = min3_acc(cm, d0, d1);
+        for (int j = 0; j < SBB; j++) {
+            const float lb = box_bound(qx, qy, qz, bx[j * 6 + 0], bx[j * 6 + 1], bx[j * 6 + 2], bx[j * 6 + 3],
+                                       bx[j * 6 + 4], bx[j * 6 + 5]);
+            if (__ballot(valid && lb <= cull) != 0ull) need |= 1u << j;
+        }
+        if (need == 0) continue;
+        // Surviving blocks: 16 records = two halves of 8 (24 SGPRs each), ping-pong: while one half
+        // is being evaluated the next one -- of this block or of the next surviving block -- is in
+        // flight.  Scalar loads return out of order, so every wait is lgkmcnt(0), placed BEFORE
+        // the next issue (as in nn_sweep_kernel).
+        float ra[24], rb[24];
+        int j = __builtin_ctz(need);
+        need &= need - 1;
+        {
+            const float *cp = C + (size_t)(s * SBB + j) * BS * 3;
+#pragma unroll
+            for (int i = 0; i < 24; i++) ra[i] = cp[i];
+        }
+        for (;;) {
+            const int blk = s * SBB + j;
+            n_scan++;
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const float *cp = C + (size_t)blk * BS * 3 + 24;
+#pragma unroll
+                for (int i = 0; i < 24; i++) rb[i] = cp[i];
             }
+            __builtin_amdgcn_sched_barrier(0);
+            float cm = scan8(ra, qx, qy, qz, INFINITY);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_sched_barrier(0);
+            const bool more = need != 0;
+            if (more) {
+                j = __builtin_ctz(need);
+                need &= need - 1;
+                const float *cp = C + (size_t)(s * SBB + j) * BS * 3;
+#pragma unroll
+                for (int i = 0; i < 24; i++) ra[i] = cp[i];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            cm = scan8(rb, qx, qy, qz, cm);
             if (cm < best) {
                 best = cm;
                 bblk = blk;
@@ -435,6 +873,7 @@ __global__ __launch_bounds__(256) void nnp_sweep_kernel(
             } else if (cm == best) {
                 tie = true;
             }
+            if (!more) break;
         }
         cull = fminf(cull, best);
         if (shared4) atomicMin(&shbest[lane], __float_as_int(cull));
@@ -443,12 +882,12 @@ __global__ __launch_bounds__(256) void nnp_sweep_kernel(
     // lowest original index among the exact matches of the winning block
     unsigned besti = 0xFFFFFFFFu;
     {
-        const float4 *cp = C + (size_t)bblk * BS;  // per lane
+        const float *cp = C + (size_t)bblk * BS * 3;  // per lane
+        const int *co = Co + (size_t)bblk * BS;
 #pragma unroll 4
         for (int u = 0; u < BS; u++) {
-            const float4 c = cp[u];
-            const float d = rf::d2_fma(c.x - q.x, c.y - q.y, c.z - q.z);
-            if (d == best) besti = min(besti, __float_as_uint(c.w));  // padding carries 0xFFFFFFFF
+            const float d = rf::d2_fma(cp[u * 3 + 0] - qx, cp[u * 3 + 1] - qy, cp[u * 3 + 2] - qz);
+            if (d == best) besti = min(besti, (unsigned)co[u]);  // padding carries 0xFFFFFFFF
         }
     }
     // queries whose minimum was attained in more than one visited block: exact re-scan, one query
@@ -457,22 +896,25 @@ __global__ __launch_bounds__(256) void nnp_sweep_kernel(
     while (tm) {
         const int L = __builtin_ctzll(tm);
         tm &= tm - 1;
-        const float qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.x), L));
-        const float qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.y), L));
-        const float qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.z), L));
+        const float tx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx), L));
+        const float ty = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy), L));
+        const float tz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz), L));
         const float bL = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best), L));
         unsigned cand = 0xFFFFFFFFu;
         for (int s0 = 0; s0 < nsb; s0 += 64) {
             const int s = s0 + lane;
             bool need = false;
-            if (s < nsb) need = box_bound(qx, qy, qz, CB64[(size_t)s * 2], CB64[(size_t)s * 2 + 1]) <= bL;
+            if (s < nsb) {
+                const float *cb = CB64 + (size_t)s * B64F;
+                need = box_bound(tx, ty, tz, cb[0], cb[1], cb[2], cb[4], cb[5], cb[6]) <= bL;
+            }
             unsigned long long m2 = __ballot(need);
             while (m2) {
                 const int k = __builtin_ctzll(m2);
                 m2 &= m2 - 1;
-                const float4 c = C[(size_t)(s0 + k) * SB + lane];
-                const float d = rf::d2_fma(c.x - qx, c.y - qy, c.z - qz);
-                if (d == bL) cand = min(cand, __float_as_uint(c.w));
+                const size_t r = (size_t)(s0 + k) * SB + lane;
+                const float d = rf::d2_fma(C[r * 3 + 0] - tx, C[r * 3 + 1] - ty, C[r * 3 + 2] - tz);
+                if (d == bL) cand = min(cand, (unsigned)Co[r]);
             }
         }
         cand = wave_min_u32(cand);
@@ -482,7 +924,7 @@ __global__ __launch_bounds__(256) void nnp_sweep_kernel(
     if (stats && lane == 0) {
         atomicAdd(&stats[dir * 4 + 0], 1ull);
         atomicAdd(&stats[dir * 4 + 1], (unsigned long long)n_step);
-        atomicAdd(&stats[dir * 4 + 2], (unsigned long long)n_test);
+        atomicAdd(&stats[dir * 4 + 2], (unsigned long long)n_step * SBB);
         atomicAdd(&stats[dir * 4 + 3], (unsigned long long)n_scan);
     }
 
@@ -511,7 +953,7 @@ int round_up(long v, int q) { return (int)((v + q - 1) / q * q); }
 
 struct PPlan {
     int npad[2];
-    size_t off_sorted[2], off_b16[2], off_b64[2], off_stats, bytes;
+    size_t off_xyz[2], off_orig[2], off_b16[2], off_b64[2], off_stats, bytes;
 };
 
 PPlan make_pplan(int b, int n, int m) {
@@ -525,9 +967,10 @@ PPlan make_pplan(int b, int n, int m) {
     };
     for (int s = 0; s < 2; s++) {
         p.npad[s] = round_up(nn[s], SB);
-        p.off_sorted[s] = take((size_t)b * p.npad[s] * sizeof(float4));
-        p.off_b16[s] = take((size_t)b * (p.npad[s] / BS) * 2 * sizeof(float4));
-        p.off_b64[s] = take((size_t)b * (p.npad[s] / SB) * 2 * sizeof(float4));
+        p.off_xyz[s] = take((size_t)b * p.npad[s] * 3 * sizeof(float) + 256);  // + prefetch overrun
+        p.off_orig[s] = take((size_t)b * p.npad[s] * sizeof(int));
+        p.off_b16[s] = take((size_t)b * (p.npad[s] / SB) * B16F * sizeof(float));
+        p.off_b64[s] = take((size_t)b * (p.npad[s] / SB) * B64F * sizeof(float));
     }
     p.off_stats = take(8 * sizeof(unsigned long long));
     p.bytes = off;
@@ -563,9 +1006,10 @@ int pruned_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2
         sa.n[k] = wa.n[k] = nn[k];
         sa.npad[k] = wa.npad[k] = p.npad[k];
         sa.src[k] = src[k];
-        sa.sorted[k] = (float4 *)(w + p.off_sorted[k]);
-        sa.box16[k] = (float4 *)(w + p.off_b16[k]);
-        sa.box64[k] = (float4 *)(w + p.off_b64[k]);
+        sa.xyz[k] = (float *)(w + p.off_xyz[k]);
+        sa.orig[k] = (int *)(w + p.off_orig[k]);
+        sa.box16[k] = (float *)(w + p.off_b16[k]);
+        sa.box64[k] = (float *)(w + p.off_b64[k]);
         wa.groups[k] = p.npad[k] / SB;
         // a set with few groups cannot fill the chip with one wave per group: 4 waves share a group
         static const long split_below = getenv("RF_NNP_SPLIT") ? atol(getenv("RF_NNP_SPLIT")) : 4096;
@@ -576,14 +1020,18 @@ int pruned_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2
         stats = (unsigned long long *)(w + p.off_stats);
         RF_HIP(hipMemsetAsync(stats, 0, 8 * sizeof(unsigned long long), s));
     }
-    RF_LAUNCH("nnp_sort", nnp_sort_kernel, dim3(2 * b), dim3(STPB), 0, s, sa);
+    if (n <= RPT * STPB && m <= RPT * STPB) {
+        RF_LAUNCH("nnp_sort", nnp_sort_reg_kernel, dim3(2 * b), dim3(STPB), 0, s, sa);
+    } else {
+        RF_LAUNCH("nnp_sort", nnp_sort_kernel<false>, dim3(2 * b), dim3(STPB), 0, s, sa);
+    }
     const long g0 = (long)b * wa.groups[0], g1 = (long)b * wa.groups[1];
     wa.wg0 = wa.nw[0] == 4 ? (int)g0 : rf::ceil_div(g0, 4);
     const int wg1 = wa.nw[1] == 4 ? (int)g1 : rf::ceil_div(g1, 4);
-    RF_LAUNCH("nnp_sweep", nnp_sweep_kernel, dim3(wa.wg0 + wg1), dim3(256), 0, s, wa,
-              (const float4 *)sa.sorted[0], (const float4 *)sa.sorted[1], (const float4 *)sa.box16[0],
-              (const float4 *)sa.box16[1], (const float4 *)sa.box64[0], (const float4 *)sa.box64[1], dist1, dist2,
-              idx1, idx2, stats);
+    RF_LAUNCH("nnp_sweep", nnp_sweep_kernel, dim3(wa.wg0 + wg1), dim3(256), 0, s, wa, (const float *)sa.xyz[0],
+              (const float *)sa.xyz[1], (const int *)sa.orig[0], (const int *)sa.orig[1],
+              (const float *)sa.box16[0], (const float *)sa.box16[1], (const float *)sa.box64[0],
+              (const float *)sa.box64[1], dist1, dist2, idx1, idx2, stats);
     if (stats_out) {
         RF_HIP(hipMemcpyAsync(stats_out, stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         RF_HIP(hipStreamSynchronize(s));
