@@ -798,13 +798,44 @@ __global__ __launch_bounds__(256) void nnp_sweep_kernel(
     float cull = INFINITY;  // <= best: also what the other waves of the group have found
     unsigned n_step = 0, n_scan = 0;
 
+    int nact_ref = 64;  // active lanes when the keys were last (re)computed
     for (;;) {
-        const unsigned kmin = wave_min_u32(lmin);
+        unsigned kmin = wave_min_u32(lmin);
         if (kmin == 0xFFFFFFFFu) break;
         if (shared4) cull = fminf(cull, __int_as_float(shbest[lane]));
-        const float bound = __uint_as_float(kmin & ~IDMASK);
-        const float worst = wave_max_nonneg(valid ? cull : -INFINITY);
-        if (bound > worst) break;  // every remaining superblock is strictly farther than every lane's minimum
+        float bound = __uint_as_float(kmin & ~IDMASK);
+        // A lane whose minimum is below the bound of every remaining superblock is finished for
+        // good (the keys ascend).  The sweep ends when no lane is left ...
+        const unsigned long long act = __ballot(valid && cull >= bound);
+        if (act == 0ull) break;  // every remaining superblock is strictly farther than every lane's minimum
+        // ... and when half of the lanes have finished since the keys were computed, the box of
+        // the remaining lanes replaces the group box: a far outlier no longer keeps the bounds of
+        // all 64 queries loose (the heaviest waves were 6x the average, and they set the kernel's
+        // duration).  The new keys are bounds for the active lanes only, which is all that is left.
+        const int nact = __builtin_popcountll(act);
+        if (nact * 2 <= nact_ref) {
+            nact_ref = nact;
+            const bool on = (act >> lane) & 1ull;
+            const float alo[3] = {wave_min_f32(on ? qx : INFINITY), wave_min_f32(on ? qy : INFINITY),
+                                  wave_min_f32(on ? qz : INFINITY)};
+            const float ahi[3] = {wave_max_f32(on ? qx : -INFINITY), wave_max_f32(on ? qy : -INFINITY),
+                                  wave_max_f32(on ? qz : -INFINITY)};
+            lmin = 0xFFFFFFFFu;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+            for (int e = lane; e < nmine; e += 64) {
+                if (keys[wib][e] == 0xFFFFFFFFu) continue;  // consumed
+                const int s = sub + nsub * e;
+                const float4 *cb = (const float4 *)(CB64 + (size_t)s * B64F);
+                const float lb = boxbox_bound(alo, ahi, cb[0], cb[1]);
+                const unsigned key = (__float_as_uint(lb) & ~IDMASK) | (unsigned)s;
+                keys[wib][e] = key;
+                lmin = min(lmin, key);
+            }
+            kmin = wave_min_u32(lmin);
+            if (kmin == 0xFFFFFFFFu) break;
+            bound = __uint_as_float(kmin & ~IDMASK);
+            if (__ballot(valid && cull >= bound) == 0ull) break;
+        }
         const int s = (int)(kmin & IDMASK);
         const int e = (s - sub) / nsub;
         // the 4 block boxes of this superblock: 24 SGPRs, in flight during the key-list upkeep
@@ -924,8 +955,9 @@ __global__ __launch_bounds__(256) void nnp_sweep_kernel(
     if (stats && lane == 0) {
         atomicAdd(&stats[dir * 4 + 0], 1ull);
         atomicAdd(&stats[dir * 4 + 1], (unsigned long long)n_step);
-        atomicAdd(&stats[dir * 4 + 2], (unsigned long long)n_step * SBB);
+        atomicMax(&stats[dir * 4 + 2], (unsigned long long)n_step);
         atomicAdd(&stats[dir * 4 + 3], (unsigned long long)n_scan);
+        atomicMax(&stats[8 + dir], (unsigned long long)n_scan);
     }
 
     if (shared4) {
@@ -972,7 +1004,7 @@ PPlan make_pplan(int b, int n, int m) {
         p.off_b16[s] = take((size_t)b * (p.npad[s] / SB) * B16F * sizeof(float));
         p.off_b64[s] = take((size_t)b * (p.npad[s] / SB) * B64F * sizeof(float));
     }
-    p.off_stats = take(8 * sizeof(unsigned long long));
+    p.off_stats = take(16 * sizeof(unsigned long long));
     p.bytes = off;
     return p;
 }
@@ -1018,7 +1050,7 @@ int pruned_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2
     unsigned long long *stats = nullptr;
     if (stats_out) {
         stats = (unsigned long long *)(w + p.off_stats);
-        RF_HIP(hipMemsetAsync(stats, 0, 8 * sizeof(unsigned long long), s));
+        RF_HIP(hipMemsetAsync(stats, 0, 16 * sizeof(unsigned long long), s));
     }
     if (n <= RPT * STPB && m <= RPT * STPB) {
         RF_LAUNCH("nnp_sort", nnp_sort_reg_kernel, dim3(2 * b), dim3(STPB), 0, s, sa);
@@ -1033,7 +1065,7 @@ int pruned_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2
               (const float *)sa.box16[0], (const float *)sa.box16[1], (const float *)sa.box64[0],
               (const float *)sa.box64[1], dist1, dist2, idx1, idx2, stats);
     if (stats_out) {
-        RF_HIP(hipMemcpyAsync(stats_out, stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        RF_HIP(hipMemcpyAsync(stats_out, stats, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         RF_HIP(hipStreamSynchronize(s));
     }
     return RF_OK;

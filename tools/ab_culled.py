@@ -54,7 +54,7 @@ def main():
         print(f"{kind} b={b} n={n} m={m}: dense {td:.3f} ms  culled {tc:.3f} ms  ({td / tc:.2f}x)  kernels {prof}")
         for d, (q, k) in enumerate(((n, m), (m, n))):
             w, steps, tests, scans = st[4 * d:4 * d + 4]
-            print(f"    dir{d}: waves {w} steps/wave {steps / w:.1f} tests/wave {tests / w:.1f} scans/wave {scans / w:.1f}"
+            print(f"    dir{d}: waves {w} steps/wave {steps / w:.1f} (max {tests}) scans/wave {scans / w:.1f} (max {st[8 + d]})"
                   f"  pairs evaluated {scans * 16 * 64 / pairs * 100:.2f}% of b*n*m")
 
 
