@@ -574,11 +574,16 @@ Plan make_plan(int b, int n, int m) {
     return p;
 }
 
-// When the culled sweep (nn_pruned.hip) beats the dense one: its cost grows with n + m (times a
-// few hundred instructions per point) plus a fixed sort, the dense sweep's with n * m.
+// When the culled sweep (nn_pruned.hip) beats the dense one.  Its cost grows with b * (n + m) (a
+// few hundred instructions per point) plus a sort whose duration depends on the larger cloud
+// (13 us at 1024 points, 36 us at 16384: one workgroup per cloud); the dense sweep's with b*n*m at
+// ~5e12 pairs/s.  Measured on MI355X (tools/ab_culled.py, randn clouds): 32 x 1024^2 1.3x,
+// 32 x 4096^2 1.5x, 8 x 2048 x 16384 1.0x, 32 x 2048 x 16384 1.9x, 32 x 16384^2 6.7x.
 bool culled_pays(int b, int n, int m) {
-    const int lo = n < m ? n : m;
-    return rfp::pruned_supported(b, n, m) && lo >= 512 && (long)n * m >= (1L << 24);
+    const int lo = n < m ? n : m, hi = n < m ? m : n;
+    if (!rfp::pruned_supported(b, n, m) || lo < 512) return false;
+    const long pairs = (long)b * n * m;
+    return pairs >= (hi <= 4096 ? (1L << 25) : (1L << 28));
 }
 
 }  // namespace

@@ -55,7 +55,7 @@ constexpr int NBINS = 1 << KEYBITS;
 constexpr int STPB = 1024;         // sort kernel threads
 constexpr int RPT = 16;            // points per thread of the register-resident sort (n <= 16384)
 constexpr int HB = 256;            // equalisation histogram bins per axis
-constexpr int MAXSB = rfp::kMaxPoints / SB;  // 1024: superblock id fits the key's low 10 bits
+static_assert(rfp::kMaxPoints / SB <= 1024, "superblock id must fit the key low 10 bits");
 constexpr unsigned IDMASK = 0x3FFu;
 constexpr int B16F = SBB * 6;      // floats per superblock in box16: 4 x (lo.xyz, hi.xyz)
 constexpr int B64F = 8;            // floats per superblock in box64: lo.xyz, -, hi.xyz, -
@@ -671,6 +671,7 @@ struct SweepArgs {
     int groups[2];   // npad[d] / 64
     int nw[2];       // waves per query group: 1 or 4
     int wg0;         // workgroups of direction 0
+    int kstride;     // key-list entries per wave (dynamic LDS: waves * kstride * 4 bytes)
 };
 
 __device__ __forceinline__ float min3_acc(float acc, float a, float b) {
@@ -730,30 +731,22 @@ __device__ __forceinline__ float scan8(const float (&r)[24], float qx, float qy,
     return cm;
 }
 
-// direction d: nearest neighbour of every point of set d among set 1-d -> dist_d, idx_d (b, n[d]).
-// stats (optional): [dir][4] = waves, superblock steps, block tests, block scans.
-__global__ __launch_bounds__(256) void nnp_sweep_kernel(
-    SweepArgs a, const float *__restrict__ xyz0, const float *__restrict__ xyz1, const int *__restrict__ orig0,
-    const int *__restrict__ orig1, const float *__restrict__ b16_0, const float *__restrict__ b16_1,
-    const float *__restrict__ b64_0, const float *__restrict__ b64_1, float *__restrict__ dist0,
-    float *__restrict__ dist1, int *__restrict__ idx0, int *__restrict__ idx1,
+// One query group (64 sorted points of set `dir`, one per lane) against set 1-dir: nearest
+// neighbour of every point -> dist_dir, idx_dir (b, n[dir]).  SHARED4: the 4 waves of the
+// workgroup work on the same group, wave `wib` taking every 4th candidate superblock.
+// stats (optional): [dir][4] = waves, superblock steps, max steps of a wave, block scans; [8+dir] = max scans.
+template <bool SHARED4>
+__device__ __forceinline__ void sweep_group(
+    const SweepArgs &a, const int dir, const int gid, const int wib, const int lane, unsigned *__restrict__ keys_dyn,
+    int *shbest, float (*md)[64], unsigned (*mi)[64], const float *__restrict__ xyz0, const float *__restrict__ xyz1,
+    const int *__restrict__ orig0, const int *__restrict__ orig1, const float *__restrict__ b16_0,
+    const float *__restrict__ b16_1, const float *__restrict__ b64_0, const float *__restrict__ b64_1,
+    float *__restrict__ dist0, float *__restrict__ dist1, int *__restrict__ idx0, int *__restrict__ idx1,
     unsigned long long *__restrict__ stats) {
-    __shared__ unsigned keys[4][MAXSB];
-    __shared__ int shbest[64];
-    __shared__ float md[4][64];
-    __shared__ unsigned mi[4][64];
-
-    const int lane = threadIdx.x & 63;
-    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int wg = blockIdx.x;
-    const int dir = wg >= a.wg0;
-    if (dir) wg -= a.wg0;
     const int cd = 1 - dir;
-    const bool shared4 = a.nw[dir] == 4;
+    constexpr bool shared4 = SHARED4;
     const int G = a.groups[dir];
-    const int gid = shared4 ? wg : wg * 4 + wib;
     const int sub = shared4 ? wib : 0, nsub = shared4 ? 4 : 1;
-    if (gid >= a.b * G) return;  // only in the 1-wave-per-group shape (no barriers there)
     const int bi = gid / G, g = gid - bi * G;
 
     const float *__restrict__ Q = (dir ? xyz1 : xyz0) + (size_t)bi * a.npad[dir] * 3;
@@ -777,6 +770,7 @@ __global__ __launch_bounds__(256) void nnp_sweep_kernel(
     // superblock in ascending bound order.  Entry e of this wave's list is superblock sub + nsub*e;
     // lane e % 64 owns it (writes it, consumes it, keeps the minimum of its entries in `lmin`).
     const int nmine = (nsb - sub + nsub - 1) / nsub;
+    unsigned *__restrict__ keys = keys_dyn + (size_t)wib * a.kstride;
     unsigned lmin = 0xFFFFFFFFu;
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
     for (int e = lane; e < nmine; e += 64) {
@@ -784,7 +778,7 @@ __global__ __launch_bounds__(256) void nnp_sweep_kernel(
         const float4 *cb = (const float4 *)(CB64 + (size_t)s * B64F);
         const float lb = boxbox_bound(glo, ghi, cb[0], cb[1]);
         const unsigned key = (__float_as_uint(lb) & ~IDMASK) | (unsigned)s;
-        keys[wib][e] = key;
+        keys[e] = key;
         lmin = min(lmin, key);
     }
     if (shared4) {
@@ -823,12 +817,12 @@ __global__ __launch_bounds__(256) void nnp_sweep_kernel(
             lmin = 0xFFFFFFFFu;
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
             for (int e = lane; e < nmine; e += 64) {
-                if (keys[wib][e] == 0xFFFFFFFFu) continue;  // consumed
+                if (keys[e] == 0xFFFFFFFFu) continue;  // consumed
                 const int s = sub + nsub * e;
                 const float4 *cb = (const float4 *)(CB64 + (size_t)s * B64F);
                 const float lb = boxbox_bound(alo, ahi, cb[0], cb[1]);
                 const unsigned key = (__float_as_uint(lb) & ~IDMASK) | (unsigned)s;
-                keys[wib][e] = key;
+                keys[e] = key;
                 lmin = min(lmin, key);
             }
             kmin = wave_min_u32(lmin);
@@ -846,10 +840,18 @@ __global__ __launch_bounds__(256) void nnp_sweep_kernel(
             for (int i = 0; i < B16F; i++) bx[i] = bp[i];
         }
         if (lane == (e & 63)) {
-            keys[wib][e] = 0xFFFFFFFFu;
+            keys[e] = 0xFFFFFFFFu;
             lmin = 0xFFFFFFFFu;
+            // 4 entries per trip, all four LDS reads in flight together (clamped indices re-read
+            // the consumed entry: 0xFFFFFFFF, neutral)
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-            for (int ee = lane; ee < nmine; ee += 64) lmin = min(lmin, keys[wib][ee]);
+            for (int ee = lane; ee < nmine; ee += 256) {
+                const unsigned k0 = keys[ee];
+                const unsigned k1 = keys[ee + 64 < nmine ? ee + 64 : e];
+                const unsigned k2 = keys[ee + 128 < nmine ? ee + 128 : e];
+                const unsigned k3 = keys[ee + 192 < nmine ? ee + 192 : e];
+                lmin = min(min(lmin, k0), min(min(k1, k2), k3));
+            }
         }
         n_step++;
         unsigned need = 0;
@@ -981,6 +983,40 @@ __global__ __launch_bounds__(256) void nnp_sweep_kernel(
     }
 }
 
+// Direction 0's workgroups come first in the grid (the `a.wg0` first ones), then direction 1's.
+// A direction whose groups are shared by 4 waves (few, heavy groups) uses one 256-thread workgroup
+// per group.  The others use one WAVE per group: as one-wave workgroups when the launch holds
+// nothing else (the dispatcher then refills every wave slot the moment it frees up), packed 4 to
+// a 256-thread workgroup when the launch also holds shared groups (two launches, one per shape,
+// measured slower than the packing).  A persistent grid pulling group ids from an atomic counter
+// was tried as well: 3x slower -- same-address device-scope atomics serialise at ~25 ns each.
+__global__ __launch_bounds__(256) void nnp_sweep_kernel(
+    SweepArgs a, const float *__restrict__ xyz0, const float *__restrict__ xyz1, const int *__restrict__ orig0,
+    const int *__restrict__ orig1, const float *__restrict__ b16_0, const float *__restrict__ b16_1,
+    const float *__restrict__ b64_0, const float *__restrict__ b64_1, float *__restrict__ dist0,
+    float *__restrict__ dist1, int *__restrict__ idx0, int *__restrict__ idx1,
+    unsigned long long *__restrict__ stats) {
+    extern __shared__ unsigned keys_dyn[];  // [waves][kstride]: each wave's list of superblock keys
+    __shared__ int shbest[64];
+    __shared__ float md[4][64];
+    __shared__ unsigned mi[4][64];
+
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int wg = blockIdx.x;
+    const int dir = wg >= a.wg0;
+    if (dir) wg -= a.wg0;
+    if (a.nw[dir] == 4) {
+        sweep_group<true>(a, dir, wg, wib, lane, keys_dyn, shbest, md, mi, xyz0, xyz1, orig0, orig1, b16_0, b16_1,
+                          b64_0, b64_1, dist0, dist1, idx0, idx1, stats);
+    } else {
+        const int gid = wg * (int)(blockDim.x >> 6) + wib;
+        if (gid >= a.b * a.groups[dir]) return;  // (no barriers on this path)
+        sweep_group<false>(a, dir, gid, wib, lane, keys_dyn, shbest, md, mi, xyz0, xyz1, orig0, orig1, b16_0, b16_1,
+                           b64_0, b64_1, dist0, dist1, idx0, idx1, stats);
+    }
+}
+
 int round_up(long v, int q) { return (int)((v + q - 1) / q * q); }
 
 struct PPlan {
@@ -1058,10 +1094,21 @@ int pruned_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2
         RF_LAUNCH("nnp_sort", nnp_sort_kernel<false>, dim3(2 * b), dim3(STPB), 0, s, sa);
     }
     const long g0 = (long)b * wa.groups[0], g1 = (long)b * wa.groups[1];
-    wa.wg0 = wa.nw[0] == 4 ? (int)g0 : rf::ceil_div(g0, 4);
-    const int wg1 = wa.nw[1] == 4 ? (int)g1 : rf::ceil_div(g1, 4);
-    RF_LAUNCH("nnp_sweep", nnp_sweep_kernel, dim3(wa.wg0 + wg1), dim3(256), 0, s, wa, (const float *)sa.xyz[0],
-              (const float *)sa.xyz[1], (const int *)sa.orig[0], (const int *)sa.orig[1],
+    {
+        int longest = 0;  // entries in a wave's list: all superblocks of the other set, or a quarter
+        for (int k = 0; k < 2; k++) {
+            const int nsb = wa.groups[1 - k];
+            const int len = wa.nw[k] == 4 ? (nsb + 3) / 4 : nsb;
+            longest = len > longest ? len : longest;
+        }
+        wa.kstride = (longest + 63) / 64 * 64;
+    }
+    const int tpb = (wa.nw[0] == 4 || wa.nw[1] == 4) ? 256 : 64;
+    const int pack = tpb / 64;  // one-wave groups per workgroup
+    wa.wg0 = wa.nw[0] == 4 ? (int)g0 : rf::ceil_div(g0, pack);
+    const int wg1 = wa.nw[1] == 4 ? (int)g1 : rf::ceil_div(g1, pack);
+    RF_LAUNCH("nnp_sweep", nnp_sweep_kernel, dim3(wa.wg0 + wg1), dim3(tpb), pack * wa.kstride * sizeof(unsigned), s, wa,
+              (const float *)sa.xyz[0], (const float *)sa.xyz[1], (const int *)sa.orig[0], (const int *)sa.orig[1],
               (const float *)sa.box16[0], (const float *)sa.box16[1], (const float *)sa.box64[0],
               (const float *)sa.box64[1], dist1, dist2, idx1, idx2, stats);
     if (stats_out) {
