@@ -10,8 +10,8 @@ constexpr int kMaxPoints = 65536;  // per cloud: superblock ids must fit 10 bits
 
 bool pruned_supported(int b, int n, int m);
 size_t pruned_workspace_bytes(int b, int n, int m);
-// stats_out (host, 8 counters, may be NULL): per direction {waves, superblock steps, block
-// tests, block scans}; asking for them synchronises the stream.
+// stats_out (host, 16 counters, may be NULL; layout in include/rfops.h); asking for them
+// synchronises the stream.
 int pruned_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist1, int *idx1,
                        float *dist2, int *idx2, void *workspace, size_t workspace_bytes, hipStream_t s,
                        unsigned long long *stats_out);
