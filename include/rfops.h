@@ -55,9 +55,9 @@ int rf_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2, fl
  * RF_NN_CULLED sorts both clouds along a space-filling curve and skips blocks of candidates whose
  * bounding box is strictly farther than every query's current minimum (nn_pruned.hip; n, m <=
  * 65536) -- identical outputs, bit for bit, ties included.  RF_NN_AUTO (what rf_nn_distance
- * uses) picks by size.  `stats` (host pointer to 16 counters, or NULL; filled by the culled sweep
+ * uses) picks by size.  `stats` (host pointer to 32 counters, or NULL; filled by the culled sweep
  * only): per direction d at [4d..4d+3] {waves, superblock steps, most steps of one wave, 16-candidate
- * block scans (x 1024 = directed pairs evaluated)}, [8+d] most block scans of one wave; a non-NULL
+ * block scans (x 1024 = directed pairs evaluated)}, [8+d] most block scans of one wave, [16..31] phase time stamps of the sort; a non-NULL
  * pointer synchronises the stream. */
 #define RF_NN_AUTO 0
 #define RF_NN_DENSE 1

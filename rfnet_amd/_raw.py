@@ -47,7 +47,7 @@ def nn_distance(xyz1, xyz2, mode="auto", stats=None):
     d1, i1 = H.empty((b, n), F32, dev), H.empty((b, n), I32, dev)
     d2, i2 = H.empty((b, m), F32, dev), H.empty((b, m), I32, dev)
     ws, wsz = H.workspace(lib.rf_nn_distance_workspace_bytes(b, n, m), dev, "nn")
-    cnt = (C.c_ulonglong * 16)() if stats is not None else None
+    cnt = (C.c_ulonglong * 32)() if stats is not None else None
     check(lib.rf_nn_distance_mode(b, n, m, H.ptr(a), H.ptr(b_), H.ptr(d1), H.ptr(i1), H.ptr(d2),
                                   H.ptr(i2), H.ptr(ws), wsz, H.stream(dev), NN_MODES[mode],
                                   C.cast(cnt, C.c_void_p) if cnt is not None else None), "rf_nn_distance")

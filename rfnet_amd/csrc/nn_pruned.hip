@@ -73,6 +73,7 @@ struct SortArgs {
     int *orig[2];
     float *box16[2];
     float *box64[2];
+    unsigned long long *dbg;  // optional (with stats): s_memtime stamps of the sort's phases, [16..31]
 };
 
 // Skilling's axes-to-transpose Hilbert mapping, 5 bits per axis -> 15-bit index.
@@ -109,10 +110,13 @@ __device__ __forceinline__ unsigned hilbert15(unsigned x, unsigned y, unsigned z
     return key & (NBINS - 1);
 }
 
+// bin of a coordinate: (v - lo) * scale clamped to [0, HB-1].  One v_med3_f32 does the clamp; a NaN
+// (NaN input, or inf * 0 when the axis has no extent) leaves it as NaN or a bound and converts to
+// 0 or a bound -- any bin is acceptable, the keys only steer the order.
 __device__ __forceinline__ int axis_bin(float v, float lo, float scale) {
-    if (!isfinite(v)) return HB - 1;
-    const float f = fminf(fmaxf((v - lo) * scale, 0.f), (float)(HB - 1));
-    return (int)f;  // NaN products (inf * 0) fall through fmaxf as 0
+    const float f = __builtin_amdgcn_fmed3f((v - lo) * scale, 0.f, (float)(HB - 1));
+    const int b = (int)f;
+    return b < 0 ? 0 : (b > HB - 1 ? HB - 1 : b);
 }
 
 // The same curve as hilbert15() as a state machine, one octant (3 bits) per level: entry
@@ -186,6 +190,12 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     float *__restrict__ oxyz = a.xyz[set] + (size_t)bi * npad * 3;
     int *__restrict__ oorig = a.orig[set] + (size_t)bi * npad;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int stamp_no = 16;
+    auto stamp = [&]() {  // phase timing of the LAST workgroup (set 1, last batch element), thread 0
+        if (a.dbg && blockIdx.x == gridDim.x - 1 && tid == 0 && stamp_no < 32) a.dbg[stamp_no] = clock64();
+        stamp_no++;
+    };
+    stamp();
 
     float px[RPT], py[RPT], pz[RPT];
     unsigned pk[RPT];  // key, then position
@@ -207,6 +217,7 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     if (tid < 3 * HB) (&ahist[0][0])[tid] = 0;
     if (tid < 192) hlut[tid] = kHilbertLut[tid];
 
+    stamp();
     // 1. bounding box of the finite coordinates
     {
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -252,11 +263,15 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     const float fl[3] = {frame[0], frame[1], frame[2]};
     const float fs[3] = {frame[3], frame[4], frame[5]};
 
-    // 2. per-axis histograms of a quarter of the points (every 4th, staggered over the threads:
-    // the cells only need approximate quantiles, and same-address LDS atomics serialise)
+    stamp();
+    // 2. per-axis histograms of a quarter of the points: the cells only need approximate
+    // quantiles, and same-address LDS atomics serialise.  The choice of k is WAVE-uniform (a
+    // scalar branch skips the other three quarters; wave w takes k = -w mod 4, so every index
+    // range of the cloud is sampled).
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
-        if (tid + k * STPB < n && ((k + tid) & 3) == 0) {
+        if (((k + wave) & 3) != 0) continue;
+        if (tid + k * STPB < n) {
             atomicAdd(&ahist[0][axis_bin(px[k], fl[0], fs[0])], 1u);
             atomicAdd(&ahist[1][axis_bin(py[k], fl[1], fs[1])], 1u);
             atomicAdd(&ahist[2][axis_bin(pz[k], fl[2], fs[2])], 1u);
@@ -276,7 +291,7 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             // cell of a bin = the 1/32-quantile its first sample falls into
-            unsigned cell = (unsigned)(((unsigned long long)run * 32u) / total);
+            unsigned cell = (run * 32u) / total;  // run <= 65536: no overflow
             cell = cell > 31u ? 31u : cell;
             cellmap[wave][lane * 4 + k] = (unsigned short)(spread5(cell) << (2 - wave));
             run += c4[k];
@@ -284,26 +299,26 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     }
     __syncthreads();
 
-    // 3. keys and their histogram
+    stamp();
+    // 3. keys and their histogram (VALU-bound: ~50 instructions per point)
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
-        if (tid + k * STPB < n) {
-            const unsigned m = (unsigned)cellmap[0][axis_bin(px[k], fl[0], fs[0])] |
-                               (unsigned)cellmap[1][axis_bin(py[k], fl[1], fs[1])] |
-                               (unsigned)cellmap[2][axis_bin(pz[k], fl[2], fs[2])];
-            unsigned st = 0, key = 0;
+        const unsigned m = (unsigned)cellmap[0][axis_bin(px[k], fl[0], fs[0])] |
+                           (unsigned)cellmap[1][axis_bin(py[k], fl[1], fs[1])] |
+                           (unsigned)cellmap[2][axis_bin(pz[k], fl[2], fs[2])];
+        unsigned st = 0, key = 0;
 #pragma unroll
-            for (int l = 4; l >= 0; l--) {
-                const unsigned e = hlut[st * 8 + ((m >> (3 * l)) & 7u)];
-                key = (key << 3) | (e & 7u);
-                st = e >> 3;
-            }
-            pk[k] = key;
-            atomicAdd(&hist[key], 1u);
+        for (int l = 4; l >= 0; l--) {
+            const unsigned e = hlut[st * 8 + ((m >> (3 * l)) & 7u)];
+            key = (key << 3) | (e & 7u);
+            st = e >> 3;
         }
+        pk[k] = key;
+        if (tid + k * STPB < n) atomicAdd(&hist[key], 1u);
     }
     __syncthreads();
 
+    stamp();
     // 4. exclusive scan of the 32768 bins: each wave owns 2048 consecutive bins, 8 steps of 256
     // (4 per lane, one ds_read_b128: consecutive lanes on consecutive banks)
     {
@@ -336,15 +351,17 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     }
     __syncthreads();
 
+    stamp();
     // 5. positions (the order inside a key is whatever the atomics give: results do not depend on it)
 #pragma unroll
     for (int k = 0; k < RPT; k++)
         if (tid + k * STPB < n) pk[k] = atomicAdd(&hist[pk[k]], 1u);
     __syncthreads();  // the histogram is dead from here on
 
-    // 6. per half of 8192 records: stage in LDS, boxes from LDS, coalesced write-out
-    float *sx = (float *)hist, *sy = sx + HALF, *sz = sy + HALF;
-    int *so = (int *)(sz + HALF);
+    stamp();
+    // 6. per half of 8192 records: stage in LDS as (x, y, z, original index) records, boxes from
+    // LDS, coalesced write-out
+    float4 *stg = (float4 *)hist;
     float *__restrict__ b16 = a.box16[set] + (size_t)bi * (npad / SB) * B16F;
     float *__restrict__ b64 = a.box64[set] + (size_t)bi * (npad / SB) * B64F;
     for (int h0 = 0; h0 < npad; h0 += HALF) {
@@ -353,32 +370,24 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
         for (int k = 0; k < RPT; k++) {
             const int i = tid + k * STPB;
             const int p = (int)pk[k] - h0;
-            if (i < n && p >= 0 && p < HALF) {
-                sx[p] = px[k];
-                sy[p] = py[k];
-                sz[p] = pz[k];
-                so[p] = i;
-            }
+            if (i < n && p >= 0 && p < HALF) stg[p] = make_float4(px[k], py[k], pz[k], __int_as_float(i));
         }
-        for (int p = n - h0 + tid; p < cnt; p += STPB) {  // padding records live at positions >= n
-            if (p >= 0) {
-                sx[p] = sy[p] = sz[p] = INFINITY;
-                so[p] = -1;
-            }
-        }
+        for (int p = n - h0 + tid; p < cnt; p += STPB)  // padding records live at positions >= n
+            if (p >= 0) stg[p] = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(-1));
         __syncthreads();
         // boxes: one thread per 16-record block, a quad of lanes per superblock (cnt/16 is a
         // multiple of 4: quads are complete and inside one wave).  Record (u + t) % 16 at step u:
-        // lanes t and t+16 share a bank, 4-way instead of 64-way conflicts.
+        // lanes t and t+16 share banks, 4-way instead of 64-way conflicts.
         if (tid < cnt / BS) {
             float l[3] = {INFINITY, INFINITY, INFINITY}, hh[3] = {-INFINITY, -INFINITY, -INFINITY};
 #pragma unroll 4
             for (int u = 0; u < BS; u++) {
                 const int r = tid * BS + ((u + tid) & (BS - 1));
+                const float4 v = stg[r];
                 if (h0 + r < n) {  // padding excluded; NaN coordinates drop out of fminf/fmaxf
-                    l[0] = fminf(l[0], sx[r]); hh[0] = fmaxf(hh[0], sx[r]);
-                    l[1] = fminf(l[1], sy[r]); hh[1] = fmaxf(hh[1], sy[r]);
-                    l[2] = fminf(l[2], sz[r]); hh[2] = fmaxf(hh[2], sz[r]);
+                    l[0] = fminf(l[0], v.x); hh[0] = fmaxf(hh[0], v.x);
+                    l[1] = fminf(l[1], v.y); hh[1] = fmaxf(hh[1], v.y);
+                    l[2] = fminf(l[2], v.z); hh[2] = fmaxf(hh[2], v.z);
                 }
             }
             const int gblk = h0 / BS + tid;
@@ -406,12 +415,16 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
                 o64[3] = o64[7] = 0.f;
             }
         }
-        for (int j = tid; j < cnt * 3; j += STPB) {
-            const int r = j / 3, c = j - r * 3;
-            oxyz[(size_t)h0 * 3 + j] = c == 0 ? sx[r] : (c == 1 ? sy[r] : sz[r]);
+        {
+            const float *sf = (const float *)stg;
+            for (int j = tid; j < cnt * 3; j += STPB) {
+                const int r = j / 3, c = j - r * 3;
+                oxyz[(size_t)h0 * 3 + j] = sf[r * 4 + c];
+            }
+            for (int j = tid; j < cnt; j += STPB) oorig[h0 + j] = __float_as_int(sf[j * 4 + 3]);
         }
-        for (int j = tid; j < cnt; j += STPB) oorig[h0 + j] = so[j];
         __syncthreads();
+        stamp();
     }
 }
 
@@ -534,7 +547,7 @@ __global__ __launch_bounds__(STPB) void nnp_sort_kernel(SortArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             // cell of a bin = the 1/32-quantile its first sample falls into
-            const unsigned cell = (unsigned)(((unsigned long long)run * 32u) / total);
+            const unsigned cell = (run * 32u) / total;  // run <= 65536: no overflow
             cellmap[wave][lane * 4 + k] = (unsigned char)(cell > 31u ? 31u : cell);
             run += c4[k];
         }
@@ -1040,7 +1053,7 @@ PPlan make_pplan(int b, int n, int m) {
         p.off_b16[s] = take((size_t)b * (p.npad[s] / SB) * B16F * sizeof(float));
         p.off_b64[s] = take((size_t)b * (p.npad[s] / SB) * B64F * sizeof(float));
     }
-    p.off_stats = take(16 * sizeof(unsigned long long));
+    p.off_stats = take(32 * sizeof(unsigned long long));
     p.bytes = off;
     return p;
 }
@@ -1086,8 +1099,9 @@ int pruned_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2
     unsigned long long *stats = nullptr;
     if (stats_out) {
         stats = (unsigned long long *)(w + p.off_stats);
-        RF_HIP(hipMemsetAsync(stats, 0, 16 * sizeof(unsigned long long), s));
+        RF_HIP(hipMemsetAsync(stats, 0, 32 * sizeof(unsigned long long), s));
     }
+    sa.dbg = stats;
     if (n <= RPT * STPB && m <= RPT * STPB) {
         RF_LAUNCH("nnp_sort", nnp_sort_reg_kernel, dim3(2 * b), dim3(STPB), 0, s, sa);
     } else {
@@ -1112,7 +1126,7 @@ int pruned_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2
               (const float *)sa.box16[0], (const float *)sa.box16[1], (const float *)sa.box64[0],
               (const float *)sa.box64[1], dist1, dist2, idx1, idx2, stats);
     if (stats_out) {
-        RF_HIP(hipMemcpyAsync(stats_out, stats, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        RF_HIP(hipMemcpyAsync(stats_out, stats, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         RF_HIP(hipStreamSynchronize(s));
     }
     return RF_OK;

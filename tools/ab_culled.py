@@ -50,6 +50,9 @@ def main():
         torch.cuda.synchronize()
         prof = {k: round(v[0] / v[1], 4) for k, v in profile_collect().items()}
         profile_enable(False)
+        if any(st[16:26]):
+            ts = [v for v in st[16:32] if v]
+            print("    sort phases (s_memtime ticks, 100 MHz):", [ts[i + 1] - ts[i] for i in range(len(ts) - 1)])
         pairs = b * n * m
         print(f"{kind} b={b} n={n} m={m}: dense {td:.3f} ms  culled {tc:.3f} ms  ({td / tc:.2f}x)  kernels {prof}")
         for d, (q, k) in enumerate(((n, m), (m, n))):
