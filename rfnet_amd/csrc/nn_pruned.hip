@@ -42,6 +42,8 @@
 // exceed the minimum, lanes across candidates, and reduces the lowest matching index.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 #include "nn_pruned.hpp"
 
@@ -778,22 +780,8 @@ __device__ __forceinline__ void sweep_group(
     const float *gb = (dir ? b64_1 : b64_0) + ((size_t)bi * G + g) * B64F;  // uniform
     const float glo[3] = {gb[0], gb[1], gb[2]}, ghi[3] = {gb[4], gb[5], gb[6]};
 
-    // lower bound group box <-> candidate superblock, truncated (downwards) into the high 22 bits
-    // of a key whose low 10 bits are the superblock id: the wave minimum of the keys is the next
-    // superblock in ascending bound order.  Entry e of this wave's list is superblock sub + nsub*e;
-    // lane e % 64 owns it (writes it, consumes it, keeps the minimum of its entries in `lmin`).
     const int nmine = (nsb - sub + nsub - 1) / nsub;
     unsigned *__restrict__ keys = keys_dyn + (size_t)wib * a.kstride;
-    unsigned lmin = 0xFFFFFFFFu;
-#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-    for (int e = lane; e < nmine; e += 64) {
-        const int s = sub + nsub * e;
-        const float4 *cb = (const float4 *)(CB64 + (size_t)s * B64F);
-        const float lb = boxbox_bound(glo, ghi, cb[0], cb[1]);
-        const unsigned key = (__float_as_uint(lb) & ~IDMASK) | (unsigned)s;
-        keys[e] = key;
-        lmin = min(lmin, key);
-    }
     if (shared4) {
         if (wib == 0) shbest[lane] = 0x7F800000;  // +inf
         __syncthreads();
@@ -805,128 +793,186 @@ __device__ __forceinline__ void sweep_group(
     float cull = INFINITY;  // <= best: also what the other waves of the group have found
     unsigned n_step = 0, n_scan = 0;
 
-    int nact_ref = 64;  // active lanes when the keys were last (re)computed
-    for (;;) {
-        unsigned kmin = wave_min_u32(lmin);
-        if (kmin == 0xFFFFFFFFu) break;
-        if (shared4) cull = fminf(cull, __int_as_float(shbest[lane]));
-        float bound = __uint_as_float(kmin & ~IDMASK);
-        // A lane whose minimum is below the bound of every remaining superblock is finished for
-        // good (the keys ascend).  The sweep ends when no lane is left ...
-        const unsigned long long act = __ballot(valid && cull >= bound);
-        if (act == 0ull) break;  // every remaining superblock is strictly farther than every lane's minimum
-        // ... and when half of the lanes have finished since the keys were computed, the box of
-        // the remaining lanes replaces the group box: a far outlier no longer keeps the bounds of
-        // all 64 queries loose (the heaviest waves were 6x the average, and they set the kernel's
-        // duration).  The new keys are bounds for the active lanes only, which is all that is left.
-        const int nact = __builtin_popcountll(act);
-        if (nact * 2 <= nact_ref) {
-            nact_ref = nact;
-            const bool on = (act >> lane) & 1ull;
-            const float alo[3] = {wave_min_f32(on ? qx : INFINITY), wave_min_f32(on ? qy : INFINITY),
-                                  wave_min_f32(on ? qz : INFINITY)};
-            const float ahi[3] = {wave_max_f32(on ? qx : -INFINITY), wave_max_f32(on ? qy : -INFINITY),
-                                  wave_max_f32(on ? qz : -INFINITY)};
-            lmin = 0xFFFFFFFFu;
+    // One traversal of the candidate superblocks in ascending order of a lower bound, for the lanes
+    // with `part` set, whose box is [blo, bhi].
+    //   TRACK = false: the search proper.  Updates best / bblk / tie / cull.
+    //   TRACK = true:  second pass for the lanes whose minimum was attained in more than one
+    //                  visited block (duplicated points, symmetric configurations): the minima are
+    //                  final (cull == best), every block that can hold a candidate with d2 == best
+    //                  is visited again, and the lowest original index among the exact matches is
+    //                  reduced into besti2.  (A per-lane wave-cooperative re-scan was 50x slower
+    //                  than the dense sweep on clouds of identical points.)
+    // Lower bound box <-> candidate superblock, truncated (downwards) into the high 22 bits of a
+    // key whose low 10 bits are the superblock id: the wave minimum of the keys is the next
+    // superblock.  Entry e of this wave's list is superblock sub + nsub*e; lane e % 64 owns it
+    // (writes it, consumes it, keeps the minimum of its entries in `lmin`).
+    auto traverse = [&](auto track_c, const bool part, const float *blo, const float *bhi, unsigned &besti2) {
+        constexpr bool TRACK = decltype(track_c)::value;
+        unsigned lmin = 0xFFFFFFFFu;
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-            for (int e = lane; e < nmine; e += 64) {
-                if (keys[e] == 0xFFFFFFFFu) continue;  // consumed
-                const int s = sub + nsub * e;
-                const float4 *cb = (const float4 *)(CB64 + (size_t)s * B64F);
-                const float lb = boxbox_bound(alo, ahi, cb[0], cb[1]);
-                const unsigned key = (__float_as_uint(lb) & ~IDMASK) | (unsigned)s;
-                keys[e] = key;
-                lmin = min(lmin, key);
-            }
-            kmin = wave_min_u32(lmin);
-            if (kmin == 0xFFFFFFFFu) break;
-            bound = __uint_as_float(kmin & ~IDMASK);
-            if (__ballot(valid && cull >= bound) == 0ull) break;
+        for (int e = lane; e < nmine; e += 64) {
+            const int s = sub + nsub * e;
+            const float4 *cb = (const float4 *)(CB64 + (size_t)s * B64F);
+            const float lb = boxbox_bound(blo, bhi, cb[0], cb[1]);
+            const unsigned key = (__float_as_uint(lb) & ~IDMASK) | (unsigned)s;
+            keys[e] = key;
+            lmin = min(lmin, key);
         }
-        const int s = (int)(kmin & IDMASK);
-        const int e = (s - sub) / nsub;
-        // the 4 block boxes of this superblock: 24 SGPRs, in flight during the key-list upkeep
-        float bx[B16F];
-        {
-            const float *bp = CB16 + (size_t)s * B16F;  // uniform
-#pragma unroll
-            for (int i = 0; i < B16F; i++) bx[i] = bp[i];
-        }
-        if (lane == (e & 63)) {
-            keys[e] = 0xFFFFFFFFu;
-            lmin = 0xFFFFFFFFu;
-            // 4 entries per trip, all four LDS reads in flight together (clamped indices re-read
-            // the consumed entry: 0xFFFFFFFF, neutral)
-#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-            for (int ee = lane; ee < nmine; ee += 256) {
-                const unsigned k0 = keys[ee];
-                const unsigned k1 = keys[ee + 64 < nmine ? ee + 64 : e];
-                const unsigned k2 = keys[ee + 128 < nmine ? ee + 128 : e];
-                const unsigned k3 = keys[ee + 192 < nmine ? ee + 192 : e];
-                lmin = min(min(lmin, k0), min(min(k1, k2), k3));
-            }
-        }
-        n_step++;
-        unsigned need = 0;
-#pragma unroll
-        for (int j = 0; j < SBB; j++) {
-            const float lb = box_bound(qx, qy, qz, bx[j * 6 + 0], bx[j * 6 + 1], bx[j * 6 + 2], bx[j * 6 + 3],
-                                       bx[j * 6 + 4], bx[j * 6 + 5]);
-            if (__ballot(valid && lb <= cull) != 0ull) need |= 1u << j;
-        }
-        if (need == 0) continue;
-        // Surviving blocks: 16 records = two halves of 8 (24 SGPRs each), ping-pong: while one half
-        // is being evaluated the next one -- of this block or of the next surviving block -- is in
-        // flight.  Scalar loads return out of order, so every wait is lgkmcnt(0), placed BEFORE
-        // the next issue (as in nn_sweep_kernel).
-        float ra[24], rb[24];
-        int j = __builtin_ctz(need);
-        need &= need - 1;
-        {
-            const float *cp = C + (size_t)(s * SBB + j) * BS * 3;
-#pragma unroll
-            for (int i = 0; i < 24; i++) ra[i] = cp[i];
-        }
+        int nact_ref = 64;  // active lanes when the keys were last (re)computed
         for (;;) {
-            const int blk = s * SBB + j;
-            n_scan++;
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                const float *cp = C + (size_t)blk * BS * 3 + 24;
-#pragma unroll
-                for (int i = 0; i < 24; i++) rb[i] = cp[i];
+            unsigned kmin = wave_min_u32(lmin);
+            if (kmin == 0xFFFFFFFFu) break;
+            if (shared4 && !TRACK) cull = fminf(cull, __int_as_float(shbest[lane]));
+            float bound = __uint_as_float(kmin & ~IDMASK);
+            // A lane whose minimum is below the bound of every remaining superblock is finished for
+            // good (the keys ascend).  The traversal ends when no lane is left ...
+            const unsigned long long act = __ballot(part && cull >= bound);
+            if (act == 0ull) break;  // every remaining superblock is strictly farther than every lane's minimum
+            // ... and when half of the lanes have finished since the keys were computed, the box of
+            // the remaining lanes replaces the previous box: a far outlier no longer keeps the
+            // bounds of all 64 queries loose (the heaviest waves were 6x the average, and they set
+            // the kernel's duration).  The new keys are bounds for the active lanes only, which is
+            // all that is left.
+            const int nact = __builtin_popcountll(act);
+            if (nact * 2 <= nact_ref) {  // (thresholds between 1/4 and 7/8 measure the same)
+                nact_ref = nact;
+                const bool on = (act >> lane) & 1ull;
+                const float alo[3] = {wave_min_f32(on ? qx : INFINITY), wave_min_f32(on ? qy : INFINITY),
+                                      wave_min_f32(on ? qz : INFINITY)};
+                const float ahi[3] = {wave_max_f32(on ? qx : -INFINITY), wave_max_f32(on ? qy : -INFINITY),
+                                      wave_max_f32(on ? qz : -INFINITY)};
+                lmin = 0xFFFFFFFFu;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+                for (int e = lane; e < nmine; e += 64) {
+                    if (keys[e] == 0xFFFFFFFFu) continue;  // consumed
+                    const int s = sub + nsub * e;
+                    const float4 *cb = (const float4 *)(CB64 + (size_t)s * B64F);
+                    const float lb = boxbox_bound(alo, ahi, cb[0], cb[1]);
+                    const unsigned key = (__float_as_uint(lb) & ~IDMASK) | (unsigned)s;
+                    keys[e] = key;
+                    lmin = min(lmin, key);
+                }
+                kmin = wave_min_u32(lmin);
+                if (kmin == 0xFFFFFFFFu) break;
+                bound = __uint_as_float(kmin & ~IDMASK);
+                if (__ballot(part && cull >= bound) == 0ull) break;
             }
-            __builtin_amdgcn_sched_barrier(0);
-            float cm = scan8(ra, qx, qy, qz, INFINITY);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            __builtin_amdgcn_sched_barrier(0);
-            const bool more = need != 0;
-            if (more) {
-                j = __builtin_ctz(need);
-                need &= need - 1;
+            const int s = (int)(kmin & IDMASK);
+            const int e = (s - sub) / nsub;
+            // the 4 block boxes of this superblock: 24 SGPRs, in flight during the key-list upkeep
+            float bx[B16F];
+            {
+                const float *bp = CB16 + (size_t)s * B16F;  // uniform
+#pragma unroll
+                for (int i = 0; i < B16F; i++) bx[i] = bp[i];
+            }
+            if (lane == (e & 63)) {
+                keys[e] = 0xFFFFFFFFu;
+                lmin = 0xFFFFFFFFu;
+                // 4 entries per trip, all four LDS reads in flight together (clamped indices
+                // re-read the consumed entry: 0xFFFFFFFF, neutral)
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+                for (int ee = lane; ee < nmine; ee += 256) {
+                    const unsigned k0 = keys[ee];
+                    const unsigned k1 = keys[ee + 64 < nmine ? ee + 64 : e];
+                    const unsigned k2 = keys[ee + 128 < nmine ? ee + 128 : e];
+                    const unsigned k3 = keys[ee + 192 < nmine ? ee + 192 : e];
+                    lmin = min(min(lmin, k0), min(min(k1, k2), k3));
+                }
+            }
+            n_step++;
+            unsigned need = 0;
+#pragma unroll
+            for (int j = 0; j < SBB; j++) {
+                const float lb = box_bound(qx, qy, qz, bx[j * 6 + 0], bx[j * 6 + 1], bx[j * 6 + 2], bx[j * 6 + 3],
+                                           bx[j * 6 + 4], bx[j * 6 + 5]);
+                if (__ballot(part && lb <= cull) != 0ull) need |= 1u << j;
+            }
+            if (need == 0) continue;
+            if constexpr (TRACK) {
+                while (need) {
+                    const int j = __builtin_ctz(need);
+                    need &= need - 1;
+                    n_scan++;
+                    const float *cp = C + (size_t)(s * SBB + j) * BS * 3;  // uniform: scalar loads
+                    const int *ob = Co + (size_t)(s * SBB + j) * BS;
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        float r[24];
+                        unsigned io[8];
+#pragma unroll
+                        for (int i = 0; i < 24; i++) r[i] = cp[h * 24 + i];
+#pragma unroll
+                        for (int i = 0; i < 8; i++) io[i] = (unsigned)ob[h * 8 + i];  // padding carries 0xFFFFFFFF
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            const float d = rf::d2_fma(r[u * 3 + 0] - qx, r[u * 3 + 1] - qy, r[u * 3 + 2] - qz);
+                            besti2 = min(besti2, d == cull ? io[u] : 0xFFFFFFFFu);
+                        }
+                    }
+                }
+                continue;
+            }
+            // Surviving blocks: 16 records = two halves of 8 (24 SGPRs each), ping-pong: while one
+            // half is being evaluated the next one -- of this block or of the next surviving block --
+            // is in flight.  Scalar loads return out of order, so every wait is lgkmcnt(0), placed
+            // BEFORE the next issue (as in nn_sweep_kernel).
+            float ra[24], rb[24];
+            int j = __builtin_ctz(need);
+            need &= need - 1;
+            {
+                // the first surviving block: both halves in one batch (one exposed latency, not two)
                 const float *cp = C + (size_t)(s * SBB + j) * BS * 3;
 #pragma unroll
                 for (int i = 0; i < 24; i++) ra[i] = cp[i];
+#pragma unroll
+                for (int i = 0; i < 24; i++) rb[i] = cp[24 + i];
             }
-            __builtin_amdgcn_sched_barrier(0);
-            cm = scan8(rb, qx, qy, qz, cm);
-            if (cm < best) {
-                best = cm;
-                bblk = blk;
-                tie = false;
-            } else if (cm == best) {
-                tie = true;
+            bool have_rb = true;
+            for (;;) {
+                const int blk = s * SBB + j;
+                n_scan++;
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!have_rb) {
+                    const float *cp = C + (size_t)blk * BS * 3 + 24;
+#pragma unroll
+                    for (int i = 0; i < 24; i++) rb[i] = cp[i];
+                }
+                have_rb = false;
+                __builtin_amdgcn_sched_barrier(0);
+                float cm = scan8(ra, qx, qy, qz, INFINITY);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_sched_barrier(0);
+                const bool more = need != 0;
+                if (more) {
+                    j = __builtin_ctz(need);
+                    need &= need - 1;
+                    const float *cp = C + (size_t)(s * SBB + j) * BS * 3;
+#pragma unroll
+                    for (int i = 0; i < 24; i++) ra[i] = cp[i];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                cm = scan8(rb, qx, qy, qz, cm);
+                if (cm < best) {
+                    best = cm;
+                    bblk = blk;
+                    tie = false;
+                } else if (cm == best) {
+                    tie = true;
+                }
+                if (!more) break;
             }
-            if (!more) break;
+            cull = fminf(cull, best);
+            if (shared4) atomicMin(&shbest[lane], __float_as_int(cull));
         }
-        cull = fminf(cull, best);
-        if (shared4) atomicMin(&shbest[lane], __float_as_int(cull));
-    }
+    };
+
+    unsigned besti = 0xFFFFFFFFu;
+    traverse(std::false_type{}, valid, glo, ghi, besti);
 
     // lowest original index among the exact matches of the winning block
-    unsigned besti = 0xFFFFFFFFu;
     {
         const float *cp = C + (size_t)bblk * BS * 3;  // per lane
         const int *co = Co + (size_t)bblk * BS;
@@ -936,35 +982,17 @@ __device__ __forceinline__ void sweep_group(
             if (d == best) besti = min(besti, (unsigned)co[u]);  // padding carries 0xFFFFFFFF
         }
     }
-    // queries whose minimum was attained in more than one visited block: exact re-scan, one query
-    // at a time, lanes across the candidates of every superblock that can hold a match
-    unsigned long long tm = __ballot(tie && valid);
-    while (tm) {
-        const int L = __builtin_ctzll(tm);
-        tm &= tm - 1;
-        const float tx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx), L));
-        const float ty = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy), L));
-        const float tz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz), L));
-        const float bL = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best), L));
-        unsigned cand = 0xFFFFFFFFu;
-        for (int s0 = 0; s0 < nsb; s0 += 64) {
-            const int s = s0 + lane;
-            bool need = false;
-            if (s < nsb) {
-                const float *cb = CB64 + (size_t)s * B64F;
-                need = box_bound(tx, ty, tz, cb[0], cb[1], cb[2], cb[4], cb[5], cb[6]) <= bL;
-            }
-            unsigned long long m2 = __ballot(need);
-            while (m2) {
-                const int k = __builtin_ctzll(m2);
-                m2 &= m2 - 1;
-                const size_t r = (size_t)(s0 + k) * SB + lane;
-                const float d = rf::d2_fma(C[r * 3 + 0] - tx, C[r * 3 + 1] - ty, C[r * 3 + 2] - tz);
-                if (d == bL) cand = min(cand, (unsigned)Co[r]);
-            }
-        }
-        cand = wave_min_u32(cand);
-        if (lane == L) besti = cand;
+    // queries whose minimum was attained in more than one visited block: second traversal
+    const bool flagged = tie && valid;
+    if (__ballot(flagged) != 0ull) {
+        const float flo[3] = {wave_min_f32(flagged ? qx : INFINITY), wave_min_f32(flagged ? qy : INFINITY),
+                              wave_min_f32(flagged ? qz : INFINITY)};
+        const float fhi[3] = {wave_max_f32(flagged ? qx : -INFINITY), wave_max_f32(flagged ? qy : -INFINITY),
+                              wave_max_f32(flagged ? qz : -INFINITY)};
+        cull = best;  // the wave's own minima are final: match against them
+        unsigned besti2 = 0xFFFFFFFFu;
+        traverse(std::true_type{}, flagged, flo, fhi, besti2);
+        if (flagged) besti = besti2;
     }
 
     if (stats && lane == 0) {

@@ -17,6 +17,11 @@ def cloud(rng, kind, b, k):
     if kind == "sphere":
         x = rng.randn(b, k, 3)
         return (x / np.linalg.norm(x, axis=-1, keepdims=True)).astype(np.float32)
+    if kind == "dup":  # every point repeated ~5 times (resample_pcd-style duplicates)
+        base = rng.randn(b, max(k // 5, 1), 3).astype(np.float32)
+        return np.take_along_axis(base, rng.randint(0, base.shape[1], size=(b, k, 1)), 1)
+    if kind == "same":  # the worst case: all points identical (nothing can be culled, every lane ties)
+        return np.ones((b, k, 3), np.float32)
     return rng.randn(b, k, 3).astype(np.float32)
 
 
