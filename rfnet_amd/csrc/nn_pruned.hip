@@ -185,8 +185,11 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     __shared__ unsigned wsum[STPB / 64];
     __shared__ float frame[6];  // lo[3], scale[3]
 
-    const int set = (int)blockIdx.x >= a.b;
-    const int bi = blockIdx.x - (set ? a.b : 0);
+    // cloud-major logical order, each XCD a contiguous eighth (as the sweep: the XCD that sorts a
+    // batch element is the one that sweeps it, its L2 still holding the records)
+    const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (int)(blockIdx.x >> 3);
+    const int bi = logical >> 1, set = logical & 1;
     const int n = a.n[set], npad = a.npad[set];
     const float *__restrict__ src = a.src[set] + (size_t)bi * n * 3;
     float *__restrict__ oxyz = a.xyz[set] + (size_t)bi * npad * 3;
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int stamp_no = 16;
     auto stamp = [&]() {  // phase timing of the LAST workgroup (set 1, last batch element), thread 0
-        if (a.dbg && blockIdx.x == gridDim.x - 1 && tid == 0 && stamp_no < 32) a.dbg[stamp_no] = clock64();
+        if (a.dbg && bi == a.b - 1 && set == 1 && tid == 0 && stamp_no < 32) a.dbg[stamp_no] = clock64();
         stamp_no++;
     };
     stamp();
@@ -441,8 +444,11 @@ __global__ __launch_bounds__(STPB) void nnp_sort_kernel(SortArgs a) {
     __shared__ unsigned wsum[STPB / 64];
     __shared__ float frame[6];  // lo[3], scale[3]
 
-    const int set = (int)blockIdx.x >= a.b;
-    const int bi = blockIdx.x - (set ? a.b : 0);
+    // cloud-major logical order, each XCD a contiguous eighth (as the sweep: the XCD that sorts a
+    // batch element is the one that sweeps it, its L2 still holding the records)
+    const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (int)(blockIdx.x >> 3);
+    const int bi = logical >> 1, set = logical & 1;
     const int n = a.n[set], npad = a.npad[set];
     const float *__restrict__ src = a.src[set] + (size_t)bi * n * 3;
     float *__restrict__ oxyz = a.xyz[set] + (size_t)bi * npad * 3;
@@ -685,7 +691,7 @@ struct SweepArgs {
     int n[2], npad[2];
     int groups[2];   // npad[d] / 64
     int nw[2];       // waves per query group: 1 or 4
-    int wg0;         // workgroups of direction 0
+    int wg0, wg1;    // workgroups per batch element of direction 0 / 1
     int kstride;     // key-list entries per wave (dynamic LDS: waves * kstride * 4 bytes)
 };
 
@@ -1044,17 +1050,26 @@ __global__ __launch_bounds__(256) void nnp_sweep_kernel(
 
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int wg = blockIdx.x;
+    // Workgroups are dealt to the 8 XCDs round-robin, and each XCD has its own 4 MB L2.  The logical
+    // order is cloud-major (per batch element: direction 0's workgroups, then direction 1's), and
+    // the swizzle hands every XCD a CONTIGUOUS eighth of it: an XCD then works on ~b/8 clouds
+    // (a few hundred KB each) instead of streaming all of them through its L2 (measured before:
+    // 145 MB of L2 misses per launch for 12 MB of clouds).
+    const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (int)(blockIdx.x >> 3);
+    const int wpc = a.wg0 + a.wg1;  // workgroups per batch element
+    const int bi = logical / wpc;
+    int wg = logical - bi * wpc;
     const int dir = wg >= a.wg0;
     if (dir) wg -= a.wg0;
     if (a.nw[dir] == 4) {
-        sweep_group<true>(a, dir, wg, wib, lane, keys_dyn, shbest, md, mi, xyz0, xyz1, orig0, orig1, b16_0, b16_1,
-                          b64_0, b64_1, dist0, dist1, idx0, idx1, stats);
+        sweep_group<true>(a, dir, bi * a.groups[dir] + wg, wib, lane, keys_dyn, shbest, md, mi, xyz0, xyz1, orig0, orig1,
+                          b16_0, b16_1, b64_0, b64_1, dist0, dist1, idx0, idx1, stats);
     } else {
-        const int gid = wg * (int)(blockDim.x >> 6) + wib;
-        if (gid >= a.b * a.groups[dir]) return;  // (no barriers on this path)
-        sweep_group<false>(a, dir, gid, wib, lane, keys_dyn, shbest, md, mi, xyz0, xyz1, orig0, orig1, b16_0, b16_1,
-                           b64_0, b64_1, dist0, dist1, idx0, idx1, stats);
+        const int g = wg * (int)(blockDim.x >> 6) + wib;
+        if (g >= a.groups[dir]) return;  // (no barriers on this path)
+        sweep_group<false>(a, dir, bi * a.groups[dir] + g, wib, lane, keys_dyn, shbest, md, mi, xyz0, xyz1, orig0, orig1,
+                           b16_0, b16_1, b64_0, b64_1, dist0, dist1, idx0, idx1, stats);
     }
 }
 
@@ -1135,7 +1150,6 @@ int pruned_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2
     } else {
         RF_LAUNCH("nnp_sort", nnp_sort_kernel<false>, dim3(2 * b), dim3(STPB), 0, s, sa);
     }
-    const long g0 = (long)b * wa.groups[0], g1 = (long)b * wa.groups[1];
     {
         int longest = 0;  // entries in a wave's list: all superblocks of the other set, or a quarter
         for (int k = 0; k < 2; k++) {
@@ -1147,9 +1161,9 @@ int pruned_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2
     }
     const int tpb = (wa.nw[0] == 4 || wa.nw[1] == 4) ? 256 : 64;
     const int pack = tpb / 64;  // one-wave groups per workgroup
-    wa.wg0 = wa.nw[0] == 4 ? (int)g0 : rf::ceil_div(g0, pack);
-    const int wg1 = wa.nw[1] == 4 ? (int)g1 : rf::ceil_div(g1, pack);
-    RF_LAUNCH("nnp_sweep", nnp_sweep_kernel, dim3(wa.wg0 + wg1), dim3(tpb), pack * wa.kstride * sizeof(unsigned), s, wa,
+    wa.wg0 = wa.nw[0] == 4 ? wa.groups[0] : rf::ceil_div(wa.groups[0], pack);
+    wa.wg1 = wa.nw[1] == 4 ? wa.groups[1] : rf::ceil_div(wa.groups[1], pack);
+    RF_LAUNCH("nnp_sweep", nnp_sweep_kernel, dim3((unsigned)b * (wa.wg0 + wa.wg1)), dim3(tpb), pack * wa.kstride * sizeof(unsigned), s, wa,
               (const float *)sa.xyz[0], (const float *)sa.xyz[1], (const int *)sa.orig[0], (const int *)sa.orig[1],
               (const float *)sa.box16[0], (const float *)sa.box16[1], (const float *)sa.box64[0],
               (const float *)sa.box64[1], dist1, dist2, idx1, idx2, stats);
