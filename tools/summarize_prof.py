@@ -41,8 +41,8 @@ def main(out):
             acc = defaultdict(lambda: defaultdict(list))
             for row in csv.DictReader(open(f)):
                 nm = short(row.get("Kernel_Name", ""))
-                if nm == "nn_sweep":
-                    nm = "nn_sweep grid_x=%s" % row.get("Grid_Size", row.get("Grid_Size_X", "?"))
+                if nm in ("nn_sweep", "nnp_sweep"):
+                    nm = "%s grid_x=%s" % (nm, row.get("Grid_Size", row.get("Grid_Size_X", "?")))
                 acc[nm][row.get("Counter_Name", "")].append(float(row.get("Counter_Value", 0)))
             print("== counters:", os.path.relpath(f, out))
             for k, cs in sorted(acc.items()):
