@@ -141,3 +141,50 @@ def test_large_clouds_65536(orc):
     with pytest.raises(RfopsError):
         _run(np.zeros((1, 65537, 3), np.float32), c, "culled")  # beyond the culled sweep's limit: explicit error
     _run(np.zeros((1, 65537, 3), np.float32), c[:, :100], "auto")  # auto falls back to the dense sweep
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_shapes_and_kinds_vs_oracle(orc, seed):
+    """Seeded random shapes / cloud kinds through the culled sweep, every output against the oracle."""
+    rng = np.random.RandomState(7000 + seed)
+    b = int(rng.randint(1, 9))
+    n, m = (int(v) for v in rng.randint(1, 2600, size=2))
+    kind = ("randn", "uniform", "lattice", "dup", "plane", "clusters")[seed % 6]
+
+    def cloud(k):
+        if kind == "randn":
+            return rng.randn(b, k, 3)
+        if kind == "uniform":
+            return rng.random_sample((b, k, 3)) * 10 - 5
+        if kind == "lattice":
+            return rng.randint(0, 7, size=(b, k, 3)).astype(np.float64) * 0.25
+        if kind == "dup":
+            base = rng.randn(b, max(k // 4, 1), 3)
+            return np.take_along_axis(base, rng.randint(0, base.shape[1], size=(b, k, 1)), 1)
+        if kind == "plane":
+            x = rng.randn(b, k, 3)
+            x[..., 2] = 0.5  # zero extent on one axis
+            return x
+        centres = rng.randn(b, 5, 3) * 20
+        return centres[np.arange(b)[:, None], rng.randint(0, 5, size=(b, k))] + rng.randn(b, k, 3) * 0.01
+
+    _check_vs_oracle(orc, cloud(n).astype(np.float32), cloud(m).astype(np.float32))
+
+
+def test_non_finite_inputs_terminate(orc):
+    """NaN / inf coordinates are outside the parity contract (the reference's result then depends
+    on its tile order); the culled sweep must still terminate, and the queries and candidates that
+    are finite and far from the poisoned ones must agree with the dense sweep."""
+    rng = np.random.RandomState(5)
+    a = rng.randn(2, 3000, 3).astype(np.float32)
+    c = rng.randn(2, 5000, 3).astype(np.float32)
+    a[0, 17] = np.nan
+    a[1, 5] = np.inf
+    c[0, 123, 1] = np.nan
+    c[1, 77] = -np.inf
+    got = _run(a, c, "culled")
+    ref = _run(a, c, "dense")
+    ok1 = np.isfinite(a).all(-1)
+    ok2 = np.isfinite(c).all(-1)
+    assert np.array_equal(got[0][ok1], ref[0][ok1])
+    assert np.array_equal(got[2][ok2], ref[2][ok2])
