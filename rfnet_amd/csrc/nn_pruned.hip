@@ -796,7 +796,9 @@ __device__ __forceinline__ void sweep_group(
     float best = INFINITY;  // this wave's own minimum, the block that first attained it, tie flag
     int bblk = 0;
     bool tie = false;
-    float cull = INFINITY;  // <= best: also what the other waves of the group have found
+    // <= best: also what the other waves of the group have found.  -inf for lanes that take no part
+    // (padding): `bound <= cull` / `cull >= bound` are then false without a separate mask.
+    float cull = valid ? INFINITY : -INFINITY;
     unsigned n_step = 0, n_scan = 0;
 
     // One traversal of the candidate superblocks in ascending order of a lower bound, for the lanes
@@ -812,7 +814,7 @@ __device__ __forceinline__ void sweep_group(
     // key whose low 10 bits are the superblock id: the wave minimum of the keys is the next
     // superblock.  Entry e of this wave's list is superblock sub + nsub*e; lane e % 64 owns it
     // (writes it, consumes it, keeps the minimum of its entries in `lmin`).
-    auto traverse = [&](auto track_c, const bool part, const float *blo, const float *bhi, unsigned &besti2) {
+    auto traverse = [&](auto track_c, const float *blo, const float *bhi, unsigned &besti2) {
         constexpr bool TRACK = decltype(track_c)::value;
         unsigned lmin = 0xFFFFFFFFu;
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
@@ -832,7 +834,7 @@ __device__ __forceinline__ void sweep_group(
             float bound = __uint_as_float(kmin & ~IDMASK);
             // A lane whose minimum is below the bound of every remaining superblock is finished for
             // good (the keys ascend).  The traversal ends when no lane is left ...
-            const unsigned long long act = __ballot(part && cull >= bound);
+            const unsigned long long act = __builtin_amdgcn_ballot_w64(cull >= bound);
             if (act == 0ull) break;  // every remaining superblock is strictly farther than every lane's minimum
             // ... and when half of the lanes have finished since the keys were computed, the box of
             // the remaining lanes replaces the previous box: a far outlier no longer keeps the
@@ -861,7 +863,7 @@ __device__ __forceinline__ void sweep_group(
                 kmin = wave_min_u32(lmin);
                 if (kmin == 0xFFFFFFFFu) break;
                 bound = __uint_as_float(kmin & ~IDMASK);
-                if (__ballot(part && cull >= bound) == 0ull) break;
+                if (__builtin_amdgcn_ballot_w64(cull >= bound) == 0ull) break;
             }
             const int s = (int)(kmin & IDMASK);
             const int e = (s - sub) / nsub;
@@ -892,7 +894,7 @@ __device__ __forceinline__ void sweep_group(
             for (int j = 0; j < SBB; j++) {
                 const float lb = box_bound(qx, qy, qz, bx[j * 6 + 0], bx[j * 6 + 1], bx[j * 6 + 2], bx[j * 6 + 3],
                                            bx[j * 6 + 4], bx[j * 6 + 5]);
-                if (__ballot(part && lb <= cull) != 0ull) need |= 1u << j;
+                if (__builtin_amdgcn_ballot_w64(lb <= cull) != 0ull) need |= 1u << j;
             }
             if (need == 0) continue;
             if constexpr (TRACK) {
@@ -976,7 +978,7 @@ __device__ __forceinline__ void sweep_group(
     };
 
     unsigned besti = 0xFFFFFFFFu;
-    traverse(std::false_type{}, valid, glo, ghi, besti);
+    traverse(std::false_type{}, glo, ghi, besti);
 
     // lowest original index among the exact matches of the winning block
     {
@@ -995,9 +997,9 @@ __device__ __forceinline__ void sweep_group(
                               wave_min_f32(flagged ? qz : INFINITY)};
         const float fhi[3] = {wave_max_f32(flagged ? qx : -INFINITY), wave_max_f32(flagged ? qy : -INFINITY),
                               wave_max_f32(flagged ? qz : -INFINITY)};
-        cull = best;  // the wave's own minima are final: match against them
+        cull = flagged ? best : -INFINITY;  // the wave's own minima are final: match against them
         unsigned besti2 = 0xFFFFFFFFu;
-        traverse(std::true_type{}, flagged, flo, fhi, besti2);
+        traverse(std::true_type{}, flo, fhi, besti2);
         if (flagged) besti = besti2;
     }
 
