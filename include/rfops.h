@@ -45,7 +45,9 @@ const char *rf_status_string(int status);
 /* Replaces NmDistanceKernelLauncher(b,n,xyz,m,xyz2,result,result_i,result2,result2_i)
  * (tf_ops/CD/tf_nndistance.cpp:168, tf_nndistance_g.cu:127-130; same op duplicated under
  * pc_distance/).  dist1[i,j] = min_k |xyz2[i,k]-xyz1[i,j]|^2, idx1 = lowest argmin;
- * dist2/idx2 symmetric.  `workspace` holds per-split partial minima. */
+ * dist2/idx2 symmetric.  `workspace`: per-split partial minima (dense sweep) or the sorted clouds
+ * and their boxes (culled sweep); rf_nn_distance_workspace_bytes sizes it for the sweep that
+ * rf_nn_distance picks for this shape. */
 size_t rf_nn_distance_workspace_bytes(int b, int n, int m);
 int rf_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist1,
                    int *idx1, float *dist2, int *idx2, void *workspace, size_t workspace_bytes,
@@ -62,6 +64,7 @@ int rf_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2, fl
 #define RF_NN_AUTO 0
 #define RF_NN_DENSE 1
 #define RF_NN_CULLED 2
+size_t rf_nn_distance_mode_workspace_bytes(int b, int n, int m, int mode);
 int rf_nn_distance_mode(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist1,
                         int *idx1, float *dist2, int *idx2, void *workspace, size_t workspace_bytes,
                         rf_stream_t stream, int mode, unsigned long long *stats);

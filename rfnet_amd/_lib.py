@@ -18,6 +18,7 @@ SIGNATURES = {
     "rf_status_string": (C.c_char_p, [_i]),
     "rf_nn_distance_workspace_bytes": (_sz, [_i, _i, _i]),
     "rf_nn_distance": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "rf_nn_distance_mode_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "rf_nn_distance_mode": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp]),
     "rf_nn_distance_grad": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rf_approxmatch_workspace_bytes": (_sz, [_i, _i, _i, _i]),

@@ -46,7 +46,7 @@ def nn_distance(xyz1, xyz2, mode="auto", stats=None):
     a, b_ = st.up(a, b_)
     d1, i1 = H.empty((b, n), F32, dev), H.empty((b, n), I32, dev)
     d2, i2 = H.empty((b, m), F32, dev), H.empty((b, m), I32, dev)
-    ws, wsz = H.workspace(lib.rf_nn_distance_workspace_bytes(b, n, m), dev, "nn")
+    ws, wsz = H.workspace(lib.rf_nn_distance_mode_workspace_bytes(b, n, m, NN_MODES[mode]), dev, "nn")
     cnt = (C.c_ulonglong * 32)() if stats is not None else None
     check(lib.rf_nn_distance_mode(b, n, m, H.ptr(a), H.ptr(b_), H.ptr(d1), H.ptr(i1), H.ptr(d2),
                                   H.ptr(i2), H.ptr(ws), wsz, H.stream(dev), NN_MODES[mode],

@@ -586,14 +586,28 @@ bool culled_pays(int b, int n, int m) {
     return pairs >= (hi <= 4096 ? (1L << 25) : (1L << 28));
 }
 
+// RF_NN_AUTO -> the sweep this shape gets.  RF_NN_MODE=dense|culled pins the choice for
+// experiments (tools/ab_chamfer.py).
+int resolve_mode(int b, int n, int m, int mode) {
+    if (mode != RF_NN_AUTO) return mode;
+    static const char *env = getenv("RF_NN_MODE");
+    if (env && env[0] == 'd') return RF_NN_DENSE;
+    if (env && env[0] == 'c') return rfp::pruned_supported(b, n, m) ? RF_NN_CULLED : RF_NN_DENSE;
+    return culled_pays(b, n, m) ? RF_NN_CULLED : RF_NN_DENSE;
+}
+
 }  // namespace
 
 extern "C" {
 
 size_t rf_nn_distance_workspace_bytes(int b, int n, int m) {
+    return rf_nn_distance_mode_workspace_bytes(b, n, m, RF_NN_AUTO);
+}
+
+size_t rf_nn_distance_mode_workspace_bytes(int b, int n, int m, int mode) {
     if (b <= 0 || n <= 0 || m <= 0) return 0;
-    const size_t dense = make_plan(b, n, m).bytes, pruned = rfp::pruned_workspace_bytes(b, n, m);
-    return dense > pruned ? dense : pruned;  // either path may be taken (rf_nn_distance_mode)
+    mode = resolve_mode(b, n, m, mode);
+    return mode == RF_NN_CULLED ? rfp::pruned_workspace_bytes(b, n, m) : make_plan(b, n, m).bytes;
 }
 
 int rf_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist1,
@@ -612,14 +626,7 @@ int rf_nn_distance_mode(int b, int n, int m, const float *xyz1, const float *xyz
     if (n == 0 || m == 0) return RF_EINVAL;  // a nearest neighbour in an empty set is undefined
     if (!xyz1 || !xyz2 || !dist1 || !idx1 || !dist2 || !idx2 || !workspace) return RF_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (mode == RF_NN_AUTO) {
-        // RF_NN_MODE=dense|culled pins the choice for experiments (tools/ab_chamfer.py)
-        static const char *env = getenv("RF_NN_MODE");
-        if (env && env[0] == 'd') mode = RF_NN_DENSE;
-        else if (env && env[0] == 'c') mode = RF_NN_CULLED;
-        else mode = culled_pays(b, n, m) ? RF_NN_CULLED : RF_NN_DENSE;
-        if (mode == RF_NN_CULLED && !rfp::pruned_supported(b, n, m)) mode = RF_NN_DENSE;
-    }
+    mode = resolve_mode(b, n, m, mode);
     if (mode == RF_NN_CULLED) {
         if (!rfp::pruned_supported(b, n, m)) return RF_EINVAL;
         return rfp::pruned_nn_distance(b, n, m, xyz1, xyz2, dist1, idx1, dist2, idx2, workspace,
