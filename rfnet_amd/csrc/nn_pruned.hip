@@ -1039,7 +1039,9 @@ __device__ __forceinline__ void sweep_group(
 // a 256-thread workgroup when the launch also holds shared groups (two launches, one per shape,
 // measured slower than the packing).  A persistent grid pulling group ids from an atomic counter
 // was tried as well: 3x slower -- same-address device-scope atomics serialise at ~25 ns each.
-__global__ __launch_bounds__(256) void nnp_sweep_kernel(
+// (7 waves per SIMD: the loop's 48 record + 24 box SGPRs put the kernel at 106 SGPRs = 6 waves; capping
+// it at 7 spills 16 cold ones to VGPR lanes and measures 2 % faster, capping at 8 spills into the loop)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void nnp_sweep_kernel(
     SweepArgs a, const float *__restrict__ xyz0, const float *__restrict__ xyz1, const int *__restrict__ orig0,
     const int *__restrict__ orig1, const float *__restrict__ b16_0, const float *__restrict__ b16_1,
     const float *__restrict__ b64_0, const float *__restrict__ b64_1, float *__restrict__ dist0,
