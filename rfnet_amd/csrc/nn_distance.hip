@@ -576,14 +576,19 @@ Plan make_plan(int b, int n, int m) {
 
 // When the culled sweep (nn_pruned.hip) beats the dense one.  Its cost grows with b * (n + m) (a
 // few hundred instructions per point) plus a sort whose duration depends on the larger cloud
-// (13 us at 1024 points, 36 us at 16384: one workgroup per cloud); the dense sweep's with b*n*m at
-// ~5e12 pairs/s.  Measured on MI355X (tools/ab_culled.py, randn clouds): 32 x 1024^2 1.3x,
-// 32 x 4096^2 1.5x, 8 x 2048 x 16384 1.0x, 32 x 2048 x 16384 1.9x, 32 x 16384^2 6.7x.
+// (13 us at 1024 points, 29 us at 16384 with one workgroup per cloud; beyond 16384 points the
+// cloud no longer fits the registers and the sort costs ~4 ns per point); the dense sweep's with
+// b*n*m at 2.5-6e12 pairs/s.  Thresholds from tools/ab_modes.py + tools/ab_culled.py on MI355X
+// (randn clouds), e.g. 1 x 4096^2 1.2x, 32 x 3000 x 1024 1.1x, 4 x 3000 x 16384 1.5x, 8 x 8192^2
+// 2.2x, 32 x 2048 x 16384 2.2x, 32 x 16384^2 8x, 1 x 65536^2 2.8x; dense stays ahead at
+// 128 x 1024^2, 32 x 512 x 16384, 2 x 65536 x 4096.
 bool culled_pays(int b, int n, int m) {
     const int lo = n < m ? n : m, hi = n < m ? m : n;
-    if (!rfp::pruned_supported(b, n, m) || lo < 512) return false;
+    if (!rfp::pruned_supported(b, n, m) || lo < 1024 || (long)n * m < (1L << 21)) return false;
     const long pairs = (long)b * n * m;
-    return pairs >= (hi <= 4096 ? (1L << 25) : (1L << 28));
+    if (hi <= 4096) return pairs >= (1L << 24);
+    if (hi <= 16384) return pairs >= (1L << 27);
+    return pairs >= 44000L * hi;
 }
 
 // RF_NN_AUTO -> the sweep this shape gets.  RF_NN_MODE=dense|culled pins the choice for
