@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""A/B of the Chamfer sweep under different RF_NN_WAVES targets, each variant in its own
-subprocess but interleaved on the SAME device (rule: never compare across devices/boxes)."""
+"""A/B of the Chamfer forward under an environment knob (default RF_NN_WAVES, a knob of the DENSE
+sweep: the tool pins RF_NN_MODE=dense unless AB_MODE says otherwise; AB_ENV=RF_NNP_SPLIT AB_MODE=culled
+for the culled sweep's), each variant in its own subprocess but interleaved on the SAME device
+(rule: never compare across devices/boxes)."""
 import os
 import subprocess
 import sys
@@ -28,6 +30,6 @@ ENVNAME = os.environ.get("AB_ENV", "RF_NN_WAVES")
 variants = sys.argv[1:] or ["2048", "4096", "8192", "16384"]
 for rnd in range(2):
     for v in variants:
-        env = dict(os.environ, **{ENVNAME: v})
+        env = dict(os.environ, **{ENVNAME: v, "RF_NN_MODE": os.environ.get("AB_MODE", "dense")})
         out = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True)
         print(f"round {rnd} {ENVNAME}={v:>6s}: {out.stdout.strip()} {out.stderr.strip()[-200:] if out.returncode else ''}")
