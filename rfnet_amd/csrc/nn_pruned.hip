@@ -75,6 +75,7 @@ struct SortArgs {
     int *orig[2];
     float *box16[2];
     float *box64[2];
+    int nsets;  // 2 for the Chamfer sweep (both clouds of every batch element), 1 for a single set
     unsigned long long *dbg;  // optional (with stats): s_memtime stamps of the sort's phases, [16..31]
 };
 
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     // batch element is the one that sweeps it, its L2 still holding the records)
     const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (int)(blockIdx.x >> 3);
-    const int bi = logical >> 1, set = logical & 1;
+    const int bi = logical / a.nsets, set = logical - bi * a.nsets;
     const int n = a.n[set], npad = a.npad[set];
     const float *__restrict__ src = a.src[set] + (size_t)bi * n * 3;
     float *__restrict__ oxyz = a.xyz[set] + (size_t)bi * npad * 3;
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(STPB) void nnp_sort_kernel(SortArgs a) {
     // batch element is the one that sweeps it, its L2 still holding the records)
     const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (int)(blockIdx.x >> 3);
-    const int bi = logical >> 1, set = logical & 1;
+    const int bi = logical / a.nsets, set = logical - bi * a.nsets;
     const int n = a.n[set], npad = a.npad[set];
     const float *__restrict__ src = a.src[set] + (size_t)bi * n * 3;
     float *__restrict__ oxyz = a.xyz[set] + (size_t)bi * npad * 3;
@@ -1128,6 +1129,7 @@ int pruned_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2
     SortArgs sa;
     SweepArgs wa;
     sa.b = wa.b = b;
+    sa.nsets = 2;
     const int nn[2] = {n, m};
     const float *src[2] = {xyz1, xyz2};
     for (int k = 0; k < 2; k++) {
@@ -1175,6 +1177,51 @@ int pruned_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2
         RF_HIP(hipMemcpyAsync(stats_out, stats, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         RF_HIP(hipStreamSynchronize(s));
     }
+    return RF_OK;
+}
+
+size_t sort_workspace_bytes(int b, int n) {
+    if (b <= 0 || n <= 0 || n > kMaxPoints) return 0;
+    const size_t npad = (size_t)round_up(n, SB);
+    size_t bytes = 0;
+    for (size_t part : {(size_t)b * npad * 3 * sizeof(float) + 256, (size_t)b * npad * sizeof(int),
+                        (size_t)b * (npad / SB) * B16F * sizeof(float), (size_t)b * (npad / SB) * B64F * sizeof(float)})
+        bytes += (part + 255) / 256 * 256;
+    return bytes;
+}
+
+int sort_clouds(int b, int n, const float *src, void *workspace, size_t workspace_bytes, hipStream_t s, Sorted *out) {
+    if (b <= 0 || n <= 0 || n > kMaxPoints || !src || !workspace || !out) return RF_EINVAL;
+    if (workspace_bytes < sort_workspace_bytes(b, n)) return RF_EWORKSPACE;
+    const int npad = round_up(n, SB);
+    char *w = (char *)workspace;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char *p = w + off;
+        off += (bytes + 255) / 256 * 256;
+        return p;
+    };
+    SortArgs sa;
+    sa.b = b;
+    sa.nsets = 1;
+    sa.dbg = nullptr;
+    sa.n[0] = sa.n[1] = n;
+    sa.npad[0] = sa.npad[1] = npad;
+    sa.src[0] = sa.src[1] = src;
+    sa.xyz[0] = sa.xyz[1] = (float *)take((size_t)b * npad * 3 * sizeof(float) + 256);
+    sa.orig[0] = sa.orig[1] = (int *)take((size_t)b * npad * sizeof(int));
+    sa.box16[0] = sa.box16[1] = (float *)take((size_t)b * (npad / SB) * B16F * sizeof(float));
+    sa.box64[0] = sa.box64[1] = (float *)take((size_t)b * (npad / SB) * B64F * sizeof(float));
+    if (n <= RPT * STPB) {
+        RF_LAUNCH("nnp_sort", nnp_sort_reg_kernel, dim3(b), dim3(STPB), 0, s, sa);
+    } else {
+        RF_LAUNCH("nnp_sort", nnp_sort_kernel<false>, dim3(b), dim3(STPB), 0, s, sa);
+    }
+    out->xyz = sa.xyz[0];
+    out->orig = sa.orig[0];
+    out->box16 = sa.box16[0];
+    out->box64 = sa.box64[0];
+    out->npad = npad;
     return RF_OK;
 }
 

@@ -16,4 +16,18 @@ int pruned_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2
                        float *dist2, int *idx2, void *workspace, size_t workspace_bytes, hipStream_t s,
                        unsigned long long *stats_out);
 
+// The sort on its own (one cloud per batch element), for other operators that want the Hilbert
+// order: records (x, y, z packed) and original indices in key order, padded to a multiple of 64
+// with +inf / -1, and the boxes of every 16-record block / 64-record superblock (layouts in
+// nn_pruned.hip).  The views point into `workspace`.
+struct Sorted {
+    const float *xyz;
+    const int *orig;
+    const float *box16;
+    const float *box64;
+    int npad;
+};
+size_t sort_workspace_bytes(int b, int n);
+int sort_clouds(int b, int n, const float *src, void *workspace, size_t workspace_bytes, hipStream_t s, Sorted *out);
+
 }  // namespace rfp
