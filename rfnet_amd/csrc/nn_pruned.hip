@@ -182,6 +182,7 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     __shared__ unsigned ahist[3][HB];
     __shared__ unsigned short cellmap[3][HB];  // equalised cell, already bit-spread and shifted per axis
     __shared__ unsigned char hlut[192];
+    __shared__ unsigned short hlut2[24 * 64];  // two octant levels per lookup, built from hlut
     __shared__ float red[STPB / 64][6];
     __shared__ unsigned wsum[STPB / 64];
     __shared__ float frame[6];  // lo[3], scale[3]
@@ -268,6 +269,13 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     __syncthreads();
     const float fl[3] = {frame[0], frame[1], frame[2]};
     const float fs[3] = {frame[3], frame[4], frame[5]};
+    // [state * 64 + (octant_hi << 3 | octant_lo)] = next state << 6 | two digits (from the
+    // one-level table, in LDS since the first barrier: no second table to fetch from memory)
+    for (int e = tid; e < 24 * 64; e += STPB) {
+        const unsigned e1 = hlut[(e >> 6) * 8 + ((e >> 3) & 7)];
+        const unsigned e2 = hlut[(e1 >> 3) * 8 + (e & 7)];
+        hlut2[e] = (unsigned short)(((e2 >> 3) << 6) | ((e1 & 7u) << 3) | (e2 & 7u));
+    }
 
     stamp();
     // 2. per-axis histograms of a quarter of the points: the cells only need approximate
@@ -312,13 +320,11 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
         const unsigned m = (unsigned)cellmap[0][axis_bin(px[k], fl[0], fs[0])] |
                            (unsigned)cellmap[1][axis_bin(py[k], fl[1], fs[1])] |
                            (unsigned)cellmap[2][axis_bin(pz[k], fl[2], fs[2])];
-        unsigned st = 0, key = 0;
-#pragma unroll
-        for (int l = 4; l >= 0; l--) {
-            const unsigned e = hlut[st * 8 + ((m >> (3 * l)) & 7u)];
-            key = (key << 3) | (e & 7u);
-            st = e >> 3;
-        }
+        // 5 octant levels = 2 + 2 + 1 table lookups
+        const unsigned e1 = hlut2[(m >> 9) & 63u];  // state 0
+        const unsigned e2 = hlut2[(e1 >> 6) * 64 + ((m >> 3) & 63u)];
+        const unsigned e3 = hlut[(e2 >> 6) * 8 + (m & 7u)];
+        const unsigned key = ((e1 & 63u) << 9) | ((e2 & 63u) << 3) | (e3 & 7u);
         pk[k] = key;
         if (tid + k * STPB < n) atomicAdd(&hist[key], 1u);
     }

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools", "experiments"))
 
 def _lut():
     src = open(os.path.join(ROOT, "rfnet_amd", "csrc", "nn_pruned.hip")).read()
-    m = re.search(r"kHilbertLut\[192\] = \{([^}]*)\}", src)
+    m = re.search(r"kHilbertLut\[192\] = \{([^}]*)\}", src)  # (the two-level table is built from it in LDS)
     return np.array([int(v) for v in m.group(1).split(",")], dtype=np.int64).reshape(24, 8)
 
 
