@@ -188,3 +188,36 @@ def test_non_finite_inputs_terminate(orc):
     ok2 = np.isfinite(c).all(-1)
     assert np.array_equal(got[0][ok1], ref[0][ok1])
     assert np.array_equal(got[2][ok2], ref[2][ok2])
+
+
+def test_stress_ties_against_dense():
+    """150 seeded clouds built to tie (coarse lattices, duplicates, mirrored halves, points on a few
+    planes): every output of the culled sweep equal to the dense sweep's, bit for bit."""
+    bad = []
+    for seed in range(150):
+        rng = np.random.RandomState(9000 + seed)
+        b = int(rng.randint(1, 4))
+        n, m = (int(v) for v in rng.randint(2048, 5000, size=2))
+        kind = seed % 5
+        if kind == 0:
+            a, c = (rng.randint(0, 9, size=(b, k, 3)).astype(np.float32) * 0.5 for k in (n, m))
+        elif kind == 1:
+            base = rng.randn(b, 600, 3).astype(np.float32)
+            a, c = (np.take_along_axis(base, rng.randint(0, 600, size=(b, k, 1)), 1) for k in (n, m))
+        elif kind == 2:
+            h = rng.randn(b, m // 2, 3).astype(np.float32)
+            c = np.concatenate([h, h * np.array([-1, 1, 1], np.float32)], 1)  # mirrored: equidistant pairs
+            a = np.zeros((b, n, 3), np.float32)
+            a[..., 1:] = rng.randn(b, n, 2)  # queries on the mirror plane
+        elif kind == 3:
+            a, c = (rng.randn(b, k, 3).astype(np.float32) for k in (n, m))
+            a[..., 2] = np.round(a[..., 2])
+            c[..., 2] = np.round(c[..., 2])
+        else:
+            a = rng.randn(b, n, 3).astype(np.float32)
+            c = np.concatenate([a[:, : m // 2], a[:, : m - m // 2]], 1)  # the queries themselves, twice over
+        a, c = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(c, np.float32)
+        got, ref = _run(a, c, "culled"), _run(a, c, "dense")
+        if not all(np.array_equal(g, r) for g, r in zip(got, ref)):
+            bad.append(seed)
+    assert not bad, f"culled != dense for seeds {bad}"
