@@ -85,7 +85,10 @@ def test_degenerate_geometry_vs_oracle(orc):
 
 
 @pytest.mark.parametrize("kind", ["randn", "uniform", "sphere", "lattice", "dup"])
-@pytest.mark.parametrize("b,n,m", [(4, 2048, 16384), (2, 16384, 16384), (40, 1000, 3000)])
+# (80 x 3500^2: one wave per group in both directions, one-wave workgroups; 70 x 700 x 5000: shared
+# groups in one direction, single-wave groups packed 4 to a workgroup in the other)
+@pytest.mark.parametrize("b,n,m", [(4, 2048, 16384), (2, 16384, 16384), (40, 1000, 3000), (80, 3500, 3500),
+                                   (70, 700, 5000)])
 def test_culled_equals_dense(orc, kind, b, n, m):
     """All four outputs identical to the dense sweep's, plus an oracle slice."""
     rng = np.random.RandomState(len(kind) * 100 + b + n)
