@@ -56,20 +56,21 @@ def sort_hilbert_eq(p, bits=5, hb=256):
         h = np.bincount(f, minlength=hb); cdf = np.cumsum(h)-h  # exclusive
         q[:,a] = np.minimum((cdf[f] * (1<<bits)) // len(p), (1<<bits)-1)
     return p[np.argsort(hilbert_index(q,bits), kind='stable')]
-rng = np.random.RandomState(100)
-kind = sys.argv[1] if len(sys.argv) > 1 else 'randn'
-def gen(n):
-    if kind=='randn': return rng.randn(n,3).astype(np.float32)
-    if kind=='outlier':
-        x = rng.randn(n,3).astype(np.float32); x[:4] *= 50; return x
-    if kind=='sphere':
-        x = rng.randn(n,3); return (x/np.linalg.norm(x,axis=1,keepdims=True)).astype(np.float32)
-A = gen(2048); B = gen(16384); B2 = gen(16384)
-orders = {'hilbert5': lambda p: sort_hilbert(p,5), 'hilbert5eq': lambda p: sort_hilbert_eq(p,5), 'hilbert6eq': lambda p: sort_hilbert_eq(p,6)}
-for name,f in orders.items():
-  As,Bs,B2s = f(A),f(B),f(B2)
-  for BS,SB in ((16,4),):
-      s1 = sim(As,Bs,64,BS,SB,16,rng); s2 = sim(Bs,As,64,BS,SB,32,rng); s3 = sim(Bs,B2s,64,BS,SB,32,rng)
-      c1,c2,c3 = cost(s1,BS,28),cost(s2,BS,22),cost(s3,BS,28)
-      tot_c2 = (c1*32*32 + c2*256*32)/9.3e11*1e6; tot_ns = 2*c3*256*32/9.3e11*1e6
-      print(f'{kind} {name} BS{BS} SB{SB}: A>B sc {s1[0]:.0f} t {s1[1]:.0f} st {s1[2]:.0f} cost {c1:.0f} | B>A sc {s2[0]:.1f} t {s2[1]:.0f} st {s2[2]:.0f} cost {c2:.0f} | B>B sc {s3[0]:.1f} t {s3[1]:.0f} st {s3[2]:.0f} cost {c3:.0f} || est C2 {tot_c2:.0f} us  NS {tot_ns:.0f} us')
+if __name__ == '__main__':
+    rng = np.random.RandomState(100)
+    kind = sys.argv[1] if len(sys.argv) > 1 else 'randn'
+    def gen(n):
+        if kind=='randn': return rng.randn(n,3).astype(np.float32)
+        if kind=='outlier':
+            x = rng.randn(n,3).astype(np.float32); x[:4] *= 50; return x
+        if kind=='sphere':
+            x = rng.randn(n,3); return (x/np.linalg.norm(x,axis=1,keepdims=True)).astype(np.float32)
+    A = gen(2048); B = gen(16384); B2 = gen(16384)
+    orders = {'hilbert5': lambda p: sort_hilbert(p,5), 'hilbert5eq': lambda p: sort_hilbert_eq(p,5), 'hilbert6eq': lambda p: sort_hilbert_eq(p,6)}
+    for name,f in orders.items():
+      As,Bs,B2s = f(A),f(B),f(B2)
+      for BS,SB in ((16,4),):
+          s1 = sim(As,Bs,64,BS,SB,16,rng); s2 = sim(Bs,As,64,BS,SB,32,rng); s3 = sim(Bs,B2s,64,BS,SB,32,rng)
+          c1,c2,c3 = cost(s1,BS,28),cost(s2,BS,22),cost(s3,BS,28)
+          tot_c2 = (c1*32*32 + c2*256*32)/9.3e11*1e6; tot_ns = 2*c3*256*32/9.3e11*1e6
+          print(f'{kind} {name} BS{BS} SB{SB}: A>B sc {s1[0]:.0f} t {s1[1]:.0f} st {s1[2]:.0f} cost {c1:.0f} | B>A sc {s2[0]:.1f} t {s2[1]:.0f} st {s2[2]:.0f} cost {c2:.0f} | B>B sc {s3[0]:.1f} t {s3[1]:.0f} st {s3[2]:.0f} cost {c3:.0f} || est C2 {tot_c2:.0f} us  NS {tot_ns:.0f} us')

@@ -36,7 +36,7 @@ def main(out):
             if "at::native" in k or "rocclr" in k:
                 continue
             print(f"  {k:30s} grid_x={grid:>9d} wg={wg:>5d} calls={len(v):>5d} avg_ns={sum(v) / len(v):12.1f}")
-    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+    for sub in ("pmc_fetch", "pmc_fetchsize", "pmc_write", "pmc_sq", "pmc_sq2"):
         for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
             acc = defaultdict(lambda: defaultdict(list))
             for row in csv.DictReader(open(f)):
