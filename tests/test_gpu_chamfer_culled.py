@@ -224,3 +224,26 @@ def test_stress_ties_against_dense():
         if not all(np.array_equal(g, r) for g, r in zip(got, ref)):
             bad.append(seed)
     assert not bad, f"culled != dense for seeds {bad}"
+
+
+def test_two_streams_concurrently():
+    """The culled sweep keeps no state outside the caller's workspace: two streams, each with its
+    own inputs (the wrapper gives each stream its own scratch), interleaved launches, results equal
+    to the sequential ones."""
+    from rfnet_amd import _raw
+    rng = np.random.RandomState(77)
+    xs = [(torch.from_numpy(rng.randn(6, 2500, 3).astype(np.float32)).cuda(),
+           torch.from_numpy(rng.randn(6, 9000, 3).astype(np.float32)).cuda()) for _ in range(2)]
+    ref = [[t.clone() for t in _raw.nn_distance(a, c, mode="culled")] for a, c in xs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [None, None]
+    for rep in range(5):
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                outs[i] = _raw.nn_distance(*xs[i], mode="culled")
+    for st in streams:
+        st.synchronize()
+    for i in range(2):
+        for g, e in zip(outs[i], ref[i]):
+            assert torch.equal(g, e)
