@@ -1,5 +1,5 @@
 """Soak: the culled Chamfer sweep against the dense one over many random shapes / cloud kinds (every
-output bit for bit).  python tools/soak_culled.py [seconds]"""
+output bit for bit).  python tools/soak_culled.py [seconds [smallest cloud]]"""
 import sys
 import time
 
@@ -15,7 +15,8 @@ case = bad = 0
 while time.time() - t0 < budget:
     rng = np.random.RandomState(123456 + case)
     b = int(rng.choice([1, 2, 3, 5, 8, 17, 33, 70]))
-    n, m = (int(v) for v in np.exp(rng.uniform(np.log(1), np.log(20000), size=2)))
+    lo = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+    n, m = (int(v) for v in np.exp(rng.uniform(np.log(lo), np.log(20000), size=2)))
     if b * (n + m) > 600000:
         b = max(1, 600000 // (n + m))
     kind = case % 7
