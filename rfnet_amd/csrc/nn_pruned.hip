@@ -823,15 +823,32 @@ __device__ __forceinline__ void sweep_group(
     // (writes it, consumes it, keeps the minimum of its entries in `lmin`).
     auto traverse = [&](auto track_c, const float *blo, const float *bhi, unsigned &besti2) {
         constexpr bool TRACK = decltype(track_c)::value;
-        unsigned lmin = 0xFFFFFFFFu;
-#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-        for (int e = lane; e < nmine; e += 64) {
+        // up to 256 entries (every cloud that fits the register-resident sort): the lane's entries
+        // e = lane + 64 i live in 4 registers and the LDS list is not used at all
+        const bool inreg = nmine <= 256;  // uniform
+        unsigned kk[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        auto entry_key = [&](int e, const float *lo3, const float *hi3) {
             const int s = sub + nsub * e;
             const float4 *cb = (const float4 *)(CB64 + (size_t)s * B64F);
-            const float lb = boxbox_bound(blo, bhi, cb[0], cb[1]);
-            const unsigned key = (__float_as_uint(lb) & ~IDMASK) | (unsigned)s;
-            keys[e] = key;
-            lmin = min(lmin, key);
+            const float lb = boxbox_bound(lo3, hi3, cb[0], cb[1]);
+            return (__float_as_uint(lb) & ~IDMASK) | (unsigned)s;
+        };
+        unsigned lmin = 0xFFFFFFFFu;
+        if (inreg) {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (i * 64 < nmine) {  // uniform
+                    const int e = lane + 64 * i;
+                    kk[i] = e < nmine ? entry_key(e, blo, bhi) : 0xFFFFFFFFu;
+                }
+            lmin = min(min(kk[0], kk[1]), min(kk[2], kk[3]));
+        } else {
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+            for (int e = lane; e < nmine; e += 64) {
+                const unsigned key = entry_key(e, blo, bhi);
+                keys[e] = key;
+                lmin = min(lmin, key);
+            }
         }
         int nact_ref = 64;  // active lanes when the keys were last (re)computed
         for (;;) {
@@ -860,15 +877,19 @@ __device__ __forceinline__ void sweep_group(
                 const float ahi[3] = {wave_max_f32(on ? qx : -INFINITY), wave_max_f32(on ? qy : -INFINITY),
                                       wave_max_f32(on ? qz : -INFINITY)};
                 lmin = 0xFFFFFFFFu;
+                if (inreg) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        if (i * 64 < nmine && kk[i] != 0xFFFFFFFFu) kk[i] = entry_key(lane + 64 * i, alo, ahi);  // (consumed ones stay)
+                    lmin = min(min(kk[0], kk[1]), min(kk[2], kk[3]));
+                } else {
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-                for (int e = lane; e < nmine; e += 64) {
-                    if (keys[e] == 0xFFFFFFFFu) continue;  // consumed
-                    const int s = sub + nsub * e;
-                    const float4 *cb = (const float4 *)(CB64 + (size_t)s * B64F);
-                    const float lb = boxbox_bound(alo, ahi, cb[0], cb[1]);
-                    const unsigned key = (__float_as_uint(lb) & ~IDMASK) | (unsigned)s;
-                    keys[e] = key;
-                    lmin = min(lmin, key);
+                    for (int e = lane; e < nmine; e += 64) {
+                        if (keys[e] == 0xFFFFFFFFu) continue;  // consumed
+                        const unsigned key = entry_key(e, alo, ahi);
+                        keys[e] = key;
+                        lmin = min(lmin, key);
+                    }
                 }
                 kmin = wave_min_u32(lmin);
                 if (kmin == 0xFFFFFFFFu) break;
@@ -884,7 +905,15 @@ __device__ __forceinline__ void sweep_group(
 #pragma unroll
                 for (int i = 0; i < B16F; i++) bx[i] = bp[i];
             }
-            if (lane == (e & 63)) {
+            if (nmine <= 64) {  // one entry per lane (C2: 32 superblocks, or a quarter of 256)
+                kk[0] = lane == e ? 0xFFFFFFFFu : kk[0];
+                lmin = kk[0];
+            } else if (inreg) {
+                const bool mine = lane == (e & 63);
+#pragma unroll
+                for (int i = 0; i < 4; i++) kk[i] = (mine && (e >> 6) == i) ? 0xFFFFFFFFu : kk[i];
+                lmin = min(min(kk[0], kk[1]), min(kk[2], kk[3]));
+            } else if (lane == (e & 63)) {
                 keys[e] = 0xFFFFFFFFu;
                 lmin = 0xFFFFFFFFu;
                 // 4 entries per trip, all four LDS reads in flight together (clamped indices
