@@ -1,33 +1,49 @@
 #!/usr/bin/env python3
 """bench.py -- the headline metric of BASELINE.json on MI355X:
-    "point-pairs/sec Chamfer (B x N x M)", configs[1] = Chamfer fwd+bwd, B=32, 2048 vs 16384.
+    "point-pairs/sec Chamfer (B x N x M) at 1/2/4/8 GPU", configs[1] = Chamfer fwd+bwd, B=32,
+    2048 vs 16384; "EMD iters/sec" as an extra field.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
-  * N>1 is launched by torch.distributed.run, one rank per GPU (RANK/LOCAL_RANK/WORLD_SIZE);
-    the batch shards across ranks with no data-path collective ("scaling": "weak": every GPU
-    runs the full B=32 workload on its own samples); only barrier + max-over-ranks timing use RCCL.
+  * N>1: when WORLD_SIZE is already set (the driver's `python -m torch.distributed.run ...
+    bench.py --gpus N`), this process IS one rank.  When it is not, the script starts the N ranks
+    ITSELF: the parent -- before any torch.cuda / HIP call -- runs `python -m
+    torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` as a CHILD
+    process, relays rank 0's JSON line and exits with the child's return code (no exec of a
+    process that touched the GPU).  `n_gpus` in the line is the process group's world size.
+  * one rank per GPU over RCCL; the batch shards across ranks with NO data-path collective
+    ("scaling": "weak": every GPU runs the full B=32 workload on its own samples); only the
+    barrier, the max-over-ranks timing and (C5) the all-gather of per-sample losses use RCCL.
   * a "step" = one pass of the hot path over one batch: nn_distance forward (both directions)
     + nn_distance_grad with upstream grads of ones (the reference bench's reduce_sum loss,
-    tf_ops/CD/tf_nndistance.py:50), inputs resident in HBM before the timed region.
+    tf_ops/CD/tf_nndistance.py:50), ONE C-ABI call (rf_chamfer_step) on buffers allocated once,
+    inputs resident in HBM before the timed region.
   * rank 0 prints ONE JSON line.  `value` = B*N*M*K*world / seconds (pairs/s, whole job).
-  * "roofline": the forward is fp32-VALU bound: 16 flop per (B*N*M) pair (8
-    per directed pair) against the fp32 peak of 157.3 TFLOP/s (= the dense f32 MFMA peak, which
-    is why the schema's "mfma" label is used); HBM is irrelevant ("roofline_hbm": 20*B*(N+M)
-    algorithmic bytes per launch).  At this size rf_nn_distance takes the CULLED sweep
-    (nn_pruned.hip: Hilbert sort + exact box-bound culling, bit-identical outputs), whose
-    dominant kernel nnp_sweep evaluates only ~10 % of the pairs: `achieved` is, as the contract
-    says, the ALGORITHMIC flop rate (it may exceed the peak: that is the culling, not the
-    pipe), `executed_*` is what the VALU really did (evaluated pairs x 8 flop, from the
-    kernel's own counters).  "roofline_dense" is the dense sweep (nn_sweep, every pair) timed
-    in the same run: the kernel-quality figure when nothing can be culled.  Durations are
-    hipEvents recorded by librfops on the launch stream during the timed steps.
-  * "cpu_baseline": the reference's own CPU kernel (nnsearch x2, oracle/_ref, kind "reference";
-    falls back to the C restatement, kind "port") on one host core, on a bounded sample of the
-    same workload.  Rank 0, N=1 only.
+  * "roofline": the forward is fp32-VALU bound: NOT HBM (20*B*(N+M) bytes) and
+    NOT MFMA ((b-a)^2 is not a product of a row and a column factor).  The dominant kernel is
+    nnp_sweep, the culled exact sweep (nn_pruned.hip: Hilbert sort + box-bound culling,
+    bit-identical outputs).  `achieved`/`frac` are what the VALU EXECUTED: 8 flop x the directed
+    pairs the kernel evaluated (its own counters) / its average launch duration (hipEvents on
+    the launch stream during the timed steps) against the 157.3 TFLOP/s fp32 vector peak -- a
+    fraction <= 1 by construction.  The culling itself is reported separately as
+    `algorithmic_speedup_vs_dense` (dense sweep time / culled sweep time on the same inputs) and
+    `algorithmic_achieved` (16 flop x B*N*M / time, may exceed the peak: that is the culling, not
+    the pipe).  "roofline_dense" is the dense sweep (nn_sweep, every pair) in the same run.
+  * "by_distribution": the same step on the point distributions the operator meets in the model
+    (randn, uniform cube, sphere surface, resample_pcd-style duplicates, the untrained RFNet's own
+    outputs): ms/step, evaluated fraction, culled vs dense forward, `identical_to_dense_sweep`.
+  * "cpu_baseline": the reference's own CPU kernels (nnsearch x2 + the NnDistanceGrad loop,
+    oracle/_ref, kind "reference"; the C restatement, kind "port", where that is absent) on one
+    host core on the same workload.  Rank 0, N=1 only.
+  * `--workload c5`: BASELINE.json configs[4] on this rank's share (B=32 per GPU): RFNet recurrent
+    forward (3 steps to 16384 points) + chamfer_big + earth_mover at 64^2 / 1024^2, per-sample
+    losses all-gathered over the ranks; reported in samples/s.  The default run carries the same
+    measurement as the extra field "c5" (few steps).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,34 +54,37 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector == dense f32 MFMA peak
+FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector peak
 HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: HBM3E spec peak
 
 
-def cpu_baseline(B, N, M, seed):
-    """Reference CPU path timed on this host: NnDistanceOp = nnsearch x2 (tf_nndistance.cpp:79-80),
-    single thread, on a bounded sample (batch elements of the same workload)."""
-    from oracle.oracle import Oracle, Ref, ref_available
-    rng = np.random.RandomState(seed)
-    sample_b = max(1, min(B, 16))  # ~5-10 s of CPU work
-    a = rng.randn(sample_b, N, 3).astype(np.float32)
-    c = rng.randn(sample_b, M, 3).astype(np.float32)
-    if ref_available():
-        impl, kind = Ref(), "reference"
-    else:
-        impl, kind = Oracle(), "port"
-    impl.nn_distance(a[:1, :256], c[:1, :256])  # warm
-    t0 = time.perf_counter()
-    impl.nn_distance(a, c)
-    dt = time.perf_counter() - t0
-    return {
-        "value": sample_b * N * M / dt,
-        "unit": "pairs/s",
-        "cores": 1,
-        "kind": kind,
-        "sample": f"nn_distance forward (both directions), {sample_b} of {B} batch elements of "
-                  f"{N}x{M}, {dt:.2f} s on 1 core",
-    }
+# ----------------------------------------------------------------------------- launching -----
+def spawn_ranks(args):
+    """--gpus N>1 without a launcher: start the N ranks as a child torch.distributed.run job.
+    This parent never initialises the GPU (nothing below touches torch.cuda)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    relayed = 0
+    for line in proc.stdout:
+        if line.startswith("{"):
+            sys.stdout.write(line)  # rank 0's single JSON line
+            sys.stdout.flush()
+            relayed += 1
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if rc == 0 and relayed != 1:
+        sys.stderr.write(f"bench.py: expected exactly one JSON line from rank 0, saw {relayed}\n")
+        rc = 1
+    sys.exit(rc)
 
 
 def dry_run_cpu(args):
@@ -75,6 +94,8 @@ def dry_run_cpu(args):
 
     from rfnet_amd import shard
     rank, world, _ = shard.init_from_env(backend="gloo")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: process group has {world} ranks but --gpus {args.gpus}")
     g = torch.Generator().manual_seed(100 + rank)
     a = torch.randn(2, 64, 3, generator=g)
     c = torch.randn(2, 128, 3, generator=g)
@@ -86,17 +107,137 @@ def dry_run_cpu(args):
     fence()
     t0 = time.perf_counter()
     for _ in range(2):
-        torch.cdist(a, c).min(-1)  # placeholder work, result unused
+        per = torch.cdist(a, c).min(-1).values.mean(-1)  # placeholder work
     fence()
     tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    full = shard.all_gather_per_sample(per, 2 * world, rank, world)  # the C5 loss gather, on gloo
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": 2, "seconds_max": float(tmax.item()),
+        print(json.dumps({"dry_run": True, "n_gpus": dist.get_world_size() if world > 1 else 1,
+                          "ranks": world, "backend": "gloo", "steps": 2, "gathered": int(full.shape[0]),
+                          "seconds_max": float(tmax.item()),
                           "note": "CPU/gloo plumbing check; no operator runs, no metric"}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------- CPU baseline --
+def cpu_baseline(B, N, M, seed, sample_b, with_grad=True):
+    """Reference CPU path timed on this host: NnDistanceOp = nnsearch x2 (tf_nndistance.cpp:79-80)
+    and, with_grad, the NnDistanceGrad CPU loop (:126-163) -- the same forward+backward the GPU
+    step runs -- single thread, on `sample_b` batch elements of the same workload."""
+    from oracle.oracle import Oracle, Ref, ref_available
+    rng = np.random.RandomState(seed)
+    sample_b = max(1, min(B, sample_b))
+    a = rng.randn(sample_b, N, 3).astype(np.float32)
+    c = rng.randn(sample_b, M, 3).astype(np.float32)
+    if ref_available():
+        impl, kind = Ref(), "reference"
+    else:
+        impl, kind = Oracle(), "port"
+    impl.nn_distance(a[:1, :256], c[:1, :256])  # warm
+    t0 = time.perf_counter()
+    d1, i1, d2, i2 = impl.nn_distance(a, c)
+    if with_grad:
+        impl.nn_distance_grad(a, c, np.ones_like(d1), i1, np.ones_like(d2), i2)
+    dt = time.perf_counter() - t0
+    return {
+        "value": sample_b * N * M / dt,
+        "unit": "pairs/s",
+        "cores": 1,
+        "kind": kind,
+        "sample": f"nn_distance forward (both directions){' + nn_distance_grad' if with_grad else ''}, "
+                  f"{sample_b} of {B} batch elements of {N}x{M}, {dt:.2f} s on 1 core",
+    }
+
+
+# ----------------------------------------------------------------------------- workloads -----
+def make_distributions(B, N, M, rank, dev, want_model=True):
+    """(name, xyz1 (B,N,3), xyz2 (B,M,3), note) for the distributions the operator meets."""
+    rng = np.random.RandomState(300 + rank)
+
+    def t(x):
+        return torch.from_numpy(np.ascontiguousarray(x.astype(np.float32))).to(dev)
+
+    yield ("uniform_cube", t(rng.rand(B, N, 3) - 0.5), t(rng.rand(B, M, 3) - 0.5), "U(-0.5,0.5)^3")
+    s1, s2 = rng.randn(B, N, 3), rng.randn(B, M, 3)
+    yield ("sphere_surface", t(s1 / np.linalg.norm(s1, axis=-1, keepdims=True)),
+           t(s2 / np.linalg.norm(s2, axis=-1, keepdims=True)), "unit sphere surface")
+    # data_util.resample_pcd (data_util.py:8-13): a partial scan with fewer points than the input
+    # size is filled up with random DUPLICATES of its own points -> exact ties
+    uniq = max(N // 3, 1)
+    base = rng.rand(B, uniq, 3) - 0.5
+    idx = np.concatenate([np.stack([rng.permutation(uniq) for _ in range(B)]),
+                          rng.randint(0, uniq, (B, N - uniq))], 1)
+    yield ("resample_pcd_duplicates", t(np.take_along_axis(base, idx[..., None], 1)), t(rng.rand(B, M, 3) - 0.5),
+           f"xyz1 = {uniq} unique points resampled to {N} (data_util.resample_pcd), xyz2 unique")
+    if want_model and M == 16384:
+        from rfnet_amd.rfnet import RFNet
+        torch.manual_seed(0)
+        net = RFNet().to(dev)
+        partial = t(rng.rand(B, 3000, 3) - 0.5)
+        with torch.no_grad():
+            out = net(partial)[3]
+        yield ("rfnet_untrained_output", partial[:, :N].contiguous() if N <= 3000 else t(rng.rand(B, N, 3) - 0.5),
+               out.contiguous(), "xyz1 = the network input (first N points), xyz2 = untrained RFNet's final output")
+        del net
+
+
+def run_c5(args, rank, world, dev, steps, warmup, use_pg):
+    """BASELINE.json configs[4], this rank's share: B=32 samples of (3000 partial, 16384 gt)."""
+    from rfnet_amd import glue, shard
+    from rfnet_amd.rfnet import RFNet
+    B = args.batch
+    rng = np.random.RandomState(500 + rank)
+    partial = torch.from_numpy((rng.rand(B, 3000, 3) - 0.5).astype(np.float32)).to(dev)
+    gt = torch.from_numpy((rng.rand(B, 16384, 3) - 0.5).astype(np.float32)).to(dev)
+    torch.manual_seed(0)  # same random-init weights on every rank (checkpoint blob is missing: T10)
+    net = RFNet().to(dev)
+
+    def step():
+        with torch.no_grad():
+            p1, p2, p3, pf = net(partial)
+            hgt = glue.SortedCloud(gt)
+            gt64, gt1024 = glue.sampling(64, gt)[1], glue.sampling(1024, gt)[1]
+            cd = glue.chamfer_per_sample(gt, pf, sorted1=hgt)[0].mean(1)            # chamfer_big, per sample
+            e1 = glue.earth_mover_cost(gt64, p1) / 64.0                              # earth_mover terms
+            e2 = glue.earth_mover_cost(gt1024, p2) / 1024.0
+            per = torch.stack([cd, e1, e2], 1)                                       # (B, 3)
+            return shard.all_gather_per_sample(per, B * world, rank, world)          # loss reduction (RCCL)
+
+    def fence():
+        torch.cuda.synchronize()
+        if use_pg:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        full = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        full = step()
+    fence()
+    dt = time.perf_counter() - t0
+    tm = torch.tensor([dt], dtype=torch.float64, device=dev)
+    chk = full.double().sum().reshape(1)
+    lo, hi = chk.clone(), chk.clone()
+    if use_pg:
+        torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tm.item())
+    return {
+        "workload": f"RFNet recurrent forward (3000 -> 64 -> 1024 -> 16384 points, random-init weights) + "
+                    f"chamfer_big(gt, out) + earth_mover at 64^2 and 1024^2, B={B} per GPU "
+                    f"(BASELINE.json configs[4]: B={B * world} over {world} GPU), per-sample losses all-gathered",
+        "value": world * B * steps / dt, "unit": "samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+        "gathered_losses_shape": list(full.shape), "finite": bool(torch.isfinite(full).all().item()),
+        "losses_equal_across_ranks": bool(lo.item() == hi.item()),
+        "mean_losses": [float(x) for x in full.double().mean(0).tolist()],
+    }
 
 
 def main():
@@ -107,24 +248,53 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--n", type=int, default=2048)
     ap.add_argument("--m", type=int, default=16384)
+    ap.add_argument("--workload", choices=["chamfer", "c5"], default="chamfer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (profiling runs)")
     ap.add_argument("--dry-run-cpu", action="store_true",
-                    help="TEST ONLY: exercise the multi-rank plumbing (init, fences, max-over-ranks, "
-                         "rank-0 JSON) on CPU/gloo with placeholder work instead of the HIP ops; prints "
+                    help="TEST ONLY: exercise the multi-rank plumbing (self-launch, init, fences, "
+                         "max-over-ranks, loss gather, rank-0 JSON) on CPU/gloo with placeholder work; prints "
                          "a line marked dry_run and measures nothing")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)  # never returns; nothing above touched the GPU
     if args.dry_run_cpu:
         return dry_run_cpu(args)
 
     from rfnet_amd import _lib, shard
-    from rfnet_amd._raw import approx_match, earth_mover, match_cost, nn_distance, nn_distance_grad
+    from rfnet_amd._raw import ChamferStep, approx_match, earth_mover, match_cost, nn_distance
 
     rank, world, local = shard.init_from_env()
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    use_pg = torch.distributed.is_available() and torch.distributed.is_initialized()
+    if use_pg:
+        world = torch.distributed.get_world_size()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: process group has {world} ranks but --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU fallback")
     dev = torch.device("cuda", torch.cuda.current_device())
     B, N, M = args.batch, args.n, args.m
+
+    def fence():
+        torch.cuda.synchronize()
+        if use_pg:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    if args.workload == "c5":
+        c5 = run_c5(args, rank, world, dev, args.steps, args.warmup, use_pg)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "samples/sec RFNet forward + CD/EMD loss (BASELINE.json configs[4])",
+                "value": c5["value"], "unit": "samples/s", "n_gpus": world, "rccl_ranks": world if use_pg else 1,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": c5["ms_per_step"],
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                "data": "synthetic", "config": {"workload": c5["workload"], "batch_per_gpu": B,
+                                                "sharding": f"batch x{world}"}, "c5": c5}), flush=True)
+        if use_pg:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        return
 
     # synthetic data of configs[1]'s shape; each rank owns its own B samples (weak scaling)
     rng = np.random.RandomState(100 + rank)
@@ -132,19 +302,10 @@ def main():
     xyz2 = torch.from_numpy(rng.randn(B, M, 3).astype(np.float32)).to(dev)
     gd1 = torch.ones(B, N, device=dev)
     gd2 = torch.ones(B, M, device=dev)
+    plan = ChamferStep(B, N, M, dev)  # outputs + workspace allocated once; a step is ONE C-ABI call
 
     def step():
-        d1, i1, d2, i2 = nn_distance(xyz1, xyz2)
-        g1, g2 = nn_distance_grad(xyz1, xyz2, gd1, i1, gd2, i2)
-        return d1, g1, g2
-
-    use_pg = torch.distributed.is_available() and torch.distributed.is_initialized()
-
-    def fence():
-        torch.cuda.synchronize()
-        if use_pg:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
+        return plan(xyz1, xyz2, gd1, gd2)
 
     for _ in range(args.warmup):
         step()
@@ -155,6 +316,7 @@ def main():
         out = step()
     fence()
     dt = time.perf_counter() - t0
+    checksum = float(out[0].double().sum().item())
     # the same K steps again with per-kernel hipEvents (librfops records them on the launch
     # stream) -> roofline.achieved; its wall time is reported next to the un-instrumented one
     _lib.profile_collect()
@@ -168,68 +330,134 @@ def main():
     _lib.profile_enable(False)
     prof = _lib.profile_collect()
 
-    # what the forward did: the culled sweep's own counters (one extra call), and the dense sweep
-    # (every pair evaluated) on the same inputs under the same hipEvent hooks
-    culled_stats = []
-    chk = nn_distance(xyz1, xyz2, stats=culled_stats)
-    _lib.profile_collect()
-    _lib.profile_enable(True)
-    for _ in range(max(3, min(20, args.steps))):
-        dense_out = nn_distance(xyz1, xyz2, mode="dense")
-    fence()
-    _lib.profile_enable(False)
-    prof_dense = _lib.profile_collect()
+    def forward_profile(a, c, mode, reps):
+        """avg ms per launch of each forward kernel in `mode`, outputs, culled counters"""
+        stats = []
+        o = nn_distance(a, c, mode=mode, stats=stats if mode != "dense" else None)
+        torch.cuda.synchronize()
+        _lib.profile_collect()
+        _lib.profile_enable(True)
+        for _ in range(reps):
+            o = nn_distance(a, c, mode=mode)
+        torch.cuda.synchronize()
+        _lib.profile_enable(False)
+        pr = _lib.profile_collect()
+        return {k: v[0] / max(v[1], 1) for k, v in pr.items()}, o, stats
+
+    # what the forward did: the culled sweep's own counters, and the dense sweep (every pair
+    # evaluated) on the same inputs under the same hipEvent hooks
+    reps = max(3, min(20, args.steps))
+    auto_ms, chk, culled_stats = forward_profile(xyz1, xyz2, "auto", reps)
+    dense_ms, dense_out, _ = forward_profile(xyz1, xyz2, "dense", reps)
     same_as_dense = all(bool(torch.equal(x, y)) for x, y in zip(chk, dense_out))
 
-    # second half of BASELINE.json's metric string, "EMD iters/sec": one iter = one
-    # approx_match + match_cost batch call on configs[3] (B=32, 2048 vs 2048, the reference's
-    # 10-level schedule).  Reported as extra fields; `value` stays the Chamfer metric.
-    eb, en = 32, 2048
-    erng = np.random.RandomState(100 + rank)
-    e1 = torch.from_numpy((erng.random_sample((eb, en, 3)) - 0.5).astype(np.float32)).to(dev)
-    e2 = torch.from_numpy((erng.random_sample((eb, en, 3)) - 0.5).astype(np.float32)).to(dev)
-    emd_steps = max(5, min(20, args.steps))
-    for _ in range(2):
-        cost = match_cost(e1, e2, approx_match(e1, e2))
-    fence()
-    t2 = time.perf_counter()
-    for _ in range(emd_steps):
-        cost = match_cost(e1, e2, approx_match(e1, e2))
-    fence()
-    dt_emd = time.perf_counter() - t2
-    emd_checksum = float(cost.double().sum().item())
-    # the same result from the fused op (row f1: match never materialised)
-    for _ in range(2):
-        fcost = earth_mover(e1, e2)
-    fence()
-    t2 = time.perf_counter()
-    for _ in range(emd_steps):
-        fcost = earth_mover(e1, e2)
-    fence()
-    dt_emdf = time.perf_counter() - t2
-    emd_fused_checksum = float(fcost.double().sum().item())
+    extras = {}
+    if not args.no_extras:
+        # ---- the distributions the operator meets in the model ---------------------------------
+        byd = {}
+        dsteps = max(5, min(20, args.steps))
 
-    # north_star's own target shape, reported as an extra field: B=32 x 16384 vs 16384 forward
-    ns_n = 16384
-    nrng = np.random.RandomState(200 + rank)
-    y1 = torch.from_numpy(nrng.randn(B, ns_n, 3).astype(np.float32)).to(dev)
-    y2 = torch.from_numpy(nrng.randn(B, ns_n, 3).astype(np.float32)).to(dev)
-    ns_steps = max(3, min(10, args.steps))
-    for _ in range(2):
-        nso = nn_distance(y1, y2)
-    fence()
-    t3 = time.perf_counter()
-    for _ in range(ns_steps):
-        nso = nn_distance(y1, y2)
-    fence()
-    dt_ns = time.perf_counter() - t3
-    del y1, y2
+        def measure(a, c, note):
+            for _ in range(2):
+                plan(a, c, gd1, gd2)
+            fence()
+            ts = time.perf_counter()
+            for _ in range(dsteps):
+                plan(a, c, gd1, gd2)
+            fence()
+            ms_step = (time.perf_counter() - ts) / dsteps * 1e3
+            am, o_auto, st = forward_profile(a, c, "auto", 5)
+            dm, o_dense, _ = forward_profile(a, c, "dense", 5)
+            ent = {"ms_per_step": ms_step, "forward_ms_auto": sum(am.values()), "forward_ms_dense": sum(dm.values()),
+                   "auto_kernels_ms": am, "note": note,
+                   "identical_to_dense_sweep": all(bool(torch.equal(x, y)) for x, y in zip(o_auto, o_dense))}
+            if "nnp_sweep" in am and len(st) >= 8:
+                ev = 1024.0 * (st[3] + st[7])
+                ent.update({"forward": "culled", "evaluated_fraction_of_2BNM": ev / (2.0 * B * N * M),
+                            "heaviest_wave_block_scans": [int(st[8]), int(st[9])],
+                            "culled_faster_than_dense": sum(am.values()) < sum(dm.values())})
+            else:
+                ent["forward"] = "dense"
+            return ent
 
-    tmax = torch.tensor([dt, dt_emd, dt_ns, dt_emdf], dtype=torch.float64, device=dev)
+        byd["randn"] = measure(xyz1, xyz2, "standard normal (the headline data)")
+        for name, a, c, note in make_distributions(B, N, M, rank, dev):
+            byd[name] = measure(a, c, note)
+            del a, c
+        extras["by_distribution"] = byd
+
+        # ---- second half of BASELINE.json's metric string, "EMD iters/sec": one iter = one
+        # approx_match + match_cost batch call on configs[3] (B=32, 2048 vs 2048, the reference's
+        # 10-level schedule)
+        eb, en = 32, 2048
+        erng = np.random.RandomState(100 + rank)
+        e1 = torch.from_numpy((erng.random_sample((eb, en, 3)) - 0.5).astype(np.float32)).to(dev)
+        e2 = torch.from_numpy((erng.random_sample((eb, en, 3)) - 0.5).astype(np.float32)).to(dev)
+        emd_steps = max(5, min(20, args.steps))
+        for _ in range(2):
+            cost = match_cost(e1, e2, approx_match(e1, e2))
+        fence()
+        t2 = time.perf_counter()
+        for _ in range(emd_steps):
+            cost = match_cost(e1, e2, approx_match(e1, e2))
+        fence()
+        dt_emd = time.perf_counter() - t2
+        emd_checksum = float(cost.double().sum().item())
+        for _ in range(2):
+            fcost = earth_mover(e1, e2)
+        fence()
+        t2 = time.perf_counter()
+        for _ in range(emd_steps):
+            fcost = earth_mover(e1, e2)
+        fence()
+        dt_emdf = time.perf_counter() - t2
+        emd_fused_checksum = float(fcost.double().sum().item())
+        del e1, e2, cost, fcost
+
+        # ---- north_star's own target shape: B=32 x 16384 vs 16384 forward ----------------------
+        ns_n = 16384
+        nrng = np.random.RandomState(200 + rank)
+        y1 = torch.from_numpy(nrng.randn(B, ns_n, 3).astype(np.float32)).to(dev)
+        y2 = torch.from_numpy(nrng.randn(B, ns_n, 3).astype(np.float32)).to(dev)
+        ns_steps = max(3, min(10, args.steps))
+        for _ in range(2):
+            nn_distance(y1, y2)
+        fence()
+        t3 = time.perf_counter()
+        for _ in range(ns_steps):
+            nn_distance(y1, y2)
+        fence()
+        dt_ns = time.perf_counter() - t3
+        del y1, y2
+
+        tmax = torch.tensor([dt_emd, dt_ns, dt_emdf], dtype=torch.float64, device=dev)
+        if use_pg:
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt_emd, dt_ns, dt_emdf = (float(tmax[i].item()) for i in range(3))
+        extras["emd"] = {
+            "metric": "EMD iters/sec (approx_match + match_cost batch calls)",
+            "value": world * emd_steps / dt_emd, "unit": "calls/s", "ms_per_call": dt_emd / emd_steps * 1e3,
+            "level_sweeps_per_s": world * emd_steps * 30 / dt_emd,
+            "exp_evals_per_s": world * emd_steps * 30.0 * eb * en * en / dt_emd,
+            "workload": f"B={eb} per GPU, {en} vs {en}, reference 10-level schedule "
+                        "(BASELINE.json configs[3]); uniform(-0.5,0.5) seed 100",
+            "steps": emd_steps, "checksum": emd_checksum,
+            "fused": {"op": "rf_earth_mover (same cost, match never written to HBM)",
+                      "value": world * emd_steps / dt_emdf, "unit": "calls/s",
+                      "ms_per_call": dt_emdf / emd_steps * 1e3, "checksum": emd_fused_checksum},
+        }
+        extras["north_star_16384sq"] = {
+            "workload": f"nn_distance forward, B={B} per GPU, {ns_n} vs {ns_n} (north_star target shape)",
+            "value": world * B * ns_n * ns_n * ns_steps / dt_ns, "unit": "pairs/s",
+            "ms_per_call": dt_ns / ns_steps * 1e3, "steps": ns_steps,
+        }
+        # ---- configs[4] on this rank's share (also `--workload c5`) -----------------------------
+        extras["c5"] = run_c5(args, rank, world, dev, steps=3, warmup=1, use_pg=use_pg)
+
+    tm = torch.tensor([dt], dtype=torch.float64, device=dev)
     if use_pg:
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-    dt, dt_emd, dt_ns, dt_emdf = (float(tmax[i].item()) for i in range(4))
-    checksum = float(out[0].double().sum().item())
+        torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tm.item())
 
     if rank == 0:
         pairs_per_step = B * N * M
@@ -237,8 +465,7 @@ def main():
         kname = "nnp_sweep" if culled else "nn_sweep"
         sweep_ms, sweep_n = prof.get(kname, (0.0, 0))
         sweep_avg_s = (sweep_ms / max(sweep_n, 1)) * 1e-3
-        dsweep_ms, dsweep_n = prof_dense.get("nn_sweep", (0.0, 0))
-        dsweep_avg_s = (dsweep_ms / max(dsweep_n, 1)) * 1e-3
+        dsweep_avg_s = dense_ms.get("nn_sweep", 0.0) * 1e-3
         flops = 16.0 * B * N * M
         hbm_bytes = 20.0 * B * (N + M)
         traffic = {}
@@ -249,35 +476,44 @@ def main():
                 traffic = {k: tj.get(k, {}).get(f"{B}x{N}x{M}") for k in ("nn_sweep", "nnp_sweep")}
             except Exception:
                 traffic = {}
-        roof = {
-            "bound": "mfma",
-            "pipe": "fp32 VALU (no MFMA use: peak = fp32 vector peak = dense f32 MFMA peak)",
-            "kernel": kname,
-            "achieved": flops / sweep_avg_s / 1e12 if sweep_avg_s else None,
-            "peak": FP32_PEAK_TFLOPS,
-            "unit": "TFLOP/s",
-            "frac": flops / sweep_avg_s / 1e12 / FP32_PEAK_TFLOPS if sweep_avg_s else None,
-            "traffic": traffic.get(kname),
-            "flops_per_launch": flops,
-            "avg_launch_ms": sweep_avg_s * 1e3,
-            "launches": sweep_n,
-        }
-        if culled and len(culled_stats) >= 8:
+        if culled and len(culled_stats) >= 8 and sweep_avg_s:
             evaluated = 1024.0 * (culled_stats[3] + culled_stats[7])  # directed pairs: 16 x 64 per block scan
-            roof.update({
-                "note": "achieved/frac are ALGORITHMIC (16 flop x B*N*M): the kernel culls, so they may exceed "
-                        "the peak; executed_* is the arithmetic actually issued",
+            executed_tf = 8.0 * evaluated / sweep_avg_s / 1e12
+            roof = {
+                "bound": "valu",
+                "pipe": "fp32 VALU (no MFMA use; peak = fp32 vector peak)",
+                "kernel": kname,
+                "achieved": executed_tf,
+                "peak": FP32_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": executed_tf / FP32_PEAK_TFLOPS,
+                "traffic": traffic.get(kname),
+                "note": "achieved = 8 flop x directed pairs the kernel evaluated (its own counters) / avg launch "
+                        "duration; the culling is reported as algorithmic_speedup_vs_dense",
+                "executed_flops_per_launch": 8.0 * evaluated,
                 "evaluated_directed_pairs": evaluated,
                 "evaluated_fraction_of_2BNM": evaluated / (2.0 * B * N * M),
-                "executed_achieved": 8.0 * evaluated / sweep_avg_s / 1e12 if sweep_avg_s else None,
-                "executed_frac": 8.0 * evaluated / sweep_avg_s / 1e12 / FP32_PEAK_TFLOPS if sweep_avg_s else None,
+                "avg_launch_ms": sweep_avg_s * 1e3,
+                "launches": sweep_n,
+                "algorithmic_flops_per_launch": flops,
+                "algorithmic_achieved": flops / sweep_avg_s / 1e12,
+                "algorithmic_speedup_vs_dense": (dsweep_avg_s / sweep_avg_s) if dsweep_avg_s else None,
+                "forward_speedup_vs_dense": (sum(dense_ms.values()) / sum(auto_ms.values())) if auto_ms else None,
                 "identical_to_dense_sweep": same_as_dense,
-            })
+            }
+        else:
+            ach = flops / sweep_avg_s / 1e12 if sweep_avg_s else None
+            roof = {"bound": "valu", "pipe": "fp32 VALU", "kernel": kname, "achieved": ach, "peak": FP32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS if ach else None,
+                    "traffic": traffic.get(kname), "flops_per_launch": flops, "avg_launch_ms": sweep_avg_s * 1e3,
+                    "launches": sweep_n}
+        kernel_sum_ms = sum(v[0] for v in prof.values()) / args.steps
         line = {
             "metric": "point-pairs/sec Chamfer (BxNxM)",
             "value": world * pairs_per_step * args.steps / dt,
             "unit": "pairs/s",
             "n_gpus": world,
+            "rccl_ranks": world if use_pg else 1,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
@@ -291,15 +527,16 @@ def main():
                             "(BASELINE.json configs[1]), randn seed 100",
                 "batch_per_gpu": B, "n": N, "m": M, "sharding": f"batch x{world}",
                 "forward": "culled sweep (nn_pruned.hip)" if culled else "dense sweep (nn_distance.hip)",
+                "step": "rf_chamfer_step: one C-ABI call, caller-allocated outputs",
             },
             "roofline": roof,
             "roofline_dense": {
-                "bound": "mfma", "kernel": "nn_sweep (RF_NN_DENSE: every pair evaluated)",
+                "bound": "valu", "kernel": "nn_sweep (RF_NN_DENSE: every pair evaluated)",
                 "achieved": flops / dsweep_avg_s / 1e12 if dsweep_avg_s else None,
                 "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": flops / dsweep_avg_s / 1e12 / FP32_PEAK_TFLOPS if dsweep_avg_s else None,
                 "traffic": traffic.get("nn_sweep"),
-                "avg_launch_ms": dsweep_avg_s * 1e3, "launches": dsweep_n,
+                "avg_launch_ms": dsweep_avg_s * 1e3,
             },
             "roofline_hbm": {
                 "bound": "hbm", "kernel": kname,
@@ -309,33 +546,18 @@ def main():
                 "bytes_per_launch": hbm_bytes,
             },
             "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items())},
+            "kernel_sum_ms_per_step": kernel_sum_ms,
+            "host_overhead_ms_per_step": dt / args.steps * 1e3 - kernel_sum_ms,
             "ms_per_step_instrumented": dt_prof / args.steps * 1e3,
             "checksum": checksum,
-            "emd": {
-                "metric": "EMD iters/sec (approx_match + match_cost batch calls)",
-                "value": world * emd_steps / dt_emd,
-                "unit": "calls/s",
-                "ms_per_call": dt_emd / emd_steps * 1e3,
-                "level_sweeps_per_s": world * emd_steps * 30 / dt_emd,
-                "exp_evals_per_s": world * emd_steps * 30.0 * eb * en * en / dt_emd,
-                "workload": f"B={eb} per GPU, {en} vs {en}, reference 10-level schedule "
-                            "(BASELINE.json configs[3]); uniform(-0.5,0.5) seed 100",
-                "steps": emd_steps,
-                "checksum": emd_checksum,
-                "fused": {"op": "rf_earth_mover (same cost, match never written to HBM)",
-                          "value": world * emd_steps / dt_emdf, "unit": "calls/s",
-                          "ms_per_call": dt_emdf / emd_steps * 1e3, "checksum": emd_fused_checksum},
-            },
         }
-        line["north_star_16384sq"] = {
-            "workload": f"nn_distance forward, B={B} per GPU, {ns_n} vs {ns_n} (north_star target shape)",
-            "value": world * B * ns_n * ns_n * ns_steps / dt_ns, "unit": "pairs/s",
-            "ms_per_call": dt_ns / ns_steps * 1e3, "steps": ns_steps,
-        }
+        line.update(extras)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(B, N, M, 100)
-            line["north_star_16384sq"]["vs_cpu_baseline"] = (
-                line["north_star_16384sq"]["value"] / line["cpu_baseline"]["value"])
+            line["cpu_baseline"] = cpu_baseline(B, N, M, 100, sample_b=B, with_grad=True)
+            if "north_star_16384sq" in line:
+                cb = cpu_baseline(B, 16384, 16384, 200, sample_b=3, with_grad=False)
+                line["north_star_16384sq"]["cpu_baseline"] = cb
+                line["north_star_16384sq"]["vs_cpu_baseline"] = line["north_star_16384sq"]["value"] / cb["value"]
         print(json.dumps(line), flush=True)
     if use_pg:
         torch.distributed.barrier()

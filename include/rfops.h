@@ -15,6 +15,11 @@
  *   - kernels are stateless and re-entrant; all work is enqueued on `stream`
  *     (a hipStream_t passed as void*; NULL = the null stream).  The reference launches
  *     on the legacy default stream with no error checking; here every call returns a status.
+ *     The library keeps no state between calls and reads no environment variables; the one
+ *     exception is the opt-in measurement hook at the end of this file (rf_profile_*), which is
+ *     process-global, thread-safe and off by default;
+ *   - every call that launches work first checks that the calling thread's current HIP device
+ *     is a gfx950 (the only code objects in the library) and returns RF_ENODEVICE otherwise.
  *
  * Status codes: 0 = success; > 0 = the hipError_t of the failing HIP call;
  *               < 0 = RF_EINVAL-style argument errors below.
@@ -40,6 +45,9 @@ typedef void *rf_stream_t; /* hipStream_t */
 
 const char *rf_version(void);
 const char *rf_status_string(int status);
+/* RF_OK when the calling thread's current HIP device is a gfx950, RF_ENODEVICE otherwise
+ * (no device visible, or another architecture).  Every launching entry point makes this check. */
+int rf_device_check(void);
 
 /* ---------------------------------------------------------------- Chamfer (tf_ops/CD) --- */
 /* Replaces NmDistanceKernelLauncher(b,n,xyz,m,xyz2,result,result_i,result2,result2_i)
@@ -74,6 +82,41 @@ int rf_nn_distance_mode(int b, int n, int m, const float *xyz1, const float *xyz
 int rf_nn_distance_grad(int b, int n, int m, const float *xyz1, const float *xyz2,
                         const float *grad_dist1, const int *idx1, const float *grad_dist2,
                         const int *idx2, float *grad_xyz1, float *grad_xyz2, rf_stream_t stream);
+
+/* ---- one direction, sorted-cloud handles, one-call step (Chamfer, continued) ------------- */
+/* The same op with only the direction(s) a caller uses.  The reference's glue calls
+ * nn_distance(xyz1, xyz2) and then drops outputs: merge_layer keeps idx2 alone
+ * (vv_recon.py:134-135), fidelity_loss dist1 (:386-390), zero_groupnear dist2 (:415-419);
+ * NmDistanceKernelLauncher (tf_nndistance_g.cu:127-130) is two independent kernel launches, one per
+ * direction, so a TF-side op with a "directions" attribute maps onto this entry.  want1: dist1/idx1
+ * (nearest neighbour of every xyz1 point in xyz2); want2: dist2/idx2.  Outputs of a direction that
+ * is not wanted may be NULL and are not written.  Bit-identical to rf_nn_distance's. */
+size_t rf_nn_distance_dir_workspace_bytes(int b, int n, int m, int want1, int want2);
+int rf_nn_distance_dir(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist1,
+                       int *idx1, float *dist2, int *idx2, void *workspace, size_t workspace_bytes,
+                       rf_stream_t stream, int want1, int want2);
+
+/* A cloud that takes part in several Chamfers (the model Chamfers `pointcloud` 3x and `gt` 5x per
+ * training step, vv_recon.py:213,225,238 and :484-498) can be put in space-filling-curve order
+ * ONCE.  `sorted` is a caller-owned device buffer of rf_nn_sort_bytes(b, n) bytes whose layout is a
+ * pure function of (b, n) (records, original indices and block boxes in key order): the library
+ * keeps no state, the buffer IS the handle, valid for as long as the caller keeps it and xyz is
+ * unchanged.  rf_nn_distance_sorted runs the culled exact sweep on two such buffers; a direction
+ * whose outputs are NULL is skipped.  n, m <= 65536.  Same results as rf_nn_distance. */
+size_t rf_nn_sort_bytes(int b, int n);
+int rf_nn_sort(int b, int n, const float *xyz, void *sorted, size_t sorted_bytes, rf_stream_t stream);
+int rf_nn_distance_sorted(int b, int n, int m, const void *sorted1, const void *sorted2, float *dist1,
+                          int *idx1, float *dist2, int *idx2, rf_stream_t stream);
+
+/* NnDistance followed by NnDistanceGrad on its own indices (what one training step of the
+ * reference's Chamfer bench does, tf_ops/CD/tf_nndistance.py:35-61) in ONE call on caller-owned
+ * buffers: one FFI crossing per step, nothing allocated.  Equivalent to rf_nn_distance +
+ * rf_nn_distance_grad(..., grad_dist1, idx1, grad_dist2, idx2, ...). */
+size_t rf_chamfer_step_workspace_bytes(int b, int n, int m);
+int rf_chamfer_step(int b, int n, int m, const float *xyz1, const float *xyz2,
+                    const float *grad_dist1, const float *grad_dist2, float *dist1, int *idx1,
+                    float *dist2, int *idx2, float *grad_xyz1, float *grad_xyz2, void *workspace,
+                    size_t workspace_bytes, rf_stream_t stream);
 
 /* ----------------------------------------------------------- EMD (pc_distance) ---------- */
 /* Replaces approxmatchLauncher(b,n,m,xyz1,xyz2,match,temp) (pc_distance/tf_approxmatch.cpp:141,
@@ -124,6 +167,13 @@ int rf_scatteraddpoint(int b, int n, int m, const float *out_g, const int *idx, 
  * empty ball are left untouched, as in the reference. */
 int rf_queryballpoint(int b, int n, int m, float radius, int nsample, const float *xyz1,
                       const float *xyz2, int *idx, int *pts_cnt, rf_stream_t stream);
+/* The reference's exact signature: `radius_dev` is a DEVICE pointer to one float, the op's input
+ * tensor (tf_grouping.cpp:18,93-95; queryBallPointLauncher(b,n,m,radius*,...), :67).  A TF-side
+ * binder passes the tensor's buffer straight through: no D2H copy, no stream synchronisation.
+ * Same results as rf_queryballpoint for the same radius value. */
+int rf_queryballpoint_dev(int b, int n, int m, const float *radius_dev, int nsample,
+                          const float *xyz1, const float *xyz2, int *idx, int *pts_cnt,
+                          rf_stream_t stream);
 
 /* Replaces groupPointLauncher / groupPointGradLauncher (tf_grouping.cpp:146,177,208).
  * points (b,n,c); idx (b,m,nsample); out / grad_out (b,m,nsample,c); grad_points (b,n,c)
@@ -182,10 +232,48 @@ int rf_earth_mover(int b, int n, int m, const float *xyz1, const float *xyz2, fl
                    float *grad1, float *grad2, void *workspace, size_t workspace_bytes,
                    rf_stream_t stream);
 
+/* `chamfer_big` / `fidelity_loss` (vv_recon.py:381-390) are reduce_mean(sqrt(dist)) over the
+ * nn_distance outputs.  rf_chamfer_loss returns the per-sample means loss (b, 2):
+ * loss[i][0] = mean_j sqrt(dist1[i][j]), loss[i][1] = mean_k sqrt(dist2[i][k]) (0 for a direction
+ * that is not computed) -- the batch means of the reference are the means of these columns -- next
+ * to the nn_distance outputs of the computed directions (a direction whose dist/idx pointers are
+ * NULL is skipped: fidelity_loss needs direction 1 only).  sorted1 / sorted2: optional rf_nn_sort
+ * handles of xyz1 / xyz2 (NULL: sorted internally when the culled sweep is used).
+ * rf_chamfer_loss_grad is its backward: NnDistanceGrad with
+ * grad_dist_d[i][j] = grad_loss[i][d] / npts_d * 0.5 / sqrt(dist_d[i][j]) formed inside the scatter
+ * kernel (no intermediate tensors); grad_xyz1 (b,n,3) / grad_xyz2 (b,m,3) fully overwritten. */
+size_t rf_chamfer_loss_workspace_bytes(int b, int n, int m, int want1, int want2, int have_sorted1,
+                                       int have_sorted2);
+int rf_chamfer_loss(int b, int n, int m, const float *xyz1, const float *xyz2, const void *sorted1,
+                    const void *sorted2, float *loss, float *dist1, int *idx1, float *dist2, int *idx2,
+                    void *workspace, size_t workspace_bytes, rf_stream_t stream);
+int rf_chamfer_loss_grad(int b, int n, int m, const float *xyz1, const float *xyz2, const float *dist1,
+                         const int *idx1, const float *dist2, const int *idx2, const float *grad_loss,
+                         float *grad_xyz1, float *grad_xyz2, rf_stream_t stream);
+
+/* `merge_layer` (vv_recon.py:132-139): idx2 of nn_distance(rawpts, newpts), the winner gathered
+ * (group_point with nsample = 1), and every new point pulled towards it:
+ *   refined = newpts + exp(-|g - newpts|^2 / (1e-8 + decfactor^2)) * (g - newpts).
+ * rawpts (b,n,3), newpts (b,m,3), decfactor_dev: DEVICE pointer to the one-element variable
+ * (vv_recon.py:211), sorted_raw: optional rf_nn_sort handle of rawpts; refined (b,m,3), idx2 (b,m)
+ * (kept for the backward).  rf_merge_layer_grad: grad_newpts (b,m,3), grad_dec (b) per-sample
+ * partial derivatives wrt decfactor (their sum is the variable's gradient), grad_raw (b,n,3) or
+ * NULL (rawpts is the network input in the model). */
+size_t rf_merge_layer_workspace_bytes(int b, int n, int m, int have_sorted_raw);
+int rf_merge_layer(int b, int n, int m, const float *rawpts, const float *newpts, const void *sorted_raw,
+                   const float *decfactor_dev, float *refined, int *idx2, void *workspace,
+                   size_t workspace_bytes, rf_stream_t stream);
+int rf_merge_layer_grad(int b, int n, int m, const float *rawpts, const float *newpts,
+                        const float *decfactor_dev, const int *idx2, const float *grad_refined,
+                        float *grad_newpts, float *grad_dec, float *grad_raw, rf_stream_t stream);
+
 /* ------------------------------------------------------------------ measurement hooks --- */
 /* When enabled, every kernel launch made by this library is bracketed by hipEvents recorded
  * on the launch stream.  rf_profile_collect() waits for them and returns the per-kernel sums
- * since the last collect.  Used by bench.py for roofline.achieved; off by default. */
+ * since the last collect.  Used by bench.py for roofline.achieved; off by default.
+ * This is the library's only process-global state: one switch and one list of pending event
+ * pairs for the whole process, shared by all threads and streams (both calls are thread-safe;
+ * a collect() concurrent with launches simply leaves those launches for the next collect). */
 void rf_profile_enable(int on);
 /* Fills up to `cap` entries; returns the number of distinct kernel names seen.  names[i] is a
  * pointer to a static string; ms[i] the summed duration in milliseconds; launches[i] the count. */

@@ -5,10 +5,30 @@ Inputs may be torch tensors on the GPU (zero-copy), or CPU tensors / numpy array
 the current GPU and the results copied back in the same kind).  There is no CPU execution
 path: without a HIP device every op raises.
 """
+import functools
+
 import numpy as np
 import torch
 
 from . import _lib
+
+
+def on_input_device(fn):
+    """Run `fn` with the device of its first GPU tensor argument current: the C ABI launches on the
+    calling thread's current HIP device with the stream it is handed, so outputs, scratch, the
+    stream and (when profiling) the events must all belong to the device that holds the inputs."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kw):
+        dev = None
+        for a in args:
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                dev = a.device
+                break
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kw)
+        with torch.cuda.device(dev):
+            return fn(*args, **kw)
+    return wrapper
 
 
 class Staged:
@@ -26,6 +46,9 @@ class Staged:
             if t.is_cuda:
                 if self.device is None:
                     self.device = t.device
+                elif t.device != self.device:
+                    raise ValueError(f"all GPU inputs of one op must live on the same device: "
+                                     f"got {self.device} and {t.device}")
             elif self.kind == "cuda":
                 self.kind = "cpu"
         else:

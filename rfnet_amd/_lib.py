@@ -16,11 +16,25 @@ _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SIGNATURES = {
     "rf_version": (C.c_char_p, []),
     "rf_status_string": (C.c_char_p, [_i]),
+    "rf_device_check": (_i, []),
     "rf_nn_distance_workspace_bytes": (_sz, [_i, _i, _i]),
     "rf_nn_distance": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rf_nn_distance_mode_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "rf_nn_distance_mode": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp]),
     "rf_nn_distance_grad": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rf_nn_distance_dir_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "rf_nn_distance_dir": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _i]),
+    "rf_nn_sort_bytes": (_sz, [_i, _i]),
+    "rf_nn_sort": (_i, [_i, _i, _vp, _vp, _sz, _vp]),
+    "rf_nn_distance_sorted": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rf_chamfer_step_workspace_bytes": (_sz, [_i, _i, _i]),
+    "rf_chamfer_step": (_i, [_i, _i, _i] + [_vp] * 11 + [_sz, _vp]),
+    "rf_chamfer_loss_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "rf_chamfer_loss": (_i, [_i, _i, _i] + [_vp] * 10 + [_sz, _vp]),
+    "rf_chamfer_loss_grad": (_i, [_i, _i, _i] + [_vp] * 10),
+    "rf_merge_layer_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "rf_merge_layer": (_i, [_i, _i, _i] + [_vp] * 7 + [_sz, _vp]),
+    "rf_merge_layer_grad": (_i, [_i, _i, _i] + [_vp] * 9),
     "rf_approxmatch_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "rf_approxmatch": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rf_approxmatch_levels": (_i, [_i, _i, _i, _vp, _vp, _vp, C.POINTER(_f), _i, _vp, _sz, _vp]),
@@ -32,6 +46,7 @@ SIGNATURES = {
     "rf_gatherpoint": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "rf_scatteraddpoint": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "rf_queryballpoint": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rf_queryballpoint_dev": (_i, [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "rf_grouppoint": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "rf_grouppoint_grad": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "rf_threenn": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

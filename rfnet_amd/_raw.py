@@ -24,6 +24,7 @@ def _shape3(t, last=None):
 NN_MODES = {"auto": 0, "dense": 1, "culled": 2}
 
 
+@H.on_input_device
 def nn_distance(xyz1, xyz2, mode="auto", stats=None):
     """NnDistanceGpuOp::Compute, tf_ops/CD/tf_nndistance.cpp:172-204.
 
@@ -56,6 +57,7 @@ def nn_distance(xyz1, xyz2, mode="auto", stats=None):
     return tuple(st.give(t) for t in (d1, i1, d2, i2))
 
 
+@H.on_input_device
 def nn_distance_grad(xyz1, xyz2, grad_dist1, idx1, grad_dist2, idx2):
     """NnDistanceGradGpuOp::Compute, tf_ops/CD/tf_nndistance.cpp:216-251."""
     st = H.Staged()
@@ -90,6 +92,219 @@ def nn_distance_grad(xyz1, xyz2, grad_dist1, idx1, grad_dist2, idx2):
     return st.give(g1), st.give(g2)
 
 
+def _nn_inputs(st, xyz1, xyz2, op="NnDistance"):
+    a, b_ = st.take(xyz1, F32), st.take(xyz2, F32)
+    if a.dim() != 3:
+        raise H.invalid(f"{op} requires xyz1 be of shape (batch,#points,3)")
+    if a.shape[2] != 3:
+        raise H.invalid(f"{op} only accepts 3d point set xyz1")
+    if b_.dim() != 3:
+        raise H.invalid(f"{op} requires xyz2 be of shape (batch,#points,3)")
+    if b_.shape[2] != 3:
+        raise H.invalid(f"{op} only accepts 3d point set xyz2")
+    if b_.shape[0] != a.shape[0]:
+        raise H.invalid(f"{op} expects xyz1 and xyz2 have same batch size")
+    return a, b_
+
+
+@H.on_input_device
+def nn_distance_dir(xyz1, xyz2, want1=True, want2=True):
+    """nn_distance with only the direction(s) the caller uses (rf_nn_distance_dir): the reference's
+    glue drops outputs -- merge_layer keeps idx2 (vv_recon.py:134-135), fidelity_loss dist1 (:386-390),
+    zero_groupnear dist2 (:415-419).  -> (dist1, idx1, dist2, idx2) with None for a skipped direction."""
+    if not (want1 or want2):
+        raise H.invalid("nn_distance_dir needs at least one direction")
+    st = H.Staged()
+    a, b_ = _nn_inputs(st, xyz1, xyz2)
+    b, n, m = a.shape[0], a.shape[1], b_.shape[1]
+    dev = st.device_()
+    a, b_ = st.up(a, b_)
+    d1 = H.empty((b, n), F32, dev) if want1 else None
+    i1 = H.empty((b, n), I32, dev) if want1 else None
+    d2 = H.empty((b, m), F32, dev) if want2 else None
+    i2 = H.empty((b, m), I32, dev) if want2 else None
+    ws, wsz = H.workspace(lib.rf_nn_distance_dir_workspace_bytes(b, n, m, int(want1), int(want2)), dev, "nn")
+    check(lib.rf_nn_distance_dir(b, n, m, H.ptr(a), H.ptr(b_), H.ptr(d1), H.ptr(i1), H.ptr(d2), H.ptr(i2),
+                                 H.ptr(ws), wsz, H.stream(dev), int(want1), int(want2)), "rf_nn_distance_dir")
+    return tuple(None if t is None else st.give(t) for t in (d1, i1, d2, i2))
+
+
+class SortedCloud:
+    """A batch of clouds in the culled sweep's space-filling-curve order (rf_nn_sort): sort once, use
+    in any number of nn_distance_sorted / chamfer_loss / merge_layer calls while `xyz` is unchanged.
+    The handle is this object's device buffer; the library itself keeps no state."""
+
+    def __init__(self, xyz):
+        st = H.Staged()
+        t = st.take(xyz, F32)
+        if not _shape3(t, 3):
+            raise H.invalid("NnDistance requires xyz1 be of shape (batch,#points,3)")
+        dev = st.device_()
+        self.xyz, = st.up(t)
+        self.b, self.n = int(t.shape[0]), int(t.shape[1])
+        nbytes = lib.rf_nn_sort_bytes(self.b, self.n)
+        if nbytes == 0:
+            raise H.invalid("nn_sort handles clouds of 1..65536 points")
+        self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.rf_nn_sort(self.b, self.n, H.ptr(self.xyz), H.ptr(self.buf), int(nbytes), H.stream(dev)),
+                  "rf_nn_sort")
+
+    @property
+    def device(self):
+        return self.buf.device
+
+
+def nn_sort(xyz):
+    return SortedCloud(xyz)
+
+
+def nn_distance_sorted(s1, s2, want1=True, want2=True):
+    """rf_nn_distance_sorted on two SortedCloud handles -> (dist1, idx1, dist2, idx2), None for a
+    skipped direction.  Bit-identical to nn_distance(s1.xyz, s2.xyz)."""
+    if s1.b != s2.b:
+        raise H.invalid("NnDistance expects xyz1 and xyz2 have same batch size")
+    if s1.device != s2.device:
+        raise ValueError("all GPU inputs of one op must live on the same device")
+    if not (want1 or want2):
+        raise H.invalid("nn_distance_sorted needs at least one direction")
+    dev, b, n, m = s1.device, s1.b, s1.n, s2.n
+    with torch.cuda.device(dev):
+        d1 = H.empty((b, n), F32, dev) if want1 else None
+        i1 = H.empty((b, n), I32, dev) if want1 else None
+        d2 = H.empty((b, m), F32, dev) if want2 else None
+        i2 = H.empty((b, m), I32, dev) if want2 else None
+        check(lib.rf_nn_distance_sorted(b, n, m, H.ptr(s1.buf), H.ptr(s2.buf), H.ptr(d1), H.ptr(i1), H.ptr(d2),
+                                        H.ptr(i2), H.stream(dev)), "rf_nn_distance_sorted")
+    return d1, i1, d2, i2
+
+
+class ChamferStep:
+    """nn_distance + nn_distance_grad of one shape as ONE C-ABI call on buffers allocated once
+    (rf_chamfer_step): the host path of a training step is a single ctypes crossing with
+    precomputed arguments -- no tensor allocation, no shape checks, no Python per-output work."""
+
+    def __init__(self, b, n, m, device):
+        dev = torch.device(device)
+        self.dev, self.shape = dev, (b, n, m)
+        self.dist1, self.idx1 = H.empty((b, n), F32, dev), H.empty((b, n), I32, dev)
+        self.dist2, self.idx2 = H.empty((b, m), F32, dev), H.empty((b, m), I32, dev)
+        self.grad1, self.grad2 = H.empty((b, n, 3), F32, dev), H.empty((b, m, 3), F32, dev)
+        nbytes = int(lib.rf_chamfer_step_workspace_bytes(b, n, m))
+        self.ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        self._tail = (H.ptr(self.dist1), H.ptr(self.idx1), H.ptr(self.dist2), H.ptr(self.idx2),
+                      H.ptr(self.grad1), H.ptr(self.grad2), H.ptr(self.ws), nbytes)
+        self._fn = lib.rf_chamfer_step
+
+    def __call__(self, xyz1, xyz2, grad_dist1, grad_dist2):
+        """Inputs: contiguous fp32 GPU tensors of the planned shape (not re-validated: this is the
+        hot loop).  Returns (dist1, idx1, dist2, idx2, grad_xyz1, grad_xyz2) -- the plan's own buffers,
+        overwritten by the next call."""
+        b, n, m = self.shape
+        st = self._fn(b, n, m, xyz1.data_ptr(), xyz2.data_ptr(), grad_dist1.data_ptr(), grad_dist2.data_ptr(),
+                      *self._tail, torch.cuda.current_stream(self.dev).cuda_stream)
+        if st:
+            check(st, "rf_chamfer_step")
+        return self.dist1, self.idx1, self.dist2, self.idx2, self.grad1, self.grad2
+
+
+def _sorted_ptr(s, b, n, dev):
+    if s is None:
+        return None
+    if (s.b, s.n) != (b, n) or s.device != dev:
+        raise ValueError("sorted handle does not match its cloud (batch, points, device)")
+    return H.ptr(s.buf)
+
+
+@H.on_input_device
+def chamfer_loss(xyz1, xyz2, sorted1=None, sorted2=None, want1=True, want2=True):
+    """rf_chamfer_loss: per-sample mean sqrt(dist) both ways, (b, 2), next to the nn_distance outputs
+    of the computed directions -> (loss, dist1, idx1, dist2, idx2)."""
+    if not (want1 or want2):
+        raise H.invalid("chamfer_loss needs at least one direction")
+    st = H.Staged()
+    a, b_ = _nn_inputs(st, xyz1, xyz2)
+    b, n, m = a.shape[0], a.shape[1], b_.shape[1]
+    dev = st.device_()
+    a, b_ = st.up(a, b_)
+    loss = H.empty((b, 2), F32, dev)
+    d1 = H.empty((b, n), F32, dev) if want1 else None
+    i1 = H.empty((b, n), I32, dev) if want1 else None
+    d2 = H.empty((b, m), F32, dev) if want2 else None
+    i2 = H.empty((b, m), I32, dev) if want2 else None
+    p1, p2 = _sorted_ptr(sorted1, b, n, dev), _sorted_ptr(sorted2, b, m, dev)
+    ws, wsz = H.workspace(lib.rf_chamfer_loss_workspace_bytes(b, n, m, int(want1), int(want2), int(p1 is not None),
+                                                              int(p2 is not None)), dev, "nn")
+    check(lib.rf_chamfer_loss(b, n, m, H.ptr(a), H.ptr(b_), p1, p2, H.ptr(loss), H.ptr(d1), H.ptr(i1), H.ptr(d2),
+                              H.ptr(i2), H.ptr(ws), wsz, H.stream(dev)), "rf_chamfer_loss")
+    return tuple(None if t is None else st.give(t) for t in (loss, d1, i1, d2, i2))
+
+
+@H.on_input_device
+def chamfer_loss_grad(xyz1, xyz2, dist1, idx1, dist2, idx2, grad_loss):
+    """rf_chamfer_loss_grad -> (grad_xyz1, grad_xyz2); dist/idx of a direction that was not computed
+    are None."""
+    st = H.Staged()
+    a, b_ = _nn_inputs(st, xyz1, xyz2, "NnDistanceGrad")
+    b, n, m = a.shape[0], a.shape[1], b_.shape[1]
+    gl = st.take(grad_loss, F32)
+    if tuple(gl.shape) != (b, 2):
+        raise H.invalid("chamfer_loss_grad requires grad_loss be of shape (batch,2)")
+    opt = []
+    for t, dt, shape in ((dist1, F32, (b, n)), (idx1, I32, (b, n)), (dist2, F32, (b, m)), (idx2, I32, (b, m))):
+        if t is None:
+            opt.append(None)
+            continue
+        t = st.take(t, dt)
+        if tuple(t.shape) != shape:
+            raise H.invalid("NnDistanceGrad requires idx/dist be of shape(batch,#points)")
+        opt.append(t)
+    dev = st.device_()
+    a, b_, gl = st.up(a, b_, gl)
+    opt = [None if t is None else st.up(t)[0] for t in opt]
+    g1, g2 = H.empty((b, n, 3), F32, dev), H.empty((b, m, 3), F32, dev)
+    check(lib.rf_chamfer_loss_grad(b, n, m, H.ptr(a), H.ptr(b_), H.ptr(opt[0]), H.ptr(opt[1]), H.ptr(opt[2]),
+                                   H.ptr(opt[3]), H.ptr(gl), H.ptr(g1), H.ptr(g2), H.stream(dev)),
+          "rf_chamfer_loss_grad")
+    return st.give(g1), st.give(g2)
+
+
+@H.on_input_device
+def merge_layer(rawpts, newpts, decfactor, sorted_raw=None):
+    """rf_merge_layer (vv_recon.py:132-139) -> (refined (b,m,3), idx2 (b,m))."""
+    st = H.Staged()
+    a, b_ = _nn_inputs(st, rawpts, newpts)
+    b, n, m = a.shape[0], a.shape[1], b_.shape[1]
+    dev = st.device_()
+    a, b_ = st.up(a, b_)
+    dec = torch.as_tensor(decfactor, dtype=F32).detach().reshape(-1)[:1].to(dev).contiguous()
+    out, i2 = H.empty((b, m, 3), F32, dev), H.empty((b, m), I32, dev)
+    ps = _sorted_ptr(sorted_raw, b, n, dev)
+    ws, wsz = H.workspace(lib.rf_merge_layer_workspace_bytes(b, n, m, int(ps is not None)), dev, "nn")
+    check(lib.rf_merge_layer(b, n, m, H.ptr(a), H.ptr(b_), ps, H.ptr(dec), H.ptr(out), H.ptr(i2), H.ptr(ws), wsz,
+                             H.stream(dev)), "rf_merge_layer")
+    return st.give(out), st.give(i2)
+
+
+@H.on_input_device
+def merge_layer_grad(rawpts, newpts, decfactor, idx2, grad_refined, want_raw=False):
+    """rf_merge_layer_grad -> (grad_newpts (b,m,3), grad_dec (b,), grad_raw (b,n,3) or None)."""
+    st = H.Staged()
+    a, b_ = _nn_inputs(st, rawpts, newpts)
+    b, n, m = a.shape[0], a.shape[1], b_.shape[1]
+    ix, go = st.take(idx2, I32), st.take(grad_refined, F32)
+    if tuple(ix.shape) != (b, m) or tuple(go.shape) != (b, m, 3):
+        raise H.invalid("merge_layer_grad expects idx2 (batch,#new) and grad (batch,#new,3)")
+    dev = st.device_()
+    a, b_, ix, go = st.up(a, b_, ix, go)
+    dec = torch.as_tensor(decfactor, dtype=F32).detach().reshape(-1)[:1].to(dev).contiguous()
+    gn, gd = H.empty((b, m, 3), F32, dev), H.empty((b,), F32, dev)
+    gr = H.empty((b, n, 3), F32, dev) if want_raw else None
+    check(lib.rf_merge_layer_grad(b, n, m, H.ptr(a), H.ptr(b_), H.ptr(dec), H.ptr(ix), H.ptr(go), H.ptr(gn),
+                                  H.ptr(gd), H.ptr(gr), H.stream(dev)), "rf_merge_layer_grad")
+    return st.give(gn), st.give(gd), (None if gr is None else st.give(gr))
+
+
 # ------------------------------------------------------------------ EMD --------------------
 def _emd_inputs(st, xyz1, xyz2, opname):
     a, b_ = st.take(xyz1, F32), st.take(xyz2, F32)
@@ -100,6 +315,7 @@ def _emd_inputs(st, xyz1, xyz2, opname):
     return a, b_
 
 
+@H.on_input_device
 def approx_match(xyz1, xyz2, levels=None):
     """ApproxMatchGpuOp::Compute, pc_distance/tf_approxmatch.cpp:148-172 -> match (b,m,n).
 
@@ -128,6 +344,7 @@ def _match_check(mt, b, n, m):
         raise H.invalid("MatchCost expects (batch_size,#query,#dataset) match shape")
 
 
+@H.on_input_device
 def match_cost(xyz1, xyz2, match):
     """MatchCostGpuOp::Compute, pc_distance/tf_approxmatch.cpp:204-230 -> cost (b)."""
     st = H.Staged()
@@ -144,6 +361,7 @@ def match_cost(xyz1, xyz2, match):
     return st.give(cost)
 
 
+@H.on_input_device
 def match_cost_grad(xyz1, xyz2, match):
     """MatchCostGradGpuOp::Compute, pc_distance/tf_approxmatch.cpp:265-295."""
     st = H.Staged()
@@ -159,6 +377,7 @@ def match_cost_grad(xyz1, xyz2, match):
     return st.give(g1), st.give(g2)
 
 
+@H.on_input_device
 def earth_mover(xyz1, xyz2, with_grad=False):
     """Row f1: the fused form of `earth_mover`'s op chain (vv_recon.py:392-399):
     approx_match -> match_cost [-> MatchCostGrad], without materialising match.
@@ -181,6 +400,7 @@ def earth_mover(xyz1, xyz2, with_grad=False):
 
 
 # ------------------------------------------------------------------ sampling ---------------
+@H.on_input_device
 def farthest_point_sample(npoint, inp):
     """FarthestPointSampleGpuOp, tf_ops/sampling/tf_sampling.cpp:95-123 -> (b,npoint) int32."""
     npoint = int(npoint)
@@ -201,6 +421,7 @@ def farthest_point_sample(npoint, inp):
     return st.give(out)
 
 
+@H.on_input_device
 def gather_point(inp, idx):
     """GatherPointGpuOp, tf_sampling.cpp:126-148 -> (b,m,3)."""
     st = H.Staged()
@@ -218,6 +439,7 @@ def gather_point(inp, idx):
     return st.give(out)
 
 
+@H.on_input_device
 def gather_point_grad(inp, idx, out_g):
     """GatherPointGradGpuOp, tf_sampling.cpp:151-178 -> (b,n,3)."""
     st = H.Staged()
@@ -238,6 +460,7 @@ def gather_point_grad(inp, idx, out_g):
 
 
 # ------------------------------------------------------------------ grouping ---------------
+@H.on_input_device
 def query_ball_point(radius, nsample, xyz1, xyz2):
     """QueryBallPointGpuOp, tf_ops/grouping/tf_grouping.cpp:68-110 -> idx (b,m,nsample), pts_cnt (b,m).
 
@@ -258,12 +481,21 @@ def query_ball_point(radius, nsample, xyz1, xyz2):
     d, q = st.up(d, q)
     idx = H.zeros((b, m, nsample), I32, dev)
     cnt = H.empty((b, m), I32, dev)
-    r = float(np.float32(radius))
-    check(lib.rf_queryballpoint(b, n, m, r, nsample, H.ptr(d), H.ptr(q), H.ptr(idx), H.ptr(cnt),
-                                H.stream(dev)), "rf_queryballpoint")
+    if isinstance(radius, torch.Tensor) and radius.is_cuda:
+        # the reference's form: radius is an op input tensor on the device (tf_grouping.cpp:18,93-95)
+        if radius.device != dev:
+            raise ValueError(f"all GPU inputs of one op must live on the same device: got {dev} and {radius.device}")
+        rt = radius.detach().reshape(-1)[:1].to(F32).contiguous()
+        check(lib.rf_queryballpoint_dev(b, n, m, H.ptr(rt), nsample, H.ptr(d), H.ptr(q), H.ptr(idx),
+                                        H.ptr(cnt), H.stream(dev)), "rf_queryballpoint_dev")
+    else:
+        r = float(np.float32(float(radius)))
+        check(lib.rf_queryballpoint(b, n, m, r, nsample, H.ptr(d), H.ptr(q), H.ptr(idx), H.ptr(cnt),
+                                    H.stream(dev)), "rf_queryballpoint")
     return st.give(idx), st.give(cnt)
 
 
+@H.on_input_device
 def group_point(points, idx):
     """GroupPointGpuOp, tf_grouping.cpp:147-175 -> (b,m,nsample,c)."""
     st = H.Staged()
@@ -282,6 +514,7 @@ def group_point(points, idx):
     return st.give(out)
 
 
+@H.on_input_device
 def group_point_grad(points, idx, grad_out):
     """GroupPointGradGpuOp, tf_grouping.cpp:178-212 -> (b,n,c)."""
     st = H.Staged()
@@ -303,6 +536,7 @@ def group_point_grad(points, idx, grad_out):
 
 
 # ------------------------------------------------------------------ interpolation ----------
+@H.on_input_device
 def three_nn(xyz1, xyz2):
     """ThreeNNOp, tf_ops/interpolation/tf_interpolate.cpp:157-187 -> dist (b,n,3), idx (b,n,3)."""
     st = H.Staged()
@@ -320,6 +554,7 @@ def three_nn(xyz1, xyz2):
     return st.give(dist), st.give(idx)
 
 
+@H.on_input_device
 def three_interpolate(points, idx, weight):
     """ThreeInterpolateOp, tf_interpolate.cpp:191-222 -> (b,n,c)."""
     st = H.Staged()
@@ -340,6 +575,7 @@ def three_interpolate(points, idx, weight):
     return st.give(out)
 
 
+@H.on_input_device
 def three_interpolate_grad(points, idx, weight, grad_out):
     """ThreeInterpolateGradOp, tf_interpolate.cpp:225-262 -> (b,m,c)."""
     st = H.Staged()
@@ -364,6 +600,7 @@ def three_interpolate_grad(points, idx, weight, grad_out):
 
 
 # ------------------------------------------------------------------ import surface (f3) -----
+@H.on_input_device
 def auction_match(xyz1, xyz2):
     """AuctionMatchGpuOp, tf_ops/emd/tf_auctionmatch.cpp:27-58 -> matchl (b,n), matchr (b,n) int32."""
     st = H.Staged()
@@ -387,6 +624,7 @@ def auction_match(xyz1, xyz2):
     return st.give(ml), st.give(mr)
 
 
+@H.on_input_device
 def select_top_k(k, dist):
     """SelectionSortGpuOp, tf_ops/grouping/tf_grouping.cpp:113-143 -> idx (b,m,n) int32, dist_out (b,m,n)."""
     k = int(k)
@@ -407,6 +645,7 @@ def select_top_k(k, dist):
     return st.give(idx), st.give(out)
 
 
+@H.on_input_device
 def prob_sample(inp, inpr):
     """ProbSampleGpuOp, tf_ops/sampling/tf_sampling.cpp:66-92 -> (b,m) int32."""
     st = H.Staged()

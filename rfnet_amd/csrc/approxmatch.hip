@@ -710,7 +710,7 @@ AmLayout am_layout(int b, int n, int m, int nlevels) {
 int pick_nseg(int b, int rows, int cols_pad, int rpt) {
     long base = (long)b * rf::ceil_div(rows, 64 * rpt);
     int nseg = 1;
-    static const long target = getenv("RF_AM_WAVES") ? atol(getenv("RF_AM_WAVES")) : 4096;
+    const long target = 4096;
     while (nseg < 16 && base * nseg < target && cols_pad / (nseg * 2) >= 64) nseg *= 2;
     return nseg;
 }

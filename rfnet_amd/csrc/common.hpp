@@ -27,8 +27,11 @@ struct ProfScope {
     ~ProfScope();
     const char *name;
     hipStream_t stream;
-    int slot;
+    void *start, *stop;  // hipEvent_t, owned by the scope until it ends
 };
+
+// RF_OK iff the current HIP device is a gfx950; RF_ENODEVICE otherwise (runtime.hip)
+int require_device();
 
 }  // namespace rf
 
@@ -41,6 +44,7 @@ struct ProfScope {
 // Launch + per-kernel event bracket (no-op unless profiling is enabled) + launch check.
 #define RF_LAUNCH(name, kernel, grid, block, shmem, stream, ...)             \
     do {                                                                     \
+        if (int _dv = rf::require_device()) return _dv;                      \
         rf::ProfScope _p(name, stream);                                      \
         hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__); \
     } while (0);                                                             \

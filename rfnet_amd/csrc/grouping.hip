@@ -27,6 +27,31 @@
 
 namespace {
 
+// Device twin of ball_threshold() below, for a radius that lives in device memory (the reference's
+// op input tensor, tf_grouping.cpp:18,93-95): the smallest float T with sqrt_rn(T) >= radius, so
+// that "max(sqrt_rn(d2), 1e-20f) < radius" <=> "d2 < T".  r*r is within a few ulps of T; walk the
+// float bit patterns from there with the correctly rounded device sqrt (HIP's default for
+// sqrtf, -fhip-fp32-correctly-rounded-divide-sqrt) -- a handful of uniform iterations per wave.
+__device__ __forceinline__ float ball_threshold_dev(float radius) {
+    if (!(radius > 1e-20f)) return 0.0f;  // also NaN: no hit ever
+    float t = radius * radius;
+    if (!(t < INFINITY)) t = INFINITY;
+    unsigned u = __float_as_uint(t);
+    // down while the predecessor still reaches the radius, then up until this one does
+    int steps = 0;
+    while (u > 0u && steps < 8 && __fsqrt_rn(__uint_as_float(u - 1u)) >= radius) { u--; steps++; }
+    while (u < 0x7F800000u && steps < 16 && !(__fsqrt_rn(__uint_as_float(u)) >= radius)) { u++; steps++; }
+    if (steps >= 8) {  // radii whose square is subnormal: plain bisection over the bit patterns
+        unsigned lo = 0u, hi = 0x7F800000u;
+        while (hi - lo > 1u) {
+            const unsigned mid = lo + (hi - lo) / 2u;
+            if (__fsqrt_rn(__uint_as_float(mid)) >= radius) hi = mid; else lo = mid;
+        }
+        u = hi;
+    }
+    return __uint_as_float(u);
+}
+
 constexpr int QB_TPB = 256;  // 4 waves per workgroup
 constexpr int QPW = 8;       // queries per wave
 constexpr int QB_NS = 64;    // nsample up to which the hit lists are staged in LDS
@@ -40,7 +65,8 @@ constexpr int QB_NS = 64;    // nsample up to which the hit lists are staged in 
 // instruction of either kind), not by memory (SQ_WAIT_INST_ANY = 20 % of wave cycles).
 template <bool STAGE>
 __global__ __launch_bounds__(QB_TPB) void query_ball_kernel(int n, int m, int nwaves_per_batch, int b,
-                                                            float thresh, int nsample,
+                                                            float thresh, const float *__restrict__ radius_dev,
+                                                            int nsample,
                                                             const float *__restrict__ xyz1,
                                                             const float *__restrict__ xyz2,
                                                             int *__restrict__ idx,
@@ -51,6 +77,7 @@ __global__ __launch_bounds__(QB_TPB) void query_ball_kernel(int n, int m, int nw
     const int w = blockIdx.x * (QB_TPB / 64) + wib;
     const int bi = w / nwaves_per_batch;
     if (bi >= b) return;
+    if (radius_dev) thresh = ball_threshold_dev(radius_dev[0]);  // uniform
     const int q0 = (w - bi * nwaves_per_batch) * QPW;  // first query of this wave (within the cloud)
     const int nq = min(QPW, m - q0);
     const float *__restrict__ D = xyz1 + (size_t)bi * n * 3;
@@ -139,7 +166,9 @@ __global__ __launch_bounds__(QB_TPB) void query_ball_kernel(int n, int m, int nw
 constexpr int QL_SUB = 8;  // dataset points per scalar-load sub-chunk
 template <int QS, int NSMAX>
 __global__ __launch_bounds__(64 * QS) void query_ball_lanes_kernel(int n, int m, int n_pad, int seg,
-                                                                   float thresh, int nsample,
+                                                                   float thresh,
+                                                                   const float *__restrict__ radius_dev,
+                                                                   int nsample,
                                                                    const float *__restrict__ xyz1,
                                                                    const float *__restrict__ xyz2,
                                                                    int *__restrict__ idx,
@@ -155,6 +184,7 @@ __global__ __launch_bounds__(64 * QS) void query_ball_lanes_kernel(int n, int m,
     const float *__restrict__ Q = xyz2 + ((size_t)bi * m + qq) * 3;
     const float qx = Q[0], qy = Q[1], qz = Q[2];
     int cnt = 0;
+    if (radius_dev) thresh = ball_threshold_dev(radius_dev[0]);  // uniform
     const int k_begin = sg * seg, k_end = min(n, k_begin + seg);
     // Whole sub-chunks of 8 points: scalar prefetch one sub-chunk ahead, no per-point range test.
     // The hit path sits behind a wave-uniform branch on the compare mask (without it the compiler
@@ -285,8 +315,8 @@ static float ball_threshold(float radius) {
     return t;
 }
 
-int rf_queryballpoint(int b, int n, int m, float radius, int nsample, const float *xyz1,
-                      const float *xyz2, int *idx, int *pts_cnt, rf_stream_t stream) {
+static int queryball_impl(int b, int n, int m, float radius, const float *radius_dev, int nsample,
+                          const float *xyz1, const float *xyz2, int *idx, int *pts_cnt, rf_stream_t stream) {
     if (b < 0 || n < 0 || m < 0 || nsample <= 0) return RF_EINVAL;
     long nquery = (long)b * m;
     if (nquery == 0) return RF_OK;
@@ -298,31 +328,43 @@ int rf_queryballpoint(int b, int n, int m, float radius, int nsample, const floa
     }
     const int wpb = rf::ceil_div(m, QPW);
     const long waves = (long)b * wpb;
+    const float thresh = radius_dev ? 0.f : ball_threshold(radius);
     // lanes <-> queries form: needs n >= 8 (scalar prefetch of whole sub-chunks) and b <= 65535
-    if (n >= QL_SUB && b <= 65535 && nsample <= 64 && getenv("RF_QB_OLD") == nullptr) {
+    if (n >= QL_SUB && b <= 65535 && nsample <= 64) {
         const int n_pad = n - QL_SUB;  // last sub-chunk start that stays in bounds
         const dim3 g(rf::ceil_div(m, 64), b);
         if (nsample <= 32) {
             constexpr int QS = 8;
             const int seg = rf::ceil_div(rf::ceil_div(n, QS), QL_SUB) * QL_SUB;
             RF_LAUNCH("query_ball_point", (query_ball_lanes_kernel<QS, 32>), g, dim3(64 * QS), 0, s, n, m, n_pad,
-                      seg, ball_threshold(radius), nsample, xyz1, xyz2, idx, pts_cnt);
+                      seg, thresh, radius_dev, nsample, xyz1, xyz2, idx, pts_cnt);
         } else {
             constexpr int QS = 4;
             const int seg = rf::ceil_div(rf::ceil_div(n, QS), QL_SUB) * QL_SUB;
             RF_LAUNCH("query_ball_point", (query_ball_lanes_kernel<QS, 64>), g, dim3(64 * QS), 0, s, n, m, n_pad,
-                      seg, ball_threshold(radius), nsample, xyz1, xyz2, idx, pts_cnt);
+                      seg, thresh, radius_dev, nsample, xyz1, xyz2, idx, pts_cnt);
         }
         return RF_OK;
     }
     if (nsample <= QB_NS) {
         RF_LAUNCH("query_ball_point", query_ball_kernel<true>, dim3(rf::ceil_div(waves, QB_TPB / 64)),
-                  dim3(QB_TPB), 0, s, n, m, wpb, b, ball_threshold(radius), nsample, xyz1, xyz2, idx, pts_cnt);
+                  dim3(QB_TPB), 0, s, n, m, wpb, b, thresh, radius_dev, nsample, xyz1, xyz2, idx, pts_cnt);
     } else {
         RF_LAUNCH("query_ball_point", query_ball_kernel<false>, dim3(rf::ceil_div(waves, QB_TPB / 64)),
-                  dim3(QB_TPB), 0, s, n, m, wpb, b, ball_threshold(radius), nsample, xyz1, xyz2, idx, pts_cnt);
+                  dim3(QB_TPB), 0, s, n, m, wpb, b, thresh, radius_dev, nsample, xyz1, xyz2, idx, pts_cnt);
     }
     return RF_OK;
+}
+
+int rf_queryballpoint(int b, int n, int m, float radius, int nsample, const float *xyz1,
+                      const float *xyz2, int *idx, int *pts_cnt, rf_stream_t stream) {
+    return queryball_impl(b, n, m, radius, nullptr, nsample, xyz1, xyz2, idx, pts_cnt, stream);
+}
+
+int rf_queryballpoint_dev(int b, int n, int m, const float *radius_dev, int nsample, const float *xyz1,
+                          const float *xyz2, int *idx, int *pts_cnt, rf_stream_t stream) {
+    if (!radius_dev) return RF_EINVAL;
+    return queryball_impl(b, n, m, 0.f, radius_dev, nsample, xyz1, xyz2, idx, pts_cnt, stream);
 }
 
 int rf_grouppoint(int b, int n, int c, int m, int nsample, const float *points, const int *idx,

@@ -32,6 +32,7 @@
 #include <stdlib.h>
 
 #include "common.hpp"
+#include "nn_dense.hpp"
 #include "nn_pruned.hpp"
 
 namespace {
@@ -147,7 +148,10 @@ __device__ __forceinline__ void who_has_it(const float (&orig)[CG], float cmin, 
     if constexpr (I + 1 < CG) who_has_it<I + 1>(orig, cmin, wl);
 }
 
-template <int R>
+// COLS = false: only the own side is wanted (rf_nn_distance_dir with one direction): the in-lane
+// candidate minima, the reduce-scatter and the winning-lane pass are compiled out (~6.5 VALU per
+// pair instead of ~7.9).
+template <int R, bool COLS>
 __global__ __launch_bounds__(TPB) void nn_sweep_kernel(Sweep a, const float *__restrict__ own_all,
                                                        const float *__restrict__ cand_all,
                                                        float *__restrict__ row_dist,
@@ -228,8 +232,10 @@ __global__ __launch_bounds__(TPB) void nn_sweep_kernel(Sweep a, const float *__r
                     d1[r] = rf::d2_fma(qx - ax[r], qy - ay[r], qz - az[r]);
                     cm[r] = min3_acc(cm[r], d0[r], d1[r]);
                 }
-                colv[sub * SUB + u] = min_over<R>(d0);
-                colv[sub * SUB + u + 1] = min_over<R>(d1);
+                if constexpr (COLS) {
+                    colv[sub * SUB + u] = min_over<R>(d0);
+                    colv[sub * SUB + u + 1] = min_over<R>(d1);
+                }
                 // keep the scheduler from interleaving candidate pairs (bounds the live set)
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -244,14 +250,16 @@ __global__ __launch_bounds__(TPB) void nn_sweep_kernel(Sweep a, const float *__r
                 }
             }
         }
-        const float cmin = reduce_scatter32(colv, lane);
-        // which lane holds it: the lowest lane whose in-lane minimum equals the wave minimum
-        int wl = 0;
-        who_has_it<0>(colv, cmin, wl);
-        const int c = c0 + (lane >> 1);
-        if ((lane & 1) == 0 && c < c_end) {
-            colp[c] = cmin;
-            collp[c] = (unsigned char)wl;
+        if constexpr (COLS) {
+            const float cmin = reduce_scatter32(colv, lane);
+            // which lane holds it: the lowest lane whose in-lane minimum equals the wave minimum
+            int wl = 0;
+            who_has_it<0>(colv, cmin, wl);
+            const int c = c0 + (lane >> 1);
+            if ((lane & 1) == 0 && c < c_end) {
+                colp[c] = cmin;
+                collp[c] = (unsigned char)wl;
+            }
         }
     }
 
@@ -436,12 +444,19 @@ struct GradDir {
     const int *idx_src;     // (b, ns) nn of each src point in dst
     float *grad;            // (b, nd, 3)
     int nd, ns, gt, tiles, slices;  // gt = destination points per tile (<= GT)
+    // LOSS mode (fused Chamfer loss backward): the upstream grads are not arrays but
+    // gd[j] = (gl[bi][col] / npts) * 0.5 / sqrt(dist[j]), from the forward's own distances
+    const float *dist_dst, *dist_src;  // (b, nd), (b, ns)
+    int col_dst, col_src;              // column of gl (b, 2) for the dst / src direction
+    int has_own, has_scatter;          // a direction that was not computed contributes nothing
 };
 struct GradArgs {
     GradDir d[2];
     int b, nblk0;
+    const float *gl;  // LOSS mode: (b, 2) upstream grads of the per-sample mean-sqrt losses
 };
 
+template <bool LOSS>
 __global__ __launch_bounds__(GTPB) void nn_grad_kernel(GradArgs a) {
     __shared__ float acc[GT * 3];
     int bid = blockIdx.x;
@@ -462,23 +477,26 @@ __global__ __launch_bounds__(GTPB) void nn_grad_kernel(GradArgs a) {
     float own[OWN];
     {
         const int *__restrict__ id = D.idx_dst + (size_t)bi * D.nd;
-        const float *__restrict__ gdd = D.gd_dst + (size_t)bi * D.nd;
+        const float *__restrict__ gdd = (LOSS ? D.dist_dst : D.gd_dst) + (size_t)bi * D.nd;
+        const float sc = LOSS ? a.gl[bi * 2 + D.col_dst] / (float)D.nd : 0.f;
 #pragma unroll
         for (int u = 0; u < OWN; u++) {
             const int i = threadIdx.x + u * GTPB;
             own[u] = 0.f;
-            if (i < jn * 3) {
+            if (i < jn * 3 && D.has_own) {
                 const int j = i / 3, c = i - j * 3;
                 const int k = id[j0 + j];
-                const float g = gdd[j0 + j] + gdd[j0 + j];
+                const float gd = LOSS ? sc * 0.5f / sqrtf(gdd[j0 + j]) : gdd[j0 + j];
+                const float g = gd + gd;
                 own[u] = (dxyz[(size_t)(j0 + j) * 3 + c] - sxyz[(size_t)k * 3 + c]) * g;
             }
         }
     }
     const int *__restrict__ is = D.idx_src + (size_t)bi * D.ns;
-    const float *__restrict__ gs = D.gd_src + (size_t)bi * D.ns;
+    const float *__restrict__ gs = (LOSS ? D.dist_src : D.gd_src) + (size_t)bi * D.ns;
+    const float scs = LOSS ? a.gl[bi * 2 + D.col_src] / (float)D.ns : 0.f;
     const int per = (D.ns + D.slices - 1) / D.slices;
-    const int k_end = min(D.ns, (slice + 1) * per);
+    const int k_end = D.has_scatter ? min(D.ns, (slice + 1) * per) : 0;
     constexpr int SU = 4;  // sources per thread in flight
     int jj[SU];
     int kb = slice * per + threadIdx.x;
@@ -517,7 +535,8 @@ __global__ __launch_bounds__(GTPB) void nn_grad_kernel(GradArgs a) {
         for (int u = 0; u < SU; u++) {
             const int j = jj[u];
             if (j >= 0 && j < jn) {
-                const float g = hg[u] + hg[u];
+                const float gd = LOSS ? scs * 0.5f / sqrtf(hg[u]) : hg[u];
+                const float g = gd + gd;
 #pragma unroll
                 for (int c = 0; c < 3; c++) atomicAdd(&acc[j * 3 + c], -((hs[u][c] - hd[u][c]) * g));
             }
@@ -552,9 +571,12 @@ struct Plan {
 
 int round_up(long v, int q) { return (int)((v + q - 1) / q * q); }
 
-Plan make_plan(int b, int n, int m) {
+// dirs: bit 0 = direction 1 (nearest neighbour of every xyz1 point in xyz2 -> dist1/idx1), bit 1 =
+// direction 2.  With one direction the wanted set is the "own" side whatever its size (the own side
+// is the per-point minimum over all candidates) and the column half of the sweep is compiled out.
+Plan make_plan(int b, int n, int m, int dirs = 3) {
     Plan p;
-    p.swap = m > n;
+    p.swap = dirs == 3 ? m > n : dirs == 2;
     p.no = p.swap ? m : n;
     p.nc = p.swap ? n : m;
     p.no_pad = round_up(p.no, PADQ);
@@ -564,11 +586,10 @@ Plan make_plan(int b, int n, int m) {
     //   * at least one residency round exists: 4096 waves (118 VGPRs -> 4 per SIMD x 1024 SIMDs);
     //   * a wave's span is ~1024 candidates when the set is large (16384 x 16384: 1.28 ms at
     //     span 1024 vs 1.36 at 4096 and 1.42 at 256), but never below 128.
-    // RF_NN_WAVES overrides the first target for experiments.
     long base = (long)b * p.oblocks;
-    static const long target = getenv("RF_NN_WAVES") ? atol(getenv("RF_NN_WAVES")) : 4096;
+    const long target = 4096;
     int want = (int)((target + base - 1) / (base > 0 ? base : 1));
-    if (!getenv("RF_NN_WAVES") && want < rf::ceil_div(p.nc, 1024)) want = rf::ceil_div(p.nc, 1024);
+    if (want < rf::ceil_div(p.nc, 1024)) want = rf::ceil_div(p.nc, 1024);
     int maxs = p.nc / 128 > 0 ? p.nc / 128 : 1;
     int s = want < 1 ? 1 : (want > maxs ? maxs : want);
     p.span = round_up(rf::ceil_div(p.nc, s), CG);
@@ -585,8 +606,8 @@ Plan make_plan(int b, int n, int m) {
     p.off_cand = take(((size_t)b * p.nc_pad + CG) * 12);  // + one group: prefetch overrun
     p.off_rowd = take(p.rslots > 1 ? (size_t)p.rslots * b * p.no * 4 : 0);
     p.off_rowi = take(p.rslots > 1 ? (size_t)p.rslots * b * p.no * 4 : 0);
-    p.off_col = take((size_t)p.oblocks * b * p.nc * 4);
-    p.off_coll = take((size_t)p.oblocks * b * p.nc);
+    p.off_col = take(dirs == 3 ? (size_t)p.oblocks * b * p.nc * 4 : 0);
+    p.off_coll = take(dirs == 3 ? (size_t)p.oblocks * b * p.nc : 0);
     p.bytes = off;
     return p;
 }
@@ -608,54 +629,25 @@ bool culled_pays(int b, int n, int m) {
     return pairs >= 44000L * hi;
 }
 
-// RF_NN_AUTO -> the sweep this shape gets.  RF_NN_MODE=dense|culled pins the choice for
-// experiments (tools/ab_chamfer.py).
+}  // namespace
+
+namespace rfd {
+
+// RF_NN_AUTO -> the sweep this shape gets (callers pin one with rf_nn_distance_mode).
 int resolve_mode(int b, int n, int m, int mode) {
     if (mode != RF_NN_AUTO) return mode;
-    static const char *env = getenv("RF_NN_MODE");
-    if (env && env[0] == 'd') return RF_NN_DENSE;
-    if (env && env[0] == 'c') return rfp::pruned_supported(b, n, m) ? RF_NN_CULLED : RF_NN_DENSE;
     return culled_pays(b, n, m) ? RF_NN_CULLED : RF_NN_DENSE;
 }
 
-}  // namespace
+size_t dense_workspace_bytes(int b, int n, int m, int dirs) { return make_plan(b, n, m, dirs).bytes; }
 
-extern "C" {
-
-size_t rf_nn_distance_workspace_bytes(int b, int n, int m) {
-    return rf_nn_distance_mode_workspace_bytes(b, n, m, RF_NN_AUTO);
-}
-
-size_t rf_nn_distance_mode_workspace_bytes(int b, int n, int m, int mode) {
-    if (b <= 0 || n <= 0 || m <= 0) return 0;
-    mode = resolve_mode(b, n, m, mode);
-    return mode == RF_NN_CULLED ? rfp::pruned_workspace_bytes(b, n, m) : make_plan(b, n, m).bytes;
-}
-
-int rf_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist1,
-                   int *idx1, float *dist2, int *idx2, void *workspace, size_t workspace_bytes,
-                   rf_stream_t stream) {
-    return rf_nn_distance_mode(b, n, m, xyz1, xyz2, dist1, idx1, dist2, idx2, workspace, workspace_bytes,
-                               stream, RF_NN_AUTO, nullptr);
-}
-
-int rf_nn_distance_mode(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist1,
-                        int *idx1, float *dist2, int *idx2, void *workspace, size_t workspace_bytes,
-                        rf_stream_t stream, int mode, unsigned long long *stats) {
-    if (b < 0 || n < 0 || m < 0) return RF_EINVAL;
-    if (mode != RF_NN_AUTO && mode != RF_NN_DENSE && mode != RF_NN_CULLED) return RF_EINVAL;
-    if (b == 0 || (n == 0 && m == 0)) return RF_OK;
-    if (n == 0 || m == 0) return RF_EINVAL;  // a nearest neighbour in an empty set is undefined
-    if (!xyz1 || !xyz2 || !dist1 || !idx1 || !dist2 || !idx2 || !workspace) return RF_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
-    mode = resolve_mode(b, n, m, mode);
-    if (mode == RF_NN_CULLED) {
-        if (!rfp::pruned_supported(b, n, m)) return RF_EINVAL;
-        return rfp::pruned_nn_distance(b, n, m, xyz1, xyz2, dist1, idx1, dist2, idx2, workspace,
-                                       workspace_bytes, s, stats);
-    }
-    Plan p = make_plan(b, n, m);
+// The dense sweep (every pair evaluated).  dirs as above; outputs of a direction that is not
+// wanted may be NULL.
+int dense_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist1, int *idx1,
+                      float *dist2, int *idx2, void *workspace, size_t workspace_bytes, hipStream_t s, int dirs) {
+    Plan p = make_plan(b, n, m, dirs);
     if (workspace_bytes < p.bytes) return RF_EWORKSPACE;
+    const bool cols = dirs == 3;
     char *w = (char *)workspace;
     float *own_p = (float *)(w + p.off_own), *cand_p = (float *)(w + p.off_cand);
     const float *own_src = p.swap ? xyz2 : xyz1, *cand_src = p.swap ? xyz1 : xyz2;
@@ -685,35 +677,97 @@ int rf_nn_distance_mode(int b, int n, int m, const float *xyz1, const float *xyz
     a.b = b; a.no = p.no; a.nc = p.nc; a.no_pad = p.no_pad; a.nc_pad = p.nc_pad;
     a.oblocks = p.oblocks; a.nsplit = p.nsplit; a.span = p.span; a.wgm = p.wgm;
     long waves = (long)b * p.oblocks * p.nsplit;
-    RF_LAUNCH("nn_sweep", nn_sweep_kernel<RR>, dim3(rf::ceil_div(waves, TPB / 64)), dim3(TPB), 0, s, a,
-              (const float *)own_p, (const float *)cand_p, row_dist, row_idx, colpart, collane);
+    if (cols) {
+        RF_LAUNCH("nn_sweep", (nn_sweep_kernel<RR, true>), dim3(rf::ceil_div(waves, TPB / 64)), dim3(TPB), 0, s, a,
+                  (const float *)own_p, (const float *)cand_p, row_dist, row_idx, colpart, collane);
+    } else {
+        RF_LAUNCH("nn_sweep_1dir", (nn_sweep_kernel<RR, false>), dim3(rf::ceil_div(waves, TPB / 64)), dim3(TPB), 0, s,
+                  a, (const float *)own_p, (const float *)cand_p, row_dist, row_idx, colpart, collane);
+    }
     {
         const int cblocks = rf::ceil_div(p.nc, TPB / 4);  // 4 lanes per candidate
-        const int nblk_col = cblocks * b;
+        const int nblk_col = cols ? cblocks * b : 0;
         const int nblk_row = p.rslots > 1 ? rf::ceil_div((long)b * p.no, TPB) : 0;
-        RF_LAUNCH("nn_resolve", nn_resolve_kernel<RR>, dim3(nblk_col + nblk_row), dim3(TPB), 0, s, a,
-                  (const float *)own_p, (const float *)cand_p, (const float *)colpart,
-                  (const unsigned char *)collane, cand_dist, cand_idx, nblk_col, (const float *)row_dist,
-                  (const int *)row_idx, own_dist, own_idx, p.rslots);
+        if (nblk_col + nblk_row > 0) {
+            RF_LAUNCH("nn_resolve", nn_resolve_kernel<RR>, dim3(nblk_col + nblk_row), dim3(TPB), 0, s, a,
+                      (const float *)own_p, (const float *)cand_p, (const float *)colpart,
+                      (const unsigned char *)collane, cand_dist, cand_idx, nblk_col, (const float *)row_dist,
+                      (const int *)row_idx, own_dist, own_idx, p.rslots);
+        }
     }
     return RF_OK;
+}
+
+}  // namespace rfd
+
+extern "C" {
+
+size_t rf_nn_distance_workspace_bytes(int b, int n, int m) {
+    return rf_nn_distance_mode_workspace_bytes(b, n, m, RF_NN_AUTO);
+}
+
+size_t rf_nn_distance_mode_workspace_bytes(int b, int n, int m, int mode) {
+    if (b <= 0 || n <= 0 || m <= 0) return 0;
+    mode = rfd::resolve_mode(b, n, m, mode);
+    return mode == RF_NN_CULLED ? rfp::pruned_workspace_bytes(b, n, m) : rfd::dense_workspace_bytes(b, n, m, 3);
+}
+
+int rf_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist1,
+                   int *idx1, float *dist2, int *idx2, void *workspace, size_t workspace_bytes,
+                   rf_stream_t stream) {
+    return rf_nn_distance_mode(b, n, m, xyz1, xyz2, dist1, idx1, dist2, idx2, workspace, workspace_bytes,
+                               stream, RF_NN_AUTO, nullptr);
+}
+
+int rf_nn_distance_mode(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist1,
+                        int *idx1, float *dist2, int *idx2, void *workspace, size_t workspace_bytes,
+                        rf_stream_t stream, int mode, unsigned long long *stats) {
+    if (b < 0 || n < 0 || m < 0) return RF_EINVAL;
+    if (mode != RF_NN_AUTO && mode != RF_NN_DENSE && mode != RF_NN_CULLED) return RF_EINVAL;
+    if (b == 0 || (n == 0 && m == 0)) return RF_OK;
+    if (n == 0 || m == 0) return RF_EINVAL;  // a nearest neighbour in an empty set is undefined
+    if (!xyz1 || !xyz2 || !dist1 || !idx1 || !dist2 || !idx2 || !workspace) return RF_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    mode = rfd::resolve_mode(b, n, m, mode);
+    if (mode == RF_NN_CULLED) {
+        if (!rfp::pruned_supported(b, n, m)) return RF_EINVAL;
+        return rfp::pruned_nn_distance(b, n, m, xyz1, xyz2, dist1, idx1, dist2, idx2, workspace,
+                                       workspace_bytes, s, stats, 3);
+    }
+    return rfd::dense_nn_distance(b, n, m, xyz1, xyz2, dist1, idx1, dist2, idx2, workspace, workspace_bytes, s, 3);
 }
 
 int rf_nn_distance_grad(int b, int n, int m, const float *xyz1, const float *xyz2,
                         const float *grad_dist1, const int *idx1, const float *grad_dist2,
                         const int *idx2, float *grad_xyz1, float *grad_xyz2, rf_stream_t stream) {
     if (b < 0 || n < 0 || m < 0) return RF_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
+    if (b > 0 && n > 0 && m > 0 && (!grad_dist1 || !grad_dist2)) return RF_EINVAL;
+    const rfd::GradSource g{grad_dist1, grad_dist2, nullptr, nullptr, nullptr};
+    return rfd::nn_distance_grad(b, n, m, xyz1, xyz2, g, idx1, idx2, grad_xyz1, grad_xyz2, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+namespace rfd {
+
+int nn_distance_grad(int b, int n, int m, const float *xyz1, const float *xyz2, const GradSource &src,
+                     const int *idx1, const int *idx2, float *grad_xyz1, float *grad_xyz2, hipStream_t s) {
+    if (b < 0 || n < 0 || m < 0) return RF_EINVAL;
     if (b == 0 || (n == 0 && m == 0)) return RF_OK;
     if (n == 0 || m == 0) {  // no neighbours exist: the gradient of nothing is zero
         if (n) RF_HIP(hipMemsetAsync(grad_xyz1, 0, sizeof(float) * 3 * (size_t)b * n, s));
         if (m) RF_HIP(hipMemsetAsync(grad_xyz2, 0, sizeof(float) * 3 * (size_t)b * m, s));
         return RF_OK;
     }
-    if (!xyz1 || !xyz2 || !grad_dist1 || !idx1 || !grad_dist2 || !idx2 || !grad_xyz1 || !grad_xyz2)
-        return RF_EINVAL;
+    const bool loss = src.gl != nullptr;
+    // a direction is present when its index array is (loss mode: fidelity_loss has direction 1 only)
+    const bool has1 = idx1 != nullptr && (loss ? src.dist1 != nullptr : src.gd1 != nullptr);
+    const bool has2 = idx2 != nullptr && (loss ? src.dist2 != nullptr : src.gd2 != nullptr);
+    if (!xyz1 || !xyz2 || !grad_xyz1 || !grad_xyz2 || (!has1 && !has2)) return RF_EINVAL;
+    if (!loss && (!has1 || !has2)) return RF_EINVAL;
     GradArgs a;
     a.b = b;
+    a.gl = src.gl;
     // Tile size per direction: small enough that b * tiles >= 256 workgroups with every workgroup
     // sweeping ALL sources (no slices: plain stores, no memset, no global atomics), down to 64
     // destination points; only when even that leaves the chip empty (tiny batches) are the sources
@@ -733,12 +787,18 @@ int rf_nn_distance_grad(int b, int n, int m, const float *xyz1, const float *xyz
     const int s0 = slices_for(t0, m), s1 = slices_for(t1, n);
     if (s0 > 1) RF_HIP(hipMemsetAsync(grad_xyz1, 0, sizeof(float) * 3 * (size_t)b * n, s));
     if (s1 > 1) RF_HIP(hipMemsetAsync(grad_xyz2, 0, sizeof(float) * 3 * (size_t)b * m, s));
-    a.d[0] = GradDir{xyz1, xyz2, grad_dist1, idx1, grad_dist2, idx2, grad_xyz1, n, m, g0, t0, s0};
-    a.d[1] = GradDir{xyz2, xyz1, grad_dist2, idx2, grad_dist1, idx1, grad_xyz2, m, n, g1, t1, s1};
+    a.d[0] = GradDir{xyz1, xyz2, src.gd1, idx1, src.gd2, idx2, grad_xyz1, n, m, g0, t0, s0,
+                     src.dist1, src.dist2, 0, 1, has1, has2};
+    a.d[1] = GradDir{xyz2, xyz1, src.gd2, idx2, src.gd1, idx1, grad_xyz2, m, n, g1, t1, s1,
+                     src.dist2, src.dist1, 1, 0, has2, has1};
     a.nblk0 = b * t0 * s0;
     const int nblk1 = b * t1 * s1;
-    RF_LAUNCH("nn_grad", nn_grad_kernel, dim3(a.nblk0 + nblk1), dim3(GTPB), 0, s, a);
+    if (loss) {
+        RF_LAUNCH("nn_grad_loss", nn_grad_kernel<true>, dim3(a.nblk0 + nblk1), dim3(GTPB), 0, s, a);
+    } else {
+        RF_LAUNCH("nn_grad", nn_grad_kernel<false>, dim3(a.nblk0 + nblk1), dim3(GTPB), 0, s, a);
+    }
     return RF_OK;
 }
 
-}  // extern "C"
+}  // namespace rfd

@@ -1120,31 +1120,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
 
 int round_up(long v, int q) { return (int)((v + q - 1) / q * q); }
 
-struct PPlan {
-    int npad[2];
-    size_t off_xyz[2], off_orig[2], off_b16[2], off_b64[2], off_stats, bytes;
-};
-
-PPlan make_pplan(int b, int n, int m) {
-    PPlan p;
-    const int nn[2] = {n, m};
-    size_t off = 0;
-    auto take = [&](size_t bytes) {
-        size_t o = off;
-        off += (bytes + 255) / 256 * 256;
-        return o;
-    };
-    for (int s = 0; s < 2; s++) {
-        p.npad[s] = round_up(nn[s], SB);
-        p.off_xyz[s] = take((size_t)b * p.npad[s] * 3 * sizeof(float) + 256);  // + prefetch overrun
-        p.off_orig[s] = take((size_t)b * p.npad[s] * sizeof(int));
-        p.off_b16[s] = take((size_t)b * (p.npad[s] / SB) * B16F * sizeof(float));
-        p.off_b64[s] = take((size_t)b * (p.npad[s] / SB) * B64F * sizeof(float));
-    }
-    p.off_stats = take(32 * sizeof(unsigned long long));
-    p.bytes = off;
-    return p;
-}
+size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
 }  // namespace
 
@@ -1154,65 +1130,120 @@ bool pruned_supported(int b, int n, int m) {
     return b > 0 && n > 0 && m > 0 && n <= kMaxPoints && m <= kMaxPoints;
 }
 
-size_t pruned_workspace_bytes(int b, int n, int m) {
-    if (!pruned_supported(b, n, m)) return 0;
-    return make_pplan(b, n, m).bytes;
+// One sorted set (b clouds of n points) in a caller-owned buffer: xyz | orig | box16 | box64, each
+// part 256-byte aligned.  The layout is a pure function of (b, n): a "handle" is just that buffer.
+size_t sorted_bytes(int b, int n) {
+    if (b <= 0 || n <= 0 || n > kMaxPoints) return 0;
+    const size_t npad = (size_t)round_up(n, SB);
+    return align256((size_t)b * npad * 3 * sizeof(float) + 256)  // + prefetch overrun
+           + align256((size_t)b * npad * sizeof(int)) + align256((size_t)b * (npad / SB) * B16F * sizeof(float)) +
+           align256((size_t)b * (npad / SB) * B64F * sizeof(float));
 }
 
-int pruned_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist1, int *idx1,
-                       float *dist2, int *idx2, void *workspace, size_t workspace_bytes, hipStream_t s,
-                       unsigned long long *stats_out) {
-    if (!pruned_supported(b, n, m)) return RF_EINVAL;
-    const PPlan p = make_pplan(b, n, m);
-    if (workspace_bytes < p.bytes) return RF_EWORKSPACE;
-    char *w = (char *)workspace;
+Sorted sorted_view(int b, int n, const void *buf) {
+    const size_t npad = (size_t)round_up(n, SB);
+    const char *w = (const char *)buf;
+    Sorted v;
+    v.npad = (int)npad;
+    v.xyz = (const float *)w;
+    w += align256((size_t)b * npad * 3 * sizeof(float) + 256);
+    v.orig = (const int *)w;
+    w += align256((size_t)b * npad * sizeof(int));
+    v.box16 = (const float *)w;
+    w += align256((size_t)b * (npad / SB) * B16F * sizeof(float));
+    v.box64 = (const float *)w;
+    return v;
+}
+
+size_t pruned_workspace_bytes(int b, int n, int m) {
+    if (!pruned_supported(b, n, m)) return 0;
+    return sorted_bytes(b, n) + sorted_bytes(b, m) + align256(32 * sizeof(unsigned long long));
+}
+
+// Sort `nsets` (1 or 2) sets of b clouds in ONE launch (one workgroup per cloud).
+int sort_sets(int b, int nsets, const int *n, const float *const *src, const Sorted *out, hipStream_t s,
+              unsigned long long *dbg) {
+    if (b <= 0 || nsets < 1 || nsets > 2) return RF_EINVAL;
     SortArgs sa;
-    SweepArgs wa;
-    sa.b = wa.b = b;
-    sa.nsets = 2;
-    const int nn[2] = {n, m};
-    const float *src[2] = {xyz1, xyz2};
+    sa.b = b;
+    sa.nsets = nsets;
+    sa.dbg = dbg;
+    bool reg = true;
     for (int k = 0; k < 2; k++) {
-        sa.n[k] = wa.n[k] = nn[k];
-        sa.npad[k] = wa.npad[k] = p.npad[k];
-        sa.src[k] = src[k];
-        sa.xyz[k] = (float *)(w + p.off_xyz[k]);
-        sa.orig[k] = (int *)(w + p.off_orig[k]);
-        sa.box16[k] = (float *)(w + p.off_b16[k]);
-        sa.box64[k] = (float *)(w + p.off_b64[k]);
-        wa.groups[k] = p.npad[k] / SB;
-        // a set with few groups cannot fill the chip with one wave per group: 4 waves share a group
-        static const long split_below = getenv("RF_NNP_SPLIT") ? atol(getenv("RF_NNP_SPLIT")) : 4096;
-        wa.nw[k] = ((long)b * wa.groups[k] < split_below) ? 4 : 1;
+        const int kk = k < nsets ? k : 0;
+        if (n[kk] <= 0 || n[kk] > kMaxPoints || !src[kk]) return RF_EINVAL;
+        sa.n[k] = n[kk];
+        sa.npad[k] = out[kk].npad;
+        sa.src[k] = src[kk];
+        sa.xyz[k] = const_cast<float *>(out[kk].xyz);
+        sa.orig[k] = const_cast<int *>(out[kk].orig);
+        sa.box16[k] = const_cast<float *>(out[kk].box16);
+        sa.box64[k] = const_cast<float *>(out[kk].box64);
+        reg = reg && n[kk] <= RPT * STPB;
     }
-    unsigned long long *stats = nullptr;
-    if (stats_out) {
-        stats = (unsigned long long *)(w + p.off_stats);
-        RF_HIP(hipMemsetAsync(stats, 0, 32 * sizeof(unsigned long long), s));
-    }
-    sa.dbg = stats;
-    if (n <= RPT * STPB && m <= RPT * STPB) {
-        RF_LAUNCH("nnp_sort", nnp_sort_reg_kernel, dim3(2 * b), dim3(STPB), 0, s, sa);
+    if (reg) {
+        RF_LAUNCH("nnp_sort", nnp_sort_reg_kernel, dim3(nsets * b), dim3(STPB), 0, s, sa);
     } else {
-        RF_LAUNCH("nnp_sort", nnp_sort_kernel<false>, dim3(2 * b), dim3(STPB), 0, s, sa);
+        RF_LAUNCH("nnp_sort", nnp_sort_kernel<false>, dim3(nsets * b), dim3(STPB), 0, s, sa);
     }
+    return RF_OK;
+}
+
+// The sweep over two sorted sets.  dirs bit 0: nearest neighbour of every point of set 0 in set 1
+// (-> dist1/idx1), bit 1: the opposite (-> dist2/idx2).  A direction that is not asked for costs
+// nothing: its workgroups are not launched.
+int sweep_sorted(int b, int n, int m, const Sorted &s0, const Sorted &s1, float *dist1, int *idx1, float *dist2,
+                 int *idx2, int dirs, hipStream_t s, unsigned long long *stats_dev) {
+    if (!pruned_supported(b, n, m) || (dirs & 3) == 0) return RF_EINVAL;
+    if (((dirs & 1) && (!dist1 || !idx1)) || ((dirs & 2) && (!dist2 || !idx2))) return RF_EINVAL;
+    SweepArgs wa;
+    wa.b = b;
+    const int nn[2] = {n, m};
+    const Sorted *ss[2] = {&s0, &s1};
+    for (int k = 0; k < 2; k++) {
+        wa.n[k] = nn[k];
+        wa.npad[k] = ss[k]->npad;
+        wa.groups[k] = ss[k]->npad / SB;
+        // a set with few groups cannot fill the chip with one wave per group: 4 waves share a group
+        wa.nw[k] = ((long)b * wa.groups[k] < 4096) ? 4 : 1;
+    }
+    const bool want[2] = {(dirs & 1) != 0, (dirs & 2) != 0};
     {
         int longest = 0;  // entries in a wave's list: all superblocks of the other set, or a quarter
         for (int k = 0; k < 2; k++) {
+            if (!want[k]) continue;
             const int nsb = wa.groups[1 - k];
             const int len = wa.nw[k] == 4 ? (nsb + 3) / 4 : nsb;
             longest = len > longest ? len : longest;
         }
         wa.kstride = (longest + 63) / 64 * 64;
     }
-    const int tpb = (wa.nw[0] == 4 || wa.nw[1] == 4) ? 256 : 64;
+    const int tpb = ((want[0] && wa.nw[0] == 4) || (want[1] && wa.nw[1] == 4)) ? 256 : 64;
     const int pack = tpb / 64;  // one-wave groups per workgroup
-    wa.wg0 = wa.nw[0] == 4 ? wa.groups[0] : rf::ceil_div(wa.groups[0], pack);
-    wa.wg1 = wa.nw[1] == 4 ? wa.groups[1] : rf::ceil_div(wa.groups[1], pack);
-    RF_LAUNCH("nnp_sweep", nnp_sweep_kernel, dim3((unsigned)b * (wa.wg0 + wa.wg1)), dim3(tpb), pack * wa.kstride * sizeof(unsigned), s, wa,
-              (const float *)sa.xyz[0], (const float *)sa.xyz[1], (const int *)sa.orig[0], (const int *)sa.orig[1],
-              (const float *)sa.box16[0], (const float *)sa.box16[1], (const float *)sa.box64[0],
-              (const float *)sa.box64[1], dist1, dist2, idx1, idx2, stats);
+    wa.wg0 = !want[0] ? 0 : (wa.nw[0] == 4 ? wa.groups[0] : rf::ceil_div(wa.groups[0], pack));
+    wa.wg1 = !want[1] ? 0 : (wa.nw[1] == 4 ? wa.groups[1] : rf::ceil_div(wa.groups[1], pack));
+    RF_LAUNCH("nnp_sweep", nnp_sweep_kernel, dim3((unsigned)b * (wa.wg0 + wa.wg1)), dim3(tpb),
+              pack * wa.kstride * sizeof(unsigned), s, wa, s0.xyz, s1.xyz, s0.orig, s1.orig, s0.box16, s1.box16,
+              s0.box64, s1.box64, dist1, dist2, idx1, idx2, stats_dev);
+    return RF_OK;
+}
+
+int pruned_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist1, int *idx1,
+                       float *dist2, int *idx2, void *workspace, size_t workspace_bytes, hipStream_t s,
+                       unsigned long long *stats_out, int dirs) {
+    if (!pruned_supported(b, n, m)) return RF_EINVAL;
+    if (workspace_bytes < pruned_workspace_bytes(b, n, m)) return RF_EWORKSPACE;
+    char *w = (char *)workspace;
+    const Sorted so[2] = {sorted_view(b, n, w), sorted_view(b, m, w + sorted_bytes(b, n))};
+    unsigned long long *stats = nullptr;
+    if (stats_out) {
+        stats = (unsigned long long *)(w + sorted_bytes(b, n) + sorted_bytes(b, m));
+        RF_HIP(hipMemsetAsync(stats, 0, 32 * sizeof(unsigned long long), s));
+    }
+    const int nn[2] = {n, m};
+    const float *src[2] = {xyz1, xyz2};
+    if (int e = sort_sets(b, 2, nn, src, so, s, stats)) return e;
+    if (int e = sweep_sorted(b, n, m, so[0], so[1], dist1, idx1, dist2, idx2, dirs, s, stats)) return e;
     if (stats_out) {
         RF_HIP(hipMemcpyAsync(stats_out, stats, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         RF_HIP(hipStreamSynchronize(s));
@@ -1220,49 +1251,13 @@ int pruned_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2
     return RF_OK;
 }
 
-size_t sort_workspace_bytes(int b, int n) {
-    if (b <= 0 || n <= 0 || n > kMaxPoints) return 0;
-    const size_t npad = (size_t)round_up(n, SB);
-    size_t bytes = 0;
-    for (size_t part : {(size_t)b * npad * 3 * sizeof(float) + 256, (size_t)b * npad * sizeof(int),
-                        (size_t)b * (npad / SB) * B16F * sizeof(float), (size_t)b * (npad / SB) * B64F * sizeof(float)})
-        bytes += (part + 255) / 256 * 256;
-    return bytes;
-}
+size_t sort_workspace_bytes(int b, int n) { return sorted_bytes(b, n); }
 
 int sort_clouds(int b, int n, const float *src, void *workspace, size_t workspace_bytes, hipStream_t s, Sorted *out) {
     if (b <= 0 || n <= 0 || n > kMaxPoints || !src || !workspace || !out) return RF_EINVAL;
-    if (workspace_bytes < sort_workspace_bytes(b, n)) return RF_EWORKSPACE;
-    const int npad = round_up(n, SB);
-    char *w = (char *)workspace;
-    size_t off = 0;
-    auto take = [&](size_t bytes) {
-        char *p = w + off;
-        off += (bytes + 255) / 256 * 256;
-        return p;
-    };
-    SortArgs sa;
-    sa.b = b;
-    sa.nsets = 1;
-    sa.dbg = nullptr;
-    sa.n[0] = sa.n[1] = n;
-    sa.npad[0] = sa.npad[1] = npad;
-    sa.src[0] = sa.src[1] = src;
-    sa.xyz[0] = sa.xyz[1] = (float *)take((size_t)b * npad * 3 * sizeof(float) + 256);
-    sa.orig[0] = sa.orig[1] = (int *)take((size_t)b * npad * sizeof(int));
-    sa.box16[0] = sa.box16[1] = (float *)take((size_t)b * (npad / SB) * B16F * sizeof(float));
-    sa.box64[0] = sa.box64[1] = (float *)take((size_t)b * (npad / SB) * B64F * sizeof(float));
-    if (n <= RPT * STPB) {
-        RF_LAUNCH("nnp_sort", nnp_sort_reg_kernel, dim3(b), dim3(STPB), 0, s, sa);
-    } else {
-        RF_LAUNCH("nnp_sort", nnp_sort_kernel<false>, dim3(b), dim3(STPB), 0, s, sa);
-    }
-    out->xyz = sa.xyz[0];
-    out->orig = sa.orig[0];
-    out->box16 = sa.box16[0];
-    out->box64 = sa.box64[0];
-    out->npad = npad;
-    return RF_OK;
+    if (workspace_bytes < sorted_bytes(b, n)) return RF_EWORKSPACE;
+    *out = sorted_view(b, n, workspace);
+    return sort_sets(b, 1, &n, &src, out, s, nullptr);
 }
 
 }  // namespace rfp

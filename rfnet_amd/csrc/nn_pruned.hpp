@@ -12,9 +12,11 @@ bool pruned_supported(int b, int n, int m);
 size_t pruned_workspace_bytes(int b, int n, int m);
 // stats_out (host, 16 counters, may be NULL; layout in include/rfops.h); asking for them
 // synchronises the stream.
+// dirs: bit 0 = direction 1 (dist1/idx1), bit 1 = direction 2; outputs of a direction not asked
+// for may be NULL.
 int pruned_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist1, int *idx1,
                        float *dist2, int *idx2, void *workspace, size_t workspace_bytes, hipStream_t s,
-                       unsigned long long *stats_out);
+                       unsigned long long *stats_out, int dirs = 3);
 
 // The sort on its own (one cloud per batch element), for other operators that want the Hilbert
 // order: records (x, y, z packed) and original indices in key order, padded to a multiple of 64
@@ -29,5 +31,14 @@ struct Sorted {
 };
 size_t sort_workspace_bytes(int b, int n);
 int sort_clouds(int b, int n, const float *src, void *workspace, size_t workspace_bytes, hipStream_t s, Sorted *out);
+
+// The pieces, for callers that keep a sorted set across several sweeps (a "handle" is a caller-owned
+// buffer of sorted_bytes(b, n) bytes whose layout is a pure function of (b, n)).
+size_t sorted_bytes(int b, int n);
+Sorted sorted_view(int b, int n, const void *buf);
+int sort_sets(int b, int nsets, const int *n, const float *const *src, const Sorted *out, hipStream_t s,
+              unsigned long long *dbg);
+int sweep_sorted(int b, int n, int m, const Sorted &s0, const Sorted &s1, float *dist1, int *idx1, float *dist2,
+                 int *idx2, int dirs, hipStream_t s, unsigned long long *stats_dev);
 
 }  // namespace rfp

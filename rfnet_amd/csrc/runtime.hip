@@ -1,5 +1,6 @@
 // runtime.hip -- version / status strings and the per-kernel hipEvent profiler behind
 // rf_profile_enable() / rf_profile_collect().
+#include <atomic>
 #include <mutex>
 #include <string.h>
 #include <vector>
@@ -13,8 +14,12 @@ struct Pending {
     hipEvent_t start, stop;
 };
 
+// The profiler is the library's ONLY process-global state (documented in rfops.h).  The enable flag
+// is an atomic; everything else is touched under g_mu.  A scope owns its two events from
+// construction to destruction and only then files them, so a collect() in between cannot
+// invalidate anything the scope refers to.
 std::mutex g_mu;
-bool g_enabled = false;
+std::atomic<bool> g_enabled{false};
 std::vector<Pending> g_pending;
 std::vector<hipEvent_t> g_pool;
 
@@ -33,19 +38,42 @@ hipEvent_t get_event() {
 
 namespace rf {
 
-ProfScope::ProfScope(const char *n, hipStream_t s) : name(n), stream(s), slot(-1) {
-    if (!g_enabled) return;
-    std::lock_guard<std::mutex> lk(g_mu);
-    Pending p{n, get_event(), get_event()};
-    (void)hipEventRecord(p.start, s);
-    slot = (int)g_pending.size();
-    g_pending.push_back(p);
+ProfScope::ProfScope(const char *n, hipStream_t s) : name(n), stream(s), start(nullptr), stop(nullptr) {
+    if (!g_enabled.load(std::memory_order_relaxed)) return;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        start = get_event();
+        stop = get_event();
+    }
+    if (start) (void)hipEventRecord((hipEvent_t)start, s);
 }
 
 ProfScope::~ProfScope() {
-    if (slot < 0) return;
+    if (!start || !stop) return;
+    (void)hipEventRecord((hipEvent_t)stop, stream);
     std::lock_guard<std::mutex> lk(g_mu);
-    (void)hipEventRecord(g_pending[slot].stop, stream);
+    g_pending.push_back(Pending{name, (hipEvent_t)start, (hipEvent_t)stop});
+}
+
+// RF_OK when the calling thread's current HIP device is a gfx950 (MI355X), RF_ENODEVICE otherwise
+// (no device, or another architecture: the library carries gfx950 code objects only).  The verdict
+// is cached per device ordinal.
+int require_device() {
+    static std::atomic<signed char> cache[64];  // 0 unknown, 1 gfx950, -1 anything else
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) {
+        (void)hipGetLastError();
+        return RF_ENODEVICE;
+    }
+    if (dev < 64) {
+        const signed char c = cache[dev].load(std::memory_order_relaxed);
+        if (c) return c > 0 ? RF_OK : RF_ENODEVICE;
+    }
+    hipDeviceProp_t prop;
+    bool ok = hipGetDeviceProperties(&prop, dev) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+    if (!ok) (void)hipGetLastError();
+    if (dev < 64) cache[dev].store(ok ? 1 : -1, std::memory_order_relaxed);
+    return ok ? RF_OK : RF_ENODEVICE;
 }
 
 }  // namespace rf
@@ -66,10 +94,9 @@ const char *rf_status_string(int status) {
     return "unknown status";
 }
 
-void rf_profile_enable(int on) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    g_enabled = on != 0;
-}
+void rf_profile_enable(int on) { g_enabled.store(on != 0, std::memory_order_relaxed); }
+
+int rf_device_check(void) { return rf::require_device(); }
 
 int rf_profile_collect(const char **names, double *ms, long *launches, int cap) {
     std::lock_guard<std::mutex> lk(g_mu);

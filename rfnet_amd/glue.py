@@ -10,10 +10,20 @@ are small elementwise / reduction tensor ops that autograd differentiates.
 """
 import torch
 
+from . import _raw
 from .pc_distance.tf_approxmatch import earth_mover_cost
 from .tf_ops.CD.tf_nndistance import nn_distance
 from .tf_ops.grouping.tf_grouping import group_point
 from .tf_ops.sampling.tf_sampling import farthest_point_sample, gather_point
+
+SortedCloud = _raw.SortedCloud  # sort a cloud once, use it in several Chamfers of a step
+
+
+def sort_if_large(xyz, min_points=1024):
+    """A SortedCloud handle for clouds the culled sweep is used on (>= 1024 points), else None."""
+    if isinstance(xyz, torch.Tensor) and xyz.is_cuda and 1024 <= xyz.shape[1] <= 65536 and xyz.shape[1] >= min_points:
+        return SortedCloud(xyz.detach())
+    return None
 
 
 def sampling(npoint, xyz, use_type='f', generator=None):
@@ -29,10 +39,36 @@ def sampling(npoint, xyz, use_type='f', generator=None):
     raise ValueError("use_type must be 'f' or 'r'")
 
 
-def merge_layer(rawpts, newpts, decfactor, knum=16):
+class _MergeLayer(torch.autograd.Function):
+    """rf_merge_layer / rf_merge_layer_grad: direction-2 Chamfer + gather + Gaussian pull as one op."""
+
+    @staticmethod
+    def forward(ctx, rawpts, newpts, decfactor, sorted_raw):
+        refined, idx2 = _raw.merge_layer(rawpts, newpts, decfactor, sorted_raw)
+        ctx.save_for_backward(rawpts, newpts, decfactor, idx2)
+        return refined
+
+    @staticmethod
+    def backward(ctx, grad_refined):
+        rawpts, newpts, decfactor, idx2 = ctx.saved_tensors
+        gn, gd, gr = _raw.merge_layer_grad(rawpts, newpts, decfactor, idx2, grad_refined.contiguous(),
+                                           want_raw=ctx.needs_input_grad[0])
+        return gr, gn, gd.sum().reshape(decfactor.shape).to(decfactor.dtype), None
+
+
+def merge_layer(rawpts, newpts, decfactor, knum=16, sorted_raw=None):
     """Pull every new point towards its nearest raw point with a Gaussian weight:
     refine = newpts + exp(-|g-newpts|^2 / (1e-8 + decfactor^2)) * (g - newpts), g = nn of newpts
-    in rawpts (idx2 of nn_distance, grouped with nsample = 1).  `knum` is unused in the reference."""
+    in rawpts (idx2 of nn_distance, grouped with nsample = 1).  `knum` is unused in the reference.
+    One fused op (direction 2 of the Chamfer only, gather and pull in its epilogue); `sorted_raw`:
+    optional SortedCloud of rawpts (the model merges into the same `pointcloud` three times)."""
+    dec = torch.as_tensor(decfactor, dtype=newpts.dtype, device=newpts.device)
+    return _MergeLayer.apply(rawpts, newpts.contiguous(), dec, sorted_raw)
+
+
+def merge_layer_unfused(rawpts, newpts, decfactor, knum=16):
+    """The same layer as the reference writes it (nn_distance -> group_point -> tensor ops); kept as
+    the cross-check of the fused op."""
     _, _, _, idx2 = nn_distance(rawpts, newpts)
     grouped = group_point(rawpts, idx2.unsqueeze(-1))  # (b, npoint_new, 1, 3)
     diff = grouped - newpts.unsqueeze(2)
@@ -42,15 +78,49 @@ def merge_layer(rawpts, newpts, decfactor, knum=16):
     return newpts + (ratio * diff).sum(2)
 
 
-def chamfer_big(pcd1, pcd2):
-    """(mean sqrt(dist1) + mean sqrt(dist2)) / 2 over the whole batch, and idx1."""
-    dist1, idx1, dist2, _ = nn_distance(pcd1, pcd2)
-    return (torch.sqrt(dist1).mean() + torch.sqrt(dist2).mean()) / 2, idx1
+class _ChamferLoss(torch.autograd.Function):
+    """rf_chamfer_loss / rf_chamfer_loss_grad: per-sample mean sqrt(dist) (b, 2) and idx1; the
+    0.5/sqrt(d)/N factor of the backward is formed inside the scatter kernel."""
+
+    @staticmethod
+    def forward(ctx, xyz1, xyz2, sorted1, sorted2, want1, want2):
+        loss, d1, i1, d2, i2 = _raw.chamfer_loss(xyz1, xyz2, sorted1, sorted2, want1, want2)
+        ctx.dirs = (want1, want2)
+        ctx.save_for_backward(xyz1, xyz2, *[t for t in (d1, i1, d2, i2) if t is not None])
+        idx1 = i1 if i1 is not None else torch.empty(0, dtype=torch.int32, device=loss.device)
+        ctx.mark_non_differentiable(idx1)
+        return loss, idx1
+
+    @staticmethod
+    def backward(ctx, grad_loss, _):
+        saved = list(ctx.saved_tensors)
+        xyz1, xyz2 = saved[0], saved[1]
+        rest = saved[2:]
+        d1 = i1 = d2 = i2 = None
+        if ctx.dirs[0]:
+            d1, i1, rest = rest[0], rest[1], rest[2:]
+        if ctx.dirs[1]:
+            d2, i2 = rest[0], rest[1]
+        g1, g2 = _raw.chamfer_loss_grad(xyz1, xyz2, d1, i1, d2, i2, grad_loss.contiguous())
+        return g1, g2, None, None, None, None
 
 
-def fidelity_loss(pcd1, pcd2):
-    dist1, _, _, _ = nn_distance(pcd1, pcd2)
-    return torch.sqrt(dist1).mean()
+def chamfer_per_sample(pcd1, pcd2, sorted1=None, sorted2=None, want1=True, want2=True):
+    """(loss (b, 2), idx1): loss[:, 0] = mean_j sqrt(dist1), loss[:, 1] = mean_k sqrt(dist2) per sample."""
+    return _ChamferLoss.apply(pcd1.contiguous(), pcd2.contiguous(), sorted1, sorted2, want1, want2)
+
+
+def chamfer_big(pcd1, pcd2, sorted1=None, sorted2=None):
+    """(mean sqrt(dist1) + mean sqrt(dist2)) / 2 over the whole batch, and idx1 (vv_recon.py:381-385).
+    One fused forward (sweep + sqrt-mean epilogue) and one fused backward."""
+    loss, idx1 = chamfer_per_sample(pcd1, pcd2, sorted1, sorted2)
+    return (loss[:, 0].mean() + loss[:, 1].mean()) / 2, idx1
+
+
+def fidelity_loss(pcd1, pcd2, sorted1=None, sorted2=None):
+    """mean sqrt(dist1) (vv_recon.py:386-390): direction 1 only is computed."""
+    loss, _ = chamfer_per_sample(pcd1, pcd2, sorted1, sorted2, True, False)
+    return loss[:, 0].mean()
 
 
 def earth_mover(pcd1, pcd2):
@@ -61,13 +131,15 @@ def earth_mover(pcd1, pcd2):
 
 def re_chamfer(gt, pred, part=8):
     """Mean of chamfer_big over `part` consecutive index slices of length ptnum(gt)//8 (the
-    reference hard-codes 8 for the interval), the same slice of pred against gt."""
+    reference hard-codes 8 for the interval), the same slice of pred against gt
+    (vv_recon.py:171-193).  The slices are contiguous, so slice i of sample s is batch element
+    s*part + i of ONE (b*part, interval, 3) Chamfer instead of `part` separate ones."""
+    b = gt.shape[0]
     interval = int(gt.shape[1] / 8)
-    losses = []
-    for i in range(part):
-        sl = slice(i * interval, (i + 1) * interval)
-        losses.append(chamfer_big(pred[:, sl].contiguous(), gt[:, sl].contiguous())[0])
-    return sum(losses) / part
+    g = gt[:, :part * interval].reshape(b * part, interval, 3)
+    p = pred[:, :part * interval].reshape(b * part, interval, 3)
+    # mean over slices of (batch mean over b) == mean over all b*part pseudo-samples
+    return chamfer_big(p, g)[0]
 
 
 def groupin_near(ptmat):
@@ -75,5 +147,9 @@ def groupin_near(ptmat):
 
 
 def zero_groupnear(ptcens, rawpts, outmat):
-    _, _, dist, _ = nn_distance(ptcens, rawpts)
+    """relu(groupin_near(outmat) - 0.4 * mean(dist2)) (vv_recon.py:410-419): direction 2 only."""
+    if isinstance(ptcens, torch.Tensor) and (ptcens.requires_grad or rawpts.requires_grad):
+        _, _, dist, _ = nn_distance(ptcens, rawpts)
+    else:
+        _, _, dist, _ = _raw.nn_distance_dir(ptcens, rawpts, False, True)
     return torch.relu(groupin_near(outmat) - 0.4 * dist.mean())

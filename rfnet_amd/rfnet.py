@@ -180,6 +180,8 @@ class RFNet(nn.Module):
     # -- the graph -------------------------------------------------------------------------------
     def forward(self, pointcloud):
         x = pointcloud
+        # `pointcloud` is the raw side of all three merge layers: put it in curve order once
+        raw_sorted = glue.sort_if_large(pointcloud)
         state0 = self.global_mlp("init_mlp", x)
         code1, state = self.encode_cell(x, state0, 0)
         code1 = self.recover_cell("recover1", code1, x)
@@ -189,18 +191,18 @@ class RFNet(nn.Module):
         ft = self.mlp("", "partfeat", 2, torch.cat([partfeat, code1], -1))
         points0, dstate0 = self.init_decode_layer(ft)
         points1, dstate = torch.cat([points0, points1], 1), torch.cat([dstate0, dstate], 1)
-        points1 = glue.merge_layer(pointcloud, points1.contiguous(), self.decline_factor0, knum=1)
+        points1 = glue.merge_layer(pointcloud, points1.contiguous(), self.decline_factor0, knum=1, sorted_raw=raw_sorted)
         points1, dstate = self.refine_layer("refine_layer1", points1, code1, dstate)
 
         code2, state = self.encode_cell(torch.cat([pointcloud, points1], 1), state, 1)
         code2 = code1 + self.recover_cell("recover2", code2, torch.cat([pointcloud, points1], 1))
         points2, dstate = self.decode_cell(code2, points1, dstate, 0)
-        points2 = glue.merge_layer(pointcloud, points2.contiguous(), self.decline_factor1, knum=1)
+        points2 = glue.merge_layer(pointcloud, points2.contiguous(), self.decline_factor1, knum=1, sorted_raw=raw_sorted)
         points2, dstate = self.refine_layer("refine_layer2", points2, code2, dstate)
 
         code3, state = self.encode_cell(torch.cat([pointcloud, points2], 1), state, 2)
         code3 = code2 + self.recover_cell("recover3", code3, torch.cat([pointcloud, points2], 1))
         points3, dstate = self.decode_cell(code3, points2, dstate, 1)
-        final = glue.merge_layer(pointcloud, points3.contiguous(), self.decline_factor, knum=1)
+        final = glue.merge_layer(pointcloud, points3.contiguous(), self.decline_factor, knum=1, sorted_raw=raw_sorted)
         final, _ = self.refine_layer("refine_layer_final", final, code3, dstate)
         return points1, points2, points3, final

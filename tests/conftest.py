@@ -16,11 +16,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # a fresh checkout has no built artefacts (*.so is git-ignored): build them once, here
-    # (hipcc cross-compiles gfx950 without a GPU; the oracle is plain gcc)
-    from rfnet_amd.build import LIB, build_library
-    if not os.path.exists(LIB):
-        build_library()
+    # *.so is git-ignored but travels with the repo snapshot: always run the (mtime-incremental)
+    # build, so that a source edited after the last build can never be tested against a stale
+    # binary (hipcc cross-compiles gfx950 without a GPU; a no-op when everything is current)
+    from rfnet_amd.build import build_library
+    build_library()
 
 
 def pytest_collection_modifyitems(config, items):
