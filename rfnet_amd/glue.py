@@ -46,24 +46,26 @@ class _MergeLayer(torch.autograd.Function):
     def forward(ctx, rawpts, newpts, decfactor, sorted_raw):
         refined, idx2 = _raw.merge_layer(rawpts, newpts, decfactor, sorted_raw)
         ctx.save_for_backward(rawpts, newpts, decfactor, idx2)
-        return refined
+        ctx.mark_non_differentiable(idx2)
+        return refined, idx2
 
     @staticmethod
-    def backward(ctx, grad_refined):
+    def backward(ctx, grad_refined, _):
         rawpts, newpts, decfactor, idx2 = ctx.saved_tensors
         gn, gd, gr = _raw.merge_layer_grad(rawpts, newpts, decfactor, idx2, grad_refined.contiguous(),
                                            want_raw=ctx.needs_input_grad[0])
         return gr, gn, gd.sum().reshape(decfactor.shape).to(decfactor.dtype), None
 
 
-def merge_layer(rawpts, newpts, decfactor, knum=16, sorted_raw=None):
+def merge_layer(rawpts, newpts, decfactor, knum=16, sorted_raw=None, return_idx=False):
     """Pull every new point towards its nearest raw point with a Gaussian weight:
     refine = newpts + exp(-|g-newpts|^2 / (1e-8 + decfactor^2)) * (g - newpts), g = nn of newpts
     in rawpts (idx2 of nn_distance, grouped with nsample = 1).  `knum` is unused in the reference.
     One fused op (direction 2 of the Chamfer only, gather and pull in its epilogue); `sorted_raw`:
     optional SortedCloud of rawpts (the model merges into the same `pointcloud` three times)."""
     dec = torch.as_tensor(decfactor, dtype=newpts.dtype, device=newpts.device)
-    return _MergeLayer.apply(rawpts, newpts.contiguous(), dec, sorted_raw)
+    refined, idx2 = _MergeLayer.apply(rawpts, newpts.contiguous(), dec, sorted_raw)
+    return (refined, idx2) if return_idx else refined
 
 
 def merge_layer_unfused(rawpts, newpts, decfactor, knum=16):
@@ -146,10 +148,13 @@ def groupin_near(ptmat):
     return (ptmat * ptmat).sum(-1).mean(-1).mean(-1).mean()
 
 
-def zero_groupnear(ptcens, rawpts, outmat):
-    """relu(groupin_near(outmat) - 0.4 * mean(dist2)) (vv_recon.py:410-419): direction 2 only."""
+def zero_groupnear(ptcens, rawpts, outmat, sorted_cens=None, sorted_raw=None):
+    """relu(groupin_near(outmat) - 0.4 * mean(dist2)) (vv_recon.py:410-419): direction 2 only.
+    With SortedCloud handles of both sets the sweep runs straight on them."""
     if isinstance(ptcens, torch.Tensor) and (ptcens.requires_grad or rawpts.requires_grad):
         _, _, dist, _ = nn_distance(ptcens, rawpts)
+    elif sorted_cens is not None and sorted_raw is not None:
+        _, _, dist, _ = _raw.nn_distance_sorted(sorted_cens, sorted_raw, False, True)
     else:
         _, _, dist, _ = _raw.nn_distance_dir(ptcens, rawpts, False, True)
     return torch.relu(groupin_near(outmat) - 0.4 * dist.mean())

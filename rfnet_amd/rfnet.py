@@ -146,18 +146,21 @@ class RFNet(nn.Module):
         so = self.mlp("init_cell", "state", 2, so)
         return pts, self.d("init_cell", "state_outo", so)
 
-    def refine_layer(self, scope, ptcoor, feat, feat2):  # :273-308
+    def refine_layer(self, scope, ptcoor, feat, feat2, collect=None):  # :273-308
         n = ptcoor.shape[1]
         t = torch.cat([ptcoor, feat.expand(-1, n, -1)], -1)
         t = self.mlp(scope, "ini_layer", 2, t)
         t = torch.cat([ptcoor, t.max(1, keepdim=True).values.expand(-1, n, -1)], -1)
         t = self.mlp(scope, "refine_layers", 3, t)
-        newcoor = ptcoor + self.d(scope, "refine_layer_final", t, act="tanh")
+        newvec = self.d(scope, "refine_layer_final", t, act="tanh")
+        if collect is not None:
+            collect[f"{scope}{n}"] = newvec  # tf.add_to_collection(scope+str(ptnum), newvec), :298
+        newcoor = ptcoor + newvec
         t = torch.cat([newcoor, feat2, feat.expand(-1, feat2.shape[1], -1)], -1)
         t = self.mlp(scope, "feat_refine", 2, t)
         return newcoor, self.d(scope, "feat_refine_final", t, act="tanh") + feat2
 
-    def decode_cell(self, code, center, state, call, up_ratio=16):  # :310-364
+    def decode_cell(self, code, center, state, call, up_ratio=16, collect=None):  # :310-364
         n = state.shape[1]
         sc = "decode_cell"
         mask = torch.cat([center, code.expand(-1, n, -1)], -1)
@@ -166,6 +169,8 @@ class RFNet(nn.Module):
         ns = torch.cat([info, self.d(sc, "state_trans", state, call=call)], -1)
         ns = self.mlp(sc, "basic_state", 2, ns, call)
         move = self.d(sc, "points_out", self.mlp(sc, "points", 2, ns, call), act="tanh", call=call)
+        if collect is not None:
+            collect[f"decode_cell{n}"] = move.reshape(-1, n, up_ratio, 3)  # collection scope+str(ptnum), :338
         pts = (center.unsqueeze(2) + move.reshape(-1, n, up_ratio, 3)).reshape(-1, n * up_ratio, 3)
         ns = torch.cat([ns, code.expand(-1, n, -1)], -1)
         ns = self.mlp(sc, "state", 2, ns, call)
@@ -178,31 +183,84 @@ class RFNet(nn.Module):
         return pts, (state.unsqueeze(2) + move_state).reshape(-1, n * up_ratio, state.shape[-1])
 
     # -- the graph -------------------------------------------------------------------------------
-    def forward(self, pointcloud):
+    def forward(self, pointcloud, collect=None):
+        """`collect` (optional dict) receives what the reference keeps in graph collections for the
+        loss block ('points1', 'points2', 'refine_layer_final16384', 'decode_cell64',
+        'decode_cell1024': vv_recon.py:210,222,298,338) and the indices taken by the
+        index-producing operators ('fps32', 'merge1', 'merge2', 'merge3')."""
         x = pointcloud
+        c = collect
         # `pointcloud` is the raw side of all three merge layers: put it in curve order once
         raw_sorted = glue.sort_if_large(pointcloud)
         state0 = self.global_mlp("init_mlp", x)
         code1, state = self.encode_cell(x, state0, 0)
         code1 = self.recover_cell("recover1", code1, x)
-        start = glue.sampling(32, pointcloud, use_type="f")[1]
+        fidx, start = glue.sampling(32, pointcloud, use_type="f")
         points1, dstate = self.init_move_layer(start, code1)
         partfeat = self.global_mlp("part_mlp", torch.cat([pointcloud, points1], 1))
         ft = self.mlp("", "partfeat", 2, torch.cat([partfeat, code1], -1))
         points0, dstate0 = self.init_decode_layer(ft)
         points1, dstate = torch.cat([points0, points1], 1), torch.cat([dstate0, dstate], 1)
-        points1 = glue.merge_layer(pointcloud, points1.contiguous(), self.decline_factor0, knum=1, sorted_raw=raw_sorted)
-        points1, dstate = self.refine_layer("refine_layer1", points1, code1, dstate)
+        pre1 = points1
+        points1, m1 = glue.merge_layer(pointcloud, points1.contiguous(), self.decline_factor0, knum=1,
+                                       sorted_raw=raw_sorted, return_idx=True)
+        points1, dstate = self.refine_layer("refine_layer1", points1, code1, dstate, c)
 
         code2, state = self.encode_cell(torch.cat([pointcloud, points1], 1), state, 1)
         code2 = code1 + self.recover_cell("recover2", code2, torch.cat([pointcloud, points1], 1))
-        points2, dstate = self.decode_cell(code2, points1, dstate, 0)
-        points2 = glue.merge_layer(pointcloud, points2.contiguous(), self.decline_factor1, knum=1, sorted_raw=raw_sorted)
-        points2, dstate = self.refine_layer("refine_layer2", points2, code2, dstate)
+        points2, dstate = self.decode_cell(code2, points1, dstate, 0, collect=c)
+        pre2 = points2
+        points2, m2 = glue.merge_layer(pointcloud, points2.contiguous(), self.decline_factor1, knum=1,
+                                       sorted_raw=raw_sorted, return_idx=True)
+        points2, dstate = self.refine_layer("refine_layer2", points2, code2, dstate, c)
 
         code3, state = self.encode_cell(torch.cat([pointcloud, points2], 1), state, 2)
         code3 = code2 + self.recover_cell("recover3", code3, torch.cat([pointcloud, points2], 1))
-        points3, dstate = self.decode_cell(code3, points2, dstate, 1)
-        final = glue.merge_layer(pointcloud, points3.contiguous(), self.decline_factor, knum=1, sorted_raw=raw_sorted)
-        final, _ = self.refine_layer("refine_layer_final", final, code3, dstate)
+        points3, dstate = self.decode_cell(code3, points2, dstate, 1, collect=c)
+        final, m3 = glue.merge_layer(pointcloud, points3.contiguous(), self.decline_factor, knum=1,
+                                     sorted_raw=raw_sorted, return_idx=True)
+        final, _ = self.refine_layer("refine_layer_final", final, code3, dstate, c)
+        if c is not None:
+            c.update({"points1": pre1, "points2": pre2, "fps32": fidx, "merge1": m1, "merge2": m2, "merge3": m3})
         return points1, points2, points3, final
+
+    def tf_state_dict(self):
+        """{TensorFlow variable name: numpy array in the reference's layout} (kernels [1,1,cin,cout])."""
+        out = {}
+        for name in self._tf_names:
+            if name.endswith("/weights"):
+                out[name] = self.weights[_key(name[:-len("/weights")])].detach().cpu().numpy()[None, None]
+            elif name.endswith("/Variable"):
+                out[name] = self.biases[_key(name[:-len("/Variable")])].detach().cpu().numpy()
+            else:
+                out[name] = getattr(self, name).detach().cpu().numpy()
+        return out
+
+
+def training_loss(net, outputs, collect, gt, alpha1=0.01, terms=None):
+    """The loss block of the reference's train() (vv_recon.py:474-500) on the fused ops:
+    loss = 0.2 (cd1 + cd2) + cd3 + cd4 + 0.2 recd3 + 0.1 moveloss + loss_d1 + loss_d2 + alpha1 loss_dec,
+    cd1/cd2 = earth_mover(FPS(gt), pre-merge points1/points2), cd3/cd4 = chamfer_big(gt, out3/out4),
+    recd3 = re_chamfer(gt, out3), loss_d* = 0.05 zero_groupnear(...), loss_dec = sum decfactor^2
+    (alpha1 = 0.01 up to step 50000, :482-483).  `gt` is Chamfered five times: sorted once."""
+    out1, out2, out3, out4 = outputs
+    hgt = glue.sort_if_large(gt)
+    i64, gt1 = glue.sampling(out1.shape[1], gt, use_type="f")   # :474
+    i1024, gt2 = glue.sampling(out2.shape[1], gt, use_type="f")  # :475
+    hgt2 = glue.sort_if_large(gt2)
+    t = {}
+    t["cd1"] = glue.earth_mover(gt1, collect["points1"])
+    t["cd2"] = glue.earth_mover(gt2, collect["points2"])
+    t["cd3"] = glue.chamfer_big(gt, out3, sorted1=hgt)[0]
+    t["cd4"] = glue.chamfer_big(gt, out4, sorted1=hgt)[0]  # = chamfer_loss, :484
+    t["recd3"] = glue.re_chamfer(gt, out3, part=8)
+    t["moveloss"] = (collect[f"refine_layer_final{out4.shape[1]}"] ** 2).sum(-1).mean()
+    t["loss_d1"] = 0.05 * glue.zero_groupnear(gt1, gt2, collect[f"decode_cell{out1.shape[1]}"])
+    t["loss_d2"] = 0.05 * glue.zero_groupnear(gt2, gt, collect[f"decode_cell{out2.shape[1]}"], hgt2, hgt)
+    t["loss_dec"] = net.decline_factor0[0] ** 2 + net.decline_factor1[0] ** 2 + net.decline_factor[0] ** 2
+    t["loss"] = (0.2 * (t["cd1"] + t["cd2"]) + t["cd3"] + t["cd4"] + 0.2 * t["recd3"] + 0.1 * t["moveloss"]
+                 + t["loss_d1"] + t["loss_d2"] + alpha1 * t["loss_dec"])
+    if terms is not None:
+        terms.update(t)
+        terms.update({"gt_fps64": i64, "gt_fps1024": i1024})
+    return t["loss"]

@@ -71,7 +71,7 @@ def test_sorted_handles_reused_across_calls(orc, b, n, m):
         d1, i1, d2, i2 = R.nn_distance_sorted(ha, h, False, True)
         assert d1 is None and np.array_equal(i2.cpu().numpy(), e[3]) and np.array_equal(d2.cpu().numpy(), e[2])
     with pytest.raises(ValueError):
-        R.nn_distance_sorted(ha, R.nn_sort(cu(c[:1])))
+        R.nn_distance_sorted(ha, R.nn_sort(cu(np.concatenate([c, c[:1]], 0))))  # batch mismatch
 
 
 def test_chamfer_step_one_call_equals_two_ops(orc):
@@ -88,7 +88,9 @@ def test_chamfer_step_one_call_equals_two_ops(orc):
         for got, exp in zip((d1, i1, d2, i2), e):
             assert np.array_equal(got.cpu().numpy(), exp)
         r1, r2 = R.nn_distance_grad(ta, tc, tg1, i1, tg2, i2)
-        assert torch.equal(g1, r1) and torch.equal(g2, r2)
+        # (LDS float atomics: the summation order of a scatter is not fixed run to run)
+        assert torch.allclose(g1, r1, rtol=1e-5, atol=1e-5 * float(r1.abs().max()))
+        assert torch.allclose(g2, r2, rtol=1e-5, atol=1e-5 * float(r2.abs().max()))
         o1, o2 = orc.nn_distance_grad(a, c, gd1, e[1], gd2, e[3])
         assert np.allclose(g1.cpu().numpy(), o1, rtol=1e-5, atol=1e-5 * np.abs(o1).max())
         assert np.allclose(g2.cpu().numpy(), o2, rtol=1e-5, atol=1e-5 * np.abs(o2).max())
@@ -144,7 +146,7 @@ def test_fused_glue_equals_the_op_chain(orc):
     d1, i1, d2, _ = nn_distance(ra, rc)
     ref = (torch.sqrt(d1).mean() + torch.sqrt(d2).mean()) / 2
     (ref * 3.0).backward()
-    assert abs(float(loss) - float(ref)) < 2e-6 * float(ref) and torch.equal(idx1, i1)
+    assert abs(float(loss.detach()) - float(ref.detach())) < 2e-6 * float(ref.detach()) and torch.equal(idx1, i1)
     for got, exp in ((ta.grad, ra.grad), (tc.grad, rc.grad)):
         assert torch.allclose(got, exp, rtol=1e-4, atol=1e-5 * float(exp.abs().max()))
     # fidelity: direction 1 only
