@@ -646,8 +646,9 @@ def select_top_k(k, dist):
 
 
 @H.on_input_device
-def prob_sample(inp, inpr):
-    """ProbSampleGpuOp, tf_ops/sampling/tf_sampling.cpp:66-92 -> (b,m) int32."""
+def prob_sample(inp, inpr, return_cumsum=False):
+    """ProbSampleGpuOp, tf_ops/sampling/tf_sampling.cpp:66-92 -> (b,m) int32 (and, on request, the
+    op's temp tensor: the (b,n) cumulative sums)."""
     st = H.Staged()
     p, r = st.take(inp, F32), st.take(inpr, F32)
     if p.dim() != 2:
@@ -660,4 +661,6 @@ def prob_sample(inp, inpr):
     temp, out = H.empty((b, n), F32, dev), H.empty((b, m), I32, dev)
     check(lib.rf_probsample(b, n, m, H.ptr(p), H.ptr(r), H.ptr(temp), H.ptr(out), H.stream(dev)),
           "rf_probsample")
+    if return_cumsum:
+        return st.give(out), st.give(temp)
     return st.give(out)

@@ -261,83 +261,162 @@ __global__ void scatteradd_kernel(int n, int m, long total, const float *__restr
     atomicAdd(p + 2, out_g[g * 3 + 2]);
 }
 
-// ---- prob_sample (ProbSample op): cumsumKernel + binarysearchKernel, tf_sampling_g.cu:7-104.
-// One workgroup per row; the scan keeps the reference's association order exactly (groups of
-// 4, up-sweep / down-sweep over the group totals with the (i + i>>5) padded index, compensated
-// carry between 8192-element chunks), so the cumulative sums -- and therefore the sampled
-// indices -- are bit-exact with oracle/rfops_oracle.c::orc_cumsum.  Adds only: no FMA question.
-constexpr int CS_BS = 2048;
-__device__ __forceinline__ int pad5(int i) { return i + (i >> 5); }
+// ---- prob_sample (ProbSample op; reference: cumsumKernel + binarysearchKernel, tf_sampling_g.cu:7-104)
+// What is pinned is the VALUE of every cumulative sum: fp32 addition is not associative, so the
+// association order of the reference's blocked scan is part of the result (and decides which index
+// a uniform draw lands on).  That order, per chunk of 8192 elements (2048 groups of 4):
+//   in a group      (a+b), (a+b)+c, (a+b)+(c+d);
+//   over the groups balanced pairwise sums of aligned power-of-two blocks B(.), and the prefix up
+//                   to group count c is folded from the HIGHEST set bit of c down:
+//                   P(c) = B(lowest block of c) + P(c - lowbit(c));
+//   an element      (in-group prefix + P(groups before it)) + carry;
+//   between chunks  a compensated (two-float) carry.
+// How it is computed here (one 512-thread workgroup per row, nothing like the reference's LDS tree):
+//   * a lane owns one group (4 consecutive elements, one 16-byte load), a wave 64 consecutive
+//     groups: the balanced block sums up to 64 groups are a DPP up-sweep inside the wave (row
+//     shifts for 1,2,4,8; two readlanes for 16, 32), no LDS, no barrier;
+//   * the 32 wave-block totals of a chunk cross waves through a double-buffered LDS line -- ONE
+//     barrier per chunk -- and every wave scans them itself (same in-wave routine);
+//   * the fold "from the highest bit down" is the in-wave down-sweep started from the prefix of the
+//     blocks before the wave (injected as the value of "lane -1"), so each lane ends with exactly
+//     the reference's P(c);
+//   * the chunk carry is wave-uniform and kept by every wave in scalar registers;
+//   * the row of cumulative sums stays in LDS (up to 32768 entries of the 160 KiB) for the
+//     inverse-CDF search of the row's draws in the same launch; `temp` still receives it.
+// Bit-exact with oracle/rfops_oracle.c::orc_cumsum / orc_prob_sample.
+constexpr int PS_T = 512;                 // threads: 8 waves
+constexpr int PS_SLOTS = 4;               // wave-blocks (64 groups) per wave and chunk
+constexpr int PS_CHUNK = PS_T * PS_SLOTS * 4;  // 8192 elements
+constexpr int PS_BLOCKS = PS_T / 64 * PS_SLOTS;  // 32 wave-blocks per chunk
+constexpr int PS_ROW_CAP = 32768;         // cumulative sums kept in LDS for the search
 
-__global__ __launch_bounds__(512) void cumsum_kernel(int n, const float *__restrict__ inp,
-                                                     float *__restrict__ out) {
-    __shared__ float buffer4[CS_BS * 4];
-    __shared__ float buffer[CS_BS + (CS_BS >> 5) + 1];
-    const int i = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
-    float runningsum = 0.f, runningsum2 = 0.f;
-    for (int j = 0; j < n; j += CS_BS * 4) {
-        const float *in = inp + (size_t)i * n + j;
-        const int n24_i = min(n - j, CS_BS * 4);
-        const int n24 = (n24_i + 3) & ~3, n2 = n24 >> 2;
-        for (int k = t * 4; k < n24_i; k += nt * 4) {
-            if (k + 3 < n24_i) {
-                float v1 = in[k], v2 = in[k + 1];
-                v2 += v1;
-                float v3 = in[k + 2], v4 = in[k + 3];
-                v4 += v3;
-                v3 += v2;
-                v4 += v2;
-                buffer4[k] = v1; buffer4[k + 1] = v2; buffer4[k + 2] = v3; buffer4[k + 3] = v4;
-                buffer[pad5(k >> 2)] = v4;
-            } else {
-                float v = 0.f;
-                for (int k2 = k; k2 < n24_i; k2++) { v += in[k2]; buffer4[k2] = v; }
-                for (int k2 = n24_i; k2 < n24; k2++) buffer4[k2] = v;
-                buffer[pad5(k >> 2)] = v;
-            }
-        }
-        int u = 0;
-        for (; (2 << u) <= n2; u++) {
-            __syncthreads();
-            for (int k = t; k < (n2 >> (u + 1)); k += nt)
-                buffer[pad5((((k << 1) + 2) << u) - 1)] += buffer[pad5((((k << 1) + 1) << u) - 1)];
-        }
-        u--;
-        for (; u >= 0; u--) {
-            __syncthreads();
-            for (int k = t; k < ((n2 - (1 << u)) >> (u + 1)); k += nt)
-                buffer[pad5((((k << 1) + 3) << u) - 1)] += buffer[pad5((((k << 1) + 2) << u) - 1)];
-        }
-        __syncthreads();
-        for (int k = t * 4; k < n24; k += nt * 4) {
-            if (k != 0) {
-                const float add = buffer[pad5((k >> 2) - 1)];
-                buffer4[k] += add; buffer4[k + 1] += add; buffer4[k + 2] += add; buffer4[k + 3] += add;
-            }
-        }
-        __syncthreads();
-        for (int k = t; k < n24_i; k += nt) out[(size_t)i * n + j + k] = buffer4[k] + runningsum;
-        const float tt = buffer[pad5(n2 - 1)] + runningsum2;
-        const float r2 = runningsum + tt;
-        runningsum2 = tt - (r2 - runningsum);
-        runningsum = r2;
-        __syncthreads();
-    }
+template <int N>
+__device__ __forceinline__ float row_shr(float v) {  // value of lane - N inside a row of 16 (0 outside)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + N, 0xf, 0xf, false));
 }
 
-__global__ void binarysearch_kernel(int n, int m, long total, const float *__restrict__ dataset,
-                                    const float *__restrict__ query, int *__restrict__ result) {
-    long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= total) return;
-    const long i = g / m;
-    const float *ds = dataset + i * n;
-    int base = 1;
-    while (base < n) base <<= 1;
-    const float q = query[g] * ds[n - 1];
-    int r = n - 1;
-    for (int k = base; k >= 1; k >>= 1)
-        if (r >= k && ds[r - k] >= q) r -= k;
-    result[g] = r;
+// Balanced pairwise sums: afterwards lane l holds the sum of the aligned block of lowbit(l+1) lanes
+// ending at l (lane 63: all 64).
+__device__ __forceinline__ float ps_upsweep(float v, int lane) {
+    float o;
+    o = row_shr<1>(v); if ((lane & 1) == 1) v = v + o;
+    o = row_shr<2>(v); if ((lane & 3) == 3) v = v + o;
+    o = row_shr<4>(v); if ((lane & 7) == 7) v = v + o;
+    o = row_shr<8>(v); if ((lane & 15) == 15) v = v + o;
+    const float t15 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 15));
+    const float t47 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 47));
+    if (lane == 31) v = v + t15;
+    if (lane == 63) v = v + t47;
+    const float t31 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+    if (lane == 63) v = v + t31;
+    return v;
+}
+
+// From block sums to prefixes: the lane with count r = lane + 1 an odd multiple of 2^u adds the
+// finished prefix at r - 2^u; for r == 2^u that is the prefix of everything BEFORE this wave
+// (`base`, present from the second wave-block on).  Lane 63 (r = 64) is a boundary of the next
+// level up and is left alone.
+__device__ __forceinline__ float ps_downsweep(float v, int lane, bool hasbase, float base) {
+    const int r = lane + 1;
+#pragma unroll
+    for (int u = 5; u >= 0; u--) {
+        const int bit = 1 << u;
+        float below = __shfl_up(v, bit, 64);
+        const bool first = r == bit;
+        if (first) below = base;
+        if ((r & (2 * bit - 1)) == bit && (!first || hasbase)) v = v + below;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(PS_T) void prob_sample_kernel(int n, int m, const float *__restrict__ weights,
+                                                           const float *__restrict__ draws,
+                                                           float *__restrict__ cum, int *__restrict__ picked) {
+    __shared__ float row[PS_ROW_CAP];
+    __shared__ float blocktot[2][PS_BLOCKS];
+    __shared__ float chunk_last[2];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float *__restrict__ in = weights + (size_t)blockIdx.x * n;
+    float *__restrict__ out = cum + (size_t)blockIdx.x * n;
+    const bool keep = n <= PS_ROW_CAP;
+
+    float carry = 0.f, carry_lo = 0.f;  // the running total as a compensated pair (wave-uniform)
+    int par = 0;
+    for (int c0 = 0; c0 < n; c0 += PS_CHUNK, par ^= 1) {
+        const int cnt = min(n - c0, PS_CHUNK);     // elements in this chunk
+        const int ngroups = (cnt + 3) >> 2;
+        float e[PS_SLOTS][4], tot[PS_SLOTS];
+#pragma unroll
+        for (int s = 0; s < PS_SLOTS; s++) {
+            const int k = (((wave * PS_SLOTS + s) << 6) + lane) << 2;  // first element of this lane's group
+            float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+            if (k + 3 < cnt) {
+                a = in[c0 + k]; b = in[c0 + k + 1]; c = in[c0 + k + 2]; d = in[c0 + k + 3];
+                const float ab = a + b, cd = c + d;
+                e[s][0] = a; e[s][1] = ab; e[s][2] = c + ab; e[s][3] = cd + ab;
+            } else {  // the row's ragged last group: a plain running sum from 0, repeated to the end
+                float run = 0.f;
+#pragma unroll
+                for (int x = 0; x < 4; x++) {
+                    if (k + x < cnt) run = run + in[c0 + k + x];
+                    e[s][x] = run;
+                }
+            }
+            tot[s] = ps_upsweep(e[s][3], lane);
+            if (lane == 63) blocktot[par][wave * PS_SLOTS + s] = tot[s];
+        }
+        __syncthreads();
+        // every wave: prefixes of the wave-block totals (lane q: blocks 0..q), and the carry from
+        // the previous chunk's grand total
+        float blk = blocktot[par][lane & (PS_BLOCKS - 1)];
+        blk = ps_downsweep(ps_upsweep(blk, lane), lane, false, 0.f);
+        if (c0 > 0) {
+            const float prev = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(chunk_last[par ^ 1])));
+            const float t = prev + carry_lo;
+            const float next = carry + t;
+            carry_lo = t - (next - carry);
+            carry = next;
+        }
+#pragma unroll
+        for (int s = 0; s < PS_SLOTS; s++) {
+            const int q = wave * PS_SLOTS + s;
+            const bool hasbase = q > 0;
+            const float base = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(blk), q > 0 ? q - 1 : 0));
+            float incl = ps_downsweep(tot[s], lane, hasbase, base);
+            if (lane == 63) incl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(blk), q));
+            float before = __shfl_up(incl, 1, 64);  // prefix of the groups before this lane's group
+            if (lane == 0) before = base;
+            const int g = (q << 6) + lane;
+            const int k = g << 2;
+            if (g == ngroups - 1) chunk_last[par] = incl;  // the chunk's grand total
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                if (k + x < cnt) {
+                    const float within = g > 0 ? e[s][x] + before : e[s][x];
+                    const float val = within + carry;
+                    out[c0 + k + x] = val;
+                    if (keep) row[c0 + k + x] = val;
+                }
+            }
+        }
+    }
+    __syncthreads();  // the row is complete (LDS copy, or global for rows beyond the LDS cap)
+    // inverse CDF: walk down from the last index in power-of-two strides, largest first; a stride is
+    // taken while the entry it lands on still reaches the target
+    const float *__restrict__ cdf = keep ? row : out;
+    int top = 1;
+    while (top < n) top <<= 1;
+    const float total = cdf[n - 1];
+    for (int j = threadIdx.x; j < m; j += PS_T) {
+        const float target = draws[(size_t)blockIdx.x * m + j] * total;
+        int pos = n - 1;
+        for (int stride = top; stride > 0; stride >>= 1) {
+            const int cand = pos - stride;
+            if (cand >= 0 && cdf[cand] >= target) pos = cand;
+        }
+        picked[(size_t)blockIdx.x * m + j] = pos;
+    }
 }
 
 }  // namespace
@@ -404,10 +483,7 @@ int rf_probsample(int b, int n, int m, const float *inp_p, const float *inp_r, f
     if (n == 0) return RF_EINVAL;
     if (!inp_p || !inp_r || !temp || !out) return RF_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    RF_LAUNCH("cumsum", cumsum_kernel, dim3(b), dim3(512), 0, s, n, inp_p, temp);
-    const long total = (long)b * m;
-    RF_LAUNCH("binarysearch", binarysearch_kernel, dim3(rf::ceil_div(total, 256)), dim3(256), 0, s, n, m,
-              total, (const float *)temp, inp_r, out);
+    RF_LAUNCH("prob_sample", prob_sample_kernel, dim3(b), dim3(PS_T), 0, s, n, m, inp_p, inp_r, temp, out);
     return RF_OK;
 }
 

@@ -68,14 +68,23 @@ def test_select_top_k_vs_oracle(orc, b, m, n, k):
     assert (np.sort(oi, -1) == np.arange(n)).all()  # every row of idx is a permutation
 
 
-@pytest.mark.parametrize("b,n,m", [(1, 1, 5), (2, 3, 7), (3, 40, 100), (2, 8192, 300), (2, 8193, 300), (2, 50001, 1000)])
+@pytest.mark.parametrize("b,n,m", [(1, 1, 5), (2, 3, 7), (3, 40, 100), (2, 255, 64), (2, 257, 64), (3, 4099, 500), (2, 8192, 300), (2, 8193, 300),
+                                   (1, 16384, 2000), (2, 24577, 100), (2, 32768, 100), (2, 50001, 1000)])
 def test_prob_sample_vs_oracle(orc, b, n, m):
+    from rfnet_amd import _raw as R
     from tf_ops.sampling.tf_sampling import prob_sample
     rng = np.random.RandomState(n)
     p = rng.rand(b, n).astype(np.float32)
+    if n > 10:
+        p[:, 3] = 0.0
+        p[:, n // 2] = -0.0  # signed zeros: x + 0.0 is not the identity on the sign bit
     r = rng.rand(b, m).astype(np.float32)
     got = prob_sample(cu(p), cu(r)).cpu().numpy()
     exp, cs = orc.prob_sample(p, r)
     assert np.array_equal(got, exp)
+    # the cumulative sums themselves, bit for bit (the association order of the blocked scan)
+    got2, gcs = R.prob_sample(cu(p), cu(r), return_cumsum=True)
+    assert np.array_equal(gcs.cpu().numpy().view(np.uint32), np.ascontiguousarray(cs).view(np.uint32))
+    assert np.array_equal(got2.cpu().numpy(), exp)
     # inverse CDF: index i is drawn with probability p[i] / sum(p)
     assert (got >= 0).all() and (got < n).all()
