@@ -78,6 +78,7 @@ __global__ __launch_bounds__(QB_TPB) void query_ball_kernel(int n, int m, int nw
     const int bi = w / nwaves_per_batch;
     if (bi >= b) return;
     if (radius_dev) thresh = ball_threshold_dev(radius_dev[0]);  // uniform
+    const int n_scan = thresh > 0.f ? n : 0;  // radius within the 1e-20 clamp: nothing is ever inside
     const int q0 = (w - bi * nwaves_per_batch) * QPW;  // first query of this wave (within the cloud)
     const int nq = min(QPW, m - q0);
     const float *__restrict__ D = xyz1 + (size_t)bi * n * 3;
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(QB_TPB) void query_ball_kernel(int n, int m, int nw
         const int kk = min(lane, n - 1);
         nx = D[kk * 3 + 0]; ny = D[kk * 3 + 1]; nz = D[kk * 3 + 2];
     }
-    for (int k0 = 0; k0 < n; k0 += 64) {
+    for (int k0 = 0; k0 < n_scan; k0 += 64) {
         int open = 0;
 #pragma unroll
         for (int i = 0; i < QPW; i++) open |= (cnt[i] < nsample) ? 1 : 0;
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(QB_TPB) void query_ball_kernel(int n, int m, int nw
 #pragma unroll
         for (int i = 0; i < QPW; i++) {
             const float d2 = rf::d2_fma(qx[i] - x1, qy[i] - y1, qz[i] - z1);
-            mask[i] = __ballot(d2 < thresh) & valid;
+            mask[i] = __ballot(!(d2 >= thresh)) & valid;  // a NaN d2 is a hit, as in the reference (fmaxf drops the NaN)
             any |= mask[i];
         }
         if (any == 0ull) continue;  // wave-uniform
@@ -185,7 +186,8 @@ __global__ __launch_bounds__(64 * QS) void query_ball_lanes_kernel(int n, int m,
     const float qx = Q[0], qy = Q[1], qz = Q[2];
     int cnt = 0;
     if (radius_dev) thresh = ball_threshold_dev(radius_dev[0]);  // uniform
-    const int k_begin = sg * seg, k_end = min(n, k_begin + seg);
+    // threshold 0: the radius does not exceed the 1e-20 clamp, nothing is ever inside (not even a NaN)
+    const int k_begin = sg * seg, k_end = thresh > 0.f ? min(n, k_begin + seg) : k_begin;
     // Whole sub-chunks of 8 points: scalar prefetch one sub-chunk ahead, no per-point range test.
     // The hit path sits behind a wave-uniform branch on the compare mask (without it the compiler
     // predicates the 5 append instructions and issues them for every point).
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(64 * QS) void query_ball_lanes_kernel(int n, int m,
 #pragma unroll
         for (int u = 0; u < QL_SUB; u++) {
             const float d2 = rf::d2_fma(qx - c[u * 3], qy - c[u * 3 + 1], qz - c[u * 3 + 2]);
-            const bool hit = d2 < thresh;
+            const bool hit = !(d2 >= thresh);  // NaN d2: a hit (the reference's fmaxf(sqrtf(NaN), 1e-20f) < r)
             if (__ballot(hit) != 0ull) {  // wave-uniform
                 // (the empty volatile asm keeps this a real s_cbranch: without it the two
                 // conditions are merged and the append is predicated instead of skipped)
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(64 * QS) void query_ball_lanes_kernel(int n, int m,
         for (int u = 0; u < QL_SUB; u++) {
             const int k = ks + u;
             const float d2 = rf::d2_fma(qx - D[k * 3], qy - D[k * 3 + 1], qz - D[k * 3 + 2]);
-            if (d2 < thresh && k >= k_full && k < k_end && cnt < nsample) {
+            if (!(d2 >= thresh) && k >= k_full && k < k_end && cnt < nsample) {
                 list[sg][cnt][lane] = k;
                 cnt++;
             }

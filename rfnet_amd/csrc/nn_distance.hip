@@ -54,6 +54,7 @@ struct Sweep {
     int span;     // candidates per split (multiple of CG)
     int wgm;      // 1: the 4 waves of a workgroup are 4 consecutive splits of one own block and merge
                   //    their own-side results in LDS (row partial slots = nsplit / 4)
+    int rslots_final;  // 1: the sweep writes the FINAL own-side outputs (one partial slot: no row merge follows)
 };
 
 // Re-pack both clouds in ONE launch: blocks [0, nblk_own) pack the own set (padded with -inf),
@@ -307,6 +308,10 @@ __global__ __launch_bounds__(TPB) void nn_sweep_kernel(Sweep a, const float *__r
                 }
             }
             if (ob * 64 * R + pnt < a.no) {
+                if (a.rslots_final) {  // this is the final own-side result: a NaN point gets (NaN, 0), as in the reference
+                    const float *q = own + (size_t)(ob * 64 * R + pnt) * 3;
+                    if (q[0] != q[0] || q[1] != q[1] || q[2] != q[2]) { bd = NAN; bk = 0; }
+                }
                 row_dist[mbase + pnt] = bd;
                 row_idx[mbase + pnt] = bk;
             }
@@ -317,8 +322,9 @@ __global__ __launch_bounds__(TPB) void nn_sweep_kernel(Sweep a, const float *__r
     for (int r = 0; r < R; r++) {
         const int j = (ob * 64 + lane) * R + r;
         if (j < a.no) {
-            row_dist[obase + j] = best[r];
-            row_idx[obase + j] = besti[r];
+            const bool qnan = a.rslots_final && (ax[r] != ax[r] || ay[r] != ay[r] || az[r] != az[r]);
+            row_dist[obase + j] = qnan ? NAN : best[r];
+            row_idx[obase + j] = qnan ? 0 : besti[r];
         }
     }
 }
@@ -326,7 +332,8 @@ __global__ __launch_bounds__(TPB) void nn_sweep_kernel(Sweep a, const float *__r
 // own side: combine the per-split partials in split order; strict '<' keeps the lowest index.
 __device__ __forceinline__ void rowmerge_body(long g, const float *__restrict__ pd,
                                               const int *__restrict__ pi, float *__restrict__ dist,
-                                              int *__restrict__ idx, int nsplit, long total) {
+                                              int *__restrict__ idx, int nsplit, long total,
+                                              const float *__restrict__ own_all, int no, int no_pad) {
     if (g >= total) return;
     float best = pd[g];
     int besti = pi[g];
@@ -337,6 +344,11 @@ __device__ __forceinline__ void rowmerge_body(long g, const float *__restrict__ 
             besti = pi[(size_t)s * total + g];
         }
     }
+    // a point with a NaN coordinate: (NaN, 0), as the reference returns (its first candidate is taken
+    // unconditionally and nothing compares below NaN, tf_nndistance_g.cu:27-31)
+    const long bi = g / no;
+    const float *q = own_all + ((size_t)bi * no_pad + (g - bi * no)) * 3;
+    if (q[0] != q[0] || q[1] != q[1] || q[2] != q[2]) { best = NAN; besti = 0; }
     dist[g] = best;
     idx[g] = besti;
 }
@@ -357,7 +369,7 @@ __global__ __launch_bounds__(TPB) void nn_resolve_kernel(Sweep a, const float *_
                                                          int *__restrict__ row_idx, int rslots) {
     if ((int)blockIdx.x >= nblk_col) {
         rowmerge_body((long)(blockIdx.x - nblk_col) * TPB + threadIdx.x, row_pd, row_pi, row_dist, row_idx,
-                      rslots, (long)a.b * a.no);
+                      rslots, (long)a.b * a.no, own_all, a.no, a.no_pad);
         return;
     }
     // 4 lanes (a quad) per candidate: lane q scans the own blocks o = q, q+4, ... (its loads are
@@ -396,7 +408,9 @@ __global__ __launch_bounds__(TPB) void nn_resolve_kernel(Sweep a, const float *_
     // the whole quad re-scans for ITS result
     best = __shfl(best, threadIdx.x & ~3, 64);
     bblk = __shfl(bblk, threadIdx.x & ~3, 64);
-    const int wl = collane[(size_t)bblk * ostride + (size_t)bi * a.nc + c];
+    // (a NaN candidate leaves no lane matching its NaN minimum: the recorded lane is then 64 -- masked
+    // here so that the re-scan stays inside the arrays; its result is overridden below)
+    const int wl = collane[(size_t)bblk * ostride + (size_t)bi * a.nc + c] & 63;
     const float cx = cand[c * 3 + 0], cy = cand[c * 3 + 1], cz = cand[c * 3 + 2];
     const int j0 = (bblk * 64 + wl) * R;
     static_assert(R % 4 == 0, "the quad shares the re-scan");
@@ -409,7 +423,11 @@ __global__ __launch_bounds__(TPB) void nn_resolve_kernel(Sweep a, const float *_
     }
     found = min(found, __shfl_xor(found, 1, 64));
     found = min(found, __shfl_xor(found, 2, 64));
-    if (found == 0x7fffffff) found = j0;  // all-inf case: block 0, lane 0 -> index 0
+    if (found == 0x7fffffff) found = j0 < a.no ? j0 : 0;  // all-inf case: block 0, lane 0 -> index 0
+    if (cx != cx || cy != cy || cz != cz) {  // a NaN point: (NaN, 0), as in the reference
+        best = NAN;
+        found = 0;
+    }
     if (writer) {
         dist[(size_t)bi * a.nc + c] = best;
         idx[(size_t)bi * a.nc + c] = found;
@@ -676,6 +694,7 @@ int dense_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2,
     unsigned char *collane = (unsigned char *)(w + p.off_coll);
     a.b = b; a.no = p.no; a.nc = p.nc; a.no_pad = p.no_pad; a.nc_pad = p.nc_pad;
     a.oblocks = p.oblocks; a.nsplit = p.nsplit; a.span = p.span; a.wgm = p.wgm;
+    a.rslots_final = p.rslots > 1 ? 0 : 1;
     long waves = (long)b * p.oblocks * p.nsplit;
     if (cols) {
         RF_LAUNCH("nn_sweep", (nn_sweep_kernel<RR, true>), dim3(rf::ceil_div(waves, TPB / 64)), dim3(TPB), 0, s, a,

@@ -790,6 +790,11 @@ __device__ __forceinline__ void sweep_group(
     const float qz = Q[(size_t)(g * SB + lane) * 3 + 2];
     const int qorig = Qo[g * SB + lane];
     const bool valid = qorig >= 0;
+    // A query with a NaN coordinate can never tighten its bound (every d2 is NaN): it takes no part
+    // in the traversal -- it would drag its whole wave through every superblock -- and is written as
+    // (NaN, 0), what the reference returns for it (tf_nndistance_g.cu:27-31).
+    const bool qnan = qx != qx || qy != qy || qz != qz;
+    const bool part = valid && !qnan;
     const float *gb = (dir ? b64_1 : b64_0) + ((size_t)bi * G + g) * B64F;  // uniform
     const float glo[3] = {gb[0], gb[1], gb[2]}, ghi[3] = {gb[4], gb[5], gb[6]};
 
@@ -805,7 +810,7 @@ __device__ __forceinline__ void sweep_group(
     bool tie = false;
     // <= best: also what the other waves of the group have found.  -inf for lanes that take no part
     // (padding): `bound <= cull` / `cull >= bound` are then false without a separate mask.
-    float cull = valid ? INFINITY : -INFINITY;
+    float cull = part ? INFINITY : -INFINITY;
     unsigned n_step = 0, n_scan = 0;
 
     // One traversal of the candidate superblocks in ascending order of a lower bound, for the lanes
@@ -1032,7 +1037,7 @@ __device__ __forceinline__ void sweep_group(
         }
     }
     // queries whose minimum was attained in more than one visited block: second traversal
-    const bool flagged = tie && valid;
+    const bool flagged = tie && part;
     if (__ballot(flagged) != 0ull) {
         const float flo[3] = {wave_min_f32(flagged ? qx : INFINITY), wave_min_f32(flagged ? qy : INFINITY),
                               wave_min_f32(flagged ? qz : INFINITY)};
@@ -1068,8 +1073,8 @@ __device__ __forceinline__ void sweep_group(
         }
     }
     if (valid) {
-        (dir ? dist1 : dist0)[(size_t)bi * a.n[dir] + qorig] = best;
-        (dir ? idx1 : idx0)[(size_t)bi * a.n[dir] + qorig] = besti == 0xFFFFFFFFu ? 0 : (int)besti;
+        (dir ? dist1 : dist0)[(size_t)bi * a.n[dir] + qorig] = qnan ? NAN : best;
+        (dir ? idx1 : idx0)[(size_t)bi * a.n[dir] + qorig] = (qnan || besti == 0xFFFFFFFFu) ? 0 : (int)besti;
     }
 }
 

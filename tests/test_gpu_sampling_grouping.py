@@ -127,6 +127,28 @@ def test_query_ball_radius_boundary_is_in_distance_domain(orc):
     assert np.array_equal(cnt.cpu().numpy(), oc) and np.array_equal(idx.cpu().numpy(), oi)
 
 
+@pytest.mark.parametrize("ns", [8, 48, 80])  # lanes kernel (<=32 / <=64 samples) and the wave-per-8-queries kernel
+def test_query_ball_nan_is_a_hit_like_the_reference(orc, ns):
+    """max(sqrtf(NaN), 1e-20f) < r: fmaxf drops the NaN, so a pair with a NaN coordinate on either side
+    IS inside every ball of radius > 1e-20 (tf_grouping_g.cu:24-26; PTX max.f32).  Pinned against the
+    oracle, whose C fmaxf has the same semantics."""
+    from rfnet_amd import _raw as R
+    rng = np.random.RandomState(ns)
+    pts = rng.rand(2, 700, 3).astype(np.float32)
+    q = pts[:, :90].copy()
+    pts[0, 3, 1] = np.nan       # a NaN dataset point: inside everyone's ball
+    pts[1, 650] = np.nan
+    q[0, 7, 0] = np.nan         # a NaN query: every dataset point is inside
+    oi, oc = orc.query_ball_point(np.float32(0.15), ns, pts, q)
+    gi, gc = R.query_ball_point(0.15, ns, cu(pts), cu(q))
+    assert np.array_equal(gc.cpu().numpy(), oc) and np.array_equal(gi.cpu().numpy(), oi)
+    assert oc[0, 7] == ns and list(oi[0, 7]) == list(range(ns))
+    assert (oi[0, :, :] == 3).any(-1).all()  # point 3 is in every ball of cloud 0
+    # a radius inside the 1e-20 clamp: nothing is inside, not even the NaNs
+    gi, gc = R.query_ball_point(1e-21, ns, cu(pts), cu(q))
+    assert int(gc.sum()) == 0
+
+
 def test_group_point_model_shape_and_autograd(orc):
     """merge_layer's use: c=3, nsample=1 (vv_recon.py:135) and the reference's gradient test
     shapes (tf_grouping_op_test.py: points (1,128,16), 8 queries, nsample 32)."""
