@@ -267,6 +267,20 @@ int rf_merge_layer_grad(int b, int n, int m, const float *rawpts, const float *n
                         const float *decfactor_dev, const int *idx2, const float *grad_refined,
                         float *grad_newpts, float *grad_dec, float *grad_raw, rf_stream_t stream);
 
+/* ------------------------------------------------ model graph helper (row f2) ------------ */
+/* The elementwise tail of RFNet's per-point dense layers in one pass.  The reference's conv2d
+ * (vv_recon.py:47-65: conv + bias_add + activation) is mostly applied to
+ * tf.concat([per-point features, tf.tile(global code word)]) (:101,127,144,148,280,288,299,317,343);
+ * computed without the concatenation that is
+ *     out[i,j,:] = act( y[i,j,:] + sum_{k<kp} p[i,j,k] w[k,:] + r[i,:] )
+ * y (b,n,c): the GEMM of the wide per-point inputs, or NULL; p (b,n,kp), w (kp,c): a narrow
+ * per-point input (the coordinates: kp = 3; kp <= 16) applied on the fly, or kp = 0; r: bias + code
+ * word term, (b,c) with r_per_sample != 0, (c) otherwise; act: 0 none, 1 relu, 2 tanh.
+ * c % 4 == 0, c <= 1024 (rf_point_affine_supported).  out may alias y. */
+int rf_point_affine_supported(int c, int kp);
+int rf_point_affine(int b, int n, int c, const float *y, const float *p, int kp, const float *w,
+                    const float *r, int r_per_sample, int act, float *out, rf_stream_t stream);
+
 /* ------------------------------------------------------------------ measurement hooks --- */
 /* When enabled, every kernel launch made by this library is bracketed by hipEvents recorded
  * on the launch stream.  rf_profile_collect() waits for them and returns the per-kernel sums

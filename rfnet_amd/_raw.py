@@ -664,3 +664,33 @@ def prob_sample(inp, inpr, return_cumsum=False):
     if return_cumsum:
         return st.give(out), st.give(temp)
     return st.give(out)
+
+
+# ------------------------------------------------------------------ model graph helper (f2) --
+_ACT = {None: 0, "none": 0, "relu": 1, "tanh": 2}
+
+
+def point_affine(y, p, w, r, act="relu", out=None):
+    """rf_point_affine: act(y + p @ w + r) in one pass.  y (b,n,c) or None, p (b,n,kp<=16) or None with
+    w (kp,c), r (b,c) / (b,1,c) per sample or (c,) shared.  GPU tensors only (a model-graph helper,
+    not one of the reference's ops)."""
+    ref = y if y is not None else p
+    b, n = ref.shape[0], ref.shape[1]
+    c = r.shape[-1]
+    kp = 0 if p is None else p.shape[-1]
+    if not lib.rf_point_affine_supported(c, kp):
+        raise H.invalid("point_affine: channels must be a multiple of 4 (<= 1024), narrow input <= 16 channels")
+    dev = ref.device
+    per_sample = r.dim() > 1 and r.shape[0] == b and r.numel() == b * c
+    if not per_sample and r.numel() != c:
+        raise H.invalid("point_affine: r must be (b,c), (b,1,c) or (c,)")
+    y_ = None if y is None else y.contiguous()
+    p_ = None if p is None else p.contiguous()
+    w_ = None if p is None else w.contiguous()
+    r_ = r.contiguous()
+    if out is None:
+        out = H.empty((b, n, c), F32, dev)
+    with torch.cuda.device(dev):
+        check(lib.rf_point_affine(b, n, c, H.ptr(y_), H.ptr(p_), kp, H.ptr(w_), H.ptr(r_), int(per_sample),
+                                  _ACT[act], H.ptr(out), H.stream(dev)), "rf_point_affine")
+    return out

@@ -49,6 +49,20 @@
 
 namespace {
 
+// experiment knobs (tools/build_variant.py compiles A/B libraries with -D...; the defaults are the product)
+#ifndef RFP_NSH
+#define RFP_NSH 4   // waves sharing one query group when a direction has few groups
+#endif
+#ifndef RFP_ORDER
+#define RFP_ORDER 0 // 0: per batch element dir0's workgroups then dir1's; 1: all of dir0 first (heavy first)
+#endif
+#ifndef RFP_SPLIT_BELOW
+#define RFP_SPLIT_BELOW 4096
+#endif
+#ifndef RFP_HIST
+#define RFP_HIST 0  // 1 (instrumented build): block scans by number of active lanes -> stats[10..13]
+#endif
+constexpr int NSH = RFP_NSH;
 constexpr int BS = 16;             // candidates per block
 constexpr int SBB = 4;             // blocks per superblock
 constexpr int SB = BS * SBB;       // 64 records: one superblock = one query group = one wave
@@ -697,7 +711,7 @@ struct SweepArgs {
     int b;
     int n[2], npad[2];
     int groups[2];   // npad[d] / 64
-    int nw[2];       // waves per query group: 1 or 4
+    int nw[2];       // waves per query group: 1 or NSH
     int wg0, wg1;    // workgroups per batch element of direction 0 / 1
     int kstride;     // key-list entries per wave (dynamic LDS: waves * kstride * 4 bytes)
 };
@@ -774,7 +788,7 @@ __device__ __forceinline__ void sweep_group(
     const int cd = 1 - dir;
     constexpr bool shared4 = SHARED4;
     const int G = a.groups[dir];
-    const int sub = shared4 ? wib : 0, nsub = shared4 ? 4 : 1;
+    const int sub = shared4 ? wib : 0, nsub = shared4 ? NSH : 1;
     const int bi = gid / G, g = gid - bi * G;
 
     const float *__restrict__ Q = (dir ? xyz1 : xyz0) + (size_t)bi * a.npad[dir] * 3;
@@ -812,6 +826,9 @@ __device__ __forceinline__ void sweep_group(
     // (padding): `bound <= cull` / `cull >= bound` are then false without a separate mask.
     float cull = part ? INFINITY : -INFINITY;
     unsigned n_step = 0, n_scan = 0;
+#if RFP_HIST
+    unsigned long long scan_hist = 0;
+#endif
 
     // One traversal of the candidate superblocks in ascending order of a lower bound, for the lanes
     // with `part` set, whose box is [blo, bhi].
@@ -985,6 +1002,9 @@ __device__ __forceinline__ void sweep_group(
             for (;;) {
                 const int blk = s * SBB + j;
                 n_scan++;
+#if RFP_HIST
+                scan_hist += 1ull << (16 * (nact <= 4 ? 0 : nact <= 16 ? 1 : nact <= 32 ? 2 : 3));
+#endif
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 __builtin_amdgcn_sched_barrier(0);
                 if (!have_rb) {
@@ -1055,6 +1075,9 @@ __device__ __forceinline__ void sweep_group(
         atomicMax(&stats[dir * 4 + 2], (unsigned long long)n_step);
         atomicAdd(&stats[dir * 4 + 3], (unsigned long long)n_scan);
         atomicMax(&stats[8 + dir], (unsigned long long)n_scan);
+#if RFP_HIST
+        for (int k = 0; k < 4; k++) atomicAdd(&stats[10 + k], (scan_hist >> (16 * k)) & 0xFFFFull);
+#endif
     }
 
     if (shared4) {
@@ -1063,7 +1086,7 @@ __device__ __forceinline__ void sweep_group(
         __syncthreads();
         if (wib != 0) return;
 #pragma unroll
-        for (int w = 1; w < 4; w++) {
+        for (int w = 1; w < NSH; w++) {
             const float d = md[w][lane];
             const unsigned i = mi[w][lane];
             if (d < best || (d == best && i < besti)) {
@@ -1087,7 +1110,7 @@ __device__ __forceinline__ void sweep_group(
 // was tried as well: 3x slower -- same-address device-scope atomics serialise at ~25 ns each.
 // (7 waves per SIMD: the loop's 48 record + 24 box SGPRs put the kernel at 106 SGPRs = 6 waves; capping
 // it at 7 spills 16 cold ones to VGPR lanes and measures 2 % faster, capping at 8 spills into the loop)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void nnp_sweep_kernel(
+__global__ __launch_bounds__(64 * NSH) __attribute__((amdgpu_waves_per_eu(7, 7))) void nnp_sweep_kernel(
     SweepArgs a, const float *__restrict__ xyz0, const float *__restrict__ xyz1, const int *__restrict__ orig0,
     const int *__restrict__ orig1, const float *__restrict__ b16_0, const float *__restrict__ b16_1,
     const float *__restrict__ b64_0, const float *__restrict__ b64_1, float *__restrict__ dist0,
@@ -1095,8 +1118,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
     unsigned long long *__restrict__ stats) {
     extern __shared__ unsigned keys_dyn[];  // [waves][kstride]: each wave's list of superblock keys
     __shared__ int shbest[64];
-    __shared__ float md[4][64];
-    __shared__ unsigned mi[4][64];
+    __shared__ float md[NSH][64];
+    __shared__ unsigned mi[NSH][64];
 
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1107,12 +1130,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
     // 145 MB of L2 misses per launch for 12 MB of clouds).
     const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (int)(blockIdx.x >> 3);
+#if RFP_ORDER == 1
+    // all of direction 0's workgroups first (batch-major), then direction 1's: with equal per-batch
+    // counts an XCD's eighth of either part covers the same batch elements
+    const int tot0 = a.b * a.wg0;
+    const int dir = logical >= tot0;
+    const int l2 = dir ? logical - tot0 : logical;
+    const int per = dir ? a.wg1 : a.wg0;
+    const int bi = l2 / per;
+    int wg = l2 - bi * per;
+#else
     const int wpc = a.wg0 + a.wg1;  // workgroups per batch element
     const int bi = logical / wpc;
     int wg = logical - bi * wpc;
     const int dir = wg >= a.wg0;
     if (dir) wg -= a.wg0;
-    if (a.nw[dir] == 4) {
+#endif
+    if (a.nw[dir] == NSH) {
         sweep_group<true>(a, dir, bi * a.groups[dir] + wg, wib, lane, keys_dyn, shbest, md, mi, xyz0, xyz1, orig0, orig1,
                           b16_0, b16_1, b64_0, b64_1, dist0, dist1, idx0, idx1, stats);
     } else {
@@ -1210,7 +1244,7 @@ int sweep_sorted(int b, int n, int m, const Sorted &s0, const Sorted &s1, float 
         wa.npad[k] = ss[k]->npad;
         wa.groups[k] = ss[k]->npad / SB;
         // a set with few groups cannot fill the chip with one wave per group: 4 waves share a group
-        wa.nw[k] = ((long)b * wa.groups[k] < 4096) ? 4 : 1;
+        wa.nw[k] = ((long)b * wa.groups[k] < RFP_SPLIT_BELOW) ? NSH : 1;
     }
     const bool want[2] = {(dirs & 1) != 0, (dirs & 2) != 0};
     {
@@ -1218,15 +1252,15 @@ int sweep_sorted(int b, int n, int m, const Sorted &s0, const Sorted &s1, float 
         for (int k = 0; k < 2; k++) {
             if (!want[k]) continue;
             const int nsb = wa.groups[1 - k];
-            const int len = wa.nw[k] == 4 ? (nsb + 3) / 4 : nsb;
+            const int len = wa.nw[k] == NSH ? (nsb + NSH - 1) / NSH : nsb;
             longest = len > longest ? len : longest;
         }
         wa.kstride = (longest + 63) / 64 * 64;
     }
-    const int tpb = ((want[0] && wa.nw[0] == 4) || (want[1] && wa.nw[1] == 4)) ? 256 : 64;
+    const int tpb = ((want[0] && wa.nw[0] == NSH) || (want[1] && wa.nw[1] == NSH)) ? 64 * NSH : 64;
     const int pack = tpb / 64;  // one-wave groups per workgroup
-    wa.wg0 = !want[0] ? 0 : (wa.nw[0] == 4 ? wa.groups[0] : rf::ceil_div(wa.groups[0], pack));
-    wa.wg1 = !want[1] ? 0 : (wa.nw[1] == 4 ? wa.groups[1] : rf::ceil_div(wa.groups[1], pack));
+    wa.wg0 = !want[0] ? 0 : (wa.nw[0] == NSH ? wa.groups[0] : rf::ceil_div(wa.groups[0], pack));
+    wa.wg1 = !want[1] ? 0 : (wa.nw[1] == NSH ? wa.groups[1] : rf::ceil_div(wa.groups[1], pack));
     RF_LAUNCH("nnp_sweep", nnp_sweep_kernel, dim3((unsigned)b * (wa.wg0 + wa.wg1)), dim3(tpb),
               pack * wa.kstride * sizeof(unsigned), s, wa, s0.xyz, s1.xyz, s0.orig, s1.orig, s0.box16, s1.box16,
               s0.box64, s1.box64, dist1, dist2, idx1, idx2, stats_dev);

@@ -1,0 +1,99 @@
+// pointmlp.hip -- the elementwise tail of RFNet's per-point dense layers, fused (row f2).
+//
+// The reference's conv2d (vv_recon.py:47-65) is conv + bias_add + activation, and most layers are
+// fed tf.concat([per-point features, tf.tile(global code word)]) (e.g. :101,127,144,148,280,288,299,
+// 317,343).  The split form computed by rfnet_amd.rfnet.RFNet.dcat,
+//     act( y[b,n,:] + sum_k p[b,n,k] w[k,:] + r[b,:] ),
+// has three kinds of terms: y = the library GEMM of the wide per-point inputs (or nothing),
+// p = a NARROW per-point input (the xyz coordinates: k = 3; at most 16 channels), whose "GEMM" is a
+// handful of FMAs per output element, and r = bias + (global code word) @ W, one row per sample.
+// As separate tensor ops that is a K=3 GEMM, two broadcast adds and an activation: four passes over
+// a (batch, points, channels) tensor (up to 32 x 16384 x 128 floats).  Here it is ONE pass: read y
+// (if any), write out -- HBM-bound, 16-byte accesses, the k weights rows of a thread's four
+// channels in registers.
+#include "common.hpp"
+
+namespace {
+
+constexpr int PA_TPB = 256;
+constexpr int PA_KMAX = 16;
+constexpr int PA_STRIP = 64;  // points per workgroup
+
+template <int ACT>
+__device__ __forceinline__ float pa_act(float v) {
+    if (ACT == 1) return fmaxf(v, 0.f);
+    if (ACT == 2) return tanhf(v);
+    return v;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(PA_TPB) void point_affine_kernel(int n, int c, int kp, long r_stride,
+                                                              const float *__restrict__ y,
+                                                              const float *__restrict__ p,
+                                                              const float *__restrict__ w,
+                                                              const float *__restrict__ r,
+                                                              float *__restrict__ out) {
+    const int quads = c >> 2;                    // float4 groups per point
+    const int ppi = PA_TPB / quads;              // points per pass of the workgroup
+    const int cq = threadIdx.x % quads, pl = threadIdx.x / quads;
+    const int bi = blockIdx.y;
+    if (pl >= ppi) return;
+    const float4 rr = *(const float4 *)(r + (size_t)bi * r_stride + cq * 4);
+    float4 wk[PA_KMAX];
+#pragma unroll
+    for (int k = 0; k < PA_KMAX; k++)
+        wk[k] = k < kp ? *(const float4 *)(w + (size_t)k * c + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int n0 = blockIdx.x * PA_STRIP;
+    const int n1 = min(n, n0 + PA_STRIP);
+    for (int j = n0 + pl; j < n1; j += ppi) {
+        const size_t e = ((size_t)bi * n + j) * c + cq * 4;
+        float4 acc = y ? *(const float4 *)(y + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p) {
+            const float *pp = p + ((size_t)bi * n + j) * kp;
+#pragma unroll
+            for (int k = 0; k < PA_KMAX; k++) {
+                if (k < kp) {
+                    const float pv = pp[k];
+                    acc.x = fmaf(pv, wk[k].x, acc.x);
+                    acc.y = fmaf(pv, wk[k].y, acc.y);
+                    acc.z = fmaf(pv, wk[k].z, acc.z);
+                    acc.w = fmaf(pv, wk[k].w, acc.w);
+                }
+            }
+        }
+        float4 o;
+        o.x = pa_act<ACT>(acc.x + rr.x);
+        o.y = pa_act<ACT>(acc.y + rr.y);
+        o.z = pa_act<ACT>(acc.z + rr.z);
+        o.w = pa_act<ACT>(acc.w + rr.w);
+        *(float4 *)(out + e) = o;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rf_point_affine_supported(int c, int kp) { return c > 0 && c % 4 == 0 && c / 4 <= PA_TPB && kp >= 0 && kp <= PA_KMAX; }
+
+int rf_point_affine(int b, int n, int c, const float *y, const float *p, int kp, const float *w, const float *r,
+                    int r_per_sample, int act, float *out, rf_stream_t stream) {
+    if (b < 0 || n < 0 || c < 0 || kp < 0 || act < 0 || act > 2) return RF_EINVAL;
+    if ((size_t)b * n * c == 0) return RF_OK;
+    if (!rf_point_affine_supported(c, kp) || b > 65535) return RF_EINVAL;
+    if (!r || !out || (kp > 0 && (!p || !w))) return RF_EINVAL;
+    const dim3 grid(rf::ceil_div(n, PA_STRIP), b);
+    const long rs = r_per_sample ? c : 0;
+    hipStream_t s = (hipStream_t)stream;
+    const float *pp = kp > 0 ? p : nullptr;
+    if (act == 0) {
+        RF_LAUNCH("point_affine", point_affine_kernel<0>, grid, dim3(PA_TPB), 0, s, n, c, kp, rs, y, pp, w, r, out);
+    } else if (act == 1) {
+        RF_LAUNCH("point_affine", point_affine_kernel<1>, grid, dim3(PA_TPB), 0, s, n, c, kp, rs, y, pp, w, r, out);
+    } else {
+        RF_LAUNCH("point_affine", point_affine_kernel<2>, grid, dim3(PA_TPB), 0, s, n, c, kp, rs, y, pp, w, r, out);
+    }
+    return RF_OK;
+}
+
+}  // extern "C"

@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import glue
+from . import _raw, glue
 
 _MLP3 = [("ini_layer0", 3, 64), ("ini_layer1", 64, 128), ("ini_layer2", 128, 256)]
 _RECOVER = [("recover20", 259, 256), ("recover21", 256, 256), ("recover2out1", 256, 256)]
@@ -58,6 +58,77 @@ LAYERS = [
 
 def _key(name):
     return name.replace("/", "__")
+
+
+class _LinearRelu(torch.autograd.Function):
+    """relu(x @ W + b) as ONE library GEMM with a bias + ReLU epilogue (hipBLASLt through
+    torch._addmm_activation): the activation costs no extra pass over the (points, channels) output.
+    torch ships no derivative for that op, hence this Function (mask from the saved output)."""
+
+    @staticmethod
+    def forward(ctx, x2d, w, b):
+        y = torch._addmm_activation(b, x2d, w)
+        ctx.save_for_backward(x2d, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad):
+        x2d, w, y = ctx.saved_tensors
+        g = torch.ops.aten.threshold_backward(grad.contiguous(), y, 0.0)  # one kernel: grad where y > 0
+        return g @ w.t(), x2d.t() @ g, g.sum(0)
+
+
+class _PointAffine(torch.autograd.Function):
+    """act(y + p @ w + r) through rf_point_affine (one pass); backward with tensor ops."""
+
+    @staticmethod
+    def forward(ctx, y, p, w, r, act):
+        out = _raw.point_affine(y, p, w, r, act)
+        ctx.act = act
+        ctx.has = (y is not None, p is not None)
+        ctx.rshape = r.shape
+        ctx.save_for_backward(out, p if p is not None else out.new_empty(0), w if w is not None else out.new_empty(0))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        out, p, w = ctx.saved_tensors
+        if ctx.act == "relu":
+            g = torch.ops.aten.threshold_backward(grad.contiguous(), out, 0.0)
+        elif ctx.act == "tanh":
+            g = grad * (1.0 - out * out)
+        else:
+            g = grad
+        gy = g if ctx.has[0] else None
+        gp = gw = None
+        if ctx.has[1]:
+            gp = g @ w.t()
+            gw = p.reshape(-1, p.shape[-1]).t() @ g.reshape(-1, g.shape[-1])
+        gr = g.sum(1) if len(ctx.rshape) > 1 else g.sum((0, 1))
+        return gy, gp, gw, gr.reshape(ctx.rshape), None
+
+
+def maxpool_points(t):
+    """max over the points axis, keepdim (tf.reduce_max(axis=1), e.g. vv_recon.py:90,107,129).  Without
+    autograd: amax (values only, 3x faster than max's value+index kernel); with autograd: max, whose
+    index-scatter backward is one pass instead of amax's compare / count / divide / multiply (every
+    pooled tensor of the graph comes out of a ReLU, so how ties share the gradient is immaterial:
+    tied entries are zeros, whose ReLU passes no gradient)."""
+    if torch.is_grad_enabled() and t.requires_grad:
+        return t.max(1, keepdim=True).values
+    return t.amax(1, keepdim=True)
+
+
+def linear_relu(x, w, b):
+    """relu(x @ w + b) on the last axis; w is (cin, cout) -- the reference's kernel layout."""
+    if not x.is_cuda:
+        return F.relu(F.linear(x, w.t(), b))
+    x2d = x.reshape(-1, x.shape[-1])
+    if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or b.requires_grad):
+        y = _LinearRelu.apply(x2d, w, b)
+    else:
+        y = torch._addmm_activation(b, x2d, w)
+    return y.reshape(*x.shape[:-1], w.shape[1])
 
 
 class RFNet(nn.Module):
@@ -97,41 +168,89 @@ class RFNet(nn.Module):
         base = f"{scope}/{name}" if scope else name
         sc = scope if call == 0 else f"{scope}_{call}"
         bname = f"{sc}/{name}" if sc else name
-        y = F.linear(x, self.weights[_key(base)].t(), self.biases[_key(bname)])
         if act == "relu":
-            return F.relu(y)
+            return linear_relu(x, self.weights[_key(base)], self.biases[_key(bname)])
+        y = F.linear(x, self.weights[_key(base)].t(), self.biases[_key(bname)])
         if act == "tanh":
             return torch.tanh(y)
         if act == "leaky_relu":
             return F.leaky_relu(y, 0.2)
         return y
 
-    def mlp(self, scope, prefix, n, x, call=0):
-        for i in range(n):
+    def dcat(self, scope, name, parts, act="relu", call=0):
+        """The same dense layer applied to the CONCATENATION of `parts` along the channel axis --
+        without building it.  The reference tiles a global code word over all points and concatenates
+        it to per-point features before most layers (tf.tile + tf.concat, e.g. vv_recon.py:101,127,
+        144,148,280,288,299,317,343): cat([p, tile(g)]) @ W  ==  p @ W[:cp] + (g @ W[cp:]) broadcast.
+        A (B,1,C) part costs one row per sample instead of one per point, the (B,N,sum C) tensor is
+        never written, and the per-point GEMM shrinks to the channels that really vary per point
+        (259 -> 3 for most first layers).  Same weights, same layout: row blocks of the [cin, cout]
+        kernel, in concatenation order."""
+        base = f"{scope}/{name}" if scope else name
+        sc = scope if call == 0 else f"{scope}_{call}"
+        bname = f"{sc}/{name}" if sc else name
+        w = self.weights[_key(base)]
+        bias = self.biases[_key(bname)]
+        npts = max(p.shape[1] for p in parts)
+        fused = parts[0].is_cuda and w.shape[1] % 4 == 0 and w.shape[1] <= 1024 and act in ("relu", "tanh", None)
+        y = r = narrow = wn = None
+        row = 0
+        for p in parts:
+            c = p.shape[-1]
+            wp = w[row:row + c]
+            row += c
+            if p.shape[1] == 1 and npts > 1:          # a tiled (global) part: one row per sample
+                t = p @ wp
+                r = t if r is None else r + t
+            elif fused and c <= 16 and narrow is None:  # the coordinates: applied inside the fused tail
+                narrow, wn = p, wp
+            elif y is None:                             # wide per-point parts: library GEMMs, accumulated
+                y = p @ wp
+            else:
+                y = torch.baddbmm(y, p, wp.unsqueeze(0).expand(p.shape[0], -1, -1)) if p.dim() == 3 else y + p @ wp
+        assert row == w.shape[0], (base, row, tuple(w.shape))
+        r = bias if r is None else r + bias
+        if fused and (y is not None or narrow is not None) and npts > 1:
+            return _PointAffine.apply(y, narrow, wn, r, act)
+        # small or CPU case: plain tensor ops
+        acc = r
+        for t in (y, None if narrow is None else narrow @ wn):
+            if t is not None:
+                acc = acc + t
+        if act == "relu":
+            return F.relu(acc)
+        if act == "tanh":
+            return torch.tanh(acc)
+        return acc
+
+    def mlp(self, scope, prefix, n, x, call=0, first=0):
+        for i in range(first, n):
             x = self.d(scope, f"{prefix}{i}", x, call=call)
         return x
 
     # -- cells ---------------------------------------------------------------------------------
     def global_mlp(self, scope, xyz):  # vv_recon.py:84-91
-        return self.mlp(scope, "ini_layer", 3, xyz).max(1, keepdim=True).values
+        return maxpool_points(self.mlp(scope, "ini_layer", 3, xyz))
 
     def encode_cell(self, x, state, call):  # :93-112
-        s = torch.cat([x, state.expand(-1, x.shape[1], -1)], -1)
-        s = self.mlp("cell", "state", 2, s, call)
-        new_state = self.d("cell", "state_end", s, call=call).max(1, keepdim=True).values
+        s = self.dcat("cell", "state0", [x, state], call=call)
+        s = self.mlp("cell", "state", 2, s, call, first=1)
+        new_state = maxpool_points(self.d("cell", "state_end", s, call=call))
         return self.mlp("cell", "codemlp", 2, new_state, call), new_state
 
     def recover_cell(self, scope, code, con):  # :124-131
-        t = torch.cat([code.expand(-1, con.shape[1], -1), con], -1)
-        t = self.mlp(scope, "recover2", 2, t).max(1, keepdim=True).values
+        t = self.dcat(scope, "recover20", [code, con])
+        t = maxpool_points(self.mlp(scope, "recover2", 2, t, first=1))
         return self.d(scope, "recover2out1", t, act=None)
 
     def init_move_layer(self, startpts, codeword):  # :140-159
-        t1 = torch.cat([startpts, codeword.expand(-1, startpts.shape[1], -1)], -1)
-        t = self.mlp("", "ini_layer", 3, t1)
-        t = torch.cat([t1, t.max(1, keepdim=True).values.expand(-1, t1.shape[1], -1)], -1)
-        feats = self.d("", "inimove_featout", self.mlp("", "ini_featout", 2, t))
-        pts = self.d("", "inimove_ptsout", self.mlp("", "ini_ptsout", 3, t), act="tanh")
+        t = self.dcat("", "ini_layer0", [startpts, codeword])
+        t = self.mlp("", "ini_layer", 3, t, first=1)
+        mx = maxpool_points(t)
+        feats = self.dcat("", "ini_featout0", [startpts, codeword, mx])
+        feats = self.d("", "inimove_featout", self.mlp("", "ini_featout", 2, feats, first=1))
+        pts = self.dcat("", "ini_ptsout0", [startpts, codeword, mx])
+        pts = self.d("", "inimove_ptsout", self.mlp("", "ini_ptsout", 3, pts, first=1), act="tanh")
         return startpts + pts, feats
 
     def init_decode_layer(self, x, ptnum=32):  # :246-272 with state_tensor=None
@@ -142,38 +261,38 @@ class RFNet(nn.Module):
         movemat = po[..., -3:].reshape(-1, 1, 3)
         pts = torch.tanh(po[..., :-12]).reshape(-1, ptnum, 3) @ transmat + movemat
         so = self.d("init_cell", "state_out", ns).reshape(-1, ptnum, 16)
-        so = torch.cat([so, ns.expand(-1, ptnum, -1)], -1)
-        so = self.mlp("init_cell", "state", 2, so)
+        so = self.dcat("init_cell", "state0", [so, ns])
+        so = self.mlp("init_cell", "state", 2, so, first=1)
         return pts, self.d("init_cell", "state_outo", so)
 
     def refine_layer(self, scope, ptcoor, feat, feat2, collect=None):  # :273-308
         n = ptcoor.shape[1]
-        t = torch.cat([ptcoor, feat.expand(-1, n, -1)], -1)
-        t = self.mlp(scope, "ini_layer", 2, t)
-        t = torch.cat([ptcoor, t.max(1, keepdim=True).values.expand(-1, n, -1)], -1)
-        t = self.mlp(scope, "refine_layers", 3, t)
+        t = self.dcat(scope, "ini_layer0", [ptcoor, feat])
+        t = self.mlp(scope, "ini_layer", 2, t, first=1)
+        t = self.dcat(scope, "refine_layers0", [ptcoor, maxpool_points(t)])
+        t = self.mlp(scope, "refine_layers", 3, t, first=1)
         newvec = self.d(scope, "refine_layer_final", t, act="tanh")
         if collect is not None:
             collect[f"{scope}{n}"] = newvec  # tf.add_to_collection(scope+str(ptnum), newvec), :298
         newcoor = ptcoor + newvec
-        t = torch.cat([newcoor, feat2, feat.expand(-1, feat2.shape[1], -1)], -1)
-        t = self.mlp(scope, "feat_refine", 2, t)
+        t = self.dcat(scope, "feat_refine0", [newcoor, feat2, feat])
+        t = self.mlp(scope, "feat_refine", 2, t, first=1)
         return newcoor, self.d(scope, "feat_refine_final", t, act="tanh") + feat2
 
     def decode_cell(self, code, center, state, call, up_ratio=16, collect=None):  # :310-364
         n = state.shape[1]
         sc = "decode_cell"
-        mask = torch.cat([center, code.expand(-1, n, -1)], -1)
-        mask = self.d(sc, "mask_tensor", self.mlp(sc, "mlp_mask", 2, mask, call), call=call)
+        mask = self.dcat(sc, "mlp_mask0", [center, code], call=call)
+        mask = self.d(sc, "mask_tensor", self.mlp(sc, "mlp_mask", 2, mask, call, first=1), call=call)
         info = self.d(sc, "input_trans", mask * code, call=call)
-        ns = torch.cat([info, self.d(sc, "state_trans", state, call=call)], -1)
-        ns = self.mlp(sc, "basic_state", 2, ns, call)
+        ns = self.dcat(sc, "basic_state0", [info, self.d(sc, "state_trans", state, call=call)], call=call)
+        ns = self.mlp(sc, "basic_state", 2, ns, call, first=1)
         move = self.d(sc, "points_out", self.mlp(sc, "points", 2, ns, call), act="tanh", call=call)
         if collect is not None:
             collect[f"decode_cell{n}"] = move.reshape(-1, n, up_ratio, 3)  # collection scope+str(ptnum), :338
         pts = (center.unsqueeze(2) + move.reshape(-1, n, up_ratio, 3)).reshape(-1, n * up_ratio, 3)
-        ns = torch.cat([ns, code.expand(-1, n, -1)], -1)
-        ns = self.mlp(sc, "state", 2, ns, call)
+        ns = self.dcat(sc, "state0", [ns, code], call=call)
+        ns = self.mlp(sc, "state", 2, ns, call, first=1)
         parts, cur = [], ns
         for i in range(up_ratio):  # a CHAIN: expansion i feeds expansion i+1
             cur = self.d(sc, f"state_expand{i}_0", cur, call=call)
@@ -206,16 +325,18 @@ class RFNet(nn.Module):
                                        sorted_raw=raw_sorted, return_idx=True)
         points1, dstate = self.refine_layer("refine_layer1", points1, code1, dstate, c)
 
-        code2, state = self.encode_cell(torch.cat([pointcloud, points1], 1), state, 1)
-        code2 = code1 + self.recover_cell("recover2", code2, torch.cat([pointcloud, points1], 1))
+        pin = torch.cat([pointcloud, points1], 1)
+        code2, state = self.encode_cell(pin, state, 1)
+        code2 = code1 + self.recover_cell("recover2", code2, pin)
         points2, dstate = self.decode_cell(code2, points1, dstate, 0, collect=c)
         pre2 = points2
         points2, m2 = glue.merge_layer(pointcloud, points2.contiguous(), self.decline_factor1, knum=1,
                                        sorted_raw=raw_sorted, return_idx=True)
         points2, dstate = self.refine_layer("refine_layer2", points2, code2, dstate, c)
 
-        code3, state = self.encode_cell(torch.cat([pointcloud, points2], 1), state, 2)
-        code3 = code2 + self.recover_cell("recover3", code3, torch.cat([pointcloud, points2], 1))
+        pin = torch.cat([pointcloud, points2], 1)
+        code3, state = self.encode_cell(pin, state, 2)
+        code3 = code2 + self.recover_cell("recover3", code3, pin)
         points3, dstate = self.decode_cell(code3, points2, dstate, 1, collect=c)
         final, m3 = glue.merge_layer(pointcloud, points3.contiguous(), self.decline_factor, knum=1,
                                      sorted_raw=raw_sorted, return_idx=True)

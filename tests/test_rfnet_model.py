@@ -186,3 +186,60 @@ def test_c5_size_forward_backward_properties():
     assert all(torch.equal(a, b) for a, b in zip(outs, again))
     for a, b in zip(outs, one):  # same sample alone: only the GEMM batch size differs
         assert torch.allclose(a[:1], b, rtol=1e-4, atol=1e-5)
+
+
+def test_split_concat_layer_equals_the_concatenated_layer():
+    """CPU: RFNet.dcat (row blocks of the kernel applied to the un-concatenated parts, broadcast parts
+    as one row per sample) == the reference's tile + concat + conv2d, for the layer shapes it is
+    used on."""
+    from rfnet_amd.rfnet import RFNet
+    net = _seeded_net()
+    g = torch.Generator().manual_seed(3)
+    B, N = 2, 37
+    cases = [("cell", "state0", [(N, 3), (1, 256)], 1), ("recover2", "recover20", [(1, 256), (N, 3)], 0),
+             ("", "ini_featout0", [(N, 3), (1, 256), (1, 256)], 0), ("init_cell", "state0", [(32, 16), (1, 256)], 0),
+             ("refine_layer2", "feat_refine0", [(N, 3), (N, 128), (1, 256)], 0),
+             ("decode_cell", "basic_state0", [(N, 256), (N, 128)], 1), ("decode_cell", "state0", [(N, 256), (1, 256)], 0)]
+    for scope, name, shapes, call in cases:
+        parts = [torch.randn(B, n, c, generator=g) for n, c in shapes]
+        npts = max(n for n, _ in shapes)
+        full = torch.cat([p.expand(-1, npts, -1) for p in parts], -1)
+        ref = net.d(scope, name, full, call=call)
+        got = net.dcat(scope, name, parts, call=call)
+        assert torch.allclose(got, ref, rtol=1e-5, atol=1e-5), (scope, name)
+
+
+@pytest.mark.gpu
+def test_fused_layer_tails_match_tensor_ops():
+    """rf_point_affine (one-pass act(y + p @ w + r)) and the GEMM+ReLU-epilogue layer against the same
+    layers written with plain tensor ops: values and every gradient."""
+    from rfnet_amd import _raw
+    from rfnet_amd.rfnet import _PointAffine, linear_relu
+    g = torch.Generator(device="cuda").manual_seed(0)
+    B, N, C = 3, 1000, 128
+    for act in ("relu", "tanh", None):
+        for has_y, kp, per_sample in ((True, 3, True), (False, 3, True), (True, 0, False), (True, 16, True), (False, 16, False)):
+            y = torch.randn(B, N, C, device="cuda", generator=g, requires_grad=True) if has_y else None
+            p = torch.randn(B, N, kp, device="cuda", generator=g, requires_grad=True) if kp else None
+            w = torch.randn(kp, C, device="cuda", generator=g, requires_grad=True) if kp else None
+            r = torch.randn((B, 1, C) if per_sample else (C,), device="cuda", generator=g, requires_grad=True)
+            out = _PointAffine.apply(y, p, w, r, act)
+            ref = r + (y if has_y else 0) + (p @ w if kp else 0)
+            ref = torch.relu(ref) if act == "relu" else torch.tanh(ref) if act == "tanh" else ref
+            assert torch.allclose(out, ref, rtol=1e-5, atol=1e-5)
+            wgt = torch.randn(B, N, C, device="cuda", generator=g)
+            leaves = [t for t in (y, p, w, r) if t is not None]
+            got = torch.autograd.grad((out * wgt).sum(), leaves)
+            exp = torch.autograd.grad((ref * wgt).sum(), leaves)
+            for a, e in zip(got, exp):
+                assert torch.allclose(a, e, rtol=1e-4, atol=1e-4 * float(e.abs().max())), (act, has_y, kp)
+    x = torch.randn(B, N, 259, device="cuda", generator=g, requires_grad=True)
+    w = torch.randn(259, 256, device="cuda", generator=g, requires_grad=True)
+    b = torch.randn(256, device="cuda", generator=g, requires_grad=True)
+    out, ref = linear_relu(x, w, b), torch.relu(x @ w + b)
+    assert torch.allclose(out, ref, rtol=1e-4, atol=1e-3)
+    got = torch.autograd.grad(out.sum(), (x, w, b))
+    exp = torch.autograd.grad(ref.sum(), (x, w, b))
+    for a, e in zip(got, exp):
+        assert torch.allclose(a, e, rtol=1e-3, atol=1e-3 * float(e.abs().max()))
+    assert _raw.lib.rf_point_affine_supported(130, 3) == 0 and _raw.lib.rf_point_affine_supported(128, 17) == 0
