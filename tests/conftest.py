@@ -68,3 +68,23 @@ def assert_rel(a, b, rel, abs_=0.0, what=""):
     tol = abs_ + rel * np.abs(b)
     bad = err > tol
     assert not bad.any(), f"{what}: {bad.sum()} / {bad.size} outside rel={rel} abs={abs_}; max err {err.max():.3e}"
+
+
+def strict_bar_report(what, got, exp, rel=1e-4, abs_=1e-6):
+    """SURVEY.md 8(d)'s bar for `match` entries is abs 1e-6 + rel 1e-4 on EVERY entry.  Where a test
+    accepts less (large clouds: the ten-level annealing amplifies 1-ulp exp differences)
+    the strict bar is still evaluated and REPORTED -- printed, attached to the junit record, and raised
+    as a warning when not every entry passes, so it shows in the pytest summary -- so that a
+    regression of the pass fraction is visible even though the test's own threshold is looser."""
+    import warnings
+    got = np.asarray(got, np.float64)
+    exp = np.asarray(exp, np.float64)
+    err = np.abs(got - exp)
+    inside = err <= abs_ + rel * np.abs(exp)
+    frac, worst = float(inside.mean()), float(err.max())
+    msg = (f"strict bar (abs {abs_:g} + rel {rel:g}) {what}: {frac * 100:.5f} % of {got.size} entries inside, "
+           f"{int((~inside).sum())} outside, max abs err {worst:.3e}")
+    print(msg)
+    if frac < 1.0:
+        warnings.warn(msg)
+    return frac, worst

@@ -119,6 +119,30 @@ def test_culled_equals_dense(orc, kind, b, n, m):
         assert pairs[0] < 0.6 * b * n * m and pairs[1] < 0.6 * b * n * m, (stats, b * n * m)
 
 
+@pytest.mark.parametrize("b,n,m,kind", [
+    (2, 2048, 16384, "randn"),     # C2's launch shape: 4 waves per group on the 2048 side, packed one-wave groups on the other
+    (1, 16384, 16384, "randn"),    # north-star shape: register-resident sort of both, one wave per group, key lists in registers
+    (1, 16384, 16384, "dup"),      # the same with every point repeated ~5x: the tie machinery at full size
+    (1, 3000, 16384, "uniform"),   # the model's merge_layer shape (ragged 3000: padded superblocks)
+    (1, 20000, 17000, "randn"),    # beyond the register-resident sort (> 16384 points): the streaming sort, LDS key lists
+])
+def test_full_cloud_oracle_at_large_sizes(orc, b, n, m, kind):
+    """No proxy: EVERY output of the culled sweep against the C oracle over the whole clouds, one case per
+    launch shape at >= 16384 points (the oracle needs a few seconds per case: up to 3.4e8 pairs per direction)."""
+    rng = np.random.RandomState(n + m)
+
+    def cloud(k):
+        if kind == "randn":
+            return rng.randn(b, k, 3).astype(np.float32)
+        if kind == "uniform":
+            return (rng.random_sample((b, k, 3)) - 0.5).astype(np.float32)
+        base = rng.randn(b, max(k // 5, 1), 3).astype(np.float32)
+        return np.take_along_axis(base, rng.randint(0, base.shape[1], size=(b, k, 1)), 1)
+
+    a, c = cloud(n), cloud(m)
+    _same(_run(a, c, "culled"), orc.nn_distance(a, c), f"{kind} {b}x{n}x{m} culled vs oracle (all points)")
+
+
 def test_c2_and_auto_mode(orc):
     """BASELINE.json configs[1] through the public op (auto mode picks the culled sweep at this size)."""
     from tf_ops.CD.tf_nndistance import nn_distance

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import assert_rel
+from conftest import assert_rel, strict_bar_report
 
 pytestmark = pytest.mark.gpu
 
@@ -71,6 +71,7 @@ def test_c4_config_full_size(orc):
     # (entries are masses in [0,1]), >= 99.99 % within the small-case bar abs 1e-6 + rel 1e-4,
     # and the cost (what the loss uses) within 1e-5 relative.
     gm = match[3:4].cpu().numpy()
+    strict_bar_report("C4 match, sample 3 (32x2048x2048)", gm, om)  # the un-relaxed bar, always reported
     assert np.abs(gm - om).max() < 2e-4
     tight = np.abs(gm - om) <= 1e-6 + 1e-4 * np.abs(om)
     assert tight.mean() > 0.9999

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import assert_rel
+from conftest import assert_rel, strict_bar_report
 
 pytestmark = pytest.mark.gpu
 
@@ -121,6 +121,7 @@ def _match_close(got, exp, what):
     entries -- while every row/column sum agrees to 1e-6.  So: >= 99.9 % of the entries inside
     abs 1e-6 + rel 1e-4, every entry inside 2e-3 of a unit mass, and all marginals inside 1e-5."""
     got, exp = np.asarray(got, np.float64), np.asarray(exp, np.float64)
+    strict_bar_report(what, got, exp)  # the un-relaxed bar, always reported
     err = np.abs(got - exp)
     frac = np.mean(err <= 1e-6 + 1e-4 * np.abs(exp))
     assert frac >= 0.999, f"{what}: only {frac:.5f} of the entries inside abs 1e-6 + rel 1e-4"
