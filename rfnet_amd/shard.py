@@ -28,7 +28,10 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if backend == "nccl":  # bind the communicator to this rank's GPU up front (no device guessing)
+            kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 
