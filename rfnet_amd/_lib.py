@@ -6,6 +6,15 @@ import-time loader raises, and if no HIP device is present every op raises at ca
 import ctypes as C
 import os
 
+# PyTorch FIRST, deliberately: the torch wheel bundles its own HIP runtime (torch/lib/libamdhip64.so),
+# and librfops.so merely NEEDS "libamdhip64.so.7".  Loaded after torch, the library binds to the
+# runtime instance torch already brought (one runtime in the process: torch's streams and device
+# pointers are the library's).  Loaded BEFORE torch it would pull in /opt/rocm's copy, torch would then
+# add its own, and the process would hold two HIP runtimes that cannot share a device context (observed
+# on the MI355X box: rf_device_check() = RF_ENODEVICE, or torch reporting no GPU, depending on who
+# initialised first).  A host without torch gets the system runtime, alone, which is equally fine.
+import torch  # noqa: F401  (import order is the point)
+
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # RFOPS_LIB: load another build of the same library (A/B of kernel variants, tools/ab_chamfer.py)
 LIB_PATH = os.environ.get("RFOPS_LIB") or os.path.join(_PKG, "librfops.so")

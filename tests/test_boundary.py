@@ -5,6 +5,7 @@ import ast
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -182,3 +183,17 @@ def test_knn_point_is_pure_tensor_ops():
     d = ((xyz1[:, None] - xyz2[:, :, None]) ** 2).sum(-1)
     assert np.array_equal(idx.numpy(), np.argsort(d, -1, kind="stable")[..., :4])
     assert np.allclose(val.numpy(), -np.sort(d, -1)[..., :4], atol=1e-6)
+
+
+def test_one_hip_runtime_in_the_process():
+    """rfnet_amd._lib must bind to the HIP runtime torch brings (import torch before dlopen): with
+    librfops.so loaded first the process ends up with two runtimes -- /opt/rocm's and the wheel's --
+    and on the GPU box whichever initialises second sees no device."""
+    import subprocess
+    code = ("import rfnet_amd._lib, sys\n"
+            "assert 'torch' in sys.modules\n"
+            "libs = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l})\n"
+            "print(libs)\n"
+            "assert len(libs) == 1, libs\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr[-1500:]
