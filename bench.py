@@ -188,7 +188,7 @@ def make_distributions(B, N, M, rank, dev, want_model=True):
 def run_c5(args, rank, world, dev, steps, warmup, use_pg):
     """BASELINE.json configs[4], this rank's share: B=32 samples of (3000 partial, 16384 gt)."""
     from rfnet_amd import glue, shard
-    from rfnet_amd.rfnet import RFNet
+    from rfnet_amd.rfnet import GroundTruth, RFNet
     B = args.batch
     rng = np.random.RandomState(500 + rank)
     partial = torch.from_numpy((rng.rand(B, 3000, 3) - 0.5).astype(np.float32)).to(dev)
@@ -198,12 +198,15 @@ def run_c5(args, rank, world, dev, steps, warmup, use_pg):
 
     def step():
         with torch.no_grad():
+            # gt preparation (one FPS run for both subsets + the sorted handle); in line: putting it on a
+            # side stream under the forward measured 8.45 .. 10.0 ms against 8.9 in line
+            # (tools/experiments/c5_overlap_ab.py: the serial FPS chain suffers when it shares CUs)
+            g = GroundTruth(gt, 64, 1024, overlap=False)
             p1, p2, p3, pf = net(partial)
-            hgt = glue.SortedCloud(gt)
-            gt64, gt1024 = glue.sampling(64, gt)[1], glue.sampling(1024, gt)[1]
-            cd = glue.chamfer_per_sample(gt, pf, sorted1=hgt)[0].mean(1)            # chamfer_big, per sample
-            e1 = glue.earth_mover_cost(gt64, p1) / 64.0                              # earth_mover terms
-            e2 = glue.earth_mover_cost(gt1024, p2) / 1024.0
+            g.join()
+            cd = glue.chamfer_per_sample(gt, pf, sorted1=g.h_gt)[0].mean(1)         # chamfer_big, per sample
+            e1 = glue.earth_mover_cost(g.gt1, p1) / 64.0                             # earth_mover terms
+            e2 = glue.earth_mover_cost(g.gt2, p2) / 1024.0
             per = torch.stack([cd, e1, e2], 1)                                       # (B, 3)
             return shard.all_gather_per_sample(per, B * world, rank, world)          # loss reduction (RCCL)
 

@@ -358,17 +358,70 @@ class RFNet(nn.Module):
         return out
 
 
-def training_loss(net, outputs, collect, gt, alpha1=0.01, terms=None):
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """One side stream per device, reused (scratch buffers are cached per (device, stream))."""
+    key = torch.device(device).index
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
+class GroundTruth:
+    """Everything the loss block derives from `gt` alone (vv_recon.py:474-475 and the Chamfers' gt side):
+    the FPS subsets gt1 (64) / gt2 (1024) and the curve-ordered handles of gt and gt2.  None of it
+    depends on the network.  FPS is a serial chain on one CU per cloud (1.1 ms at 16384 -> 1024 points
+    while 7/8 of the chip idles), so with `overlap` it can be enqueued on a SIDE STREAM underneath the
+    network's forward (`join()` makes the current stream wait for it) -- measured on the MI355X that
+    is a coin toss (C5 step 8.45 .. 10.0 ms against 8.9 in line: the latency-bound chain slows down
+    when GEMM waves share its CUs), so the default is in line.  The 64-point
+    subset is the first 64 picks of the 1024-point run (greedy FPS from the same start is a prefix
+    chain: one run instead of the reference's two, same indices)."""
+
+    def __init__(self, gt, n1=64, n2=1024, overlap=False):
+        self.gt = gt
+        self._side = None
+        if overlap and gt.is_cuda:
+            cur = torch.cuda.current_stream(gt.device)
+            self._side = _side_stream(gt.device)
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                self._compute(n1, n2)
+            # allocated on the side stream, consumed on the current one
+            held = [self.gt1, self.gt2, self.idx1, self.idx2]
+            held += [h.buf for h in (self.h_gt, self.h_gt2) if h is not None]
+            for t in held:
+                t.record_stream(cur)
+        else:
+            self._compute(n1, n2)
+
+    def _compute(self, n1, n2):
+        big = max(n1, n2)
+        idx, pts = glue.sampling(big, self.gt, use_type="f")
+        self.idx1, self.idx2 = idx[:, :n1].contiguous(), idx[:, :n2].contiguous()
+        self.gt1, self.gt2 = pts[:, :n1].contiguous(), pts[:, :n2].contiguous()
+        self.h_gt = glue.sort_if_large(self.gt)
+        self.h_gt2 = glue.sort_if_large(self.gt2)
+
+    def join(self):
+        if self._side is not None:
+            torch.cuda.current_stream(self.gt.device).wait_stream(self._side)
+            self._side = None
+        return self
+
+
+def training_loss(net, outputs, collect, gt, alpha1=0.01, terms=None, prepared=None):
     """The loss block of the reference's train() (vv_recon.py:474-500) on the fused ops:
     loss = 0.2 (cd1 + cd2) + cd3 + cd4 + 0.2 recd3 + 0.1 moveloss + loss_d1 + loss_d2 + alpha1 loss_dec,
     cd1/cd2 = earth_mover(FPS(gt), pre-merge points1/points2), cd3/cd4 = chamfer_big(gt, out3/out4),
     recd3 = re_chamfer(gt, out3), loss_d* = 0.05 zero_groupnear(...), loss_dec = sum decfactor^2
-    (alpha1 = 0.01 up to step 50000, :482-483).  `gt` is Chamfered five times: sorted once."""
+    (alpha1 = 0.01 up to step 50000, :482-483).  `gt` is Chamfered five times: sorted once.
+    `prepared`: a GroundTruth started before the forward (its FPS then overlapped the network)."""
     out1, out2, out3, out4 = outputs
-    hgt = glue.sort_if_large(gt)
-    i64, gt1 = glue.sampling(out1.shape[1], gt, use_type="f")   # :474
-    i1024, gt2 = glue.sampling(out2.shape[1], gt, use_type="f")  # :475
-    hgt2 = glue.sort_if_large(gt2)
+    g = (prepared if prepared is not None else GroundTruth(gt, out1.shape[1], out2.shape[1], overlap=False)).join()
+    hgt, hgt2, gt1, gt2 = g.h_gt, g.h_gt2, g.gt1, g.gt2
     t = {}
     t["cd1"] = glue.earth_mover(gt1, collect["points1"])
     t["cd2"] = glue.earth_mover(gt2, collect["points2"])
@@ -383,5 +436,5 @@ def training_loss(net, outputs, collect, gt, alpha1=0.01, terms=None):
                  + t["loss_d1"] + t["loss_d2"] + alpha1 * t["loss_dec"])
     if terms is not None:
         terms.update(t)
-        terms.update({"gt_fps64": i64, "gt_fps1024": i1024})
+        terms.update({"gt_fps64": g.idx1, "gt_fps1024": g.idx2})
     return t["loss"]

@@ -72,6 +72,21 @@ def test_workspace_queries_are_pure_host_functions():
     assert lib.rf_approxmatch_workspace_bytes(1, 10, 20, 50) >= 30 * 51 * 4
     assert lib.rf_farthestpointsampling_temp_floats(32, 16384) == 0
     assert lib.rf_farthestpointsampling_temp_floats(2, 20000) == 40000
+    # round-2 entry points: sizes are pure functions of the shape (no device, no state)
+    sb = lib.rf_nn_sort_bytes(32, 16384)
+    assert sb >= 32 * 16384 * 16 and lib.rf_nn_sort_bytes(32, 16384) == sb       # records + indices (+ boxes)
+    assert lib.rf_nn_sort_bytes(1, 65536) > 0 and lib.rf_nn_sort_bytes(1, 65537) == 0 and lib.rf_nn_sort_bytes(0, 10) == 0
+    both = lib.rf_nn_distance_dir_workspace_bytes(32, 2048, 16384, 1, 1)
+    assert both > 0 and lib.rf_nn_distance_dir_workspace_bytes(32, 2048, 16384, 0, 0) == 0
+    assert lib.rf_chamfer_step_workspace_bytes(32, 2048, 16384) == lib.rf_nn_distance_workspace_bytes(32, 2048, 16384)
+    # with both clouds pre-sorted the fused loss needs no scratch; with one, only the other's sort
+    assert lib.rf_chamfer_loss_workspace_bytes(32, 16384, 16384, 1, 1, 1, 1) == 0
+    one = lib.rf_chamfer_loss_workspace_bytes(32, 16384, 16384, 1, 1, 1, 0)
+    assert 0 < one < lib.rf_chamfer_loss_workspace_bytes(32, 16384, 16384, 1, 1, 0, 0)
+    assert lib.rf_merge_layer_workspace_bytes(32, 3000, 16384, 1) >= 32 * 16384 * 4
+    assert lib.rf_auctionmatch_workspace_bytes(32, 4096) == 0  # no (n, n) cost matrix any more
+    assert lib.rf_point_affine_supported(128, 3) == 1 and lib.rf_point_affine_supported(126, 3) == 0
+    assert lib.rf_device_check() in (0, -3)  # RF_OK on the MI355X box, RF_ENODEVICE here
 
 
 def test_reference_module_paths_and_names():

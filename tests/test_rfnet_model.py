@@ -180,6 +180,16 @@ def test_c5_size_forward_backward_properties():
                 (n.startswith("biases.decode_cell_1__state") and "state_trans" not in n))
     assert all(dead(n) for n in missing), [n for n in missing if not dead(n)]
     assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+    # gt preparation on a side stream (overlapping the forward) == the reference's two separate FPS runs
+    from rfnet_amd import glue
+    from rfnet_amd.rfnet import GroundTruth
+    g = GroundTruth(gt, 64, 1024, overlap=True).join()
+    i64, p64 = glue.sampling(64, gt)
+    i1024, p1024 = glue.sampling(1024, gt)
+    assert torch.equal(g.idx1, i64) and torch.equal(g.idx2, i1024) and torch.equal(g.gt1, p64) and torch.equal(g.gt2, p1024)
+    with torch.no_grad():
+        l_overlap = training_loss(net, outs, col, gt, prepared=GroundTruth(gt, 64, 1024, overlap=True))
+    assert abs(float(l_overlap) - float(loss.detach())) <= 1e-6 * abs(float(loss.detach()))
     with torch.no_grad():
         again = net(partial)
         one = net(partial[:1].contiguous())
