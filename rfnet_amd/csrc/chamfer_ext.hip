@@ -30,7 +30,7 @@ size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
 // loss[bi][dir] = mean_j sqrt(dist_dir[bi][j]): one workgroup per (sample, direction), fixed
 // summation order (strided per-thread partials, DPP inside the wave, waves in order): deterministic.
-constexpr int LR_TPB = 256;
+constexpr int LR_TPB = 1024;
 __global__ __launch_bounds__(LR_TPB) void chamfer_loss_reduce_kernel(int n, int m, const float *__restrict__ dist1,
                                                                      const float *__restrict__ dist2,
                                                                      float *__restrict__ loss) {
@@ -43,8 +43,16 @@ __global__ __launch_bounds__(LR_TPB) void chamfer_loss_reduce_kernel(int n, int 
         return;
     }
     d += (size_t)bi * cnt;
-    float acc = 0.f;
-    for (int j = threadIdx.x; j < cnt; j += LR_TPB) acc += sqrtf(d[j]);
+    // four independent partial sums per thread: the loads of a trip are all in flight together (one
+    // running sum per thread made every trip wait a full memory latency: 22 us at 16384 points)
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int j = threadIdx.x;
+    for (; j + 3 * LR_TPB < cnt; j += 4 * LR_TPB) {
+        const float v0 = d[j], v1 = d[j + LR_TPB], v2 = d[j + 2 * LR_TPB], v3 = d[j + 3 * LR_TPB];
+        a0 += sqrtf(v0); a1 += sqrtf(v1); a2 += sqrtf(v2); a3 += sqrtf(v3);
+    }
+    for (; j < cnt; j += LR_TPB) a0 += sqrtf(d[j]);
+    float acc = (a0 + a1) + (a2 + a3);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;

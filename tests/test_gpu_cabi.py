@@ -116,3 +116,26 @@ def test_two_streams_do_not_share_scratch(orc):
     for o1, o2 in outs:
         assert all(np.array_equal(x.cpu().numpy(), y) for x, y in zip(o1, e1))
         assert all(np.array_equal(x.cpu().numpy(), y) for x, y in zip(o2, e2))
+
+
+def test_bench_rccl_path_on_one_gpu():
+    """bench.py with a real RCCL process group of one rank (RF_FORCE_PG=1): communicator bound to the
+    device, barrier fences, max-over-ranks all-reduce -- the code path every rank of an N-GPU run takes --
+    and exactly ONE line on stdout although RCCL prints a version banner there."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(RF_FORCE_PG="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "2",
+                          "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
+                         env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[:500]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["value"] > 1e12
+    assert d["roofline"]["bound"] == "valu" and 0 < d["roofline"]["frac"] <= 1.0
+    assert d["roofline"]["identical_to_dense_sweep"] is True
