@@ -45,7 +45,16 @@ while time.time() - t0 < budget:
     c = torch.from_numpy(np.ascontiguousarray(cloud(m), np.float32)).cuda()
     got = _raw.nn_distance(a, c, mode="culled")
     ref = _raw.nn_distance(a, c, mode="dense")
-    if not all(torch.equal(g, r) for g, r in zip(got, ref)):
+    ok = all(torch.equal(g, r) for g, r in zip(got, ref))
+    # round-2 entry points: one direction (whichever sweep the size rule picks) and sorted handles
+    d1 = _raw.nn_distance_dir(a, c, True, False)
+    d2 = _raw.nn_distance_dir(a, c, False, True)
+    ok = ok and torch.equal(d1[0], ref[0]) and torch.equal(d1[1], ref[1]) and torch.equal(d2[2], ref[2]) and torch.equal(d2[3], ref[3])
+    if case % 3 == 0:
+        h1, h2 = _raw.nn_sort(a), _raw.nn_sort(c)
+        hs = _raw.nn_distance_sorted(h1, h2, case % 2 == 0, True)
+        ok = ok and torch.equal(hs[2], ref[2]) and torch.equal(hs[3], ref[3]) and (hs[0] is None or torch.equal(hs[0], ref[0]))
+    if not ok:
         bad += 1
         print("MISMATCH case", case, "b,n,m,kind", b, n, m, kind, flush=True)
     case += 1
