@@ -277,6 +277,14 @@ int rf_merge_layer_grad(int b, int n, int m, const float *rawpts, const float *n
  * per-point input (the coordinates: kp = 3; kp <= 16) applied on the fly, or kp = 0; r: bias + code
  * word term, (b,c) with r_per_sample != 0, (c) otherwise; act: 0 none, 1 relu, 2 tanh.
  * c % 4 == 0, c <= 1024 (rf_point_affine_supported).  out may alias y. */
+/* tf.reduce_max(axis=1) of a (b, n, c) feature tensor -> (b, c) (global_mlp / encode_cell /
+ * recover_cell / init_move_layer / refine_layer, vv_recon.py:90,107,129,151,286).  c % 4 == 0,
+ * c <= 1024.  Two launches (strips, fold); exact and deterministic (max in any order).  NaNs are
+ * ignored (fmaxf), which the graph never produces after a ReLU. */
+size_t rf_maxpool_points_workspace_bytes(int b, int n, int c);
+int rf_maxpool_points(int b, int n, int c, const float *x, float *out, void *workspace,
+                      size_t workspace_bytes, rf_stream_t stream);
+
 int rf_point_affine_supported(int c, int kp);
 int rf_point_affine(int b, int n, int c, const float *y, const float *p, int kp, const float *w,
                     const float *r, int r_per_sample, int act, float *out, rf_stream_t stream);

@@ -101,6 +101,11 @@ def workspace(nbytes, dev, tag):
     the same op concurrently must not share scratch."""
     if nbytes == 0:
         return None, 0
+    if torch.cuda.is_current_stream_capturing():
+        # inside a HIP-graph capture the scratch must belong to the graph's own memory pool and to
+        # nobody else: a fresh buffer, not cached (a cached one would later be handed to eager calls)
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        return buf, int(buf.numel())
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:

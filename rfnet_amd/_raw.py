@@ -694,3 +694,15 @@ def point_affine(y, p, w, r, act="relu", out=None):
         check(lib.rf_point_affine(b, n, c, H.ptr(y_), H.ptr(p_), kp, H.ptr(w_), H.ptr(r_), int(per_sample),
                                   _ACT[act], H.ptr(out), H.stream(dev)), "rf_point_affine")
     return out
+
+
+def maxpool_points(x):
+    """rf_maxpool_points: max over the points axis of a (b, n, c) GPU tensor -> (b, 1, c) (keepdim)."""
+    b, n, c = x.shape
+    dev = x.device
+    x_ = x.contiguous()
+    out = H.empty((b, 1, c), F32, dev)
+    with torch.cuda.device(dev):
+        ws, wsz = H.workspace(lib.rf_maxpool_points_workspace_bytes(b, n, c), dev, "maxpool")
+        check(lib.rf_maxpool_points(b, n, c, H.ptr(x_), H.ptr(out), H.ptr(ws), wsz, H.stream(dev)), "rf_maxpool_points")
+    return out

@@ -70,9 +70,71 @@ __global__ __launch_bounds__(PA_TPB) void point_affine_kernel(int n, int c, int 
     }
 }
 
+// ---- max over the points axis: (b, n, c) -> (b, c)   (tf.reduce_max(axis=1), vv_recon.py:90,107,129,...)
+// Stage 1: one workgroup per (strip of MP_STRIP points, sample): a thread owns four channels (16-byte
+// loads) of every ppi-th point of the strip, the point-lanes of a channel quad meet in LDS.
+// Stage 2: one workgroup per sample folds the strips.  max is exact in any order: deterministic.
+constexpr int MP_TPB = 256;
+constexpr int MP_STRIP = 256;
+
+__device__ __forceinline__ float4 max4(float4 a, float4 b) {
+    return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
+}
+
+__global__ __launch_bounds__(MP_TPB) void maxpool_stage1_kernel(int n, int c, int nstrips, const float *__restrict__ x,
+                                                                float *__restrict__ part) {
+    __shared__ float4 red[MP_TPB];
+    const int quads = c >> 2, ppi = MP_TPB / quads;
+    const int cq = threadIdx.x % quads, pl = threadIdx.x / quads;
+    const int bi = blockIdx.y, strip = blockIdx.x;
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    if (pl < ppi) {
+        const int n1 = min(n, (strip + 1) * MP_STRIP);
+        for (int j = strip * MP_STRIP + pl; j < n1; j += ppi)
+            m = max4(m, *(const float4 *)(x + ((size_t)bi * n + j) * c + cq * 4));
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    if (pl == 0) {
+        for (int k = 1; k < ppi; k++) m = max4(m, red[k * quads + cq]);
+        *(float4 *)(part + ((size_t)bi * nstrips + strip) * c + cq * 4) = m;
+    }
+}
+
+__global__ __launch_bounds__(MP_TPB) void maxpool_stage2_kernel(int c, int nstrips, const float *__restrict__ part,
+                                                                float *__restrict__ out) {
+    const int bi = blockIdx.x;
+    for (int ch = threadIdx.x; ch < c; ch += MP_TPB) {
+        float m = -INFINITY;
+        for (int s = 0; s < nstrips; s++) m = fmaxf(m, part[((size_t)bi * nstrips + s) * c + ch]);
+        out[(size_t)bi * c + ch] = m;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t rf_maxpool_points_workspace_bytes(int b, int n, int c) {
+    if (b <= 0 || n <= 0 || c <= 0) return 0;
+    return (size_t)b * rf::ceil_div(n, MP_STRIP) * c * sizeof(float);
+}
+
+int rf_maxpool_points(int b, int n, int c, const float *x, float *out, void *workspace, size_t workspace_bytes,
+                      rf_stream_t stream) {
+    if (b < 0 || n < 0 || c < 0) return RF_EINVAL;
+    if ((size_t)b * c == 0) return RF_OK;
+    if (n == 0 || c % 4 != 0 || c / 4 > MP_TPB || b > 65535) return RF_EINVAL;
+    if (!x || !out || !workspace) return RF_EINVAL;
+    if (workspace_bytes < rf_maxpool_points_workspace_bytes(b, n, c)) return RF_EWORKSPACE;
+    const int nstrips = rf::ceil_div(n, MP_STRIP);
+    hipStream_t s = (hipStream_t)stream;
+    RF_LAUNCH("maxpool_points", maxpool_stage1_kernel, dim3(nstrips, b), dim3(MP_TPB), 0, s, n, c, nstrips, x,
+              (float *)workspace);
+    RF_LAUNCH("maxpool_points_fold", maxpool_stage2_kernel, dim3(b), dim3(MP_TPB), 0, s, c, nstrips,
+              (const float *)workspace, out);
+    return RF_OK;
+}
 
 int rf_point_affine_supported(int c, int kp) { return c > 0 && c % 4 == 0 && c / 4 <= PA_TPB && kp >= 0 && kp <= PA_KMAX; }
 

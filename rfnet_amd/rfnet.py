@@ -110,12 +110,17 @@ class _PointAffine(torch.autograd.Function):
 
 def maxpool_points(t):
     """max over the points axis, keepdim (tf.reduce_max(axis=1), e.g. vv_recon.py:90,107,129).  Without
-    autograd: amax (values only, 3x faster than max's value+index kernel); with autograd: max, whose
+    autograd: rf_maxpool_points (values only); with autograd: torch's max, whose
     index-scatter backward is one pass instead of amax's compare / count / divide / multiply (every
     pooled tensor of the graph comes out of a ReLU, so how ties share the gradient is immaterial:
     tied entries are zeros, whose ReLU passes no gradient)."""
     if torch.is_grad_enabled() and t.requires_grad:
         return t.max(1, keepdim=True).values
+    if t.is_cuda and t.dtype == torch.float32 and t.shape[-1] % 4 == 0 and t.shape[-1] <= 1024 and t.shape[1] > 0:
+        # this repository's own two-launch kernel: faster than amax, and -- unlike a torch reduction that
+        # follows a GEMM -- it replays correctly from a captured HIP graph on this ROCm / torch build
+        # (tools/experiments/graph_gemm_reduce_debug.py: `(x @ w).amax(1)` is wrong from the 2nd replay on)
+        return _raw.maxpool_points(t)
     return t.amax(1, keepdim=True)
 
 

@@ -253,3 +253,12 @@ def test_fused_layer_tails_match_tensor_ops():
     for a, e in zip(got, exp):
         assert torch.allclose(a, e, rtol=1e-3, atol=1e-3 * float(e.abs().max()))
     assert _raw.lib.rf_point_affine_supported(130, 3) == 0 and _raw.lib.rf_point_affine_supported(128, 17) == 0
+
+
+@pytest.mark.gpu
+def test_maxpool_points_kernel():
+    from rfnet_amd import _raw
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for (b, n, c) in ((1, 1, 4), (2, 255, 64), (3, 3000, 256), (2, 16384, 128), (1, 4024, 384), (2, 257, 1024)):
+        x = torch.randn(b, n, c, device="cuda", generator=g)
+        assert torch.equal(_raw.maxpool_points(x), x.amax(1, keepdim=True))
