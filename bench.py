@@ -196,19 +196,45 @@ def run_c5(args, rank, world, dev, steps, warmup, use_pg):
     torch.manual_seed(0)  # same random-init weights on every rank (checkpoint blob is missing: T10)
     net = RFNet().to(dev)
 
-    def step():
+    def compute():
         with torch.no_grad():
             # gt preparation (one FPS run for both subsets + the sorted handle); in line: putting it on a
             # side stream under the forward measured 8.45 .. 10.0 ms against 8.9 in line
             # (tools/experiments/c5_overlap_ab.py: the serial FPS chain suffers when it shares CUs)
             g = GroundTruth(gt, 64, 1024, overlap=False)
             p1, p2, p3, pf = net(partial)
-            g.join()
             cd = glue.chamfer_per_sample(gt, pf, sorted1=g.h_gt)[0].mean(1)         # chamfer_big, per sample
             e1 = glue.earth_mover_cost(g.gt1, p1) / 64.0                             # earth_mover terms
             e2 = glue.earth_mover_cost(g.gt2, p2) / 1024.0
-            per = torch.stack([cd, e1, e2], 1)                                       # (B, 3)
-            return shard.all_gather_per_sample(per, B * world, rank, world)          # loss reduction (RCCL)
+            return torch.stack([cd, e1, e2], 1)                                      # (B, 3)
+
+    # The step has static shapes and ~450 kernel launches: captured ONCE into a HIP graph and replayed
+    # (same kernels, same results, no per-launch host work, no gaps between dependent launches).  The
+    # loss all-gather (RCCL) stays outside the graph.  Falls back to eager launches if capture fails.
+    graphed = None
+    if not args.c5_eager:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    compute()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_per = compute()
+            graphed = (graph, static_per)
+        except Exception as exc:  # noqa: BLE001
+            sys.stderr.write(f"bench.py: C5 step not captured ({type(exc).__name__}: {exc}); running it eagerly\n")
+            graphed = None
+
+    def step():
+        if graphed is not None:
+            graphed[0].replay()
+            per = graphed[1]
+        else:
+            per = compute()
+        return shard.all_gather_per_sample(per, B * world, rank, world)              # loss reduction (RCCL)
 
     def fence():
         torch.cuda.synchronize()
@@ -237,6 +263,7 @@ def run_c5(args, rank, world, dev, steps, warmup, use_pg):
                     f"chamfer_big(gt, out) + earth_mover at 64^2 and 1024^2, B={B} per GPU "
                     f"(BASELINE.json configs[4]: B={B * world} over {world} GPU), per-sample losses all-gathered",
         "value": world * B * steps / dt, "unit": "samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+        "hip_graph": graphed is not None,
         "gathered_losses_shape": list(full.shape), "finite": bool(torch.isfinite(full).all().item()),
         "losses_equal_across_ranks": bool(lo.item() == hi.item()),
         "mean_losses": [float(x) for x in full.double().mean(0).tolist()],
@@ -253,6 +280,7 @@ def main():
     ap.add_argument("--m", type=int, default=16384)
     ap.add_argument("--workload", choices=["chamfer", "c5"], default="chamfer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--c5-eager", action="store_true", help="run the C5 step with eager launches instead of a captured HIP graph")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (profiling runs)")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="TEST ONLY: exercise the multi-rank plumbing (self-launch, init, fences, "
