@@ -59,6 +59,12 @@ namespace {
 #ifndef RFP_SPLIT_BELOW
 #define RFP_SPLIT_BELOW 4096
 #endif
+#ifndef RFP_SORT_SPLIT
+#define RFP_SORT_SPLIT 2     // workgroups per cloud of more than RFP_SORT_SPLIT_ABOVE points (1 = never split)
+#endif
+#ifndef RFP_SORT_SPLIT_ABOVE
+#define RFP_SORT_SPLIT_ABOVE 8192
+#endif
 #ifndef RFP_HIST
 #define RFP_HIST 0  // 1 (instrumented build): block scans by number of active lanes -> stats[10..13]
 #endif
@@ -90,6 +96,7 @@ struct SortArgs {
     float *box16[2];
     float *box64[2];
     int nsets;  // 2 for the Chamfer sweep (both clouds of every batch element), 1 for a single set
+    int split[2];  // workgroups per cloud of the set (register-resident kernel): 1, or 2 = one per half of the key space
     unsigned long long *dbg;  // optional (with stats): s_memtime stamps of the sort's phases, [16..31]
 };
 
@@ -185,14 +192,15 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 }
 #undef RFP_ROW
 
-constexpr int HALF = 8192;  // records staged in LDS at a time (4 arrays x 32 KiB over the dead histogram)
+constexpr int HALF = 9216;  // records staged in LDS at a time (16 B each, over the dead histogram + 16 KiB): a
+                            // split cloud's half (8192 +- the quantiles' sampling error) fits one round
 
 // Clouds of up to RPT * STPB = 16384 points: the points are loaded ONCE into registers; every
 // later phase is LDS and ALU work.  The sorted records are staged in LDS (over the histogram,
 // dead once every point has its position), 8192 at a time, so that the boxes come from LDS and
 // the arrays leave the CU as coalesced stores (a direct scatter is 4 x 16384 single-dword stores).
 __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned hist[NBINS];
+    __shared__ __attribute__((aligned(16))) unsigned hist[HALF * 4];  // NBINS bins, later HALF staged records
     __shared__ unsigned ahist[3][HB];
     __shared__ unsigned short cellmap[3][HB];  // equalised cell, already bit-spread and shifted per axis
     __shared__ unsigned char hlut[192];
@@ -205,7 +213,18 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     // batch element is the one that sweeps it, its L2 still holding the records)
     const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (int)(blockIdx.x >> 3);
-    const int bi = logical / a.nsets, set = logical - bi * a.nsets;
+    // A large cloud is shared by H = 2 workgroups, one per HALF OF THE KEY SPACE (top key bit).  Both
+    // load the whole cloud and derive the same frame, cells and keys (no communication: the frame is a
+    // pure function of the cloud); each then histograms, scans, places and writes out only the points
+    // of its own half -- the half of the work that does not shrink otherwise (LDS atomics, scan,
+    // staging, boxes, write-out).  Half 0's segment is padded to a multiple of 64 records and half 1
+    // starts behind it, so the two never share a superblock; the set is allocated 64 records longer.
+    const int wpb = a.split[0] + (a.nsets > 1 ? a.split[1] : 0);  // workgroups per batch element
+    const int bi = logical / wpb;
+    int rem = logical - bi * wpb;
+    const int set = (a.nsets > 1 && rem >= a.split[0]) ? 1 : 0;
+    if (set) rem -= a.split[0];
+    const int H = a.split[set], half = rem;  // H = 1: half = 0, the whole key space
     const int n = a.n[set], npad = a.npad[set];
     const float *__restrict__ src = a.src[set] + (size_t)bi * n * 3;
     float *__restrict__ oxyz = a.xyz[set] + (size_t)bi * npad * 3;
@@ -213,7 +232,7 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int stamp_no = 16;
     auto stamp = [&]() {  // phase timing of the LAST workgroup (set 1, last batch element), thread 0
-        if (a.dbg && bi == a.b - 1 && set == 1 && tid == 0 && stamp_no < 32) a.dbg[stamp_no] = clock64();
+        if (a.dbg && bi == a.b - 1 && set == a.nsets - 1 && half == H - 1 && tid == 0 && stamp_no < 32) a.dbg[stamp_no] = clock64();
         stamp_no++;
     };
     stamp();
@@ -339,22 +358,27 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
         const unsigned e2 = hlut2[(e1 >> 6) * 64 + ((m >> 3) & 63u)];
         const unsigned e3 = hlut[(e2 >> 6) * 8 + (m & 7u)];
         const unsigned key = ((e1 & 63u) << 9) | ((e2 & 63u) << 3) | (e3 & 7u);
-        pk[k] = key;
-        if (tid + k * STPB < n) atomicAdd(&hist[key], 1u);
+        // bins of this workgroup: the low KEYBITS-1 bits when the cloud is split; 0xFFFFFFFF marks a
+        // point of the other half (or beyond n)
+        const bool own = tid + k * STPB < n && (H == 1 || (int)(key >> (KEYBITS - 1)) == half);
+        pk[k] = own ? (H == 1 ? key : (key & (NBINS / 2 - 1))) : 0xFFFFFFFFu;
+        if (own) atomicAdd(&hist[pk[k]], 1u);
     }
     __syncthreads();
 
     stamp();
     // 4. exclusive scan of the 32768 bins: each wave owns 2048 consecutive bins, 8 steps of 256
     // (4 per lane, one ds_read_b128: consecutive lanes on consecutive banks)
+    int cown = 0;  // points of this workgroup's half
     {
-        constexpr int STEPS = NBINS / (STPB / 64) / 256;  // 8
-        uint4 *h4 = (uint4 *)hist + (size_t)wave * (NBINS / (STPB / 64) / 4);
+        constexpr int STEPS = NBINS / (STPB / 64) / 256;  // 8 (4 when the cloud is split: half the bins)
+        const int steps = STEPS / H;
+        uint4 *h4 = (uint4 *)hist + (size_t)wave * (NBINS / H / (STPB / 64) / 4);
         uint4 v[STEPS];
         unsigned tot = 0;
 #pragma unroll
         for (int it = 0; it < STEPS; it++) {
-            v[it] = h4[it * 64 + lane];
+            v[it] = it < steps ? h4[it * 64 + lane] : make_uint4(0, 0, 0, 0);
             tot += v[it].x + v[it].y + v[it].z + v[it].w;
         }
         tot = wave_incl_scan(tot);
@@ -362,17 +386,20 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
         __syncthreads();
         unsigned carry = 0;
         for (int w = 0; w < wave; w++) carry += wsum[w];
+        for (int w = 0; w < STPB / 64; w++) cown += (int)wsum[w];
 #pragma unroll
         for (int it = 0; it < STEPS; it++) {
-            const unsigned sm = v[it].x + v[it].y + v[it].z + v[it].w;
-            const unsigned incl = wave_incl_scan(sm);
-            uint4 out;
-            out.x = carry + incl - sm;
-            out.y = out.x + v[it].x;
-            out.z = out.y + v[it].y;
-            out.w = out.z + v[it].z;
-            h4[it * 64 + lane] = out;
-            carry += (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+            if (it < steps) {  // uniform
+                const unsigned sm = v[it].x + v[it].y + v[it].z + v[it].w;
+                const unsigned incl = wave_incl_scan(sm);
+                uint4 out;
+                out.x = carry + incl - sm;
+                out.y = out.x + v[it].x;
+                out.z = out.y + v[it].y;
+                out.w = out.z + v[it].z;
+                h4[it * 64 + lane] = out;
+                carry += (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+            }
         }
     }
     __syncthreads();
@@ -381,7 +408,7 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     // 5. positions (the order inside a key is whatever the atomics give: results do not depend on it)
 #pragma unroll
     for (int k = 0; k < RPT; k++)
-        if (tid + k * STPB < n) pk[k] = atomicAdd(&hist[pk[k]], 1u);
+        if (pk[k] != 0xFFFFFFFFu) pk[k] = atomicAdd(&hist[pk[k]], 1u);  // position inside this half's segment
     __syncthreads();  // the histogram is dead from here on
 
     stamp();
@@ -390,15 +417,32 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     float4 *stg = (float4 *)hist;
     float *__restrict__ b16 = a.box16[set] + (size_t)bi * (npad / SB) * B16F;
     float *__restrict__ b64 = a.box64[set] + (size_t)bi * (npad / SB) * B64F;
-    for (int h0 = 0; h0 < npad; h0 += HALF) {
-        const int cnt = min(HALF, npad - h0);  // multiple of 64
+    // this workgroup's segment of the sorted set: records [base, base + seglen), of which the first
+    // `cown` are points and the rest padding.  Half 0: [0, roundup(cown, 64)); half 1 (or the only
+    // workgroup): from behind half 0's segment to the end of the set.
+    const int base = (H == 2 && half == 1) ? ((n - cown + SB - 1) / SB) * SB : 0;
+    const int seglen = ((cown + SB - 1) / SB) * SB;  // the points and the padding of their last superblock
+    // whole superblocks of padding behind the last segment (a split set is allocated one more than
+    // it may need): written straight to memory, no staging round for them
+    if (half == H - 1) {
+        const int t0 = base + seglen;
+        for (int j = t0 * 3 + tid; j < npad * 3; j += STPB) oxyz[j] = INFINITY;
+        for (int j = t0 + tid; j < npad; j += STPB) oorig[j] = -1;
+        for (int j = (t0 / SB) * B16F + tid; j < (npad / SB) * B16F; j += STPB) b16[j] = ((j % 6) < 3) ? INFINITY : -INFINITY;
+        for (int j = (t0 / SB) * B64F + tid; j < (npad / SB) * B64F; j += STPB) {
+            const int c = j % B64F;
+            b64[j] = c < 3 ? INFINITY : (c >= 4 && c < 7 ? -INFINITY : 0.f);
+        }
+    }
+    for (int h0 = 0; h0 < seglen; h0 += HALF) {
+        const int cnt = min(HALF, seglen - h0);  // multiple of 64
 #pragma unroll
         for (int k = 0; k < RPT; k++) {
             const int i = tid + k * STPB;
             const int p = (int)pk[k] - h0;
-            if (i < n && p >= 0 && p < HALF) stg[p] = make_float4(px[k], py[k], pz[k], __int_as_float(i));
+            if (pk[k] != 0xFFFFFFFFu && p >= 0 && p < HALF) stg[p] = make_float4(px[k], py[k], pz[k], __int_as_float(i));
         }
-        for (int p = n - h0 + tid; p < cnt; p += STPB)  // padding records live at positions >= n
+        for (int p = cown - h0 + tid; p < cnt; p += STPB)  // padding records live at positions >= cown
             if (p >= 0) stg[p] = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(-1));
         __syncthreads();
         // boxes: one thread per 16-record block, a quad of lanes per superblock (cnt/16 is a
@@ -410,13 +454,13 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
             for (int u = 0; u < BS; u++) {
                 const int r = tid * BS + ((u + tid) & (BS - 1));
                 const float4 v = stg[r];
-                if (h0 + r < n) {  // padding excluded; NaN coordinates drop out of fminf/fmaxf
+                if (h0 + r < cown) {  // padding excluded; NaN coordinates drop out of fminf/fmaxf
                     l[0] = fminf(l[0], v.x); hh[0] = fmaxf(hh[0], v.x);
                     l[1] = fminf(l[1], v.y); hh[1] = fmaxf(hh[1], v.y);
                     l[2] = fminf(l[2], v.z); hh[2] = fmaxf(hh[2], v.z);
                 }
             }
-            const int gblk = h0 / BS + tid;
+            const int gblk = (base + h0) / BS + tid;
             float *o = b16 + (size_t)(gblk >> 2) * B16F + (gblk & 3) * 6;
 #pragma unroll
             for (int c = 0; c < 3; c++) {
@@ -445,9 +489,9 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
             const float *sf = (const float *)stg;
             for (int j = tid; j < cnt * 3; j += STPB) {
                 const int r = j / 3, c = j - r * 3;
-                oxyz[(size_t)h0 * 3 + j] = sf[r * 4 + c];
+                oxyz[(size_t)(base + h0) * 3 + j] = sf[r * 4 + c];
             }
-            for (int j = tid; j < cnt; j += STPB) oorig[h0 + j] = __float_as_int(sf[j * 4 + 3]);
+            for (int j = tid; j < cnt; j += STPB) oorig[base + h0 + j] = __float_as_int(sf[j * 4 + 3]);
         }
         __syncthreads();
         stamp();
@@ -845,10 +889,13 @@ __device__ __forceinline__ void sweep_group(
     // (writes it, consumes it, keeps the minimum of its entries in `lmin`).
     auto traverse = [&](auto track_c, const float *blo, const float *bhi, unsigned &besti2) {
         constexpr bool TRACK = decltype(track_c)::value;
-        // up to 256 entries (every cloud that fits the register-resident sort): the lane's entries
-        // e = lane + 64 i live in 4 registers and the LDS list is not used at all
-        const bool inreg = nmine <= 256;  // uniform
-        unsigned kk[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        // up to 320 entries (every cloud that fits the register-resident sort: 16384 points = 256
+        // superblocks, 257 when two workgroups sorted it): the lane's entries e = lane + 64 i live in
+        // KK registers and the LDS list is not used at all
+        constexpr int KK = 5;
+        const bool inreg = nmine <= 64 * KK;  // uniform
+        unsigned kk[KK] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        auto kk_min = [&]() { return min(min(min(kk[0], kk[1]), min(kk[2], kk[3])), kk[4]); };
         auto entry_key = [&](int e, const float *lo3, const float *hi3) {
             const int s = sub + nsub * e;
             const float4 *cb = (const float4 *)(CB64 + (size_t)s * B64F);
@@ -858,12 +905,12 @@ __device__ __forceinline__ void sweep_group(
         unsigned lmin = 0xFFFFFFFFu;
         if (inreg) {
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int i = 0; i < KK; i++)
                 if (i * 64 < nmine) {  // uniform
                     const int e = lane + 64 * i;
                     kk[i] = e < nmine ? entry_key(e, blo, bhi) : 0xFFFFFFFFu;
                 }
-            lmin = min(min(kk[0], kk[1]), min(kk[2], kk[3]));
+            lmin = kk_min();
         } else {
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
             for (int e = lane; e < nmine; e += 64) {
@@ -901,9 +948,9 @@ __device__ __forceinline__ void sweep_group(
                 lmin = 0xFFFFFFFFu;
                 if (inreg) {
 #pragma unroll
-                    for (int i = 0; i < 4; i++)
+                    for (int i = 0; i < KK; i++)
                         if (i * 64 < nmine && kk[i] != 0xFFFFFFFFu) kk[i] = entry_key(lane + 64 * i, alo, ahi);  // (consumed ones stay)
-                    lmin = min(min(kk[0], kk[1]), min(kk[2], kk[3]));
+                    lmin = kk_min();
                 } else {
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
                     for (int e = lane; e < nmine; e += 64) {
@@ -933,8 +980,8 @@ __device__ __forceinline__ void sweep_group(
             } else if (inreg) {
                 const bool mine = lane == (e & 63);
 #pragma unroll
-                for (int i = 0; i < 4; i++) kk[i] = (mine && (e >> 6) == i) ? 0xFFFFFFFFu : kk[i];
-                lmin = min(min(kk[0], kk[1]), min(kk[2], kk[3]));
+                for (int i = 0; i < KK; i++) kk[i] = (mine && (e >> 6) == i) ? 0xFFFFFFFFu : kk[i];
+                lmin = kk_min();  // (guarding the unused registers by nmine measured slower: 158 vs 153 us at 16384^2)
             } else if (lane == (e & 63)) {
                 keys[e] = 0xFFFFFFFFu;
                 lmin = 0xFFFFFFFFu;
@@ -1161,6 +1208,11 @@ int round_up(long v, int q) { return (int)((v + q - 1) / q * q); }
 
 size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
+// workgroups sorting one cloud of n points, and the padded record count of a sorted set: a split
+// cloud carries one more superblock (half 0's segment is padded to a multiple of 64 on its own)
+int sort_split_of(int n) { return (RFP_SORT_SPLIT == 2 && n > RFP_SORT_SPLIT_ABOVE && n <= RPT * STPB) ? 2 : 1; }
+size_t npad_of(int n) { return (size_t)round_up(n, SB) + (sort_split_of(n) == 2 ? SB : 0); }
+
 }  // namespace
 
 namespace rfp {
@@ -1173,14 +1225,14 @@ bool pruned_supported(int b, int n, int m) {
 // part 256-byte aligned.  The layout is a pure function of (b, n): a "handle" is just that buffer.
 size_t sorted_bytes(int b, int n) {
     if (b <= 0 || n <= 0 || n > kMaxPoints) return 0;
-    const size_t npad = (size_t)round_up(n, SB);
+    const size_t npad = npad_of(n);
     return align256((size_t)b * npad * 3 * sizeof(float) + 256)  // + prefetch overrun
            + align256((size_t)b * npad * sizeof(int)) + align256((size_t)b * (npad / SB) * B16F * sizeof(float)) +
            align256((size_t)b * (npad / SB) * B64F * sizeof(float));
 }
 
 Sorted sorted_view(int b, int n, const void *buf) {
-    const size_t npad = (size_t)round_up(n, SB);
+    const size_t npad = npad_of(n);
     const char *w = (const char *)buf;
     Sorted v;
     v.npad = (int)npad;
@@ -1219,9 +1271,11 @@ int sort_sets(int b, int nsets, const int *n, const float *const *src, const Sor
         sa.box16[k] = const_cast<float *>(out[kk].box16);
         sa.box64[k] = const_cast<float *>(out[kk].box64);
         reg = reg && n[kk] <= RPT * STPB;
+        sa.split[k] = sort_split_of(n[kk]);
     }
     if (reg) {
-        RF_LAUNCH("nnp_sort", nnp_sort_reg_kernel, dim3(nsets * b), dim3(STPB), 0, s, sa);
+        const int wpb = sa.split[0] + (nsets > 1 ? sa.split[1] : 0);
+        RF_LAUNCH("nnp_sort", nnp_sort_reg_kernel, dim3(wpb * b), dim3(STPB), 0, s, sa);
     } else {
         RF_LAUNCH("nnp_sort", nnp_sort_kernel<false>, dim3(nsets * b), dim3(STPB), 0, s, sa);
     }

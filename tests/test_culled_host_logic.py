@@ -49,10 +49,11 @@ def test_workspace_planner_and_auto_rule():
         assert a in (d, c) and d != c
         return a == c
 
-    # sorted xyz (12 B) + original index (4 B) per padded record, boxes 96 + 32 B per 64 records
+    # sorted xyz (12 B) + original index (4 B) per padded record, boxes 96 + 32 B per 64 records; a cloud
+    # sorted by two workgroups (8192 < points <= 16384) carries one more superblock of padding
     b, n, m = 32, 2048, 16384
     need = b * (n + m) * 16 + b * ((n + m) // 64) * 128
-    assert need <= ws(b, n, m, CULLED) <= need + 16 * 1024
+    assert need <= ws(b, n, m, CULLED) <= need + b * (64 * 16 + 128) + 16 * 1024
     assert ws(1, 70000, 100, CULLED) == 0  # beyond the culled sweep's 65536-point limit
     assert ws(0, 5, 5, AUTO) == 0
     for shape in [(32, 2048, 16384), (32, 16384, 16384), (1, 4096, 4096), (4, 3000, 16384), (32, 3000, 1024),
