@@ -977,7 +977,7 @@ __device__ __forceinline__ void sweep_group(
             if (nmine <= 64) {  // one entry per lane (C2: 32 superblocks, or a quarter of 256)
                 kk[0] = lane == e ? 0xFFFFFFFFu : kk[0];
                 lmin = kk[0];
-            } else if (inreg) {
+            } else if (inreg) {  // (a two-register path for 65..128 entries measured slower for every shape: one more branch level)
                 const bool mine = lane == (e & 63);
 #pragma unroll
                 for (int i = 0; i < KK; i++) kk[i] = (mine && (e >> 6) == i) ? 0xFFFFFFFFu : kk[i];
