@@ -6,14 +6,15 @@ from rfnet_amd import _raw as R
 rng = np.random.RandomState(100)
 a = torch.from_numpy(rng.randn(32, 2048, 3).astype(np.float32)).cuda()
 c = torch.from_numpy(rng.randn(32, 16384, 3).astype(np.float32)).cuda()
-names = ["start", "loaded+zeroed", "bbox+tables", "quantiles", "keys+hist", "scan", "positions", "half0 done", "half1 done"]
+names = ["start", "loads issued+zeroed", "bbox+tables", "quantiles", "keys+hist", "scan", "positions", "staging round 1", "staging round 2"]
 acc = []
 for _ in range(5):
     st = []
     R.nn_distance(a, c, mode="culled", stats=st)
     s = [x for x in st[16:32] if x]
     acc.append(s)
-s = np.median(np.array([x[:9] for x in acc if len(x) >= 9], dtype=np.float64), 0)
+k = min(len(x) for x in acc)
+s = np.median(np.array([x[:k] for x in acc], dtype=np.float64), 0)
 for i in range(1, len(s)):
     print(f"{names[i]:16s} {int(s[i] - s[i - 1]):8d} ticks")
-print("total", int(s[-1] - s[0]), "ticks (100 MHz clock64? or shader clock -- compare with 29 us)")
+print("total", int(s[-1] - s[0]), "shader-clock ticks (the last workgroup of the launch: second half of the last 16384-point cloud)")
