@@ -384,9 +384,12 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
         tot = wave_incl_scan(tot);
         if (lane == 63) wsum[wave] = tot;
         __syncthreads();
-        unsigned carry = 0;
-        for (int w = 0; w < wave; w++) carry += wsum[w];
-        for (int w = 0; w < STPB / 64; w++) cown += (int)wsum[w];
+        // the 16 wave totals: ONE LDS read per lane and a wave scan (a loop over wsum[] is a chain of
+        // dependent LDS latencies in every wave)
+        const unsigned wtot = lane < STPB / 64 ? wsum[lane] : 0u;
+        const unsigned wincl = wave_incl_scan(wtot);
+        unsigned carry = (unsigned)__builtin_amdgcn_readlane((int)(wincl - wtot), __builtin_amdgcn_readfirstlane(wave));
+        cown = __builtin_amdgcn_readlane((int)wincl, STPB / 64 - 1);
 #pragma unroll
         for (int it = 0; it < STEPS; it++) {
             if (it < steps) {  // uniform
