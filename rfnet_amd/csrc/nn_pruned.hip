@@ -60,7 +60,9 @@ namespace {
 #define RFP_SPLIT_BELOW 4096
 #endif
 #ifndef RFP_SORT_SPLIT
-#define RFP_SORT_SPLIT 2     // workgroups per cloud of more than RFP_SORT_SPLIT_ABOVE points (1 = never split)
+#define RFP_SORT_SPLIT 2     // workgroups per cloud of more than RFP_SORT_SPLIT_ABOVE points: 1 (never split), 2 or 4
+                             // (4 measures the same as 2: 26.4 vs 26.3 us at C2 -- what is left of a workgroup's time
+                             // no longer scales with its share of the records)
 #endif
 #ifndef RFP_SORT_SPLIT_ABOVE
 #define RFP_SORT_SPLIT_ABOVE 8192
@@ -96,7 +98,7 @@ struct SortArgs {
     float *box16[2];
     float *box64[2];
     int nsets;  // 2 for the Chamfer sweep (both clouds of every batch element), 1 for a single set
-    int split[2];  // workgroups per cloud of the set (register-resident kernel): 1, or 2 = one per half of the key space
+    int split[2];  // workgroups per cloud of the set (register-resident kernel): 1, or 2 / 4 = one per slice of the key space
     unsigned long long *dbg;  // optional (with stats): s_memtime stamps of the sort's phases, [16..31]
 };
 
@@ -207,13 +209,14 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     __shared__ unsigned short hlut2[24 * 64];  // two octant levels per lookup, built from hlut
     __shared__ float red[STPB / 64][6];
     __shared__ unsigned wsum[STPB / 64];
+    __shared__ unsigned lowcnt[STPB / 64][3];
     __shared__ float frame[6];  // lo[3], scale[3]
 
     // cloud-major logical order, each XCD a contiguous eighth (as the sweep: the XCD that sorts a
     // batch element is the one that sweeps it, its L2 still holding the records)
     const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (int)(blockIdx.x >> 3);
-    // A large cloud is shared by H = 2 workgroups, one per HALF OF THE KEY SPACE (top key bit).  Both
+    // A large cloud is shared by H = 2 or 4 workgroups, one per SLICE OF THE KEY SPACE (top key bits).  All
     // load the whole cloud and derive the same frame, cells and keys (no communication: the frame is a
     // pure function of the cloud); each then histograms, scans, places and writes out only the points
     // of its own half -- the half of the work that does not shrink otherwise (LDS atomics, scan,
@@ -347,6 +350,9 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     __syncthreads();
 
     stamp();
+    const int hshift = H == 4 ? KEYBITS - 2 : (H == 2 ? KEYBITS - 1 : KEYBITS);  // (key >> KEYBITS == 0)
+    const unsigned hmask = (unsigned)(NBINS / H - 1);
+    unsigned below[3] = {0u, 0u, 0u};  // wave-uniform counters
     // 3. keys and their histogram (VALU-bound: ~50 instructions per point)
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
@@ -360,9 +366,21 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
         const unsigned key = ((e1 & 63u) << 9) | ((e2 & 63u) << 3) | (e3 & 7u);
         // bins of this workgroup: the low KEYBITS-1 bits when the cloud is split; 0xFFFFFFFF marks a
         // point of the other half (or beyond n)
-        const bool own = tid + k * STPB < n && (H == 1 || (int)(key >> (KEYBITS - 1)) == half);
-        pk[k] = own ? (H == 1 ? key : (key & (NBINS / 2 - 1))) : 0xFFFFFFFFu;
+        const bool valid = tid + k * STPB < n;
+        const int slice = (int)(key >> hshift);  // H slices of the key space (H = 1: everything is slice 0)
+        const bool own = valid && slice == half;
+        pk[k] = own ? (key & hmask) : 0xFFFFFFFFu;
         if (own) atomicAdd(&hist[pk[k]], 1u);
+        // points of the slices below this workgroup's (its segment starts behind theirs)
+        if (H > 1) {
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+                if (q < half) below[q] += (unsigned)__builtin_popcountll(__ballot(valid && slice == q));
+        }
+    }
+    if (H > 1 && lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) lowcnt[wave][q] = below[q];
     }
     __syncthreads();
 
@@ -423,7 +441,12 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     // this workgroup's segment of the sorted set: records [base, base + seglen), of which the first
     // `cown` are points and the rest padding.  Half 0: [0, roundup(cown, 64)); half 1 (or the only
     // workgroup): from behind half 0's segment to the end of the set.
-    const int base = (H == 2 && half == 1) ? ((n - cown + SB - 1) / SB) * SB : 0;
+    int base = 0;  // every slice's segment is padded to a multiple of 64 records on its own
+    for (int q = 0; q < half; q++) {
+        unsigned c = 0;
+        for (int w = 0; w < STPB / 64; w++) c += lowcnt[w][q];
+        base += ((int)c + SB - 1) / SB * SB;
+    }
     const int seglen = ((cown + SB - 1) / SB) * SB;  // the points and the padding of their last superblock
     // whole superblocks of padding behind the last segment (a split set is allocated one more than
     // it may need): written straight to memory, no staging round for them
@@ -1213,8 +1236,8 @@ size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
 // workgroups sorting one cloud of n points, and the padded record count of a sorted set: a split
 // cloud carries one more superblock (half 0's segment is padded to a multiple of 64 on its own)
-int sort_split_of(int n) { return (RFP_SORT_SPLIT == 2 && n > RFP_SORT_SPLIT_ABOVE && n <= RPT * STPB) ? 2 : 1; }
-size_t npad_of(int n) { return (size_t)round_up(n, SB) + (sort_split_of(n) == 2 ? SB : 0); }
+int sort_split_of(int n) { return (RFP_SORT_SPLIT > 1 && n > RFP_SORT_SPLIT_ABOVE && n <= RPT * STPB) ? RFP_SORT_SPLIT : 1; }
+size_t npad_of(int n) { return (size_t)round_up(n, SB) + (size_t)(sort_split_of(n) - 1) * SB; }
 
 }  // namespace
 
