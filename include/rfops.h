@@ -285,6 +285,24 @@ size_t rf_maxpool_points_workspace_bytes(int b, int n, int c);
 int rf_maxpool_points(int b, int n, int c, const float *x, float *out, void *workspace,
                       size_t workspace_bytes, rf_stream_t stream);
 
+/* The same with the point index of each maximum (idx (b, c) int32, the lowest index among ties): the
+ * forward of the pooling when a backward follows (training: tf.gradients of reduce_max routes the
+ * gradient to the arg-max rows). */
+size_t rf_maxpool_points_idx_workspace_bytes(int b, int n, int c);
+int rf_maxpool_points_idx(int b, int n, int c, const float *x, float *out, int *idx, void *workspace,
+                          size_t workspace_bytes, rf_stream_t stream);
+
+/* Backward of a layer tail (training step of the graph; conv2d's bias_add + activation,
+ * vv_recon.py:47-65, differentiated):  g[i,j,:] = grad[i,j,:] * act'(out[i,j,:])  and
+ * sums[i,:] = sum_j g[i,j,:]  (the bias gradient is the sum of `sums` over i; the gradient of a
+ * per-sample row r of rf_point_affine is `sums` itself) in ONE pass over grad/out.  act: 0 none, 1 relu
+ * (out > 0), 2 tanh (1 - out^2), 3 leaky relu with slope 0.2 (sign of out); `out` is the layer's
+ * OUTPUT (NULL with act 0).  g may alias grad; g NULL (or act 0 with g == grad) writes nothing.
+ * c % 4 == 0, c <= 1024.  Deterministic (fixed summation order). */
+size_t rf_act_grad_colsum_workspace_bytes(int b, int n, int c);
+int rf_act_grad_colsum(int b, int n, int c, const float *grad, const float *out, int act, float *g,
+                       float *sums, void *workspace, size_t workspace_bytes, rf_stream_t stream);
+
 int rf_point_affine_supported(int c, int kp);
 int rf_point_affine(int b, int n, int c, const float *y, const float *p, int kp, const float *w,
                     const float *r, int r_per_sample, int act, float *out, rf_stream_t stream);

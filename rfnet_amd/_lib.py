@@ -70,6 +70,10 @@ SIGNATURES = {
     "rf_earth_mover": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rf_maxpool_points_workspace_bytes": (_sz, [_i, _i, _i]),
     "rf_maxpool_points": (_i, [_i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "rf_maxpool_points_idx_workspace_bytes": (_sz, [_i, _i, _i]),
+    "rf_maxpool_points_idx": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "rf_act_grad_colsum_workspace_bytes": (_sz, [_i, _i, _i]),
+    "rf_act_grad_colsum": (_i, [_i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "rf_point_affine_supported": (_i, [_i, _i]),
     "rf_point_affine": (_i, [_i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "rf_profile_enable": (None, [_i]),

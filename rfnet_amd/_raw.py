@@ -696,6 +696,45 @@ def point_affine(y, p, w, r, act="relu", out=None):
     return out
 
 
+def maxpool_points_idx(x):
+    """rf_maxpool_points_idx: max over the points axis of a (b, n, c) GPU tensor -> values (b, 1, c) and
+    the point index of each maximum (b, c) int32 (lowest index among ties)."""
+    b, n, c = x.shape
+    dev = x.device
+    x_ = x.contiguous()
+    out, idx = H.empty((b, 1, c), F32, dev), H.empty((b, c), I32, dev)
+    with torch.cuda.device(dev):
+        ws, wsz = H.workspace(lib.rf_maxpool_points_idx_workspace_bytes(b, n, c), dev, "maxpool")
+        check(lib.rf_maxpool_points_idx(b, n, c, H.ptr(x_), H.ptr(out), H.ptr(idx), H.ptr(ws), wsz, H.stream(dev)),
+              "rf_maxpool_points_idx")
+    return out, idx
+
+
+_ACT_GRAD = {None: 0, "none": 0, "relu": 1, "tanh": 2, "leaky_relu": 3}
+
+
+def act_grad_colsum_supported(c):
+    return c > 0 and c % 4 == 0 and c <= 1024
+
+
+def act_grad_colsum(grad, out, act, inplace=False):
+    """rf_act_grad_colsum: g = grad * act'(out) and sums[i,:] = sum_j g[i,j,:] for (b, n, c) GPU tensors,
+    one pass.  `out` is the layer's OUTPUT (None with act None).  Returns (g (b,n,c), sums (b,c));
+    with act None g is `grad` itself.  inplace: g overwrites grad."""
+    b, n, c = grad.shape
+    dev = grad.device
+    a = _ACT_GRAD[act]
+    grad_ = grad.contiguous()
+    out_ = None if a == 0 else out.contiguous()
+    g = grad_ if (a == 0 or inplace) else H.empty((b, n, c), F32, dev)
+    sums = H.empty((b, c), F32, dev)
+    with torch.cuda.device(dev):
+        ws, wsz = H.workspace(lib.rf_act_grad_colsum_workspace_bytes(b, n, c), dev, "maxpool")
+        check(lib.rf_act_grad_colsum(b, n, c, H.ptr(grad_), H.ptr(out_), a, H.ptr(g), H.ptr(sums), H.ptr(ws), wsz,
+                                     H.stream(dev)), "rf_act_grad_colsum")
+    return g, sums
+
+
 def maxpool_points(x):
     """rf_maxpool_points: max over the points axis of a (b, n, c) GPU tensor -> (b, 1, c) (keepdim)."""
     b, n, c = x.shape

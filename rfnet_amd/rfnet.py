@@ -60,6 +60,100 @@ def _key(name):
     return name.replace("/", "__")
 
 
+def _splits(rows):
+    """How many batches to cut the row axis of a weight-gradient GEMM into (see _wgrad)."""
+    s = 1
+    while s < 128 and rows // (2 * s) >= 2048:
+        s *= 2
+    return s
+
+
+def _wgrad(x2d, g2d):
+    """x2d^T @ g2d for x2d (R, cin), g2d (R, cout): the weight gradient of a per-point dense layer.
+    R = batch * points (up to 620 288 here) and the output is tiny, so the library's plain GEMM runs on
+    a handful of workgroups, one per output tile, each looping over all R rows (1.3 ms for 128 x 256 at
+    R = 524 288).  Cut into S row blocks as ONE strided-batched GEMM plus a sum over the S partial
+    products it fills the chip: 0.27 ms (tools/experiments/wgrad_splitk.py; 143 TFLOP/s at 256 x 256)."""
+    rows = x2d.shape[0]
+    s = _splits(rows) if x2d.is_cuda else 1
+    if s == 1:
+        return x2d.t() @ g2d
+    q = rows // s
+    main = s * q
+    out = torch.bmm(x2d[:main].view(s, q, -1).transpose(1, 2), g2d[:main].view(s, q, -1)).sum(0)
+    if main < rows:
+        out = out + x2d[main:].t() @ g2d[main:]
+    return out
+
+
+def _tail_grad(grad, y, act):
+    """(g, bias gradient) of a layer tail act(. + b) from the upstream gradient and the layer's OUTPUT y,
+    both (rows, c): g = grad * act'(y), bias gradient = column sums of g.  One pass through
+    rf_act_grad_colsum (the rows cut into pseudo-samples so that the strip partials fold in parallel)
+    instead of an activation-backward kernel plus a sum reduction that reads g again."""
+    grad = grad.contiguous()
+    rows, c = grad.shape
+    if grad.is_cuda and _raw.act_grad_colsum_supported(c) and rows >= 1024:
+        nb = 1
+        while nb < 64 and rows % (2 * nb) == 0 and rows // (2 * nb) >= 256:
+            nb *= 2
+        g, sums = _raw.act_grad_colsum(grad.view(nb, rows // nb, c), None if act is None else y.view(nb, rows // nb, c), act)
+        return g.view(rows, c), sums.sum(0)
+    if act == "relu":
+        g = torch.ops.aten.threshold_backward(grad, y, 0.0)
+    elif act == "tanh":
+        g = grad * (1.0 - y * y)
+    elif act == "leaky_relu":
+        g = torch.where(y > 0, grad, grad * 0.2)
+    else:
+        g = grad
+    return g, g.sum(0)
+
+
+class _MaxPool(torch.autograd.Function):
+    """max over the points axis with rf_maxpool_points_idx; the backward routes each channel's gradient
+    to its arg-max point (zero fill + one scatter)."""
+
+    @staticmethod
+    def forward(ctx, t):
+        out, idx = _raw.maxpool_points_idx(t)
+        ctx.save_for_backward(idx)
+        ctx.n = t.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        (idx,) = ctx.saved_tensors
+        b, _, c = grad.shape
+        gin = grad.new_zeros(b, ctx.n, c)
+        gin.scatter_(1, idx.long().unsqueeze(1), grad.contiguous())
+        return gin
+
+
+class _MatW(torch.autograd.Function):
+    """x @ w for per-point features x (..., cin) and a layer kernel w (cin, cout); torch's own matmul
+    with the weight gradient computed by _wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x @ w
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, w = ctx.saved_tensors
+        grad = grad.contiguous()
+        gx = grad @ w.t() if ctx.needs_input_grad[0] else None
+        gw = _wgrad(x.reshape(-1, x.shape[-1]), grad.reshape(-1, grad.shape[-1])) if ctx.needs_input_grad[1] else None
+        return gx, gw
+
+
+def matw(x, w):
+    if x.is_cuda and torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
+        return _MatW.apply(x, w)
+    return x @ w
+
+
 class _LinearRelu(torch.autograd.Function):
     """relu(x @ W + b) as ONE library GEMM with a bias + ReLU epilogue (hipBLASLt through
     torch._addmm_activation): the activation costs no extra pass over the (points, channels) output.
@@ -74,8 +168,30 @@ class _LinearRelu(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad):
         x2d, w, y = ctx.saved_tensors
-        g = torch.ops.aten.threshold_backward(grad.contiguous(), y, 0.0)  # one kernel: grad where y > 0
-        return g @ w.t(), x2d.t() @ g, g.sum(0)
+        g, gb = _tail_grad(grad, y, "relu")
+        return g @ w.t(), _wgrad(x2d, g), gb
+
+
+class _LinearAct(torch.autograd.Function):
+    """act(x @ W + b) for the layers that do not end in a ReLU (none / tanh / leaky_relu 0.2): library
+    GEMM with the bias folded in (addmm) + the activation; backward as _LinearRelu's."""
+
+    @staticmethod
+    def forward(ctx, x2d, w, b, act):
+        y = torch.addmm(b, x2d, w)
+        if act == "tanh":
+            y.tanh_()
+        elif act == "leaky_relu":
+            F.leaky_relu(y, 0.2, inplace=True)
+        ctx.act = act
+        ctx.save_for_backward(x2d, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad):
+        x2d, w, y = ctx.saved_tensors
+        g, gb = _tail_grad(grad, y, ctx.act)
+        return g @ w.t(), _wgrad(x2d, g), gb, None
 
 
 class _PointAffine(torch.autograd.Function):
@@ -93,30 +209,27 @@ class _PointAffine(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad):
         out, p, w = ctx.saved_tensors
-        if ctx.act == "relu":
-            g = torch.ops.aten.threshold_backward(grad.contiguous(), out, 0.0)
-        elif ctx.act == "tanh":
-            g = grad * (1.0 - out * out)
-        else:
-            g = grad
+        g, sums = _raw.act_grad_colsum(grad, None if ctx.act is None else out, ctx.act)  # (b,n,c), (b,c)
         gy = g if ctx.has[0] else None
         gp = gw = None
         if ctx.has[1]:
             gp = g @ w.t()
-            gw = p.reshape(-1, p.shape[-1]).t() @ g.reshape(-1, g.shape[-1])
-        gr = g.sum(1) if len(ctx.rshape) > 1 else g.sum((0, 1))
+            gw = _wgrad(p.reshape(-1, p.shape[-1]), g.reshape(-1, g.shape[-1]))
+        gr = sums if len(ctx.rshape) > 1 else sums.sum(0)
         return gy, gp, gw, gr.reshape(ctx.rshape), None
 
 
 def maxpool_points(t):
     """max over the points axis, keepdim (tf.reduce_max(axis=1), e.g. vv_recon.py:90,107,129).  Without
-    autograd: rf_maxpool_points (values only); with autograd: torch's max, whose
-    index-scatter backward is one pass instead of amax's compare / count / divide / multiply (every
-    pooled tensor of the graph comes out of a ReLU, so how ties share the gradient is immaterial:
-    tied entries are zeros, whose ReLU passes no gradient)."""
+    autograd: rf_maxpool_points (values only); with autograd: rf_maxpool_points_idx and an index-scatter
+    backward (one pass, as torch's `max`, instead of amax's compare / count / divide / multiply; every
+    pooled tensor of the graph comes out of a ReLU, so how ties share the gradient is immaterial: tied
+    entries are zeros, whose ReLU passes no gradient).  torch's own max reduction takes 0.14 ms per call
+    at 32 x 16384 x 256 against 0.03 ms here."""
+    own = t.is_cuda and t.dtype == torch.float32 and t.shape[-1] % 4 == 0 and t.shape[-1] <= 1024 and t.shape[1] > 0
     if torch.is_grad_enabled() and t.requires_grad:
-        return t.max(1, keepdim=True).values
-    if t.is_cuda and t.dtype == torch.float32 and t.shape[-1] % 4 == 0 and t.shape[-1] <= 1024 and t.shape[1] > 0:
+        return _MaxPool.apply(t) if own else t.max(1, keepdim=True).values
+    if own:
         # this repository's own two-launch kernel: faster than amax, and -- unlike a torch reduction that
         # follows a GEMM -- it replays correctly from a captured HIP graph on this ROCm / torch build
         # (tools/experiments/graph_gemm_reduce_debug.py: `(x @ w).amax(1)` is wrong from the 2nd replay on)
@@ -175,7 +288,10 @@ class RFNet(nn.Module):
         bname = f"{sc}/{name}" if sc else name
         if act == "relu":
             return linear_relu(x, self.weights[_key(base)], self.biases[_key(bname)])
-        y = F.linear(x, self.weights[_key(base)].t(), self.biases[_key(bname)])
+        w, bias = self.weights[_key(base)], self.biases[_key(bname)]
+        if x.is_cuda and torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or bias.requires_grad):
+            return _LinearAct.apply(x.reshape(-1, x.shape[-1]), w, bias, act).reshape(*x.shape[:-1], w.shape[1])
+        y = F.linear(x, w.t(), bias)
         if act == "tanh":
             return torch.tanh(y)
         if act == "leaky_relu":
@@ -210,7 +326,9 @@ class RFNet(nn.Module):
             elif fused and c <= 16 and narrow is None:  # the coordinates: applied inside the fused tail
                 narrow, wn = p, wp
             elif y is None:                             # wide per-point parts: library GEMMs, accumulated
-                y = p @ wp
+                y = matw(p, wp)
+            elif torch.is_grad_enabled() and (p.requires_grad or wp.requires_grad):
+                y = y + matw(p, wp)
             else:
                 y = torch.baddbmm(y, p, wp.unsqueeze(0).expand(p.shape[0], -1, -1)) if p.dim() == 3 else y + p @ wp
         assert row == w.shape[0], (base, row, tuple(w.shape))

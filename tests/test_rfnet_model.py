@@ -262,3 +262,67 @@ def test_maxpool_points_kernel():
     for (b, n, c) in ((1, 1, 4), (2, 255, 64), (3, 3000, 256), (2, 16384, 128), (1, 4024, 384), (2, 257, 1024)):
         x = torch.randn(b, n, c, device="cuda", generator=g)
         assert torch.equal(_raw.maxpool_points(x), x.amax(1, keepdim=True))
+
+
+@pytest.mark.gpu
+def test_backward_kernels_match_tensor_ops():
+    """Training-step backward pieces: rf_act_grad_colsum, rf_maxpool_points_idx and the split weight
+    gradient against plain tensor ops."""
+    from rfnet_amd import _raw
+    from rfnet_amd.rfnet import _LinearAct, _MaxPool, _splits, _wgrad, maxpool_points
+    g = torch.Generator(device="cuda").manual_seed(2)
+    for (b, n, c) in ((1, 1, 4), (2, 255, 64), (3, 3000, 256), (2, 16384, 128), (5, 1031, 1024)):
+        grad = torch.randn(b, n, c, device="cuda", generator=g)
+        out = torch.randn(b, n, c, device="cuda", generator=g)
+        out[0, 0, 0] = 0.0  # relu / leaky: zero is NOT positive
+        for act, ref in (("relu", torch.where(out > 0, grad, torch.zeros_like(grad))),
+                         ("tanh", grad * (1.0 - out * out)),
+                         ("leaky_relu", torch.where(out > 0, grad, grad * 0.2)),
+                         (None, grad)):
+            got, sums = _raw.act_grad_colsum(grad, out, act)
+            assert torch.equal(got, ref) if act != "tanh" else torch.allclose(got, ref, rtol=1e-6, atol=1e-7), act
+            exp = ref.double().sum(1)
+            assert torch.allclose(sums.double(), exp, rtol=1e-5, atol=1e-5 * float(exp.abs().max()) + 1e-6), (act, b, n, c)
+            again = _raw.act_grad_colsum(grad, out, act)[1]
+            assert torch.equal(sums, again), "fixed summation order"
+        # in place
+        g2 = grad.clone()
+        got, _ = _raw.act_grad_colsum(g2, out, "relu", inplace=True)
+        assert got.data_ptr() == g2.data_ptr() and torch.equal(g2, torch.where(out > 0, grad, torch.zeros_like(grad)))
+        # pooling with indices
+        x = torch.randn(b, n, c, device="cuda", generator=g)
+        if n > 3:
+            x[:, 3] = x[:, 1]  # ties: the lower point index wins
+        val, idx = _raw.maxpool_points_idx(x)
+        assert torch.equal(val, x.amax(1, keepdim=True))
+        first = (x == val).float().argmax(1)  # first position of the maximum
+        assert torch.equal(idx.long(), first)
+        xr = x.clone().requires_grad_(True)
+        up = torch.randn(b, 1, c, device="cuda", generator=g)
+        (gin,) = torch.autograd.grad((_MaxPool.apply(xr) * up).sum(), xr)
+        exp = torch.zeros_like(x).scatter_(1, first.unsqueeze(1), up)
+        assert torch.equal(gin, exp)
+    assert maxpool_points(torch.randn(2, 50, 8, device="cuda", requires_grad=True)).grad_fn is not None
+    # weight gradient cut into row blocks (with a remainder block)
+    for rows, cin, cout in ((524288, 3, 256), (96000, 128, 64), (32 * 4024, 64, 48), (2049 * 5, 16, 128), (1000, 7, 5)):
+        x = torch.randn(rows, cin, device="cuda", generator=g)
+        gr = torch.randn(rows, cout, device="cuda", generator=g)
+        exp = (x.double().t() @ gr.double())
+        got = _wgrad(x, gr)
+        assert torch.allclose(got.double(), exp, rtol=1e-4, atol=1e-4 * float(exp.abs().max())), (rows, cin, cout)
+    assert _splits(524288) == 128 and _splits(96000) == 32 and _splits(2048) == 1
+    # the non-ReLU dense layer
+    for act in (None, "tanh", "leaky_relu"):
+        for cout in (128, 3):
+            x = torch.randn(4000, 64, device="cuda", generator=g, requires_grad=True)
+            w = torch.randn(64, cout, device="cuda", generator=g, requires_grad=True)
+            bias = torch.randn(cout, device="cuda", generator=g, requires_grad=True)
+            out = _LinearAct.apply(x, w, bias, act)
+            ref = x @ w + bias
+            ref = torch.tanh(ref) if act == "tanh" else torch.nn.functional.leaky_relu(ref, 0.2) if act == "leaky_relu" else ref
+            assert torch.allclose(out, ref, rtol=1e-4, atol=1e-4)
+            up = torch.randn(4000, cout, device="cuda", generator=g)
+            got = torch.autograd.grad((out * up).sum(), (x, w, bias))
+            exp = torch.autograd.grad((ref * up).sum(), (x, w, bias))
+            for a, e in zip(got, exp):
+                assert torch.allclose(a, e, rtol=1e-3, atol=1e-3 * float(e.abs().max())), (act, cout)
