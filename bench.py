@@ -47,8 +47,12 @@ import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
+# before the HIP runtime starts: captured hipMemsetAsync nodes (torch's reductions use them) replay
+# garbage under ROCm 7's graph packet capture -- rfnet_amd/_lib.py has the story; no replay-time cost
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -259,38 +263,31 @@ def run_c5(args, rank, world, dev, steps, warmup, use_pg):
         torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
     dt = float(tm.item())
 
-    # Beyond configs[4]: the reference's TRAINING step on the same shard (vv_recon.py:474-500: forward,
-    # the whole loss block, backward), eager launches, gradients all-reduced over the ranks (RCCL, one
-    # flat 15 MB bucket); no optimizer update.  A few steps only: it is an extra, not the metric.
+    # Beyond configs[4]: the reference's TRAINING step on the same shard (vv_recon.py:474-504: forward, the
+    # whole loss block, backward, Adam) through rfnet_amd.trainrun.TrainStep: forward + loss + backward
+    # replayed from a HIP graph (checked against the eager gradients at capture), gradients all-reduced
+    # over the ranks (RCCL, one flat 15 MB bucket), TensorFlow-form Adam.  A few steps: an extra, not the metric.
     train = None
     if not args.no_extras:
-        from rfnet_amd.rfnet import training_loss
-
-        def train_step():
-            net.zero_grad(set_to_none=True)
-            collect = {}
-            outs = net(partial, collect=collect)
-            loss = training_loss(net, outs, collect, gt, 0.01)
-            loss.backward()
-            shard.allreduce_gradients(net.parameters())
-            return loss
-
+        from rfnet_amd.trainrun import TrainStep
+        ts = TrainStep(net, B, graph=not args.c5_eager)
         for _ in range(2):
-            train_step()
+            ts(partial, gt)
         fence()
-        tsteps = 5
+        tsteps = 8
         t0 = time.perf_counter()
         for _ in range(tsteps):
-            tl = train_step()
+            tl = ts(partial, gt)
         fence()
         tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         if use_pg:
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         gnorm = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in net.parameters() if p.grad is not None))
         train = {"ms_per_step": float(tt.item()) / tsteps * 1e3, "samples_per_s": world * B * tsteps / float(tt.item()),
-                 "steps": tsteps, "what": "forward + full training loss (vv_recon.py:474-500) + backward + "
-                                          "gradient all-reduce over the ranks, eager, no optimizer update",
-                 "loss": float(tl), "grad_norm": float(gnorm), "finite": bool(torch.isfinite(gnorm).item())}
+                 "steps": tsteps, "what": "forward + full training loss (vv_recon.py:474-500) + backward + gradient "
+                                          "all-reduce over the ranks + Adam update (rfnet_amd.trainrun.TrainStep)",
+                 "mode": ts.graph_note, "loss_after": float(tl), "grad_norm": float(gnorm),
+                 "finite": bool(torch.isfinite(gnorm).item())}
     return {
         "train_step": train,
         "workload": f"RFNet recurrent forward (3000 -> 64 -> 1024 -> 16384 points, random-init weights) + "

@@ -11,7 +11,8 @@
  *   - the caller owns every buffer (outputs, gradients, scratch); the library never
  *     allocates or frees device memory, and never synchronises the stream;
  *   - gradient outputs are zero-filled by the call itself (the reference's ops do the
- *     cudaMemset inside the launcher / OpKernel);
+ *     cudaMemset inside the launcher / OpKernel) -- by a kernel, never hipMemset*: every call can
+ *     be captured into a HIP graph and replayed;
  *   - kernels are stateless and re-entrant; all work is enqueued on `stream`
  *     (a hipStream_t passed as void*; NULL = the null stream).  The reference launches
  *     on the legacy default stream with no error checking; here every call returns a status.

@@ -732,7 +732,7 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
     float *ratios = w + L.V;                            // slot 1+v: [ratioL npad | ratioR mpad]
     float *x1p = w + L.off_x1, *x2p = w + L.off_x2;
     // padded entries of every vector must read 0 (they are column scalars of padded columns)
-    RF_HIP(hipMemsetAsync(w, 0, sizeof(float) * ((size_t)b * L.bstride + 64), s));
+    RF_ZERO(w, sizeof(float) * ((size_t)b * L.bstride + 64), s);
     RF_LAUNCH("am_init", am_init_kernel, dim3(rf::ceil_div(L.npad, 256), b), dim3(256), 0, s, n, L.npad,
               multiL, xyz1, x1p, (size_t)L.npad * 3, remainL, L.bstride);
     RF_LAUNCH("am_init", am_init_kernel, dim3(rf::ceil_div(L.mpad, 256), b), dim3(256), 0, s, m, L.mpad,
@@ -855,7 +855,7 @@ int rf_matchcost(int b, int n, int m, const float *xyz1, const float *xyz2, cons
     if (b == 0) return RF_OK;
     hipStream_t s = (hipStream_t)stream;
     if (n == 0 || m == 0) {
-        RF_HIP(hipMemsetAsync(cost, 0, sizeof(float) * b, s));
+        RF_ZERO(cost, sizeof(float) * b, s);
         return RF_OK;
     }
     if (!xyz1 || !xyz2 || !match || !cost || !workspace) return RF_EINVAL;
@@ -872,8 +872,8 @@ int rf_matchcost_grad(int b, int n, int m, const float *xyz1, const float *xyz2,
                       const float *match, float *grad1, float *grad2, rf_stream_t stream) {
     if (b < 0 || b > MAX_BATCH || n < 0 || m < 0) return RF_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if ((size_t)b * n) RF_HIP(hipMemsetAsync(grad1, 0, sizeof(float) * 3 * (size_t)b * n, s));
-    if ((size_t)b * m) RF_HIP(hipMemsetAsync(grad2, 0, sizeof(float) * 3 * (size_t)b * m, s));
+    if ((size_t)b * n) RF_ZERO(grad1, sizeof(float) * 3 * (size_t)b * n, s);
+    if ((size_t)b * m) RF_ZERO(grad2, sizeof(float) * 3 * (size_t)b * m, s);
     if (b == 0 || n == 0 || m == 0) return RF_OK;
     int lsplit = MG_LSPLIT;
     while (lsplit > 1 && m / lsplit < MG_TL) lsplit /= 2;
@@ -931,11 +931,11 @@ int rf_earth_mover(int b, int n, int m, const float *xyz1, const float *xyz2, fl
     const bool want_grad = grad1 != nullptr;
     if (!cost) return RF_EINVAL;
     if (want_grad) {
-        if ((size_t)b * n) RF_HIP(hipMemsetAsync(grad1, 0, sizeof(float) * 3 * (size_t)b * n, s));
-        if ((size_t)b * m) RF_HIP(hipMemsetAsync(grad2, 0, sizeof(float) * 3 * (size_t)b * m, s));
+        if ((size_t)b * n) RF_ZERO(grad1, sizeof(float) * 3 * (size_t)b * n, s);
+        if ((size_t)b * m) RF_ZERO(grad2, sizeof(float) * 3 * (size_t)b * m, s);
     }
     if (n == 0 || m == 0) {
-        RF_HIP(hipMemsetAsync(cost, 0, sizeof(float) * b, s));
+        RF_ZERO(cost, sizeof(float) * b, s);
         return RF_OK;
     }
     if (!xyz1 || !xyz2 || !workspace) return RF_EINVAL;

@@ -312,9 +312,9 @@ int rf_merge_layer_grad(int b, int n, int m, const float *rawpts, const float *n
     if (b == 0) return RF_OK;
     if (!grad_dec) return RF_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (grad_raw && n) RF_HIP(hipMemsetAsync(grad_raw, 0, sizeof(float) * 3 * (size_t)b * n, s));
+    if (grad_raw && n) RF_ZERO(grad_raw, sizeof(float) * 3 * (size_t)b * n, s);
     if (m == 0 || n == 0) {
-        RF_HIP(hipMemsetAsync(grad_dec, 0, sizeof(float) * (size_t)b, s));
+        RF_ZERO(grad_dec, sizeof(float) * (size_t)b, s);
         return RF_OK;
     }
     if (!rawpts || !newpts || !decfactor_dev || !idx2 || !grad_refined || !grad_newpts) return RF_EINVAL;

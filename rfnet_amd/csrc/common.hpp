@@ -33,6 +33,12 @@ struct ProfScope {
 // RF_OK iff the current HIP device is a gfx950; RF_ENODEVICE otherwise (runtime.hip)
 int require_device();
 
+// Zero `bytes` bytes (a multiple of 4, 4-byte aligned) at p on stream s with a KERNEL, never
+// hipMemsetAsync: on ROCm 7 a memset node of a small buffer captured into a HIP graph writes garbage
+// from the second replay on (tools/experiments/graph_memset_probe.py), and callers may be capturing.
+// Returns an RF_* / hipError status (runtime.hip).
+int zero_async(void *p, size_t bytes, hipStream_t s);
+
 }  // namespace rf
 
 #define RF_HIP(expr)                            \
@@ -49,3 +55,8 @@ int require_device();
         hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__); \
     } while (0);                                                             \
     RF_HIP(hipGetLastError())
+
+#define RF_ZERO(ptr, bytes, stream)                                    \
+    do {                                                               \
+        if (int _zs = rf::zero_async((ptr), (bytes), (stream))) return _zs; \
+    } while (0)

@@ -325,7 +325,7 @@ static int queryball_impl(int b, int n, int m, float radius, const float *radius
     if (!xyz2 || !idx || !pts_cnt || (n > 0 && !xyz1)) return RF_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) {  // empty dataset: every ball is empty
-        RF_HIP(hipMemsetAsync(pts_cnt, 0, sizeof(int) * (size_t)nquery, s));
+        RF_ZERO(pts_cnt, sizeof(int) * (size_t)nquery, s);
         return RF_OK;
     }
     const int wpb = rf::ceil_div(m, QPW);
@@ -387,7 +387,7 @@ int rf_grouppoint_grad(int b, int n, int c, int m, int nsample, const float *gra
     hipStream_t s = (hipStream_t)stream;
     if ((size_t)b * n * c) {
         if (!grad_points) return RF_EINVAL;
-        RF_HIP(hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * n * c, s));
+        RF_ZERO(grad_points, sizeof(float) * (size_t)b * n * c, s);
     }
     long per_batch = (long)m * nsample;
     long total = (long)b * per_batch * c;

@@ -155,7 +155,7 @@ int rf_threeinterpolate_grad(int b, int n, int c, int m, const float *grad_out, 
     hipStream_t s = (hipStream_t)stream;
     if ((size_t)b * m * c) {
         if (!grad_points) return RF_EINVAL;
-        RF_HIP(hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * m * c, s));
+        RF_ZERO(grad_points, sizeof(float) * (size_t)b * m * c, s);
     }
     long total = (long)b * n * c;
     if (total == 0 || m == 0) return RF_OK;

@@ -774,8 +774,8 @@ int nn_distance_grad(int b, int n, int m, const float *xyz1, const float *xyz2, 
     if (b < 0 || n < 0 || m < 0) return RF_EINVAL;
     if (b == 0 || (n == 0 && m == 0)) return RF_OK;
     if (n == 0 || m == 0) {  // no neighbours exist: the gradient of nothing is zero
-        if (n) RF_HIP(hipMemsetAsync(grad_xyz1, 0, sizeof(float) * 3 * (size_t)b * n, s));
-        if (m) RF_HIP(hipMemsetAsync(grad_xyz2, 0, sizeof(float) * 3 * (size_t)b * m, s));
+        if (n) RF_ZERO(grad_xyz1, sizeof(float) * 3 * (size_t)b * n, s);
+        if (m) RF_ZERO(grad_xyz2, sizeof(float) * 3 * (size_t)b * m, s);
         return RF_OK;
     }
     const bool loss = src.gl != nullptr;
@@ -804,8 +804,8 @@ int nn_distance_grad(int b, int n, int m, const float *xyz1, const float *xyz2, 
         return want < 1 ? 1 : (want > maxs ? maxs : want);
     };
     const int s0 = slices_for(t0, m), s1 = slices_for(t1, n);
-    if (s0 > 1) RF_HIP(hipMemsetAsync(grad_xyz1, 0, sizeof(float) * 3 * (size_t)b * n, s));
-    if (s1 > 1) RF_HIP(hipMemsetAsync(grad_xyz2, 0, sizeof(float) * 3 * (size_t)b * m, s));
+    if (s0 > 1) RF_ZERO(grad_xyz1, sizeof(float) * 3 * (size_t)b * n, s);
+    if (s1 > 1) RF_ZERO(grad_xyz2, sizeof(float) * 3 * (size_t)b * m, s);
     a.d[0] = GradDir{xyz1, xyz2, src.gd1, idx1, src.gd2, idx2, grad_xyz1, n, m, g0, t0, s0,
                      src.dist1, src.dist2, 0, 1, has1, has2};
     a.d[1] = GradDir{xyz2, xyz1, src.gd2, idx2, src.gd1, idx1, grad_xyz2, m, n, g1, t1, s1,

@@ -1357,7 +1357,7 @@ int pruned_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2
     unsigned long long *stats = nullptr;
     if (stats_out) {
         stats = (unsigned long long *)(w + sorted_bytes(b, n) + sorted_bytes(b, m));
-        RF_HIP(hipMemsetAsync(stats, 0, 32 * sizeof(unsigned long long), s));
+        RF_ZERO(stats, 32 * sizeof(unsigned long long), s);
     }
     const int nn[2] = {n, m};
     const float *src[2] = {xyz1, xyz2};

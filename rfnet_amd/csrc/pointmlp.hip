@@ -311,7 +311,7 @@ int rf_act_grad_colsum(int b, int n, int c, const float *grad, const float *out,
     if (!sums) return RF_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) {
-        RF_HIP(hipMemsetAsync(sums, 0, sizeof(float) * (size_t)b * c, s));
+        RF_ZERO(sums, sizeof(float) * (size_t)b * c, s);
         return RF_OK;
     }
     if (!grad || (act != 0 && !out) || !workspace) return RF_EINVAL;

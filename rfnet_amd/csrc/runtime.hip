@@ -76,6 +76,33 @@ int require_device() {
     return ok ? RF_OK : RF_ENODEVICE;
 }
 
+namespace {
+// words [0, head) one by one up to the first 16-byte boundary, then 16-byte stores, then the tail words
+__global__ __launch_bounds__(256) void zero_kernel(uint32_t *p, size_t head, size_t quads, size_t words) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    if (i < head) p[i] = 0u;
+    uint4 *q = (uint4 *)(p + head);
+    for (size_t k = i; k < quads; k += stride) q[k] = make_uint4(0u, 0u, 0u, 0u);
+    const size_t t0 = head + quads * 4;
+    if (t0 + i < words) p[t0 + i] = 0u;  // fewer than 4 words
+}
+}  // namespace
+
+int zero_async(void *p, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return RF_OK;
+    if (!p || (bytes & 3) || ((uintptr_t)p & 3)) return RF_EINVAL;
+    const size_t words = bytes / 4;
+    size_t head = ((16 - ((uintptr_t)p & 15)) & 15) / 4;
+    if (head > words) head = words;
+    const size_t quads = (words - head) / 4;
+    size_t blocks = (quads + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 8192) blocks = 8192;  // grid-stride beyond 32 MB
+    RF_LAUNCH("zero_fill", zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (uint32_t *)p, head, quads, words);
+    return RF_OK;
+}
+
 }  // namespace rf
 
 extern "C" {

@@ -466,7 +466,7 @@ int rf_scatteraddpoint(int b, int n, int m, const float *out_g, const int *idx, 
     hipStream_t s = (hipStream_t)stream;
     if ((size_t)b * n) {
         if (!inp_g) return RF_EINVAL;
-        RF_HIP(hipMemsetAsync(inp_g, 0, sizeof(float) * 3 * (size_t)b * n, s));
+        RF_ZERO(inp_g, sizeof(float) * 3 * (size_t)b * n, s);
     }
     long total = (long)b * m;
     if (total == 0 || n == 0) return RF_OK;

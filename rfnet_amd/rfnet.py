@@ -230,9 +230,8 @@ def maxpool_points(t):
     if torch.is_grad_enabled() and t.requires_grad:
         return _MaxPool.apply(t) if own else t.max(1, keepdim=True).values
     if own:
-        # this repository's own two-launch kernel: faster than amax, and -- unlike a torch reduction that
-        # follows a GEMM -- it replays correctly from a captured HIP graph on this ROCm / torch build
-        # (tools/experiments/graph_gemm_reduce_debug.py: `(x @ w).amax(1)` is wrong from the 2nd replay on)
+        # this repository's own two-launch kernel: faster than amax, and independent of the ROCm graph replay
+        # fault that makes torch reductions go stale inside a captured HIP graph
         return _raw.maxpool_points(t)
     return t.amax(1, keepdim=True)
 

@@ -1,0 +1,109 @@
+"""The training step of vv_recon.py:train() on this stack (rfnet_amd/trainrun.py): schedules, the
+TensorFlow-form Adam update, and -- on the GPU -- the captured step against the eager one."""
+import numpy as np
+import pytest
+import torch
+
+
+def test_piecewise_constant_is_tensorflows():
+    from rfnet_amd.trainrun import A1_BOUNDARIES, A1_VALUES, LR_BOUNDARIES, LR_VALUES, piecewise_constant
+    # tf.train.piecewise_constant: values[0] for x <= boundaries[0], values[i] for b[i-1] < x <= b[i]
+    assert piecewise_constant(0, LR_BOUNDARIES, LR_VALUES) == 0.0005
+    assert piecewise_constant(50000, LR_BOUNDARIES, LR_VALUES) == 0.0005
+    assert piecewise_constant(50001, LR_BOUNDARIES, LR_VALUES) == 0.0002
+    assert piecewise_constant(150000, LR_BOUNDARIES, LR_VALUES) == 0.0002
+    assert piecewise_constant(150001, LR_BOUNDARIES, LR_VALUES) == 0.0001
+    assert piecewise_constant(200001, LR_BOUNDARIES, LR_VALUES) == 0.00001
+    assert piecewise_constant(10 ** 9, LR_BOUNDARIES, LR_VALUES) == 0.00001
+    assert [piecewise_constant(s, A1_BOUNDARIES, A1_VALUES) for s in (0, 50000, 50001, 150000, 150001)] == \
+        [0.01, 0.01, 0.01, 0.01, 0.001]
+    assert len(LR_VALUES) == len(LR_BOUNDARIES) + 1 and len(A1_VALUES) == len(A1_BOUNDARIES) + 1
+
+
+def test_tf_adam_update_matches_a_numpy_restatement():
+    """tf.train.AdamOptimizer (training/adam.py): lr_t = lr sqrt(1-b2^t)/(1-b1^t); p -= lr_t m/(sqrt(v)+eps)."""
+    from rfnet_amd.trainrun import TfAdam
+    rng = np.random.RandomState(0)
+    shapes = [(5, 7), (3,), (1,)]
+    ps = [torch.nn.Parameter(torch.from_numpy(rng.randn(*s))) for s in shapes]  # float64
+    ref = [p.detach().numpy().copy() for p in ps]
+    m = [np.zeros(s) for s in shapes]
+    v = [np.zeros(s) for s in shapes]
+    opt = TfAdam(ps)
+    for t in range(1, 6):
+        lr = 0.01 / t
+        gs = [rng.randn(*s) for s in shapes]
+        for p, g in zip(ps, gs):
+            p.grad = torch.from_numpy(g.copy())
+        if t == 3:
+            ps[2].grad = None  # a parameter the loss does not reach keeps its value and its moments
+        opt.step(lr)
+        lr_t = lr * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        for i, g in enumerate(gs):
+            if t == 3 and i == 2:
+                continue
+            m[i] = 0.9 * m[i] + 0.1 * g
+            v[i] = 0.999 * v[i] + 0.001 * g * g
+            ref[i] = ref[i] - lr_t * m[i] / (np.sqrt(v[i]) + 1e-8)
+        for p, r in zip(ps, ref):
+            assert np.allclose(p.detach().numpy(), r, rtol=1e-12, atol=1e-14), t
+
+
+@pytest.mark.gpu
+def test_captured_training_step_equals_the_eager_one():
+    """Three steps from the same weights on the same batches: the HIP-graph step (forward + loss +
+    backward replayed, Adam eager) and the all-eager step give the same losses and the same weights."""
+    from rfnet_amd.rfnet import RFNet
+    from rfnet_amd.trainrun import TrainStep
+    B = 2
+    g = torch.Generator().manual_seed(5)
+    batches = [((torch.rand(B, 3000, 3, generator=g) - 0.5).cuda(), (torch.rand(B, 16384, 3, generator=g) - 0.5).cuda())
+               for _ in range(3)]
+    runs = {}
+    for mode in ("graph", "eager"):
+        torch.manual_seed(0)
+        net = RFNet().cuda()
+        step = TrainStep(net, B, graph=(mode == "graph"))
+        if mode == "graph":
+            assert step.graph is not None, step.graph_note
+        else:
+            assert step.graph is None
+        losses = [float(step(p, t)) for p, t in batches]
+        assert step.global_step == 3 and step.opt.t == 3
+        runs[mode] = (losses, [p.detach().clone() for p in net.parameters()])
+    assert all(np.isfinite(runs["graph"][0]))
+    assert np.allclose(runs["graph"][0], runs["eager"][0], rtol=1e-4), (runs["graph"][0], runs["eager"][0])
+    moved = 0
+    torch.manual_seed(0)
+    init = [p.detach().clone() for p in RFNet().parameters()]
+    for a, b, i in zip(runs["graph"][1], runs["eager"][1], init):
+        # Adam's first steps are +-lr per entry whatever the gradient's size: compare on the update's scale
+        assert float((a - b).abs().max()) <= 0.2 * 3 * 0.0005 + 1e-7
+        moved += int(float((a.cpu() - i).abs().max()) > 0)
+    assert moved >= 200  # 239 of the 279 parameters are reached by the loss
+
+
+@pytest.mark.gpu
+def test_library_zero_fill_replays_correctly_from_a_graph():
+    """rf::zero_async is a kernel: a captured op that zero-fills a SMALL output (where a hipMemsetAsync node
+    would replay garbage on ROCm 7) gives the same result on every replay."""
+    from rfnet_amd import _raw
+    inp = torch.randn(2, 50, 3, device="cuda")
+    idx = torch.tensor([[0, 3, 3, 49], [1, 1, 2, 7]], dtype=torch.int32, device="cuda")
+    grad_out = torch.randn(2, 4, 3, device="cuda")
+    ref = _raw.gather_point_grad(inp, idx, grad_out)  # zero fill of 1200 bytes + scatter-add
+    exp = torch.zeros_like(inp).index_put_((torch.arange(2, device="cuda")[:, None].expand(2, 4), idx.long()), grad_out,
+                                           accumulate=True)
+    assert torch.allclose(ref, exp, atol=1e-6)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        _raw.gather_point_grad(inp, idx, grad_out)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = _raw.gather_point_grad(inp, idx, grad_out)
+    for _ in range(4):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.allclose(out, exp, atol=1e-6)
