@@ -204,7 +204,8 @@ def run_c5(args, rank, world, dev, steps, warmup, use_pg):
         with torch.no_grad():
             # gt preparation (one FPS run for both subsets + the sorted handle); in line: putting it on a
             # side stream under the forward measured 8.45 .. 10.0 ms against 8.9 in line
-            # (tools/experiments/c5_overlap_ab.py: the serial FPS chain suffers when it shares CUs)
+            # (tools/experiments/c5_overlap_ab.py: the serial FPS chain suffers when it shares CUs), and a
+            # second stream inside the capture is refused by this runtime ("operation not permitted")
             g = GroundTruth(gt, 64, 1024, overlap=False)
             p1, p2, p3, pf = net(partial)
             cd = glue.chamfer_per_sample(gt, pf, sorted1=g.h_gt)[0].mean(1)         # chamfer_big, per sample

@@ -308,6 +308,16 @@ int rf_point_affine_supported(int c, int kp);
 int rf_point_affine(int b, int n, int c, const float *y, const float *p, int kp, const float *w,
                     const float *r, int r_per_sample, int act, float *out, rf_stream_t stream);
 
+/* ------------------------------------------------------------------ runtime diagnostic --- */
+/* hipMemsetAsync(p, 0, bytes) on `stream` -- the ONE place this library issues a memset, and only for
+ * this purpose: on ROCm 7 with the graph "packet capture" on (the default; DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
+ * before the runtime starts turns it off) a memset node of a small buffer captured into a HIP graph writes
+ * garbage on later launches of the graph -- harmless for this library, whose zero fills are kernels, fatal
+ * for anything else in the same graph that does (PyTorch's reduction kernels clear their semaphores that
+ * way).  A host that captures graphs captures this call in a small test graph first and checks the buffer
+ * after every replay (rfnet_amd/_host.py:graph_replay_ok). */
+int rf_probe_memset_async(void *p, size_t bytes, rf_stream_t stream);
+
 /* ------------------------------------------------------------------ measurement hooks --- */
 /* When enabled, every kernel launch made by this library is bracketed by hipEvents recorded
  * on the launch stream.  rf_profile_collect() waits for them and returns the per-kernel sums

@@ -126,3 +126,55 @@ def invalid(msg):
     """The reference raises tf.errors.InvalidArgumentError with this wording (OP_REQUIRES in
     the OpKernels); here it is a ValueError with the same text."""
     return ValueError(msg)
+
+
+_replay_ok = {}
+
+
+def graph_replay_ok(dev=None):
+    """True when HIP graphs that contain small memset nodes -- i.e. graphs that contain torch reductions,
+    which clear their semaphores with cudaMemsetAsync -- replay correctly in this process.
+
+    On ROCm 7 a captured hipMemsetAsync of a small buffer replays garbage from the second launch on unless
+    the runtime was STARTED with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0; a captured `sum` / `max` then returns
+    stale or wrong values on some later replay (tools/experiments/graph_bug_probe2.py, train_graph.py) --
+    not reliably on the first few, so checking a captured graph's outputs is no substitute.
+    rfnet_amd/_lib.py sets the switch at import, which works only if nothing has touched the HIP runtime
+    yet (`torch.cuda.is_available()` already does).  This asks the runtime itself: a graph of
+    [rf_probe_memset_async; += 1] replayed four times must read 1 every time (measured: True exactly when
+    the switch took effect).  Callers that capture graphs holding torch reductions (trainrun.TrainStep) go
+    eager when it says no.  Cached per device; not callable during a capture."""
+    from ._lib import lib
+    dev = torch.device("cuda", torch.cuda.current_device()) if dev is None else torch.device(dev)
+    key = dev.index
+    if key not in _replay_ok:
+        ok = True
+        try:
+            with torch.cuda.device(dev), torch.no_grad():
+                buf = torch.full((64,), 5.0, device=dev)
+
+                def body():
+                    rc = lib.rf_probe_memset_async(buf.data_ptr(), 256, torch.cuda.current_stream().cuda_stream)
+                    if rc != 0:
+                        raise RuntimeError(f"rf_probe_memset_async: {rc}")
+                    buf.add_(1.0)
+
+                cur = torch.cuda.current_stream()
+                side = torch.cuda.Stream()
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    body()
+                cur.wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    body()
+                for _ in range(4):
+                    graph.replay()
+                    torch.cuda.synchronize()
+                    # (the reductions in between are part of the probe: ordinary launches between replays)
+                    ok = ok and float(buf.min()) == 1.0 and float(buf.max()) == 1.0
+                del graph
+        except Exception:  # noqa: BLE001 -- a runtime that cannot capture at all
+            ok = False
+        _replay_ok[key] = ok
+    return _replay_ok[key]

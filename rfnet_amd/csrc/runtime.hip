@@ -125,6 +125,15 @@ void rf_profile_enable(int on) { g_enabled.store(on != 0, std::memory_order_rela
 
 int rf_device_check(void) { return rf::require_device(); }
 
+// Diagnostic: the one place this library issues a hipMemsetAsync -- so that a host can capture it into a
+// graph and see whether the runtime replays memset nodes correctly (rfnet_amd/_host.py:graph_replay_ok).
+int rf_probe_memset_async(void *p, size_t bytes, rf_stream_t stream) {
+    if (!p || bytes == 0) return RF_EINVAL;
+    if (int dv = rf::require_device()) return dv;
+    RF_HIP(hipMemsetAsync(p, 0, bytes, (hipStream_t)stream));
+    return RF_OK;
+}
+
 int rf_profile_collect(const char **names, double *ms, long *launches, int cap) {
     std::lock_guard<std::mutex> lk(g_mu);
     int count = 0;

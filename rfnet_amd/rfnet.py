@@ -130,6 +130,51 @@ class _MaxPool(torch.autograd.Function):
         return gin
 
 
+class _PooledChain(torch.autograd.Function):
+    """maxpool_points(fn(*tensors)) for a per-point MLP chain `fn` whose output feeds ONLY the pooling
+    (global_mlp, encode_cell, recover_cell, the first half of refine_layer: vv_recon.py:84-131,273-286).
+    The pooled gradient reaches at most C rows per sample -- row idx[b, c] for channel c -- out of up to
+    19 384, and every layer of the chain acts row by row, so the WHOLE chain's backward lives on those
+    rows: it is recomputed on the (B, C, .) gather of the per-point inputs and differentiated there
+    (the diagonal of the recomputed (B, C, C) block is the pooled output).  Same derivative as the dense
+    backward -- which multiplies (B, N, C) matrices that are zero outside those rows: at C5 size 75 % of
+    the step's backward GEMM flops plus the activation-gradient and zero-fill passes over them -- and the
+    (B, N, C) activations of the chain are not kept for the backward at all."""
+
+    @staticmethod
+    def forward(ctx, fn, nparams, *args):
+        # args = the chain's parameters (the module's own Parameter objects: `fn` reads them from the
+        # module; they are inputs here so that autograd accumulates their gradients), then its tensors
+        tensors = args[nparams:]
+        with torch.no_grad():
+            t = fn(*tensors)
+            out, idx = _raw.maxpool_points_idx(t)
+        ctx.fn, ctx.params, ctx.n = fn, args[:nparams], t.shape[1]
+        ctx.save_for_backward(idx, *tensors)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        idx, *tensors = ctx.saved_tensors
+        ix = idx.long()  # (B, C): the arg-max row of every channel
+        np_ = len(ctx.params)
+        need_p, need_t = ctx.needs_input_grad[2:2 + np_], ctx.needs_input_grad[2 + np_:]
+        with torch.enable_grad():
+            leaves, rows = [], []
+            for t, nd in zip(tensors, need_t):
+                d = t.detach().requires_grad_(nd)
+                leaves.append(d)
+                per_point = d.dim() == 3 and d.shape[1] == ctx.n and ctx.n > 1
+                rows.append(torch.gather(d, 1, ix.unsqueeze(-1).expand(-1, -1, d.shape[-1])) if per_point else d)
+            block = ctx.fn(*rows)                               # (B, C, C)
+            pooled = torch.diagonal(block, dim1=1, dim2=2)      # (B, C) = the pooled output
+            wanted = [p for p, nd in zip(ctx.params, need_p) if nd] + [d for d, nd in zip(leaves, need_t) if nd]
+            got = iter(torch.autograd.grad(pooled, wanted, grad.reshape(pooled.shape), allow_unused=True))
+        gp = tuple(next(got) if nd else None for nd in need_p)
+        gt = tuple(next(got) if nd else None for nd in need_t)
+        return (None, None) + gp + gt
+
+
 class _MatW(torch.autograd.Function):
     """x @ w for per-point features x (..., cin) and a layer kernel w (cin, cout); torch's own matmul
     with the weight gradient computed by _wgrad."""
@@ -345,6 +390,23 @@ class RFNet(nn.Module):
             return torch.tanh(acc)
         return acc
 
+    # chains that feed only a max-pool: dense forward, row-sparse backward (_PooledChain)
+    sparse_pool_backward = True
+
+    def pooled(self, fn, layers, *tensors):
+        """maxpool_points(fn(*tensors)); `layers` = [(scope, name, call)] the chain applies."""
+        ps = []
+        for scope, name, call in layers:
+            base = f"{scope}/{name}" if scope else name
+            sc = scope if call == 0 else f"{scope}_{call}"
+            ps += [self.weights[_key(base)], self.biases[_key(f"{sc}/{name}" if sc else name)]]
+        npts = max(t.shape[1] for t in tensors)
+        cout = ps[-1].shape[0]
+        if (self.sparse_pool_backward and torch.is_grad_enabled() and tensors[0].is_cuda and npts > 2 * cout
+                and cout % 4 == 0 and cout <= 1024 and any(t.requires_grad for t in list(tensors) + ps)):
+            return _PooledChain.apply(fn, len(ps), *ps, *tensors)
+        return maxpool_points(fn(*tensors))
+
     def mlp(self, scope, prefix, n, x, call=0, first=0):
         for i in range(first, n):
             x = self.d(scope, f"{prefix}{i}", x, call=call)
@@ -352,17 +414,20 @@ class RFNet(nn.Module):
 
     # -- cells ---------------------------------------------------------------------------------
     def global_mlp(self, scope, xyz):  # vv_recon.py:84-91
-        return maxpool_points(self.mlp(scope, "ini_layer", 3, xyz))
+        return self.pooled(lambda x: self.mlp(scope, "ini_layer", 3, x),
+                           [(scope, f"ini_layer{i}", 0) for i in range(3)], xyz)
 
     def encode_cell(self, x, state, call):  # :93-112
-        s = self.dcat("cell", "state0", [x, state], call=call)
-        s = self.mlp("cell", "state", 2, s, call, first=1)
-        new_state = maxpool_points(self.d("cell", "state_end", s, call=call))
+        def chain(x_, st):
+            s = self.dcat("cell", "state0", [x_, st], call=call)
+            s = self.mlp("cell", "state", 2, s, call, first=1)
+            return self.d("cell", "state_end", s, call=call)
+        new_state = self.pooled(chain, [("cell", n, call) for n in ("state0", "state1", "state_end")], x, state)
         return self.mlp("cell", "codemlp", 2, new_state, call), new_state
 
     def recover_cell(self, scope, code, con):  # :124-131
-        t = self.dcat(scope, "recover20", [code, con])
-        t = maxpool_points(self.mlp(scope, "recover2", 2, t, first=1))
+        t = self.pooled(lambda cd, cn: self.mlp(scope, "recover2", 2, self.dcat(scope, "recover20", [cd, cn]), first=1),
+                        [(scope, "recover20", 0), (scope, "recover21", 0)], code, con)
         return self.d(scope, "recover2out1", t, act=None)
 
     def init_move_layer(self, startpts, codeword):  # :140-159
@@ -389,9 +454,9 @@ class RFNet(nn.Module):
 
     def refine_layer(self, scope, ptcoor, feat, feat2, collect=None):  # :273-308
         n = ptcoor.shape[1]
-        t = self.dcat(scope, "ini_layer0", [ptcoor, feat])
-        t = self.mlp(scope, "ini_layer", 2, t, first=1)
-        t = self.dcat(scope, "refine_layers0", [ptcoor, maxpool_points(t)])
+        mx = self.pooled(lambda pc, ft: self.mlp(scope, "ini_layer", 2, self.dcat(scope, "ini_layer0", [pc, ft]), first=1),
+                         [(scope, "ini_layer0", 0), (scope, "ini_layer1", 0)], ptcoor, feat)
+        t = self.dcat(scope, "refine_layers0", [ptcoor, mx])
         t = self.mlp(scope, "refine_layers", 3, t, first=1)
         newvec = self.d(scope, "refine_layer_final", t, act="tanh")
         if collect is not None:

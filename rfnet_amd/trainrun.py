@@ -16,9 +16,11 @@ MI355X specifics:
     from the second replay on (tools/experiments/graph_memset_probe.py) -- which is how torch's reduction
     kernels clear their semaphores, i.e. every captured `sum` / `max` goes stale.  This package sets
     DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 when it is imported before the HIP runtime starts (no cost in replay
-    time), its own library never issues a memset, and -- because an application may have initialised HIP
-    first -- the captured step is CHECKED here: two replays must reproduce the eager gradients, else the
-    step stays eager.
+    time) and its own library never issues a memset.  An application may have started HIP first
+    (`torch.cuda.is_available()` is enough), so `TrainStep` asks `_host.graph_replay_ok()` -- a memset node
+    replayed from a test graph -- and stays eager when the runtime fails it; the captured step is also
+    checked against eager gradients on a second batch (which catches what a capture froze, though not
+    this fault: it shows on later replays only).
   * data parallel: one process per GPU, each on its batch shard; after the backward the gradients are
     all-reduced in one flat bucket (RCCL over xGMI, `shard.allreduce_gradients`), outside the graph.
 """
@@ -109,27 +111,44 @@ class TrainStep:
         return loss.detach()
 
     def _capture(self, tol):
+        from ._host import graph_replay_ok
+        if not graph_replay_ok(self.partial.device):
+            self.graph_note = ("eager (torch reductions do not replay from a HIP graph in this process: the HIP "
+                               "runtime was started without DEBUG_CLR_GRAPH_PACKET_CAPTURE=0)")
+            sys.stderr.write(f"rfnet_amd.trainrun: training step not captured -- {self.graph_note}\n")
+            return
         g = torch.Generator(device="cpu").manual_seed(1234)
-        self.partial.copy_(torch.rand(self.partial.shape, generator=g) - 0.5)
-        self.gt.copy_(torch.rand(self.gt.shape, generator=g) - 0.5)
+        first = (torch.rand(self.partial.shape, generator=g) - 0.5, torch.rand(self.gt.shape, generator=g) - 0.5)
+        second = (torch.rand(self.partial.shape, generator=g) - 0.5, torch.rand(self.gt.shape, generator=g) - 0.5)
         self.alpha1.fill_(A1_VALUES[0])
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
         try:
             with torch.cuda.stream(side):
-                for _ in range(2):  # warm-up: library handles, scratch, autotuning -- none of it capturable
+                # eager on the SECOND pair of clouds (also the warm-up: library handles, scratch, autotuning --
+                # none of it capturable): the reference the replays are checked against
+                for _ in range(2):
+                    self.partial.copy_(second[0])
+                    self.gt.copy_(second[1])
                     self.net.zero_grad(set_to_none=True)
                     self._fwd_bwd()
                 ref = [None if p.grad is None else p.grad.clone() for p in self.params]
+                # captured on the FIRST pair ...
+                self.partial.copy_(first[0])
+                self.gt.copy_(first[1])
                 self.net.zero_grad(set_to_none=True)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=side):
                     loss = self._fwd_bwd()
             cur.wait_stream(side)
             worst = 0.0
-            for _ in range(2):  # the replay fault shows from the SECOND replay on
-                graph.replay()
+            graph.replay()
+            # ... and the second replay (where the runtime's replay fault shows: stale or garbage) runs on
+            # the second pair: anything the graph froze at capture, or fails to recompute, shows up here
+            self.partial.copy_(second[0])
+            self.gt.copy_(second[1])
+            graph.replay()
             torch.cuda.synchronize()
             for p, r in zip(self.params, ref):
                 if (p.grad is None) != (r is None):

@@ -5,7 +5,12 @@ checks them against the CPU oracle (oracle/) -- the oracle is imported ONLY from
 import os
 import sys
 
-import numpy as np
+# Before anything starts the HIP runtime (pytest_collection_modifyitems below asks torch for a device):
+# captured graphs that hold torch reductions replay stale results on ROCm 7 without it
+# (rfnet_amd/_lib.py).
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
+import numpy as np  # noqa: E402
 import pytest
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))

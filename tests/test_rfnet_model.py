@@ -326,3 +326,34 @@ def test_backward_kernels_match_tensor_ops():
             exp = torch.autograd.grad((ref * up).sum(), (x, w, bias))
             for a, e in zip(got, exp):
                 assert torch.allclose(a, e, rtol=1e-3, atol=1e-3 * float(e.abs().max())), (act, cout)
+
+
+@pytest.mark.gpu
+def test_row_sparse_pool_backward_equals_the_dense_backward():
+    """_PooledChain (backward of an MLP chain that feeds only a max-pool, recomputed on the arg-max rows)
+    against the ordinary dense backward of the same graph: outputs, loss and every parameter gradient."""
+    from rfnet_amd.rfnet import training_loss
+    rng = np.random.RandomState(3)
+    partial = torch.from_numpy((rng.rand(2, 3000, 3) - 0.5).astype(np.float32)).cuda()
+    gt = torch.from_numpy((rng.rand(2, 16384, 3) - 0.5).astype(np.float32)).cuda()
+    net = _seeded_net(4).cuda()
+    res = {}
+    for sparse in (True, False):
+        net.sparse_pool_backward = sparse
+        net.zero_grad(set_to_none=True)
+        collect = {}
+        outs = net(partial, collect=collect)
+        loss = training_loss(net, outs, collect, gt, 0.01)
+        loss.backward()
+        res[sparse] = (outs, float(loss), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None})
+    net.sparse_pool_backward = True
+    for a, b in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, b)  # the forward is the same code
+    assert res[True][1] == res[False][1]
+    assert set(res[True][2]) == set(res[False][2])
+    worst = ("", 0.0)
+    for n, gs in res[True][2].items():
+        gd = res[False][2][n]
+        err = float((gs - gd).abs().max()) / (float(gd.abs().max()) + 1e-12)
+        worst = max(worst, (n, err), key=lambda t: t[1])
+    assert worst[1] < 2e-3, worst

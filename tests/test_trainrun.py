@@ -51,8 +51,8 @@ def test_tf_adam_update_matches_a_numpy_restatement():
 
 @pytest.mark.gpu
 def test_captured_training_step_equals_the_eager_one():
-    """Three steps from the same weights on the same batches: the HIP-graph step (forward + loss +
-    backward replayed, Adam eager) and the all-eager step give the same losses and the same weights."""
+    """The same weights, the same batches: the HIP-graph step (forward + loss + backward replayed, Adam
+    eager) and the all-eager step give the same loss and the same gradients; three steps of either train."""
     from rfnet_amd.rfnet import RFNet
     from rfnet_amd.trainrun import TrainStep
     B = 2
@@ -68,19 +68,22 @@ def test_captured_training_step_equals_the_eager_one():
             assert step.graph is not None, step.graph_note
         else:
             assert step.graph is None
-        losses = [float(step(p, t)) for p, t in batches]
+        losses = [float(step(*batches[0]))]
+        grads0 = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+        losses += [float(step(p, t)) for p, t in batches[1:]]
         assert step.global_step == 3 and step.opt.t == 3
-        runs[mode] = (losses, [p.detach().clone() for p in net.parameters()])
-    assert all(np.isfinite(runs["graph"][0]))
-    assert np.allclose(runs["graph"][0], runs["eager"][0], rtol=1e-4), (runs["graph"][0], runs["eager"][0])
-    moved = 0
-    torch.manual_seed(0)
-    init = [p.detach().clone() for p in RFNet().parameters()]
-    for a, b, i in zip(runs["graph"][1], runs["eager"][1], init):
-        # Adam's first steps are +-lr per entry whatever the gradient's size: compare on the update's scale
-        assert float((a - b).abs().max()) <= 0.2 * 3 * 0.0005 + 1e-7
-        moved += int(float((a.cpu() - i).abs().max()) > 0)
-    assert moved >= 200  # 239 of the 279 parameters are reached by the loss
+        runs[mode] = (losses, grads0)
+    lg, le = runs["graph"][0], runs["eager"][0]
+    assert all(np.isfinite(lg)) and lg[2] < lg[0] and le[2] < le[0], (lg, le)
+    # step 0 runs on identical weights: same loss, same gradients (up to the order of the backward's atomic
+    # scatter-adds); afterwards Adam -- +-lr per entry whatever the gradient's size -- amplifies those last
+    # bits in the entries whose gradient is rounding noise, so later steps are compared loosely
+    assert abs(lg[0] - le[0]) <= 1e-6 * abs(le[0])
+    assert np.allclose(lg, le, rtol=2e-2), (lg, le)
+    assert set(runs["graph"][1]) == set(runs["eager"][1]) and len(runs["graph"][1]) >= 200
+    for n, a in runs["graph"][1].items():
+        e = runs["eager"][1][n]
+        assert float((a - e).abs().max()) <= 1e-4 * float(e.abs().max()) + 1e-9, n
 
 
 @pytest.mark.gpu
@@ -107,3 +110,17 @@ def test_library_zero_fill_replays_correctly_from_a_graph():
         graph.replay()
         torch.cuda.synchronize()
         assert torch.allclose(out, exp, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_graph_replay_probe_and_eager_fallback(monkeypatch):
+    """graph_replay_ok() is True in this process (conftest sets the runtime switch before HIP starts); when
+    it reports False the step is not captured."""
+    from rfnet_amd import _host
+    from rfnet_amd.rfnet import RFNet
+    from rfnet_amd.trainrun import TrainStep
+    assert _host.graph_replay_ok() is True
+    monkeypatch.setattr(_host, "_replay_ok", {torch.cuda.current_device(): False})
+    torch.manual_seed(0)
+    step = TrainStep(RFNet().cuda(), 1, graph=True)
+    assert step.graph is None and "DEBUG_CLR_GRAPH_PACKET_CAPTURE" in step.graph_note
