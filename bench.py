@@ -202,12 +202,14 @@ def run_c5(args, rank, world, dev, steps, warmup, use_pg):
 
     def compute():
         with torch.no_grad():
-            # gt preparation (one FPS run for both subsets + the sorted handle); in line: putting it on a
-            # side stream under the forward measured 8.45 .. 10.0 ms against 8.9 in line
-            # (tools/experiments/c5_overlap_ab.py: the serial FPS chain suffers when it shares CUs), and a
-            # second stream inside the capture is refused by this runtime ("operation not permitted")
-            g = GroundTruth(gt, 64, 1024, overlap=False)
+            # gt preparation (one FPS run for both subsets + the sorted handle).  With eager launches: in line
+            # (on a side stream under the forward it measured 8.45 .. 10.0 ms against 8.9,
+            # tools/experiments/c5_overlap_ab.py).  Inside the captured graph it is a forked branch: the
+            # serial FPS chain (32 workgroups) runs under the network's forward, 8.49 -> 8.05 ms
+            # (tools/experiments/c5_graph_overlap.py)
+            g = GroundTruth(gt, 64, 1024, overlap=torch.cuda.is_current_stream_capturing())
             p1, p2, p3, pf = net(partial)
+            g.join()
             cd = glue.chamfer_per_sample(gt, pf, sorted1=g.h_gt)[0].mean(1)         # chamfer_big, per sample
             e1 = glue.earth_mover_cost(g.gt1, p1) / 64.0                             # earth_mover terms
             e2 = glue.earth_mover_cost(g.gt2, p2) / 1024.0

@@ -561,9 +561,11 @@ class GroundTruth:
     the FPS subsets gt1 (64) / gt2 (1024) and the curve-ordered handles of gt and gt2.  None of it
     depends on the network.  FPS is a serial chain on one CU per cloud (1.1 ms at 16384 -> 1024 points
     while 7/8 of the chip idles), so with `overlap` it can be enqueued on a SIDE STREAM underneath the
-    network's forward (`join()` makes the current stream wait for it) -- measured on the MI355X that
-    is a coin toss (C5 step 8.45 .. 10.0 ms against 8.9 in line: the latency-bound chain slows down
-    when GEMM waves share its CUs), so the default is in line.  The 64-point
+    network's forward (`join()` makes the current stream wait for it).  With eager launches that is a coin
+    toss on the MI355X (C5 step 8.45 .. 10.0 ms against 8.9 in line: the latency-bound chain slows down
+    when GEMM waves share its CUs, and the host's enqueue order decides who gets there first), so the
+    default is in line; INSIDE a captured HIP graph the fork is a branch of the graph and pays reliably
+    (8.49 -> 8.05 ms per C5 step, tools/experiments/c5_graph_overlap.py).  The 64-point
     subset is the first 64 picks of the 1024-point run (greedy FPS from the same start is a prefix
     chain: one run instead of the reference's two, same indices)."""
 
@@ -572,15 +574,18 @@ class GroundTruth:
         self._side = None
         if overlap and gt.is_cuda:
             cur = torch.cuda.current_stream(gt.device)
+            capturing = torch.cuda.is_current_stream_capturing()
             self._side = _side_stream(gt.device)
-            self._side.wait_stream(cur)
+            self._side.wait_stream(cur)  # (inside a capture: a fork of the graph)
             with torch.cuda.stream(self._side):
                 self._compute(n1, n2)
-            # allocated on the side stream, consumed on the current one
-            held = [self.gt1, self.gt2, self.idx1, self.idx2]
-            held += [h.buf for h in (self.h_gt, self.h_gt2) if h is not None]
-            for t in held:
-                t.record_stream(cur)
+            if not capturing:
+                # allocated on the side stream, consumed on the current one (a capturing graph owns its
+                # pool, and record_stream is not permitted there)
+                held = [self.gt1, self.gt2, self.idx1, self.idx2]
+                held += [h.buf for h in (self.h_gt, self.h_gt2) if h is not None]
+                for t in held:
+                    t.record_stream(cur)
         else:
             self._compute(n1, n2)
 

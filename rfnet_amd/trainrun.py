@@ -106,6 +106,8 @@ class TrainStep:
     def _fwd_bwd(self):
         collect = {}
         outs = self.net(self.partial, collect=collect)
+        # (the ground truth's FPS as a forked branch of the graph under the forward, which pays in the
+        # forward-only C5 step -- 8.49 -> 8.05 ms -- measured SLOWER here: 18.7 -> 19.3 ms per step)
         loss = training_loss(self.net, outs, collect, self.gt, self.alpha1)
         loss.backward()
         return loss.detach()

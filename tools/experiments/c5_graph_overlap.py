@@ -1,0 +1,65 @@
+"""C5 step (gt preparation + forward + losses) as one HIP graph with the ground truth's FPS on a forked
+branch of the graph (a second stream inside the capture) vs in line."""
+import os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..")))
+from rfnet_amd import glue
+from rfnet_amd.rfnet import RFNet
+
+B = 32
+rng = np.random.RandomState(500)
+partial = torch.from_numpy((rng.rand(B, 3000, 3) - 0.5).astype(np.float32)).cuda()
+gt = torch.from_numpy((rng.rand(B, 16384, 3) - 0.5).astype(np.float32)).cuda()
+torch.manual_seed(0)
+net = RFNet().cuda()
+side = torch.cuda.Stream(priority=int(os.environ.get("SIDE_PRIO", "0")))
+
+
+def gt_prep():
+    idx, pts = glue.sampling(1024, gt, use_type="f")
+    return pts[:, :64].contiguous(), pts.contiguous(), glue.sort_if_large(gt)
+
+
+def compute(fork):
+    with torch.no_grad():
+        cur = torch.cuda.current_stream()
+        if fork:
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                gt1, gt2, h = gt_prep()
+        else:
+            gt1, gt2, h = gt_prep()
+        p1, p2, p3, pf = net(partial)
+        if fork:
+            cur.wait_stream(side)
+        cd = glue.chamfer_per_sample(gt, pf, sorted1=h)[0].mean(1)
+        e1 = glue.earth_mover_cost(gt1, p1) / 64.0
+        e2 = glue.earth_mover_cost(gt2, p2) / 1024.0
+        return torch.stack([cd, e1, e2], 1)
+
+
+for fork in (False, True, False, True):
+    try:
+        warm = torch.cuda.Stream()
+        warm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(warm):
+            for _ in range(2):
+                ref = compute(fork)
+        torch.cuda.current_stream().wait_stream(warm)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = compute(fork)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(30):
+            g.replay()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 30 * 1e3
+        print(f"fork={fork}: {ms:.3f} ms per step, equal to eager: {bool(torch.equal(out, ref))}", flush=True)
+    except Exception as exc:  # noqa: BLE001
+        print(f"fork={fork}: capture failed: {type(exc).__name__}: {str(exc)[:300]}", flush=True)
+        break
