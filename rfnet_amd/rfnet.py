@@ -452,7 +452,10 @@ class RFNet(nn.Module):
         so = self.mlp("init_cell", "state", 2, so, first=1)
         return pts, self.d("init_cell", "state_outo", so)
 
-    def refine_layer(self, scope, ptcoor, feat, feat2, collect=None):  # :273-308
+    def refine_layer(self, scope, ptcoor, feat, feat2, collect=None, need_feat=True):  # :273-308
+        """need_feat=False: only the refined coordinates are wanted -- `full_process` drops the features
+        the LAST refine layer returns (vv_recon.py:238), and a TensorFlow session never executes a branch
+        no fetch depends on, so the reference does not run `feat_refine*` there either."""
         n = ptcoor.shape[1]
         mx = self.pooled(lambda pc, ft: self.mlp(scope, "ini_layer", 2, self.dcat(scope, "ini_layer0", [pc, ft]), first=1),
                          [(scope, "ini_layer0", 0), (scope, "ini_layer1", 0)], ptcoor, feat)
@@ -462,11 +465,16 @@ class RFNet(nn.Module):
         if collect is not None:
             collect[f"{scope}{n}"] = newvec  # tf.add_to_collection(scope+str(ptnum), newvec), :298
         newcoor = ptcoor + newvec
+        if not need_feat:
+            return newcoor, None
         t = self.dcat(scope, "feat_refine0", [newcoor, feat2, feat])
         t = self.mlp(scope, "feat_refine", 2, t, first=1)
         return newcoor, self.d(scope, "feat_refine_final", t, act="tanh") + feat2
 
-    def decode_cell(self, code, center, state, call, up_ratio=16, collect=None):  # :310-364
+    def decode_cell(self, code, center, state, call, up_ratio=16, collect=None, need_state=True):  # :310-364
+        """need_state=False: the expanded state is not wanted (the second application's state only feeds
+        the features of the last refine layer, which `full_process` drops: its 34 layers are never
+        executed by the reference's session, nor here)."""
         n = state.shape[1]
         sc = "decode_cell"
         mask = self.dcat(sc, "mlp_mask0", [center, code], call=call)
@@ -478,6 +486,8 @@ class RFNet(nn.Module):
         if collect is not None:
             collect[f"decode_cell{n}"] = move.reshape(-1, n, up_ratio, 3)  # collection scope+str(ptnum), :338
         pts = (center.unsqueeze(2) + move.reshape(-1, n, up_ratio, 3)).reshape(-1, n * up_ratio, 3)
+        if not need_state:
+            return pts, None
         ns = self.dcat(sc, "state0", [ns, code], call=call)
         ns = self.mlp(sc, "state", 2, ns, call, first=1)
         parts, cur = [], ns
@@ -524,10 +534,12 @@ class RFNet(nn.Module):
         pin = torch.cat([pointcloud, points2], 1)
         code3, state = self.encode_cell(pin, state, 2)
         code3 = code2 + self.recover_cell("recover3", code3, pin)
-        points3, dstate = self.decode_cell(code3, points2, dstate, 1, collect=c)
+        # the state of the last decoder and the features of the last refine layer reach no output and no
+        # loss term (their parameters get no gradient in the reference either): not computed
+        points3, _ = self.decode_cell(code3, points2, dstate, 1, collect=c, need_state=False)
         final, m3 = glue.merge_layer(pointcloud, points3.contiguous(), self.decline_factor, knum=1,
                                      sorted_raw=raw_sorted, return_idx=True)
-        final, _ = self.refine_layer("refine_layer_final", final, code3, dstate, c)
+        final, _ = self.refine_layer("refine_layer_final", final, code3, None, c, need_feat=False)
         if c is not None:
             c.update({"points1": pre1, "points2": pre2, "fps32": fidx, "merge1": m1, "merge2": m2, "merge3": m3})
         return points1, points2, points3, final
