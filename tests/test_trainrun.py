@@ -124,3 +124,18 @@ def test_graph_replay_probe_and_eager_fallback(monkeypatch):
     torch.manual_seed(0)
     step = TrainStep(RFNet().cuda(), 1, graph=True)
     assert step.graph is None and "DEBUG_CLR_GRAPH_PACKET_CAPTURE" in step.graph_note
+
+
+@pytest.mark.gpu
+def test_library_zero_fill_large_and_unaligned():
+    """rf::zero_async beyond one sweep of its grid (> 32 MB), on a length that is not a multiple of 16 bytes."""
+    from rfnet_amd import _raw
+    b, n = 3, 5_000_001  # 180 MB of gradient = 45 000 009 words: head / 16-byte body / tail words all in play
+    inp = torch.empty(b, n, 3, device="cuda")
+    idx = torch.tensor([[0, n - 1, 7], [5, 5, n // 2], [n - 1, n - 2, 1]], dtype=torch.int32, device="cuda")
+    g = torch.arange(27, dtype=torch.float32, device="cuda").reshape(b, 3, 3) + 1.0
+    out = _raw.gather_point_grad(inp, idx, g)
+    assert out.shape == inp.shape
+    assert float(out.abs().sum()) == float(g.abs().sum())  # everything else is zero
+    assert torch.equal(out[0, 0], g[0, 0]) and torch.equal(out[0, n - 1], g[0, 1])
+    assert torch.equal(out[1, 5], g[1, 0] + g[1, 1]) and torch.equal(out[2, n - 2], g[2, 1])
