@@ -427,6 +427,43 @@ def main():
 
     extras = {}
     if not args.no_extras:
+        # ---- independent steps in flight: throughput when the caller has more than one batch ----
+        # `value` above issues the K steps back to back on ONE stream (a step = sort -> sweep -> grad, each
+        # waiting for the one before).  A caller with several independent Chamfers (an evaluation over many
+        # models, the five Chamfer terms of a training step) can issue them round-robin on S streams, each
+        # with its own ChamferStep plan: the 96-workgroup sort and the kernel tails of one step then run
+        # under another step's sweep.  Same kernels, same outputs, the latency of ONE step unchanged; cutting
+        # a single step's batch over streams instead does NOT pay (tools/experiments/split_step_streams.py).
+        pipe = {}
+        for ns in (2, 3):
+            streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
+            plans = [ChamferStep(B, N, M, dev) for _ in range(ns)]
+
+            def run(k):
+                for i in range(k):
+                    with torch.cuda.stream(streams[i % ns]):
+                        plans[i % ns](xyz1, xyz2, gd1, gd2)
+
+            for st in streams:
+                st.wait_stream(torch.cuda.current_stream())
+            run(max(args.warmup, ns))
+            fence()
+            tp = time.perf_counter()
+            run(args.steps)
+            fence()
+            tpipe = torch.tensor([time.perf_counter() - tp], dtype=torch.float64, device=dev)
+            if use_pg:
+                torch.distributed.all_reduce(tpipe, op=torch.distributed.ReduceOp.MAX)
+            same = all(bool(torch.equal(x, y)) for pl in plans
+                       for x, y in zip((pl.dist1, pl.idx1, pl.dist2, pl.idx2), out[:4]))
+            pipe[str(ns)] = {"value": world * float(B) * N * M * args.steps / float(tpipe.item()), "unit": "pairs/s",
+                             "ms_per_step": float(tpipe.item()) / args.steps * 1e3,
+                             "outputs_identical_to_the_serial_step": same}
+            del plans, streams
+        extras["independent_steps_in_flight"] = {
+            "what": "the same K steps issued round-robin on S streams, one ChamferStep plan per stream (throughput "
+                    "with several independent batches in flight; `value` is the one-stream figure)",
+            "streams": pipe}
         # ---- the distributions the operator meets in the model ---------------------------------
         byd = {}
         dsteps = max(5, min(20, args.steps))
