@@ -11,3 +11,28 @@ The reference's import paths (`tf_ops.CD.tf_nndistance`, `pc_distance.tf_approxm
 exist at the repository root and re-export these modules.
 """
 __version__ = "0.1.0"
+
+
+def enable_graph_safe_runtime():
+    """Opt-in, for hosts that capture HIP graphs holding torch reductions (`sum`, `max`, `amax`, ...).
+
+    ROCm 7's HIP-graph "packet capture" replays a captured hipMemsetAsync of a small buffer with garbage
+    from the second replay on (tools/experiments/graph_memset_probe.py).  librfops.so never issues a memset
+    (rf::zero_async is a kernel), but torch's reduction kernels clear their semaphores that way, so such a
+    graph goes stale.  The runtime switch DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 costs nothing in replay time
+    (measured: 8.51 vs 8.52 ms per C5 step) but only counts if it is set BEFORE the HIP runtime starts
+    (`torch.cuda.is_available()` starts it).  This function sets it (unless the host already chose a value)
+    and returns True when it was set in time to matter as far as this process can tell, i.e. torch has not
+    initialised CUDA/HIP yet; `rfnet_amd._host.graph_replay_ok()` asks the running runtime itself.
+
+    `import rfnet_amd` does NOT call this: the binding leaves os.environ untouched.  The package's own
+    entry points that capture such graphs (`python -m rfnet_amd.trainrun`, `python -m rfnet_amd.evalrun`,
+    bench.py) call it first thing.
+    """
+    import os
+    os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+    try:
+        import torch
+        return not torch.cuda.is_initialized()
+    except ImportError:
+        return True

@@ -13,18 +13,15 @@ import os
 # add its own, and the process would hold two HIP runtimes that cannot share a device context (observed
 # on the MI355X box: rf_device_check() = RF_ENODEVICE, or torch reporting no GPU, depending on who
 # initialised first).  A host without torch gets the system runtime, alone, which is equally fine.
-# ROCm 7's HIP-graph "packet capture" replays a captured hipMemsetAsync of a small buffer with garbage
-# from the second replay on (tools/experiments/graph_memset_probe.py).  librfops.so never issues a memset
-# (rf::zero_async is a kernel), but torch's reduction kernels clear their semaphores that way, so any
-# `sum` / `max` inside a captured graph goes stale -- and this package captures graphs that contain them
-# (evalrun.GraphedForward, trainrun.TrainStep, bench.py's C5 step).  The switch costs nothing in replay
-# time (measured: 8.51 vs 8.52 ms per C5 step, 2.23 vs 2.20 ms batch-1) and only takes effect if the HIP
-# runtime has not started yet; an application that wants otherwise sets the variable itself.
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
-import torch  # noqa: F401,E402  (import order is the point)
+# (Importing this module changes nothing in the host process: no environment variable is written.  Hosts
+# that capture HIP graphs holding torch reductions call rfnet_amd.enable_graph_safe_runtime() first.)
+try:
+    import torch  # noqa: F401  (import order is the point)
+except ImportError:  # a host without PyTorch: the system HIP runtime, alone
+    torch = None
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-# RFOPS_LIB: load another build of the same library (A/B of kernel variants, tools/ab_chamfer.py)
+# RFOPS_LIB: load another build of the same library (A/B of kernel variants, tools/ab_variants.py)
 LIB_PATH = os.environ.get("RFOPS_LIB") or os.path.join(_PKG, "librfops.so")
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t

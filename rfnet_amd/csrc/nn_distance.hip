@@ -600,7 +600,7 @@ Plan make_plan(int b, int n, int m, int dirs = 3) {
     p.no_pad = round_up(p.no, PADQ);
     p.nc_pad = round_up(p.nc, PADQ);
     p.oblocks = rf::ceil_div(p.no, 64 * RR);
-    // Split the candidate range so that (measured, tools/ab_chamfer.py, one device):
+    // Split the candidate range so that (measured in round 1 with an environment-knob A/B tool, one device; the knobs are compile-time now: tools/build_variant.py + tools/ab_variants.py):
     //   * at least one residency round exists: 4096 waves (118 VGPRs -> 4 per SIMD x 1024 SIMDs);
     //   * a wave's span is ~1024 candidates when the set is large (16384 x 16384: 1.28 ms at
     //     span 1024 vs 1.36 at 4096 and 1.42 at 256), but never below 128.

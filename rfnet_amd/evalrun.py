@@ -13,6 +13,7 @@ graphs instead of a tracing compiler").  Replay runs the very same kernels: outp
 bit-identical to the eager forward.
 """
 import os
+import sys
 import time
 
 import numpy as np
@@ -24,11 +25,24 @@ from . import evalio, glue
 class GraphedForward:
     """net(x) for one fixed input shape as a captured HIP graph.  `__call__` copies the input into
     the graph's static buffer, replays, and returns the outputs (the graph's own static tensors:
-    valid until the next call)."""
+    valid until the next call).
 
-    def __init__(self, net, example, warmup=3):
+    The forward holds torch reductions, which replay stale on ROCm 7 unless the HIP runtime was started
+    with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (`rfnet_amd.enable_graph_safe_runtime()`): the runtime is asked
+    (`_host.graph_replay_ok`) and, beyond that, ONE replay on a second input is compared with the eager
+    forward before the graph is trusted.  Either check failing leaves `self.graph = None` and every call
+    eager, with a note on stderr (`self.mode` says which)."""
+
+    def __init__(self, net, example, warmup=3, check=True):
+        from ._host import graph_replay_ok
         self.net = net
+        self.graph = None
         self.static_in = example.detach().clone()
+        if not graph_replay_ok(example.device):
+            self.mode = ("eager (torch reductions do not replay from a HIP graph in this process: the HIP runtime "
+                         "was started without DEBUG_CLR_GRAPH_PACKET_CAPTURE=0)")
+            sys.stderr.write(f"rfnet_amd.evalrun: forward not captured -- {self.mode}\n")
+            return
         cur = torch.cuda.current_stream(example.device)
         side = torch.cuda.Stream(device=example.device)
         side.wait_stream(cur)
@@ -39,8 +53,24 @@ class GraphedForward:
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self.static_out = net(self.static_in)
+        self.mode = "hip graph"
+        if check:
+            # a replay on a SECOND input against the eager forward (what a capture froze shows here)
+            probe = torch.roll(example.detach(), 1, dims=-2) * 0.97
+            with torch.no_grad():
+                want = [t.clone() for t in net(probe)]
+            got = self(probe)
+            same = all(bool(torch.allclose(a, b, rtol=1e-5, atol=1e-6)) for a, b in zip(got, want))
+            self.static_in.copy_(example)
+            if not same:
+                self.graph = None
+                self.mode = "eager (a replay on a second input differed from the eager forward)"
+                sys.stderr.write(f"rfnet_amd.evalrun: captured forward discarded -- {self.mode}\n")
 
     def __call__(self, x):
+        if self.graph is None:
+            with torch.no_grad():
+                return self.net(x)
         self.static_in.copy_(x)
         self.graph.replay()
         return self.static_out
@@ -89,7 +119,8 @@ def evaluate(net, list_path, data_dir, results_dir, num_input_points=3000, save_
         "average_cd": float(np.mean([r[1] for r in rows])) if rows else 0.0,
         "average_emd": float(np.mean([r[2] for r in rows])) if rows else 0.0,
         "per_category": evalio.per_category_means(rows),
-        "graph": fwd is not None,
+        "graph": fwd is not None and fwd.graph is not None,
+        "mode": fwd.mode if fwd is not None else "eager (graph not requested)",
     }
 
 
@@ -109,6 +140,8 @@ def main(argv=None):
     ap.add_argument("--save_pcd", action="store_true")
     ap.add_argument("--no_graph", action="store_true", help="eager forward instead of the captured HIP graph")
     a = ap.parse_args(argv)
+    from . import enable_graph_safe_runtime
+    enable_graph_safe_runtime()  # before the HIP runtime starts
     net = RFNet().cuda().eval()
     if a.checkpoint:
         net.load_state_dict(torch.load(a.checkpoint, map_location="cuda"))

@@ -150,12 +150,19 @@ class _PooledChain(torch.autograd.Function):
             t = fn(*tensors)
             out, idx = _raw.maxpool_points_idx(t)
         ctx.fn, ctx.params, ctx.n = fn, args[:nparams], t.shape[1]
+        # the backward RE-RUNS fn, which reads the module's CURRENT weights: their versions are recorded
+        # so that an in-place update between forward and backward (two forwards, an optimizer step, then
+        # the first one's backward) raises instead of silently differentiating other weights
+        ctx.versions = tuple(p._version for p in ctx.params)
         ctx.save_for_backward(idx, *tensors)
         return out
 
     @staticmethod
     def backward(ctx, grad):
         idx, *tensors = ctx.saved_tensors
+        if tuple(p._version for p in ctx.params) != ctx.versions:
+            raise RuntimeError("_PooledChain: a parameter of the chain was modified in place between this forward "
+                               "and its backward (the backward recomputes the chain from the current weights)")
         ix = idx.long()  # (B, C): the arg-max row of every channel
         np_ = len(ctx.params)
         need_p, need_t = ctx.needs_input_grad[2:2 + np_], ctx.needs_input_grad[2 + np_:]
@@ -394,7 +401,11 @@ class RFNet(nn.Module):
     sparse_pool_backward = True
 
     def pooled(self, fn, layers, *tensors):
-        """maxpool_points(fn(*tensors)); `layers` = [(scope, name, call)] the chain applies."""
+        """maxpool_points(fn(*tensors)); `layers` = [(scope, name, call)] the chain applies.
+        The row-sparse backward (_PooledChain) sends each channel's pooled gradient to ONE arg-max row, as
+        torch's `max` does; every chain routed here ENDS IN A ReLU (ties are zeros, whose derivative is
+        zero on every tied row, so the choice of row cannot matter) -- a chain ending otherwise must use
+        the dense path (`sparse_pool_backward = False`)."""
         ps = []
         for scope, name, call in layers:
             base = f"{scope}/{name}" if scope else name

@@ -68,6 +68,10 @@ def scatter_from_rank0(full, rank, world, device=None, group=None):
         dev = torch.device("cuda", torch.cuda.current_device())
     else:
         dev = full.device if rank == 0 else torch.device("cpu")
+    if rank == 0 and full.device != dev:
+        # the usual case: rank 0 loaded the data on the host.  The collective needs the source where the
+        # receive buffers are (RCCL moves device buffers only; gloo takes CPU tensors)
+        full = full.to(dev, non_blocking=True)
     B = shape[0]
     if B % world == 0:
         mine = torch.empty((B // world,) + tuple(shape[1:]), dtype=dtype, device=dev)

@@ -14,9 +14,10 @@ MI355X specifics:
     schedules move without re-capturing.
   * ROCm 7's graph "packet capture" replays a captured hipMemsetAsync of a small buffer with garbage
     from the second replay on (tools/experiments/graph_memset_probe.py) -- which is how torch's reduction
-    kernels clear their semaphores, i.e. every captured `sum` / `max` goes stale.  This package sets
-    DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 when it is imported before the HIP runtime starts (no cost in replay
-    time) and its own library never issues a memset.  An application may have started HIP first
+    kernels clear their semaphores, i.e. every captured `sum` / `max` goes stale.  This module's `main()`
+    (like evalrun's and bench.py) calls `rfnet_amd.enable_graph_safe_runtime()`, which sets
+    DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before the HIP runtime starts (no cost in replay time; importing the
+    package does not touch the environment), and the library never issues a memset.  An application may have started HIP first
     (`torch.cuda.is_available()` is enough), so `TrainStep` asks `_host.graph_replay_ok()` -- a memset node
     replayed from a test graph -- and stays eager when the runtime fails it; the captured step is also
     checked against eager gradients on a second batch (which catches what a capture froze, though not
@@ -195,6 +196,8 @@ def main(argv=None):
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args(argv)
+    from . import enable_graph_safe_runtime
+    enable_graph_safe_runtime()  # before anything starts the HIP runtime (the next line does)
     if not torch.cuda.is_available():
         raise SystemExit("rfnet_amd.trainrun needs a HIP device (MI355X); there is no CPU fallback")
     rank, world, _ = shard.init_from_env()
