@@ -234,11 +234,25 @@ int rf_nn_distance_sorted(int b, int n, int m, const void *sorted1, const void *
 }
 
 // ------------------------------------------------------------------ forward + backward -----
-size_t rf_chamfer_step_workspace_bytes(int b, int n, int m) { return rf_nn_distance_workspace_bytes(b, n, m); }
+size_t rf_chamfer_step_workspace_bytes(int b, int n, int m) {
+    if (b <= 0 || n <= 0 || m <= 0) return 0;
+    if (rfd::resolve_mode(b, n, m, RF_NN_AUTO) == RF_NN_CULLED) return rfp::pruned_step_workspace_bytes(b, n, m);
+    return rf_nn_distance_workspace_bytes(b, n, m);
+}
 
 int rf_chamfer_step(int b, int n, int m, const float *xyz1, const float *xyz2, const float *grad_dist1,
                     const float *grad_dist2, float *dist1, int *idx1, float *dist2, int *idx2, float *grad_xyz1,
                     float *grad_xyz2, void *workspace, size_t workspace_bytes, rf_stream_t stream) {
+    // Large clouds (the culled sweep's sizes): the sweep leaves, per query and in sorted order, its winner's
+    // sorted position and its upstream gradient, and the backward runs in sorted index space
+    // (nnp_grad_sorted_kernel).  Other shapes: the two ops back to back.
+    if (b > 0 && n > 0 && m > 0 && rfd::resolve_mode(b, n, m, RF_NN_AUTO) == RF_NN_CULLED) {
+        if (!xyz1 || !xyz2 || !dist1 || !idx1 || !dist2 || !idx2 || !workspace || !grad_dist1 || !grad_dist2 ||
+            !grad_xyz1 || !grad_xyz2)
+            return RF_EINVAL;
+        return rfp::pruned_step(b, n, m, xyz1, xyz2, grad_dist1, grad_dist2, dist1, idx1, dist2, idx2, grad_xyz1,
+                                grad_xyz2, workspace, workspace_bytes, (hipStream_t)stream);
+    }
     if (int e = rf_nn_distance(b, n, m, xyz1, xyz2, dist1, idx1, dist2, idx2, workspace, workspace_bytes, stream))
         return e;
     return rf_nn_distance_grad(b, n, m, xyz1, xyz2, grad_dist1, idx1, grad_dist2, idx2, grad_xyz1, grad_xyz2,

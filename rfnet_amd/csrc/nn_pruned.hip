@@ -70,6 +70,10 @@ namespace {
 #ifndef RFP_HIST
 #define RFP_HIST 0  // 1 (instrumented build): block scans by number of active lanes -> stats[10..13]
 #endif
+#ifndef RFP_GS_ABL
+#define RFP_GS_ABL 0  // ablation builds of the sorted-space backward (WRONG results, timing only; profiles/r03_ab_grad_sorted.txt):
+                      // 1 no group visits, 2 no LDS atomics
+#endif
 constexpr int NSH = RFP_NSH;
 constexpr int BS = 16;             // candidates per block
 constexpr int SBB = 4;             // blocks per superblock
@@ -99,6 +103,8 @@ struct SortArgs {
     float *box64[2];
     int nsets;  // 2 for the Chamfer sweep (both clouds of every batch element), 1 for a single set
     int split[2];  // workgroups per cloud of the set (register-resident kernel): 1, or 2 / 4 = one per slice of the key space
+    int *pos0[2];  // (b) sorted position of the point with original index 0 (what an index "0" of the reference's
+                   // NaN / no-candidate policy refers to, for the sorted-space backward)
     unsigned long long *dbg;  // optional (with stats): s_memtime stamps of the sort's phases, [16..31]
 };
 
@@ -460,6 +466,7 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
             b64[j] = c < 3 ? INFINITY : (c >= 4 && c < 7 ? -INFINITY : 0.f);
         }
     }
+    if (tid == 0 && pk[0] != 0xFFFFFFFFu) a.pos0[set][bi] = base + (int)pk[0];  // point 0 is thread 0's first
     for (int h0 = 0; h0 < seglen; h0 += HALF) {
         const int cnt = min(HALF, seglen - h0);  // multiple of 64
 #pragma unroll
@@ -713,6 +720,7 @@ __global__ __launch_bounds__(STPB) void nnp_sort_kernel(SortArgs a) {
         if constexpr (REG) key = pkey[k];
         else key = key_of(x, y, z);
         const unsigned pos = atomicAdd(&hist[key], 1u);
+        if (i == 0) a.pos0[set][bi] = (int)pos;
         oxyz[(size_t)pos * 3 + 0] = x;
         oxyz[(size_t)pos * 3 + 1] = y;
         oxyz[(size_t)pos * 3 + 2] = z;
@@ -786,6 +794,46 @@ struct SweepArgs {
     int kstride;     // key-list entries per wave (dynamic LDS: waves * kstride * 4 bytes)
 };
 
+// What the sweep of rf_chamfer_step leaves behind for the sorted-space backward (nnp_grad_sorted_kernel), per
+// query and in SORTED query order -- coalesced stores from the lane that owns the query:
+//   wp   sorted position of its nearest neighbour in the other set (-1: padding)
+//   own  its own gradient term (q - winner) * 2 gd, three floats (the winner's coordinates are one gather at
+//        the end of the wave's life, hidden under the other waves' scans).  The term the query scatters into
+//        its winner's gradient is exactly -own (tf_nndistance_g.cu:146-151: the same product, subtracted), so
+//        the backward needs no coordinates at all.
+// and per 64-query group a 64-bit mask of the BUCKETS of the other set its winners fall into (bucket = sorted
+// position / qbucket, 64 buckets per set): a destination tile of the backward -- a whole number of buckets --
+// then visits only the groups whose mask meets its own.  gd: (b, n[dir]) upstream gradients in original order.
+// Few kernel arguments on purpose (the sweep is SGPR-bound): the three arrays of both sets live in ONE buffer
+// whose layout is a function of (b, npad) -- emit_layout() below, host and device alike -- and pos0 (the sorted
+// position of original index 0) sits behind box64 inside the sorted set.
+struct GradEmit {
+    const float *gd[2];
+    char *base;
+    int qbucket[2];  // sorted positions per bucket of set d: ceil(npad[d] / 64)
+};
+struct EmitView {
+    int *wp;       // (b, npad)
+    float *own;    // (b, npad, 3)
+    unsigned long long *mask;  // (b, npad / 64)
+};
+__host__ __device__ inline size_t emit_align(size_t v) { return (v + 255) / 256 * 256; }
+__host__ __device__ inline size_t emit_set_bytes(int b, int npad) {
+    return emit_align((size_t)b * npad * sizeof(int)) + emit_align((size_t)b * npad * 3 * sizeof(float)) +
+           emit_align((size_t)b * (npad / 64) * sizeof(unsigned long long));
+}
+__host__ __device__ inline EmitView emit_layout(char *base, int b, int npad0, int npad1, int set) {
+    char *p = base + (set ? emit_set_bytes(b, npad0) : 0);
+    const int npad = set ? npad1 : npad0;
+    EmitView v;
+    v.wp = (int *)p;
+    p += emit_align((size_t)b * npad * sizeof(int));
+    v.own = (float *)p;
+    p += emit_align((size_t)b * npad * 3 * sizeof(float));
+    v.mask = (unsigned long long *)p;
+    return v;
+}
+
 __device__ __forceinline__ float min3_acc(float acc, float a, float b) {
     asm("v_min3_f32 %0, %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
     return acc;
@@ -847,10 +895,11 @@ __device__ __forceinline__ float scan8(const float (&r)[24], float qx, float qy,
 // neighbour of every point -> dist_dir, idx_dir (b, n[dir]).  SHARED4: the 4 waves of the
 // workgroup work on the same group, wave `wib` taking every 4th candidate superblock.
 // stats (optional): [dir][4] = waves, superblock steps, max steps of a wave, block scans; [8+dir] = max scans.
-template <bool SHARED4>
+template <bool SHARED4, bool GRAD>
 __device__ __forceinline__ void sweep_group(
-    const SweepArgs &a, const int dir, const int gid, const int wib, const int lane, unsigned *__restrict__ keys_dyn,
-    int *shbest, float (*md)[64], unsigned (*mi)[64], const float *__restrict__ xyz0, const float *__restrict__ xyz1,
+    const SweepArgs &a, const GradEmit &ge, const int dir, const int gid, const int wib, const int lane,
+    unsigned *__restrict__ keys_dyn, int *shbest, float (*md)[64], unsigned (*mi)[64], int (*mp)[64],
+    const float *__restrict__ xyz0, const float *__restrict__ xyz1,
     const int *__restrict__ orig0, const int *__restrict__ orig1, const float *__restrict__ b16_0,
     const float *__restrict__ b16_1, const float *__restrict__ b64_0, const float *__restrict__ b64_1,
     float *__restrict__ dist0, float *__restrict__ dist1, int *__restrict__ idx0, int *__restrict__ idx1,
@@ -874,6 +923,10 @@ __device__ __forceinline__ void sweep_group(
     const float qz = Q[(size_t)(g * SB + lane) * 3 + 2];
     const int qorig = Qo[g * SB + lane];
     const bool valid = qorig >= 0;
+    float gq = 0.f;  // upstream gradient of this query's distance (GRAD): fetched now, used in the epilogue
+    if constexpr (GRAD) {
+        if (valid) gq = ge.gd[dir][(size_t)bi * a.n[dir] + qorig];
+    }
     // A query with a NaN coordinate can never tighten its bound (every d2 is NaN): it takes no part
     // in the traversal -- it would drag its whole wave through every superblock -- and is written as
     // (NaN, 0), what the reference returns for it (tf_nndistance_g.cu:27-31).
@@ -913,7 +966,7 @@ __device__ __forceinline__ void sweep_group(
     // key whose low 10 bits are the superblock id: the wave minimum of the keys is the next
     // superblock.  Entry e of this wave's list is superblock sub + nsub*e; lane e % 64 owns it
     // (writes it, consumes it, keeps the minimum of its entries in `lmin`).
-    auto traverse = [&](auto track_c, const float *blo, const float *bhi, unsigned &besti2) {
+    auto traverse = [&](auto track_c, const float *blo, const float *bhi, unsigned &besti2, int &wpos2) {
         constexpr bool TRACK = decltype(track_c)::value;
         // up to 320 entries (every cloud that fits the register-resident sort: 16384 points = 256
         // superblocks, 257 when two workgroups sorted it): the lane's entries e = lane + 64 i live in
@@ -1049,6 +1102,10 @@ __device__ __forceinline__ void sweep_group(
 #pragma unroll
                         for (int u = 0; u < 8; u++) {
                             const float d = rf::d2_fma(r[u * 3 + 0] - qx, r[u * 3 + 1] - qy, r[u * 3 + 2] - qz);
+                            if constexpr (GRAD) {
+                                const bool better = d == cull && io[u] < besti2;
+                                wpos2 = better ? (s * SBB + j) * BS + h * 8 + u : wpos2;
+                            }
                             besti2 = min(besti2, d == cull ? io[u] : 0xFFFFFFFFu);
                         }
                     }
@@ -1116,7 +1173,8 @@ __device__ __forceinline__ void sweep_group(
     };
 
     unsigned besti = 0xFFFFFFFFu;
-    traverse(std::false_type{}, glo, ghi, besti);
+    int wpos = -1;  // (GRAD) sorted position of the winner in the candidate set
+    traverse(std::false_type{}, glo, ghi, besti, wpos);
     __builtin_amdgcn_s_setprio(0);
 
     // lowest original index among the exact matches of the winning block
@@ -1126,6 +1184,9 @@ __device__ __forceinline__ void sweep_group(
 #pragma unroll 4
         for (int u = 0; u < BS; u++) {
             const float d = rf::d2_fma(cp[u * 3 + 0] - qx, cp[u * 3 + 1] - qy, cp[u * 3 + 2] - qz);
+            if constexpr (GRAD) {
+                if (d == best && (unsigned)co[u] < besti) wpos = bblk * BS + u;
+            }
             if (d == best) besti = min(besti, (unsigned)co[u]);  // padding carries 0xFFFFFFFF
         }
     }
@@ -1138,8 +1199,12 @@ __device__ __forceinline__ void sweep_group(
                               wave_max_f32(flagged ? qz : -INFINITY)};
         cull = flagged ? best : -INFINITY;  // the wave's own minima are final: match against them
         unsigned besti2 = 0xFFFFFFFFu;
-        traverse(std::true_type{}, flo, fhi, besti2);
-        if (flagged) besti = besti2;
+        int wpos2 = -1;
+        traverse(std::true_type{}, flo, fhi, besti2, wpos2);
+        if (flagged) {
+            besti = besti2;
+            wpos = wpos2;
+        }
     }
 
     if (stats && lane == 0) {
@@ -1156,6 +1221,7 @@ __device__ __forceinline__ void sweep_group(
     if (shared4) {
         md[wib][lane] = best;
         mi[wib][lane] = besti;
+        if constexpr (GRAD) mp[wib][lane] = wpos;
         __syncthreads();
         if (wib != 0) return;
 #pragma unroll
@@ -1165,12 +1231,40 @@ __device__ __forceinline__ void sweep_group(
             if (d < best || (d == best && i < besti)) {
                 best = d;
                 besti = i;
+                if constexpr (GRAD) wpos = mp[w][lane];
             }
         }
     }
     if (valid) {
         (dir ? dist1 : dist0)[(size_t)bi * a.n[dir] + qorig] = qnan ? NAN : best;
         (dir ? idx1 : idx0)[(size_t)bi * a.n[dir] + qorig] = (qnan || besti == 0xFFFFFFFFu) ? 0 : (int)besti;
+    }
+    if constexpr (GRAD) {
+        // index 0 of the NaN / no-match policy above = the candidate set's point with ORIGINAL index 0
+        const int *pos0 = (const int *)((const char *)(cd ? b64_1 : b64_0) +
+                                        emit_align((size_t)a.b * (a.npad[cd] / SB) * B64F * sizeof(float)));
+        const int p0 = pos0[bi];  // uniform
+        const EmitView ev = emit_layout(ge.base, a.b, a.npad[0], a.npad[1], dir);
+        const int w = (qnan || besti == 0xFFFFFFFFu) ? p0 : wpos;
+        const int wc = valid ? w : 0;
+        const float cx = C[(size_t)wc * 3 + 0], cy = C[(size_t)wc * 3 + 1], cz = C[(size_t)wc * 3 + 2];
+        const float g2 = gq + gq;  // the reference's arithmetic: g = gd + gd; (a - b) * g rounded on its own
+        const size_t r = (size_t)bi * a.npad[dir] + g * SB + lane;
+        ev.wp[r] = valid ? w : -1;
+        float *ow = ev.own + r * 3;
+        ow[0] = (qx - cx) * g2;
+        ow[1] = (qy - cy) * g2;
+        ow[2] = (qz - cz) * g2;
+        // the buckets this group's winners fall into: one trip per DISTINCT bucket (a handful: the winners of 64
+        // consecutive sorted queries are neighbours)
+        const int bkt = w / ge.qbucket[cd];
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(valid), gm = 0ull;
+        while (todo) {
+            const int bb = __builtin_amdgcn_readlane(bkt, __builtin_ctzll(todo));
+            gm |= 1ull << bb;
+            todo &= ~__builtin_amdgcn_ballot_w64(bkt == bb);
+        }
+        if (lane == 0) ev.mask[(size_t)bi * G + g] = gm;
     }
 }
 
@@ -1183,8 +1277,9 @@ __device__ __forceinline__ void sweep_group(
 // was tried as well: 3x slower -- same-address device-scope atomics serialise at ~25 ns each.
 // (7 waves per SIMD: the loop's 48 record + 24 box SGPRs put the kernel at 106 SGPRs = 6 waves; capping
 // it at 7 spills 16 cold ones to VGPR lanes and measures 2 % faster, capping at 8 spills into the loop)
+template <bool GRAD>
 __global__ __launch_bounds__(64 * NSH) __attribute__((amdgpu_waves_per_eu(7, 7))) void nnp_sweep_kernel(
-    SweepArgs a, const float *__restrict__ xyz0, const float *__restrict__ xyz1, const int *__restrict__ orig0,
+    SweepArgs a, GradEmit ge, const float *__restrict__ xyz0, const float *__restrict__ xyz1, const int *__restrict__ orig0,
     const int *__restrict__ orig1, const float *__restrict__ b16_0, const float *__restrict__ b16_1,
     const float *__restrict__ b64_0, const float *__restrict__ b64_1, float *__restrict__ dist0,
     float *__restrict__ dist1, int *__restrict__ idx0, int *__restrict__ idx1,
@@ -1193,6 +1288,7 @@ __global__ __launch_bounds__(64 * NSH) __attribute__((amdgpu_waves_per_eu(7, 7))
     __shared__ int shbest[64];
     __shared__ float md[NSH][64];
     __shared__ unsigned mi[NSH][64];
+    __shared__ int mp[GRAD ? NSH : 1][64];
 
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1220,13 +1316,169 @@ __global__ __launch_bounds__(64 * NSH) __attribute__((amdgpu_waves_per_eu(7, 7))
     if (dir) wg -= a.wg0;
 #endif
     if (a.nw[dir] == NSH) {
-        sweep_group<true>(a, dir, bi * a.groups[dir] + wg, wib, lane, keys_dyn, shbest, md, mi, xyz0, xyz1, orig0, orig1,
-                          b16_0, b16_1, b64_0, b64_1, dist0, dist1, idx0, idx1, stats);
+        sweep_group<true, GRAD>(a, ge, dir, bi * a.groups[dir] + wg, wib, lane, keys_dyn, shbest, md, mi, mp, xyz0, xyz1,
+                                orig0, orig1, b16_0, b16_1, b64_0, b64_1, dist0, dist1, idx0, idx1, stats);
     } else {
         const int g = wg * (int)(blockDim.x >> 6) + wib;
         if (g >= a.groups[dir]) return;  // (no barriers on this path)
-        sweep_group<false>(a, dir, bi * a.groups[dir] + g, wib, lane, keys_dyn, shbest, md, mi, xyz0, xyz1, orig0, orig1,
-                           b16_0, b16_1, b64_0, b64_1, dist0, dist1, idx0, idx1, stats);
+        sweep_group<false, GRAD>(a, ge, dir, bi * a.groups[dir] + g, wib, lane, keys_dyn, shbest, md, mi, mp, xyz0, xyz1,
+                                 orig0, orig1, b16_0, b16_1, b64_0, b64_1, dist0, dist1, idx0, idx1, stats);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward of rf_chamfer_step in SORTED index space.  Same arithmetic as nn_grad_kernel (nn_distance.hip):
+//   grad_D[j] = (x_j - y_{w(j)}) * 2 gd_D[j]  -  sum_{k in S: w(k) = j} (y_k - x_j) * 2 gd_S[k]
+//             = own_D[j] - sum_{k in S: w(k) = j} own_S[k]
+// with every own term already formed by the sweep.  A workgroup owns a tile of consecutive SORTED destination
+// positions.  Nearest neighbours of consecutive sorted sources are spatially clustered, so the 64-source groups
+// whose winners can fall into a tile are few (the sweep's bucket mask per group says which): a tile reads the
+// masks of all groups (8 bytes per 64 sources), lists the matching ones and visits only those, one wave per
+// group, several groups in flight: position and own term of a source are 16 bytes of coalesced loads.  The
+// original-order kernel reads every source index in every tile's workgroup and issues seven loads per source for
+// it (22 us at C2: 0.14 of its HBM roof).  Scatter terms meet in LDS (ds_add_f32: ~30 cycles per wave
+// instruction on the CU's one LDS pipe -- what bounds this kernel, hence tiles as fat as the grid allows), the
+// tile leaves through its original indices.
+#ifndef RFP_GS_TPB
+#define RFP_GS_TPB 256
+#endif
+#ifndef RFP_GS_KB
+#define RFP_GS_KB 4
+#endif
+#ifndef RFP_GS_WG
+#define RFP_GS_WG 1024  // workgroups per set aimed at
+#endif
+constexpr int GS_TPB = RFP_GS_TPB;
+constexpr int GS_GT = 1280;             // destination records per tile at most (>= one bucket of the largest cloud: 1025)
+constexpr int GS_MAXG = rfp::kMaxPoints / SB + 4;
+constexpr int GS_KB = RFP_GS_KB;        // groups in flight per wave
+struct GradSArgs {
+    int b;
+    int n[2], npad[2], gt[2], tiles[2];
+    const int *orig[2];    // (b, npad)
+    const int *wp[2];      // (b, npad) winner's sorted position in the other set
+    const float *own[2];   // (b, npad, 3) own terms
+    const unsigned long long *mask[2];  // (b, npad / 64) buckets of the OTHER set the group's winners fall into
+    int qbucket[2];        // positions per bucket of set d; gt[d] is a multiple of it
+    float *grad[2];        // (b, n, 3) original order
+};
+
+__global__ __launch_bounds__(GS_TPB) void nnp_grad_sorted_kernel(GradSArgs a) {
+    extern __shared__ float acc[];  // [gt * 3], gt = the larger of the two sets' tile sizes
+    __shared__ unsigned short list[GS_MAXG];
+    __shared__ int nlist;
+    // cloud-major logical order, each XCD a contiguous eighth (as sort and sweep): the re-reads of a cloud's
+    // records by its tiles then hit that XCD's L2 instead of crossing the fabric once per tile
+    const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (int)(blockIdx.x >> 3);
+    const int wpc = a.tiles[0] + a.tiles[1];
+    const int bi = logical / wpc;
+    int tile = logical - bi * wpc;
+    const int D = tile >= a.tiles[0];
+    if (D) tile -= a.tiles[0];
+    const int S = 1 - D;
+    const int j0 = tile * a.gt[D], jn = min(a.gt[D], a.npad[D] - j0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int *__restrict__ sw = a.wp[S] + (size_t)bi * a.npad[S];
+    const float *__restrict__ so = a.own[S] + (size_t)bi * a.npad[S] * 3;
+    const int ng = a.npad[S] / SB;
+    const unsigned long long *__restrict__ rg = a.mask[S] + (size_t)bi * ng;
+    // this tile's buckets (gt is a whole number of buckets, at most 64 of them per set)
+    const int b0 = j0 / a.qbucket[D], nb = (jn + a.qbucket[D] - 1) / a.qbucket[D];
+    const unsigned long long tmask = (nb >= 64 ? ~0ull : ((1ull << nb) - 1ull)) << b0;
+
+    if (tid == 0) nlist = 0;
+    // every independent load first: the groups' masks, this thread's destinations (original index, own term)
+    constexpr int RG = (GS_MAXG + GS_TPB - 1) / GS_TPB;
+    unsigned long long rr[RG];
+#pragma unroll
+    for (int u = 0; u < RG; u++) {
+        const int gi = tid + u * GS_TPB;
+        rr[u] = 0ull;
+        if (gi < ng) rr[u] = rg[gi];
+    }
+    constexpr int OWN = GS_GT / GS_TPB;
+    float own[OWN][3];
+    int oo[OWN];
+#pragma unroll
+    for (int u = 0; u < OWN; u++) {
+        const int j = tid + u * GS_TPB;
+        oo[u] = -1;
+        own[u][0] = own[u][1] = own[u][2] = 0.f;
+        if (j < jn) {
+            oo[u] = a.orig[D][(size_t)bi * a.npad[D] + j0 + j];
+            const float *ow = a.own[D] + ((size_t)bi * a.npad[D] + j0 + j) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; c++) own[u][c] = ow[c];
+        }
+    }
+    for (int i = tid; i < jn * 3; i += GS_TPB) acc[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < RG; u++)
+        if (rr[u] & tmask) list[atomicAdd(&nlist, 1)] = (unsigned short)(tid + u * GS_TPB);
+    __syncthreads();
+    const int nl = (RFP_GS_ABL & 1) ? 0 : nlist;
+    for (int base = wave; base < nl; base += (GS_TPB / 64) * GS_KB) {
+        int w[GS_KB];
+        float v[GS_KB][3];
+#pragma unroll
+        for (int i = 0; i < GS_KB; i++) {
+            const int li = base + i * (GS_TPB / 64);  // uniform
+            w[i] = -1;
+            v[i][0] = v[i][1] = v[i][2] = 0.f;
+            if (li < nl) {
+                const int k = (int)list[li] * SB + lane;
+                w[i] = sw[k];
+#pragma unroll
+                for (int c = 0; c < 3; c++) v[i][c] = so[(size_t)k * 3 + c];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < GS_KB; i++) {
+            // ds_add_f32 costs per ACTIVE LANE on the CU's one LDS pipe (measured: an eighth of the lanes, an
+            // eighth of the time), and consecutive sorted sources mostly share their winner: runs of equal
+            // destination inside a 16-lane row are summed in registers first (segmented scan by DPP row
+            // shifts) and only the last lane of a run touches LDS.
+            const int j = w[i] - j0;
+            const int key = (unsigned)j < (unsigned)jn ? j : -1;
+            const int kprev = __builtin_amdgcn_update_dpp(-2, key, 0x111, 0xf, 0xf, false);  // row_shr:1
+            const int knext = __builtin_amdgcn_update_dpp(-2, key, 0x101, 0xf, 0xf, false);  // row_shl:1
+            int f = key != kprev;  // head of a run (or of the row)
+            float sx = -v[i][0], sy = -v[i][1], sz = -v[i][2];
+#define RFP_SEG(CTRL)                                                                                   \
+    {                                                                                                   \
+        const int fp = __builtin_amdgcn_update_dpp(1, f, CTRL, 0xf, 0xf, false);                        \
+        const float px = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sx), CTRL, 0xf, 0xf, false)); \
+        const float py = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sy), CTRL, 0xf, 0xf, false)); \
+        const float pz = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sz), CTRL, 0xf, 0xf, false)); \
+        sx = f ? sx : sx + px;                                                                          \
+        sy = f ? sy : sy + py;                                                                          \
+        sz = f ? sz : sz + pz;                                                                          \
+        f |= fp;                                                                                        \
+    }
+            RFP_SEG(0x111) RFP_SEG(0x112) RFP_SEG(0x114) RFP_SEG(0x118)
+#undef RFP_SEG
+            if (key >= 0 && key != knext) {
+                if (RFP_GS_ABL & 2) {
+                    if (sx == 12345.f) acc[key * 3] = sx + sy + sz;
+                } else {
+                    atomicAdd(&acc[key * 3 + 0], sx);
+                    atomicAdd(&acc[key * 3 + 1], sy);
+                    atomicAdd(&acc[key * 3 + 2], sz);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float *__restrict__ out = a.grad[D] + (size_t)bi * a.n[D] * 3;
+#pragma unroll
+    for (int u = 0; u < OWN; u++) {
+        const int j = tid + u * GS_TPB;
+        if (j < jn && oo[u] >= 0) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) out[(size_t)oo[u] * 3 + c] = own[u][c] + acc[j * 3 + c];
+        }
     }
 }
 
@@ -1254,7 +1506,7 @@ size_t sorted_bytes(int b, int n) {
     const size_t npad = npad_of(n);
     return align256((size_t)b * npad * 3 * sizeof(float) + 256)  // + prefetch overrun
            + align256((size_t)b * npad * sizeof(int)) + align256((size_t)b * (npad / SB) * B16F * sizeof(float)) +
-           align256((size_t)b * (npad / SB) * B64F * sizeof(float));
+           align256((size_t)b * (npad / SB) * B64F * sizeof(float)) + align256((size_t)b * sizeof(int));
 }
 
 Sorted sorted_view(int b, int n, const void *buf) {
@@ -1269,6 +1521,8 @@ Sorted sorted_view(int b, int n, const void *buf) {
     v.box16 = (const float *)w;
     w += align256((size_t)b * (npad / SB) * B16F * sizeof(float));
     v.box64 = (const float *)w;
+    w += align256((size_t)b * (npad / SB) * B64F * sizeof(float));
+    v.pos0 = (const int *)w;
     return v;
 }
 
@@ -1296,6 +1550,7 @@ int sort_sets(int b, int nsets, const int *n, const float *const *src, const Sor
         sa.orig[k] = const_cast<int *>(out[kk].orig);
         sa.box16[k] = const_cast<float *>(out[kk].box16);
         sa.box64[k] = const_cast<float *>(out[kk].box64);
+        sa.pos0[k] = const_cast<int *>(out[kk].pos0);
         reg = reg && n[kk] <= RPT * STPB;
         sa.split[k] = sort_split_of(n[kk]);
     }
@@ -1311,8 +1566,9 @@ int sort_sets(int b, int nsets, const int *n, const float *const *src, const Sor
 // The sweep over two sorted sets.  dirs bit 0: nearest neighbour of every point of set 0 in set 1
 // (-> dist1/idx1), bit 1: the opposite (-> dist2/idx2).  A direction that is not asked for costs
 // nothing: its workgroups are not launched.
-int sweep_sorted(int b, int n, int m, const Sorted &s0, const Sorted &s1, float *dist1, int *idx1, float *dist2,
-                 int *idx2, int dirs, hipStream_t s, unsigned long long *stats_dev) {
+static int sweep_sorted_impl(int b, int n, int m, const Sorted &s0, const Sorted &s1, float *dist1, int *idx1,
+                             float *dist2, int *idx2, int dirs, hipStream_t s, unsigned long long *stats_dev,
+                             const GradEmit *ge) {
     if (!pruned_supported(b, n, m) || (dirs & 3) == 0) return RF_EINVAL;
     if (((dirs & 1) && (!dist1 || !idx1)) || ((dirs & 2) && (!dist2 || !idx2))) return RF_EINVAL;
     SweepArgs wa;
@@ -1341,9 +1597,73 @@ int sweep_sorted(int b, int n, int m, const Sorted &s0, const Sorted &s1, float 
     const int pack = tpb / 64;  // one-wave groups per workgroup
     wa.wg0 = !want[0] ? 0 : (wa.nw[0] == NSH ? wa.groups[0] : rf::ceil_div(wa.groups[0], pack));
     wa.wg1 = !want[1] ? 0 : (wa.nw[1] == NSH ? wa.groups[1] : rf::ceil_div(wa.groups[1], pack));
-    RF_LAUNCH("nnp_sweep", nnp_sweep_kernel, dim3((unsigned)b * (wa.wg0 + wa.wg1)), dim3(tpb),
-              pack * wa.kstride * sizeof(unsigned), s, wa, s0.xyz, s1.xyz, s0.orig, s1.orig, s0.box16, s1.box16,
-              s0.box64, s1.box64, dist1, dist2, idx1, idx2, stats_dev);
+    if (ge) {
+        RF_LAUNCH("nnp_sweep", nnp_sweep_kernel<true>, dim3((unsigned)b * (wa.wg0 + wa.wg1)), dim3(tpb),
+                  pack * wa.kstride * sizeof(unsigned), s, wa, *ge, s0.xyz, s1.xyz, s0.orig, s1.orig, s0.box16,
+                  s1.box16, s0.box64, s1.box64, dist1, dist2, idx1, idx2, stats_dev);
+    } else {
+        RF_LAUNCH("nnp_sweep", nnp_sweep_kernel<false>, dim3((unsigned)b * (wa.wg0 + wa.wg1)), dim3(tpb),
+                  pack * wa.kstride * sizeof(unsigned), s, wa, GradEmit{}, s0.xyz, s1.xyz, s0.orig, s1.orig, s0.box16,
+                  s1.box16, s0.box64, s1.box64, dist1, dist2, idx1, idx2, stats_dev);
+    }
+    return RF_OK;
+}
+
+int sweep_sorted(int b, int n, int m, const Sorted &s0, const Sorted &s1, float *dist1, int *idx1, float *dist2,
+                 int *idx2, int dirs, hipStream_t s, unsigned long long *stats_dev) {
+    return sweep_sorted_impl(b, n, m, s0, s1, dist1, idx1, dist2, idx2, dirs, s, stats_dev, nullptr);
+}
+
+// ---- forward + backward of one Chamfer (rf_chamfer_step) on the culled path -----------------------------
+// workspace: sorted(n) | sorted(m) | per set: rec (b, npad) int2 | own (b, npad, 3) | range (b, npad / 64) int2
+static size_t step_set_bytes(int b, int n) { return emit_set_bytes(b, (int)npad_of(n)); }
+
+size_t pruned_step_workspace_bytes(int b, int n, int m) {
+    if (!pruned_supported(b, n, m)) return 0;
+    return sorted_bytes(b, n) + sorted_bytes(b, m) + step_set_bytes(b, n) + step_set_bytes(b, m);
+}
+
+int pruned_step(int b, int n, int m, const float *xyz1, const float *xyz2, const float *gd1, const float *gd2,
+                float *dist1, int *idx1, float *dist2, int *idx2, float *grad_xyz1, float *grad_xyz2, void *workspace,
+                size_t workspace_bytes, hipStream_t s) {
+    if (!pruned_supported(b, n, m) || !gd1 || !gd2 || !grad_xyz1 || !grad_xyz2) return RF_EINVAL;
+    if (workspace_bytes < pruned_step_workspace_bytes(b, n, m)) return RF_EWORKSPACE;
+    char *w = (char *)workspace;
+    const Sorted so[2] = {sorted_view(b, n, w), sorted_view(b, m, w + sorted_bytes(b, n))};
+    const int nn[2] = {n, m};
+    const float *src[2] = {xyz1, xyz2};
+    const float *gds[2] = {gd1, gd2};
+    float *grads[2] = {grad_xyz1, grad_xyz2};
+    GradEmit ge;
+    GradSArgs ga;
+    ga.b = b;
+    ge.base = w + sorted_bytes(b, n) + sorted_bytes(b, m);
+    for (int k = 0; k < 2; k++) {
+        const EmitView ev = emit_layout(ge.base, b, so[0].npad, so[1].npad, k);
+        ge.gd[k] = gds[k];
+        ga.n[k] = nn[k];
+        ga.npad[k] = so[k].npad;
+        // tile size: a whole number of buckets (64 per set), about 1024 workgroups per set
+        const int q = rf::ceil_div(so[k].npad, 64);
+        ge.qbucket[k] = ga.qbucket[k] = q;
+        long want = ((long)so[k].npad * b + RFP_GS_WG - 1) / RFP_GS_WG;
+        int nbk = (int)((want + q - 1) / q);
+        nbk = nbk < 1 ? 1 : nbk;
+        while (nbk > 1 && nbk * q > GS_GT) nbk--;
+        const int gt = nbk * q;
+        ga.gt[k] = gt;
+        ga.tiles[k] = rf::ceil_div(so[k].npad, gt);
+        ga.orig[k] = so[k].orig;
+        ga.wp[k] = ev.wp;
+        ga.own[k] = ev.own;
+        ga.mask[k] = ev.mask;
+        ga.grad[k] = grads[k];
+    }
+    if (int e = sort_sets(b, 2, nn, src, so, s, nullptr)) return e;
+    if (int e = sweep_sorted_impl(b, n, m, so[0], so[1], dist1, idx1, dist2, idx2, 3, s, nullptr, &ge)) return e;
+    const int gtmax = ga.gt[0] > ga.gt[1] ? ga.gt[0] : ga.gt[1];
+    RF_LAUNCH("nnp_grad_sorted", nnp_grad_sorted_kernel, dim3(b * (ga.tiles[0] + ga.tiles[1])), dim3(GS_TPB),
+              (size_t)gtmax * 3 * sizeof(float), s, ga);
     return RF_OK;
 }
 

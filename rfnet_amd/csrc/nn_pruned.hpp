@@ -27,6 +27,7 @@ struct Sorted {
     const int *orig;
     const float *box16;
     const float *box64;
+    const int *pos0;  // (b) sorted position of original index 0
     int npad;
 };
 size_t sort_workspace_bytes(int b, int n);
@@ -40,5 +41,12 @@ int sort_sets(int b, int nsets, const int *n, const float *const *src, const Sor
               unsigned long long *dbg);
 int sweep_sorted(int b, int n, int m, const Sorted &s0, const Sorted &s1, float *dist1, int *idx1, float *dist2,
                  int *idx2, int dirs, hipStream_t s, unsigned long long *stats_dev);
+
+// rf_chamfer_step on the culled path: sort, sweep (which also leaves {winner position, upstream gradient}
+// records in sorted order) and the backward in sorted index space.  gd1 (b, n), gd2 (b, m) upstream gradients.
+size_t pruned_step_workspace_bytes(int b, int n, int m);
+int pruned_step(int b, int n, int m, const float *xyz1, const float *xyz2, const float *gd1, const float *gd2,
+                float *dist1, int *idx1, float *dist2, int *idx2, float *grad_xyz1, float *grad_xyz2, void *workspace,
+                size_t workspace_bytes, hipStream_t s);
 
 }  // namespace rfp
