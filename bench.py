@@ -33,7 +33,13 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
     outputs): ms/step, evaluated fraction, culled vs dense forward, `identical_to_dense_sweep`.
   * "cpu_baseline": the reference's own CPU kernels (nnsearch x2 + the NnDistanceGrad loop,
     oracle/_ref, kind "reference"; the C restatement, kind "port", where that is absent) on one
-    host core on the same workload.  Rank 0, N=1 only.
+    host core on the same workload (the reference op is single-threaded); "cpu_baseline_all_cores":
+    the same bodies, one batch element per OpenMP thread, on every host core.
+    Rank 0, N=1 only.
+  * "c3": BASELINE.json configs[2] (FPS 16384 -> 1024 + gather_point + query_ball_point(0.1, 32) +
+    group_point, B=32, uniform seed 100) with per-op rooflines; "per_op_roofline": the HBM-bound
+    operators of the path (Chamfer backward, match_cost, match_cost_grad) against the 8 TB/s roof;
+    "emd.roofline": the EMD half of the metric against its transcendental-VALU issue floor.
   * `--workload c5`: BASELINE.json configs[4] on this rank's share (B=32 per GPU): RFNet recurrent
     forward (3 steps to 16384 points) + chamfer_big + earth_mover at 64^2 / 1024^2, per-sample
     losses all-gathered over the ranks; reported in samples/s.  The default run carries the same
@@ -48,7 +54,8 @@ import sys
 import time
 
 # before the HIP runtime starts: captured hipMemsetAsync nodes (torch's reductions use them) replay
-# garbage under ROCm 7's graph packet capture -- rfnet_amd/_lib.py has the story; no replay-time cost
+# garbage under ROCm 7's graph packet capture -- rfnet_amd.enable_graph_safe_runtime() has the story (it sets
+# exactly this; spelled out here because it must precede `import torch` + any HIP call); no replay-time cost
 os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
 import numpy as np  # noqa: E402
@@ -59,6 +66,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector peak
+EMD_ISSUE_FLOOR_MS = 0.75  # approx_match at C4: issue floor of its instruction mix, measured with tools/ubench
 HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: HBM3E spec peak
 
 
@@ -157,6 +165,35 @@ def cpu_baseline(B, N, M, seed, sample_b, with_grad=True):
     }
 
 
+def cpu_baseline_all_cores(B, N, M, seed, with_grad=True):
+    """"additionally an OpenMP-over-batch run on all host cores, with core count printed" --
+    the SAME reference bodies (oracle/_ref: nnsearch x2 + the NnDistanceGrad loop), one batch element per
+    OpenMP thread (the wrapper loop is oracle/build_ref.sh's; the bodies are the reference's, untouched)."""
+    from oracle.oracle import Ref, ref_available
+    if not ref_available():
+        return None
+    ref = Ref()
+    rng = np.random.RandomState(seed)
+    a = rng.randn(B, N, 3).astype(np.float32)
+    c = rng.randn(B, M, 3).astype(np.float32)
+    g1, g2 = np.ones((B, N), np.float32), np.ones((B, M), np.float32)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    host_cores = cores
+    cores = min(cores, B)  # one batch element per thread: more threads than batch elements would idle
+    ref.nn_step_all_cores(a[:cores, :256], c[:cores, :256], threads=cores)  # warm (thread pool)
+    t0 = time.perf_counter()
+    _, used = ref.nn_step_all_cores(a, c, g1 if with_grad else None, g2 if with_grad else None, threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": B * N * M / dt, "unit": "pairs/s", "cores": int(used), "kind": "reference",
+            "sample": f"nn_distance forward (both directions){' + nn_distance_grad' if with_grad else ''}, all {B} batch "
+                      f"elements of {N}x{M}, one batch element per OpenMP thread: {used} threads busy on a host of "
+                      f"{host_cores} cores, {dt:.2f} s", "host_cores": int(host_cores)}
+
+
 # ----------------------------------------------------------------------------- workloads -----
 def make_distributions(B, N, M, rank, dev, want_model=True):
     """(name, xyz1 (B,N,3), xyz2 (B,M,3), note) for the distributions the operator meets."""
@@ -189,6 +226,83 @@ def make_distributions(B, N, M, rank, dev, want_model=True):
         del net
 
 
+def timed(fn, reps, fence):
+    """(wall ms per call between fences, {kernel: ms per call} by the library's hipEvents in a second pass)"""
+    from rfnet_amd import _lib
+    for _ in range(2):
+        fn()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    fence()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    _lib.profile_collect()
+    _lib.profile_enable(True)
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    _lib.profile_enable(False)
+    pr = _lib.profile_collect()
+    return ms, {k: v[0] / reps for k, v in pr.items()}  # per CALL (a call may launch a kernel several times)
+
+
+def hbm_roof(bytes_per_call, ms, kernel, note=None):
+    gbps = bytes_per_call / (ms * 1e-3) / 1e9
+    d = {"bound": "hbm", "kernel": kernel, "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+         "frac": gbps / HBM_PEAK_GBPS, "bytes_per_call": float(bytes_per_call), "avg_launch_ms": ms}
+    if note:
+        d["note"] = note
+    return d
+
+
+def run_c3(rank, dev, fence, reps):
+    """BASELINE.json configs[2] / SURVEY.md 8(d) C3: xyz = U[0,1)^3 seed 100, (32, 16384, 3);
+    idx = farthest_point_sample(1024, xyz); new_xyz = gather_point(xyz, idx);
+    query_ball_point(0.1, 32, xyz, new_xyz); group_point(xyz, idx).  Which roof binds each op: SURVEY.md 8(d)
+    (FPS: serial-reduction latency, reported as us per iteration and distance updates/s; ball query: VALU scan
+    with early exit, reported as pair tests/s against the scan's upper bound; gather / group: HBM)."""
+    from rfnet_amd._raw import farthest_point_sample, gather_point, group_point, query_ball_point
+    B, n, m, ns, r = 32, 16384, 1024, 32, 0.1
+    rng = np.random.RandomState(100 + rank)
+    xyz = torch.from_numpy(rng.random_sample((B, n, 3)).astype(np.float32)).to(dev)
+    idx = farthest_point_sample(m, xyz)
+    new_xyz = gather_point(xyz, idx)
+    gi, cnt = query_ball_point(r, ns, xyz, new_xyz)
+    fps_ms, fps_k = timed(lambda: farthest_point_sample(m, xyz), max(3, reps // 2), fence)
+    ga_ms, ga_k = timed(lambda: gather_point(xyz, idx), reps, fence)
+    qb_ms, qb_k = timed(lambda: query_ball_point(r, ns, xyz, new_xyz), reps, fence)
+    gp_ms, gp_k = timed(lambda: group_point(xyz, gi), reps, fence)
+    fps_kms = fps_k.get("fps_reg", fps_k.get("fps_mem", fps_ms))
+    updates = float(B) * n * (m - 1)
+    return {
+        "workload": f"B={B} per GPU, farthest_point_sample {n} -> {m} + gather_point + query_ball_point(r={r}, nsample={ns}) "
+                    "+ group_point(c=3), U[0,1)^3 seed 100 (BASELINE.json configs[2])",
+        "ms_per_pass": fps_ms + ga_ms + qb_ms + gp_ms,
+        "farthest_point_sample": {
+            "ms": fps_ms, "kernel_ms": fps_kms, "us_per_iteration": fps_kms * 1e3 / (m - 1),
+            "distance_updates_per_s": updates / (fps_kms * 1e-3),
+            "roofline": {"bound": "latency", "what": "serial chain of npoint-1 dependent arg-max reductions, one workgroup "
+                         "(one CU) per cloud: B of the 256 CUs busy by construction; no bandwidth or FLOP roof applies",
+                         "cus_busy": B, "valu_flops_per_s": 8.0 * updates / (fps_kms * 1e-3),
+                         "frac_of_fp32_peak_on_busy_cus": 8.0 * updates / (fps_kms * 1e-3) / 1e12 / (FP32_PEAK_TFLOPS * B / 256.0)}},
+        "gather_point": {"ms": ga_ms, "roofline": hbm_roof(28.0 * B * m, ga_k.get("gather_point", ga_ms), "gather_point",
+                                                            "28*B*m bytes (SURVEY 8(d)): 0.9 MB -- launch-bound, not a bandwidth test")},
+        "query_ball_point": {
+            "ms": qb_ms, "kernel_ms": qb_k.get("query_ball_point", qb_ms),
+            "pair_tests_upper_bound_per_s": float(B) * n * m / (qb_k.get("query_ball_point", qb_ms) * 1e-3),
+            "mean_pts_cnt": float(cnt.float().mean().item()),
+            "roofline": {"bound": "valu", "what": "scan with early exit: <= B*n*m pair tests, 6 VALU ops each (sub x3, mul, fma x2) "
+                         "+ 1 compare; achieved counts every pair as tested (upper bound on the work)",
+                         "achieved": 8.0 * B * n * m / (qb_k.get("query_ball_point", qb_ms) * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s",
+                         "frac": 8.0 * B * n * m / (qb_k.get("query_ball_point", qb_ms) * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}},
+        "group_point": {"ms": gp_ms, "roofline": hbm_roof(4.0 * B * m * ns * (1 + 2 * 3), gp_k.get("group_point", gp_ms), "group_point",
+                                                          "4*B*m*nsample*(1+2c) bytes (SURVEY 8(d)): 29 MB")},
+        "checksum": {"fps_idx_sum": int(idx.long().sum().item()), "ball_idx_sum": int(gi.long().sum().item())},
+    }
+
+
 def run_c5(args, rank, world, dev, steps, warmup, use_pg):
     """BASELINE.json configs[4], this rank's share: B=32 samples of (3000 partial, 16384 gt)."""
     from rfnet_amd import glue, shard
@@ -219,7 +333,13 @@ def run_c5(args, rank, world, dev, steps, warmup, use_pg):
     # (same kernels, same results, no per-launch host work, no gaps between dependent launches).  The
     # loss all-gather (RCCL) stays outside the graph.  Falls back to eager launches if capture fails.
     graphed = None
-    if not args.c5_eager:
+    graph_mode = "eager (--c5-eager)"
+    from rfnet_amd._host import graph_replay_ok
+    if not args.c5_eager and not graph_replay_ok(dev):
+        graph_mode = ("eager (torch reductions do not replay from a HIP graph in this process: the HIP runtime was started "
+                      "without DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 -- under a profiler, for instance)")
+        sys.stderr.write(f"bench.py: C5 step not captured -- {graph_mode}\n")
+    elif not args.c5_eager:
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -231,9 +351,19 @@ def run_c5(args, rank, world, dev, steps, warmup, use_pg):
             with torch.cuda.graph(graph):
                 static_per = compute()
             graphed = (graph, static_per)
+            graph_mode = "hip graph"
+            # one replay against the eager result before the graph is trusted (what a capture froze shows here)
+            graph.replay()
+            torch.cuda.synchronize()
+            want = compute()
+            if not torch.allclose(static_per, want, rtol=1e-4, atol=1e-6, equal_nan=True):
+                graphed = None
+                graph_mode = "eager (a replay differed from the eager step)"
+                sys.stderr.write(f"bench.py: captured C5 step discarded -- {graph_mode}\n")
         except Exception as exc:  # noqa: BLE001
             sys.stderr.write(f"bench.py: C5 step not captured ({type(exc).__name__}: {exc}); running it eagerly\n")
             graphed = None
+            graph_mode = f"eager (capture failed: {type(exc).__name__})"
 
     def step():
         if graphed is not None:
@@ -297,7 +427,7 @@ def run_c5(args, rank, world, dev, steps, warmup, use_pg):
                     f"chamfer_big(gt, out) + earth_mover at 64^2 and 1024^2, B={B} per GPU "
                     f"(BASELINE.json configs[4]: B={B * world} over {world} GPU), per-sample losses all-gathered",
         "value": world * B * steps / dt, "unit": "samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-        "hip_graph": graphed is not None,
+        "hip_graph": graphed is not None, "mode": graph_mode,
         "gathered_losses_shape": list(full.shape), "finite": bool(torch.isfinite(full).all().item()),
         "losses_equal_across_ranks": bool(lo.item() == hi.item()),
         "mean_losses": [float(x) for x in full.double().mean(0).tolist()],
@@ -523,6 +653,25 @@ def main():
         fence()
         dt_emdf = time.perf_counter() - t2
         emd_fused_checksum = float(fcost.double().sum().item())
+        # the EMD half of the metric against ITS roof.  approx_match is 30 level sweeps of B*n*m evaluations, each
+        # one v_exp_f32 (transcendental: 8 issue cycles) + 8 plain VALU ops; nothing in it is a product of a row
+        # and a column factor, so MFMA does not apply (the K=4 distance-GEMM trial is recorded
+        # there).  The roof is the measured issue floor of that instruction mix (tools/ubench/valu_rate.hip:
+        # 3.4 cycles per instruction incl. the exp at the clock the chip holds): issue_floor_ms for C4.
+        am_ms, am_k = timed(lambda: approx_match(e1, e2), max(3, emd_steps // 2), fence)
+        mt = approx_match(e1, e2)
+        mc_ms, mc_k = timed(lambda: match_cost(e1, e2, mt), emd_steps, fence)
+        from rfnet_amd._raw import match_cost_grad
+        mg_ms, mg_k = timed(lambda: match_cost_grad(e1, e2, mt), emd_steps, fence)
+        del mt
+        am_kernel_ms = sum(am_k.values())
+        lane_ops = 9.0 * 30.0 * eb * en * en  # 8 VALU + 1 transcendental per evaluation
+        extras["per_op_roofline"] = {
+            "match_cost": hbm_roof(4.0 * eb * en * en + 12.0 * eb * 2 * en, mc_k.get("mc_partial", mc_ms), "mc_partial",
+                                   "4*B*n*m + 12*B*(n+m) bytes (SURVEY 8(d)): one pass over match"),
+            "match_cost_grad": hbm_roof(4.0 * eb * en * en + 24.0 * eb * 2 * en, mg_k.get("mc_grad", mg_ms), "mc_grad",
+                                        "ONE pass over match for both gradients (the reference makes two: SURVEY 8(d) counts 2x)"),
+        }
         del e1, e2, cost, fcost
 
         # ---- north_star's own target shape: B=32 x 16384 vs 16384 forward ----------------------
@@ -539,13 +688,29 @@ def main():
             nn_distance(y1, y2)
         fence()
         dt_ns = time.perf_counter() - t3
-        del y1, y2
+        ns_auto_ms, ns_out, ns_stats = forward_profile(y1, y2, "auto", 3)
+        ns_dense_ms, ns_dense_out, _ = forward_profile(y1, y2, "dense", 2)
+        ns_same = all(bool(torch.equal(x, y)) for x, y in zip(ns_out, ns_dense_out))
+        del y1, y2, ns_out, ns_dense_out
 
         tmax = torch.tensor([dt_emd, dt_ns, dt_emdf], dtype=torch.float64, device=dev)
         if use_pg:
             torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt_emd, dt_ns, dt_emdf = (float(tmax[i].item()) for i in range(3))
         extras["emd"] = {
+            "roofline": {
+                "bound": "valu+trans", "kernel": "am_p3p1 + am_p2 + am_match (approx_match, 21 launches)",
+                "lane_ops_per_pair": 9 * 30, "exp_per_pair": 30,
+                "achieved": lane_ops / (am_kernel_ms * 1e-3) / 1e12, "unit": "T lane-ops/s",
+                "issue_floor_ms": EMD_ISSUE_FLOOR_MS * (eb / 32.0) * (en / 2048.0) ** 2,
+                "frac": EMD_ISSUE_FLOOR_MS * (eb / 32.0) * (en / 2048.0) ** 2 / am_kernel_ms,
+                "frac_of_fp32_peak": 2.0 * lane_ops / (am_kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                "avg_kernel_sum_ms": am_kernel_ms, "approx_match_ms_wall": am_ms, "kernels_ms": am_k,
+                "mfma": "not applicable: every matrix element needs its own exp(level * d2) (8 of the 9 ops and all of the "
+                        "transcendental work); d2 via the |a|^2+|b|^2-2ab GEMM is ruled out because exp(-16384 d2) amplifies "
+                        "its cancellation error to ~7e-4 relative (DESIGN.md 5.5, K=4 trial recorded there)",
+                "note": "frac = measured issue floor of the instruction mix / measured kernel time; frac_of_fp32_peak counts "
+                        "2 flop per lane-op against the 157.3 TFLOP/s vector peak"},
             "metric": "EMD iters/sec (approx_match + match_cost batch calls)",
             "value": world * emd_steps / dt_emd, "unit": "calls/s", "ms_per_call": dt_emd / emd_steps * 1e3,
             "level_sweeps_per_s": world * emd_steps * 30 / dt_emd,
@@ -561,7 +726,20 @@ def main():
             "workload": f"nn_distance forward, B={B} per GPU, {ns_n} vs {ns_n} (north_star target shape)",
             "value": world * B * ns_n * ns_n * ns_steps / dt_ns, "unit": "pairs/s",
             "ms_per_call": dt_ns / ns_steps * 1e3, "steps": ns_steps,
+            "identical_to_dense_sweep": ns_same,
+            "kernels_ms": ns_auto_ms, "dense_kernels_ms": ns_dense_ms,
         }
+        if "nnp_sweep" in ns_auto_ms and len(ns_stats) >= 8:
+            ev = 1024.0 * (ns_stats[3] + ns_stats[7])
+            t_sw = ns_auto_ms["nnp_sweep"] * 1e-3
+            extras["north_star_16384sq"]["roofline"] = {
+                "bound": "valu", "kernel": "nnp_sweep", "achieved": 8.0 * ev / t_sw / 1e12, "peak": FP32_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": 8.0 * ev / t_sw / 1e12 / FP32_PEAK_TFLOPS,
+                "evaluated_fraction_of_2BNM": ev / (2.0 * B * ns_n * ns_n), "avg_launch_ms": t_sw * 1e3,
+                "algorithmic_achieved": 16.0 * B * ns_n * ns_n / t_sw / 1e12,
+                "forward_speedup_vs_dense": sum(ns_dense_ms.values()) / sum(ns_auto_ms.values())}
+        # ---- configs[2]: FPS + gather + ball query + group ------------------------------------
+        extras["c3"] = run_c3(rank, dev, fence, max(5, min(20, args.steps)))
         # ---- configs[4] on this rank's share (also `--workload c5`) -----------------------------
         extras["c5"] = run_c5(args, rank, world, dev, steps=3, warmup=1, use_pg=use_pg)
 
@@ -599,6 +777,8 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": executed_tf / FP32_PEAK_TFLOPS,
                 "traffic": traffic.get(kname),
+                "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                                  "committed; NOT measured in this run)",
                 "note": "achieved = 8 flop x directed pairs the kernel evaluated (its own counters) / avg launch "
                         "duration; the culling is reported as algorithmic_speedup_vs_dense",
                 "executed_flops_per_launch": 8.0 * evaluated,
@@ -639,6 +819,8 @@ def main():
                 "batch_per_gpu": B, "n": N, "m": M, "sharding": f"batch x{world}",
                 "forward": "culled sweep (nn_pruned.hip)" if culled else "dense sweep (nn_distance.hip)",
                 "step": "rf_chamfer_step: one C-ABI call, caller-allocated outputs",
+                "scaling_note": f"weak: every GPU runs B={B}; N GPUs = a global batch of {B}*N (BASELINE.json configs[4]'s "
+                                "B=256 is 8 x 32)",
             },
             "roofline": roof,
             "roofline_dense": {
@@ -656,6 +838,12 @@ def main():
                 "frac": hbm_bytes / sweep_avg_s / 1e9 / HBM_PEAK_GBPS if sweep_avg_s else None,
                 "bytes_per_launch": hbm_bytes,
             },
+            "roofline_backward": hbm_roof(
+                44.0 * B * (N + M), (prof.get("nnp_grad_sorted", prof.get("nn_grad", (0.0, 1)))[0] /
+                                     max(prof.get("nnp_grad_sorted", prof.get("nn_grad", (0.0, 1)))[1], 1)) or 1e-9,
+                "nnp_grad_sorted" if "nnp_grad_sorted" in prof else "nn_grad",
+                "44*B*(N+M) algorithmic bytes incl. zero fill (SURVEY 8(d)); the sorted-space backward is bound by LDS "
+                "atomic lanes and kernel-boundary latency, not by HBM (profiles/r03_ab_grad_sorted.txt)"),
             "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items())},
             "kernel_sum_ms_per_step": kernel_sum_ms,
             "host_overhead_ms_per_step": dt / args.steps * 1e3 - kernel_sum_ms,
@@ -676,6 +864,9 @@ def main():
         line.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(B, N, M, 100, sample_b=B, with_grad=True)
+            allc = cpu_baseline_all_cores(B, N, M, 100, with_grad=True)
+            if allc:
+                line["cpu_baseline_all_cores"] = allc
             if "north_star_16384sq" in line:
                 cb = cpu_baseline(B, 16384, 16384, 200, sample_b=3, with_grad=False)
                 line["north_star_16384sq"]["cpu_baseline"] = cb

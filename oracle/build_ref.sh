@@ -20,7 +20,8 @@
 #                                  tf_ops/grouping/query_ball_point.cpp:17-84
 #
 # Flags follow the reference's own compile scripts (g++ -std=c++11 -O2, no -march, so
-# no FMA contraction: tf_ops/CD/tf_cd_compile_abi.sh, pc_distance/makefile).
+# no FMA contraction: tf_ops/CD/tf_cd_compile_abi.sh, pc_distance/makefile); -fopenmp only
+# gives meaning to the pragmas of the wrapper loops at the end (the bodies hold none).
 set -euo pipefail
 REF=${RFNET_REFERENCE:-/root/reference}
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
@@ -50,6 +51,25 @@ EOF
     sed -n '23,140p' "$REF/pc_distance/tf_approxmatch.cpp"
     sed -n '57,153p' "$REF/tf_ops/interpolation/tf_interpolate.cpp"
     sed -n '17,84p' "$REF/tf_ops/grouping/query_ball_point.cpp"
+    # OpenMP-over-batch wrappers around the UNTOUCHED bodies above ("an OpenMP-over-batch run on
+    # all host cores, with core count printed"): each thread calls the reference function on ONE batch
+    # element (b = 1) of its own; the reference op itself is single-threaded (tf_nndistance.cpp:79-80).
+    cat <<'OMP'
+#include <omp.h>
+int ref_omp_max_threads(void){ return omp_get_max_threads(); }
+void ref_nn_forward_omp(int b,int n,int m,const float*xyz1,const float*xyz2,float*dist1,int*idx1,float*dist2,int*idx2,int threads){
+#pragma omp parallel for schedule(dynamic,1) num_threads(threads)
+    for (int i=0;i<b;i++){
+        nnsearch(1,n,m,xyz1+(size_t)i*n*3,xyz2+(size_t)i*m*3,dist1+(size_t)i*n,idx1+(size_t)i*n);
+        nnsearch(1,m,n,xyz2+(size_t)i*m*3,xyz1+(size_t)i*n*3,dist2+(size_t)i*m,idx2+(size_t)i*m);
+    }
+}
+void ref_nn_grad_omp(int b,int n,int m,const float*xyz1,const float*xyz2,const float*gd1,const int*idx1,const float*gd2,const int*idx2,float*g1,float*g2,int threads){
+#pragma omp parallel for schedule(dynamic,1) num_threads(threads)
+    for (int i=0;i<b;i++)
+        ref_nn_distance_grad(1,n,m,xyz1+(size_t)i*n*3,xyz2+(size_t)i*m*3,gd1+(size_t)i*n,idx1+(size_t)i*n,gd2+(size_t)i*m,idx2+(size_t)i*m,g1+(size_t)i*n*3,g2+(size_t)i*m*3);
+}
+OMP
     echo '}'
-} | g++ -x c++ -std=c++11 -O2 -fPIC -shared -o "$OUT/libref.so" -
+} | g++ -x c++ -std=c++11 -O2 -fopenmp -fPIC -shared -o "$OUT/libref.so" -
 echo "built $OUT/libref.so"

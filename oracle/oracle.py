@@ -245,6 +245,27 @@ class Ref:
                                       _i(idx2), _f(g1), _f(g2))
         return g1, g2
 
+    def omp_max_threads(self):
+        return int(self.lib.ref_omp_max_threads())
+
+    def nn_step_all_cores(self, xyz1, xyz2, gd1=None, gd2=None, threads=0):
+        """The same reference bodies (nnsearch x2, then the NnDistanceGrad loop when gd1/gd2 are given), one
+        batch element per OpenMP thread (oracle/build_ref.sh: the wrapper loop only, the bodies untouched).
+        -> (dist1, idx1, dist2, idx2[, grad1, grad2]), threads used."""
+        xyz1, xyz2 = _f32(xyz1), _f32(xyz2)
+        b, n, _ = xyz1.shape
+        m = xyz2.shape[1]
+        threads = int(threads) or self.omp_max_threads()
+        d1, i1 = np.empty((b, n), np.float32), np.empty((b, n), np.int32)
+        d2, i2 = np.empty((b, m), np.float32), np.empty((b, m), np.int32)
+        self.lib.ref_nn_forward_omp(b, n, m, _f(xyz1), _f(xyz2), _f(d1), _i(i1), _f(d2), _i(i2), threads)
+        if gd1 is None:
+            return (d1, i1, d2, i2), threads
+        gd1, gd2 = _f32(gd1), _f32(gd2)
+        g1, g2 = np.empty((b, n, 3), np.float32), np.empty((b, m, 3), np.float32)
+        self.lib.ref_nn_grad_omp(b, n, m, _f(xyz1), _f(xyz2), _f(gd1), _i(i1), _f(gd2), _i(i2), _f(g1), _f(g2), threads)
+        return (d1, i1, d2, i2, g1, g2), threads
+
     def approxmatch_cpu(self, xyz1, xyz2):
         """Returns the reference CPU layout [b][n][m] (11 levels, double) -- SURVEY T4."""
         xyz1, xyz2 = _f32(xyz1), _f32(xyz2)

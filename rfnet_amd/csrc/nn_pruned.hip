@@ -72,7 +72,8 @@ namespace {
 #endif
 #ifndef RFP_GS_ABL
 #define RFP_GS_ABL 0  // ablation builds of the sorted-space backward (WRONG results, timing only; profiles/r03_ab_grad_sorted.txt):
-                      // 1 no group visits, 2 no LDS atomics
+                      // 1 no group visits, 2 no LDS atomics; in the sweep's emit: 16 no upstream-gradient load, 32 no bucket
+                      // mask, 64 no winner-coordinate gather, 128 no emit stores
 #endif
 constexpr int NSH = RFP_NSH;
 constexpr int BS = 16;             // candidates per block
@@ -925,7 +926,7 @@ __device__ __forceinline__ void sweep_group(
     const bool valid = qorig >= 0;
     float gq = 0.f;  // upstream gradient of this query's distance (GRAD): fetched now, used in the epilogue
     if constexpr (GRAD) {
-        if (valid) gq = ge.gd[dir][(size_t)bi * a.n[dir] + qorig];
+        if (valid && !(RFP_GS_ABL & 16)) gq = ge.gd[dir][(size_t)bi * a.n[dir] + qorig];
     }
     // A query with a NaN coordinate can never tighten its bound (every d2 is NaN): it takes no part
     // in the traversal -- it would drag its whole wave through every superblock -- and is written as
@@ -1247,18 +1248,21 @@ __device__ __forceinline__ void sweep_group(
         const EmitView ev = emit_layout(ge.base, a.b, a.npad[0], a.npad[1], dir);
         const int w = (qnan || besti == 0xFFFFFFFFu) ? p0 : wpos;
         const int wc = valid ? w : 0;
-        const float cx = C[(size_t)wc * 3 + 0], cy = C[(size_t)wc * 3 + 1], cz = C[(size_t)wc * 3 + 2];
+        const float cx = (RFP_GS_ABL & 64) ? 1.f : C[(size_t)wc * 3 + 0], cy = (RFP_GS_ABL & 64) ? 1.f : C[(size_t)wc * 3 + 1],
+                    cz = (RFP_GS_ABL & 64) ? 1.f : C[(size_t)wc * 3 + 2];
         const float g2 = gq + gq;  // the reference's arithmetic: g = gd + gd; (a - b) * g rounded on its own
         const size_t r = (size_t)bi * a.npad[dir] + g * SB + lane;
-        ev.wp[r] = valid ? w : -1;
-        float *ow = ev.own + r * 3;
-        ow[0] = (qx - cx) * g2;
-        ow[1] = (qy - cy) * g2;
-        ow[2] = (qz - cz) * g2;
+        if (!(RFP_GS_ABL & 128) || cx == 12345.f) {
+            ev.wp[r] = valid ? w : -1;
+            float *ow = ev.own + r * 3;
+            ow[0] = (qx - cx) * g2;
+            ow[1] = (qy - cy) * g2;
+            ow[2] = (qz - cz) * g2;
+        }
         // the buckets this group's winners fall into: one trip per DISTINCT bucket (a handful: the winners of 64
         // consecutive sorted queries are neighbours)
         const int bkt = w / ge.qbucket[cd];
-        unsigned long long todo = __builtin_amdgcn_ballot_w64(valid), gm = 0ull;
+        unsigned long long todo = (RFP_GS_ABL & 32) ? 0ull : __builtin_amdgcn_ballot_w64(valid), gm = 0ull;
         while (todo) {
             const int bb = __builtin_amdgcn_readlane(bkt, __builtin_ctzll(todo));
             gm |= 1ull << bb;

@@ -54,7 +54,7 @@ def shard_batch(tensors, rank, world):
 def scatter_from_rank0(full, rank, world, device=None, group=None):
     """Optional input distribution: rank 0 holds `full` (B, ...); every rank receives its shard.
     Uses dist.scatter on equal shards (B % R == 0), else a broadcast + local slice."""
-    if world == 1:
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
         return full
     meta = [None]
     if rank == 0:

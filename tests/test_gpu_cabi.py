@@ -139,3 +139,58 @@ def test_bench_rccl_path_on_one_gpu():
     assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["value"] > 1e12
     assert d["roofline"]["bound"] == "valu" and 0 < d["roofline"]["frac"] <= 1.0
     assert d["roofline"]["identical_to_dense_sweep"] is True
+
+
+def test_bench_c5_through_rccl_on_one_gpu():
+    """BASELINE.json configs[4] on one rank's share THROUGH RCCL (RF_FORCE_PG=1: a real nccl process group of one
+    rank): communicator bound to the device, barrier fences, the all-gather of per-sample losses, the cross-rank
+    loss check -- so that the day a driver runs `--gpus 8 --workload c5` the path has been through RCCL on this
+    box.  (The 8-way split itself is covered on CPU/gloo: tests/test_shard.py.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(RF_FORCE_PG="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--workload", "c5", "--steps", "3",
+                          "--warmup", "1", "--no-extras"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[:500]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["unit"] == "samples/s" and d["scaling"] == "weak"
+    c5 = d["c5"]
+    assert c5["gathered_losses_shape"] == [32, 3] and c5["losses_equal_across_ranks"] is True and c5["finite"] is True
+    assert c5["mode"].startswith("hip graph") or c5["mode"].startswith("eager"), c5["mode"]
+    assert c5["value"] > 1000  # samples/s per GPU (round 2: ~5000)
+
+
+def test_scatter_from_rank0_takes_a_cpu_source_under_rccl():
+    """rank 0 usually holds the batch on the HOST; RCCL moves device buffers only, so the source is staged to the
+    receive device first (round-2 advisor finding).  One-rank nccl group on this GPU."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    code = r"""
+import os, sys, torch
+sys.path.insert(0, %r)
+import torch.distributed as dist
+from rfnet_amd import shard
+os.environ.update(RF_FORCE_PG="1")
+rank, world, local = shard.init_from_env()
+assert dist.is_initialized() and dist.get_backend() == "nccl"
+full = torch.arange(4 * 5 * 3, dtype=torch.float32).reshape(4, 5, 3)  # on the CPU
+mine = shard.scatter_from_rank0(full, rank, world)
+assert mine.is_cuda and torch.equal(mine.cpu(), full)
+odd = torch.arange(3 * 2, dtype=torch.float32).reshape(3, 2)
+assert torch.equal(shard.scatter_from_rank0(odd, rank, world).cpu(), odd)
+dist.destroy_process_group()
+print("ok")
+""" % root
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(RF_FORCE_PG="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29535", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    # (RCCL prints its version banner on stdout too)
+    assert out.returncode == 0 and "ok" in out.stdout.split(), out.stdout + out.stderr[-2000:]

@@ -34,7 +34,18 @@ _lib.profile_collect(); _lib.profile_enable(True)
 for _ in range(50): plan(a, c, g1, g2)
 torch.cuda.synchronize(); _lib.profile_enable(False)
 pr = _lib.profile_collect()
-print(json.dumps({"ok": ok, "okg": okg, "wall_us": round(wall, 1), **{k: round(v[0] / v[1] * 1e3, 1) for k, v in pr.items()}}))
+res = {"ok": ok, "okg": okg, "wall_us": round(wall, 1), **{k: round(v[0] / v[1] * 1e3, 1) for k, v in pr.items()}}
+# the two-op path in the same process (culled sweep without the emit + the original-order backward)
+def two():
+    o = R.nn_distance(a, c)
+    return R.nn_distance_grad(a, c, g1, o[1], g2, o[3])
+for _ in range(5): two()
+torch.cuda.synchronize(); _lib.profile_collect(); _lib.profile_enable(True)
+for _ in range(50): two()
+torch.cuda.synchronize(); _lib.profile_enable(False)
+pr = _lib.profile_collect()
+res.update({"twoop_" + k: round(v[0] / v[1] * 1e3, 1) for k, v in pr.items()})
+print(json.dumps(res))
 ''' % ROOT
 
 
