@@ -32,6 +32,7 @@ SIGNATURES = {
     "rf_status_string": (C.c_char_p, [_i]),
     "rf_device_check": (_i, []),
     "rf_probe_memset_async": (_i, [_vp, _sz, _vp]),
+    "rf_probe_exp2": (_i, [_vp, _vp, _i, _vp]),
     "rf_nn_distance_workspace_bytes": (_sz, [_i, _i, _i]),
     "rf_nn_distance": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rf_nn_distance_mode_workspace_bytes": (_sz, [_i, _i, _i, _i]),

@@ -232,3 +232,48 @@ def test_earth_mover_fused_eval_size_16384():
     assert_rel(fused[1:2], chain, 1e-5, what="fused vs chain at 16384^2")
     solo = _raw.earth_mover(a[2:3].contiguous(), c[2:3].contiguous()).cpu().numpy()
     assert_rel(fused[2:3], solo, 1e-6, what="batch independence")
+
+
+def test_exp2_is_exactly_zero_below_the_cull_argument():
+    """What the culled sweeps of the sharp levels rest on (approxmatch.hip kCullArg): v_exp_f32(x) == +0 for every
+    x <= -160, bit for bit, so a skipped pair would have added fma(0, s, acc) = acc."""
+    from rfnet_amd._lib import check, lib
+    x = np.concatenate([-np.linspace(160.0, 400.0, 200001), -np.logspace(np.log10(160.0), 30.0, 20000),
+                        [-160.0, -np.inf, -3.0e38]]).astype(np.float32)
+    tx = cu(x)
+    ty = torch.empty_like(tx)
+    check(lib.rf_probe_exp2(tx.data_ptr(), ty.data_ptr(), tx.numel(), None), "rf_probe_exp2")
+    y = ty.cpu().numpy()
+    assert (y.view(np.uint32) == 0).all(), "v_exp_f32 returned a non-zero (or -0) below -160"
+    # and it is an exponential above: spot values
+    v = cu(np.array([0.0, -1.0, -10.0, -126.0, 3.0], np.float32))
+    o = torch.empty_like(v)
+    check(lib.rf_probe_exp2(v.data_ptr(), o.data_ptr(), v.numel(), None), "rf_probe_exp2")
+    assert np.allclose(o.cpu().numpy(), np.exp2(np.array([0.0, -1.0, -10.0, -126.0, 3.0])), rtol=1e-6)
+
+
+@pytest.mark.parametrize("b,n,m", [(1, 4096, 4096), (1, 4096, 5000), (2, 6000, 4100)])
+def test_earth_mover_culled_sharp_levels(orc, b, n, m):
+    """The cost-only rf_earth_mover on clouds of >= 4096 points runs the three sharpest levels as culled sweeps
+    over Hilbert-sorted copies (approxmatch.hip am_cull_kernel): same schedule, pairs whose weight is exactly 0
+    skipped, sums in sorted column order.  Cost against the oracle's chain (approx_match -> match_cost,
+    tf_approxmatch.cu restated) within 1e-5; the gradient form and approx_match itself (the ops that hand out
+    per-entry results) stay on the dense sweeps and keep their tolerances."""
+    from rfnet_amd import _raw as R
+    rng = np.random.RandomState(n + m)
+    a = (rng.random_sample((b, n, 3)) - 0.5).astype(np.float32)
+    c = (rng.random_sample((b, m, 3)) - 0.5).astype(np.float32)
+    om = orc.approx_match(a, c)
+    oc = orc.match_cost(a, c, om)
+    assert_rel(R.earth_mover(cu(a), cu(c)).cpu().numpy(), oc, 1e-5, what="fused earth_mover cost")
+    cost, g1, g2 = R.earth_mover(cu(a), cu(c), with_grad=True)
+    assert_rel(cost.cpu().numpy(), oc, 1e-5, what="cost (with_grad)")
+    o1, o2 = orc.match_cost_grad(a, c, om)
+    multiL, multiR = (1.0, float(n // m)) if n >= m else (float(m // n), 1.0)
+    # (the gradient form runs the DENSE sweeps; at these sizes -- twice to three times test_earth_mover_fused's -- the
+    # fast-exp noise of single match entries reaches 1.2e-4 of a unit mass in one component of 36000)
+    assert_rel(g1.cpu().numpy(), o1, 1e-4, 2e-4 * multiL, what="grad1")
+    assert_rel(g2.cpu().numpy(), o2, 1e-4, 2e-4 * multiR, what="grad2")
+    # the dense pipeline on the same clouds gives the same cost to fp32 summation noise
+    match = R.approx_match(cu(a), cu(c))
+    assert_rel(R.match_cost(cu(a), cu(c), match).cpu().numpy(), oc, 1e-5, what="dense chain cost")
