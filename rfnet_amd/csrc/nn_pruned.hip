@@ -67,6 +67,10 @@ namespace {
 #ifndef RFP_SORT_SPLIT_ABOVE
 #define RFP_SORT_SPLIT_ABOVE 8192
 #endif
+#ifndef RFP_STR
+#define RFP_STR 1   // order of the register-resident sort: 1 = sort-tile-recursive key (x slabs, y strips per slab, z inside a
+                    // strip, boustrophedon), 0 = Hilbert curve over per-axis equalised cells (rounds 1-2)
+#endif
 #ifndef RFP_HIST
 #define RFP_HIST 0  // 1 (instrumented build): block scans by number of active lanes -> stats[10..13]
 #endif
@@ -106,6 +110,7 @@ struct SortArgs {
     int split[2];  // workgroups per cloud of the set (register-resident kernel): 1, or 2 / 4 = one per slice of the key space
     int *pos0[2];  // (b) sorted position of the point with original index 0 (what an index "0" of the reference's
                    // NaN / no-candidate policy refers to, for the sorted-space backward)
+    int str_s[2];  // STR order: slabs per cloud = strips per slab = round(cbrt(n / 64))
     unsigned long long *dbg;  // optional (with stats): s_memtime stamps of the sort's phases, [16..31]
 };
 
@@ -152,11 +157,13 @@ __device__ __forceinline__ int axis_bin(float v, float lo, float scale) {
     return b < 0 ? 0 : (b > HB - 1 ? HB - 1 : b);
 }
 
+#if !RFP_STR
 // The same curve as hilbert15() as a state machine, one octant (3 bits) per level: entry
 // [state * 8 + octant] = next state << 3 | digit; 24 orientations (derived from, and verified
 // against, Skilling's mapping over all 32768 cells).  ~6 ALU ops + one LDS byte per level
 // instead of ~30.
 __constant__ unsigned char kHilbertLut[192] = {32, 9, 147, 2, 103, 118, 44, 5, 40, 1, 111, 126, 155, 10, 36, 13, 8, 163, 33, 18, 119, 28, 102, 21, 0, 171, 127, 20, 41, 26, 110, 29, 24, 135, 17, 142, 179, 12, 34, 37, 16, 143, 187, 4, 25, 134, 42, 45, 50, 153, 59, 176, 53, 94, 132, 79, 58, 145, 61, 86, 51, 184, 140, 71, 66, 83, 177, 152, 69, 108, 78, 95, 74, 91, 77, 100, 185, 144, 70, 87, 82, 85, 161, 62, 67, 124, 168, 55, 90, 93, 75, 116, 169, 54, 160, 63, 76, 115, 101, 98, 167, 56, 22, 137, 68, 123, 175, 48, 109, 106, 30, 129, 92, 117, 99, 114, 151, 6, 80, 121, 84, 125, 159, 14, 107, 122, 88, 113, 52, 191, 139, 64, 133, 46, 130, 105, 60, 183, 141, 38, 131, 72, 138, 97, 166, 57, 149, 146, 23, 136, 188, 3, 174, 49, 31, 128, 157, 154, 180, 11, 150, 165, 81, 162, 7, 172, 120, 19, 158, 173, 15, 164, 89, 170, 112, 27, 190, 47, 65, 104, 181, 156, 178, 35, 182, 39, 189, 148, 73, 96, 186, 43};
+#endif
 
 __device__ __forceinline__ unsigned spread5(unsigned v) {  // bit b -> bit 3b
     v = (v | (v << 8)) & 0x100Fu;
@@ -211,9 +218,15 @@ constexpr int HALF = 9216;  // records staged in LDS at a time (16 B each, over 
 __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned hist[HALF * 4];  // NBINS bins, later HALF staged records
     __shared__ unsigned ahist[3][HB];
+#if RFP_STR
+    __shared__ unsigned char slabmap[HB];        // x bin -> slab (equal mass)
+    __shared__ unsigned short zmap[HB];          // z bin -> rank in 0..511 (equal mass)
+    __shared__ unsigned char stripmap[16 * HB];  // (slab, y bin) -> strip of that slab (equal mass inside the slab), snaked
+#else
     __shared__ unsigned short cellmap[3][HB];  // equalised cell, already bit-spread and shifted per axis
     __shared__ unsigned char hlut[192];
     __shared__ unsigned short hlut2[24 * 64];  // two octant levels per lookup, built from hlut
+#endif
     __shared__ float red[STPB / 64][6];
     __shared__ unsigned wsum[STPB / 64];
     __shared__ unsigned lowcnt[STPB / 64][3];
@@ -265,7 +278,12 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
         for (int k = 0; k < NBINS / 4 / STPB; k++) h4[tid + k * STPB] = make_uint4(0, 0, 0, 0);
     }
     if (tid < 3 * HB) (&ahist[0][0])[tid] = 0;
+#if RFP_STR
+    unsigned *yhist = hist + NBINS;  // [slab][HB], in the part of `hist` that only the staging uses (dead until then)
+    for (int i = tid; i < 16 * HB; i += STPB) yhist[i] = 0;
+#else
     if (tid < 192) hlut[tid] = kHilbertLut[tid];
+#endif
 
     stamp();
     // 1. bounding box of the finite coordinates
@@ -312,6 +330,7 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     __syncthreads();
     const float fl[3] = {frame[0], frame[1], frame[2]};
     const float fs[3] = {frame[3], frame[4], frame[5]};
+#if !RFP_STR
     // [state * 64 + (octant_hi << 3 | octant_lo)] = next state << 6 | two digits (from the
     // one-level table, in LDS since the first barrier: no second table to fetch from memory)
     for (int e = tid; e < 24 * 64; e += STPB) {
@@ -319,6 +338,7 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
         const unsigned e2 = hlut[(e1 >> 3) * 8 + (e & 7)];
         hlut2[e] = (unsigned short)(((e2 >> 3) << 6) | ((e1 & 7u) << 3) | (e2 & 7u));
     }
+#endif
 
     stamp();
     // 2. per-axis histograms of a quarter of the points: the cells only need approximate
@@ -335,6 +355,71 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
         }
     }
     __syncthreads();
+#if RFP_STR
+    // Sort-tile-recursive order from histograms: SS slabs of equal mass along x (marginal x histogram), inside
+    // every slab SS strips of equal mass along y (the slab's own y histogram), inside a strip the points by z
+    // (rank of the z bin, 9 bits) -- tiles of 64 consecutive records are then near-cubic cells with disjoint boxes
+    // (the Hilbert runs of rounds 1-2 are ragged unions of curve cells whose boxes overlap their neighbours': -35 %
+    // superblock steps and box tests, -10 % block scans in the numpy model tools/experiments/str_model.py).  Strips
+    // alternate direction from slab to slab and z from strip to strip (boustrophedon), so a tile that straddles two
+    // strips stays compact; in raster order the same key is 50 % WORSE than Hilbert.
+    const int SS = a.str_s[set];
+    if (wave == 0 || wave == 2) {
+        unsigned c4[4], sm = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            c4[k] = ahist[wave][lane * 4 + k];
+            sm += c4[k];
+        }
+        const unsigned incl = wave_incl_scan(sm);
+        const unsigned total = max((unsigned)__builtin_amdgcn_readlane((int)incl, 63), 1u);
+        unsigned run = incl - sm;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (wave == 0) {
+                unsigned sl = (run * (unsigned)SS) / total;
+                slabmap[lane * 4 + k] = (unsigned char)(sl > (unsigned)SS - 1u ? (unsigned)SS - 1u : sl);
+            } else {
+                unsigned zq = (run * 512u) / total;
+                zmap[lane * 4 + k] = (unsigned short)(zq > 511u ? 511u : zq);
+            }
+            run += c4[k];
+        }
+    }
+    __syncthreads();
+    // the y histogram of every slab, from the same quarter of the points
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+        if (((k + wave) & 3) != 0) continue;
+        if (tid + k * STPB < n)
+            atomicAdd(&yhist[(int)slabmap[axis_bin(px[k], fl[0], fs[0])] * HB + axis_bin(py[k], fl[1], fs[1])], 1u);
+    }
+    __syncthreads();
+    if (wave < SS) {  // wave <-> slab
+        unsigned c4[4], sm = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            c4[k] = yhist[wave * HB + lane * 4 + k];
+            sm += c4[k];
+        }
+        const unsigned incl = wave_incl_scan(sm);
+        const unsigned total = max((unsigned)__builtin_amdgcn_readlane((int)incl, 63), 1u);
+        unsigned run = incl - sm;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            unsigned st = (run * (unsigned)SS) / total;
+            st = st > (unsigned)SS - 1u ? (unsigned)SS - 1u : st;
+            stripmap[wave * HB + lane * 4 + k] = (unsigned char)((wave & 1) ? (unsigned)SS - 1u - st : st);
+            run += c4[k];
+        }
+    }
+    __syncthreads();
+    // (yhist's words are staging space again from phase 6 on; the histogram proper is the first NBINS words)
+    const int ncol = SS * SS;
+    auto col_start = [&](int q) { return (q * ncol + H - 1) / H; };  // first column of slice q (H slices of equal column count)
+    const unsigned kbase = (unsigned)col_start(half) << 9;
+    const int nb_local = (col_start(half + 1) - col_start(half)) << 9;
+#else
     if (wave < 3) {
         unsigned c4[4], s = 0;
 #pragma unroll
@@ -355,14 +440,28 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
         }
     }
     __syncthreads();
-
-    stamp();
     const int hshift = H == 4 ? KEYBITS - 2 : (H == 2 ? KEYBITS - 1 : KEYBITS);  // (key >> KEYBITS == 0)
     const unsigned hmask = (unsigned)(NBINS / H - 1);
+    const int nb_local = NBINS / H;
+#endif
+
+    stamp();
     unsigned below[3] = {0u, 0u, 0u};  // wave-uniform counters
     // 3. keys and their histogram (VALU-bound: ~50 instructions per point)
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
+        const bool valid = tid + k * STPB < n;
+#if RFP_STR
+        const int slab = slabmap[axis_bin(px[k], fl[0], fs[0])];
+        const int col = slab * SS + (int)stripmap[slab * HB + axis_bin(py[k], fl[1], fs[1])];
+        const unsigned zq = zmap[axis_bin(pz[k], fl[2], fs[2])];
+        const unsigned key = ((unsigned)col << 9) | ((col & 1) ? 511u - zq : zq);
+        int slice = 0;
+#pragma unroll
+        for (int q = 1; q < 4; q++) slice += (q < H && col >= col_start(q)) ? 1 : 0;
+        const bool own = valid && slice == half;
+        pk[k] = own ? key - kbase : 0xFFFFFFFFu;
+#else
         const unsigned m = (unsigned)cellmap[0][axis_bin(px[k], fl[0], fs[0])] |
                            (unsigned)cellmap[1][axis_bin(py[k], fl[1], fs[1])] |
                            (unsigned)cellmap[2][axis_bin(pz[k], fl[2], fs[2])];
@@ -373,10 +472,10 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
         const unsigned key = ((e1 & 63u) << 9) | ((e2 & 63u) << 3) | (e3 & 7u);
         // bins of this workgroup: the low KEYBITS-1 bits when the cloud is split; 0xFFFFFFFF marks a
         // point of the other half (or beyond n)
-        const bool valid = tid + k * STPB < n;
         const int slice = (int)(key >> hshift);  // H slices of the key space (H = 1: everything is slice 0)
         const bool own = valid && slice == half;
         pk[k] = own ? (key & hmask) : 0xFFFFFFFFu;
+#endif
         if (own) atomicAdd(&hist[pk[k]], 1u);
         // points of the slices below this workgroup's (its segment starts behind theirs)
         if (H > 1) {
@@ -396,9 +495,9 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     // (4 per lane, one ds_read_b128: consecutive lanes on consecutive banks)
     int cown = 0;  // points of this workgroup's half
     {
-        constexpr int STEPS = NBINS / (STPB / 64) / 256;  // 8 (4 when the cloud is split: half the bins)
-        const int steps = STEPS / H;
-        uint4 *h4 = (uint4 *)hist + (size_t)wave * (NBINS / H / (STPB / 64) / 4);
+        constexpr int STEPS = NBINS / (STPB / 64) / 256;  // 8
+        const int steps = min(STEPS, (nb_local + 4095) / 4096);  // each wave owns steps * 256 consecutive bins
+        uint4 *h4 = (uint4 *)hist + (size_t)wave * steps * 64;
         uint4 v[STEPS];
         unsigned tot = 0;
 #pragma unroll
@@ -1557,6 +1656,10 @@ int sort_sets(int b, int nsets, const int *n, const float *const *src, const Sor
         sa.pos0[k] = const_cast<int *>(out[kk].pos0);
         reg = reg && n[kk] <= RPT * STPB;
         sa.split[k] = sort_split_of(n[kk]);
+        {
+            int ss = (int)lround(cbrt((double)n[kk] / SB));
+            sa.str_s[k] = ss < 1 ? 1 : (ss > 16 ? 16 : ss);
+        }
     }
     if (reg) {
         const int wpb = sa.split[0] + (nsets > 1 ? sa.split[1] : 0);

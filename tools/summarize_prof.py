@@ -9,7 +9,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for key in ("nnp_sweep", "nnp_sort_reg", "nnp_sort", "nn_sweep", "nn_pack", "nn_rowmerge", "nn_colresolve", "nn_resolve", "nn_grad", "pack_kernel",
+    for key in ("nnp_grad_sorted", "nnp_sweep", "nnp_sort_reg", "nnp_sort", "nn_sweep", "nn_pack", "nn_rowmerge", "nn_colresolve", "nn_resolve", "nn_grad", "pack_kernel",
                 "am_rowk_kernelILb1ELb1", "am_rowk_kernelILb0ELb1", "am_rowl", "am_match", "am_init", "mcg_kernel",
                 "mc_partial", "fps_reg", "query_ball", "three_nn"):
         if key in name:
