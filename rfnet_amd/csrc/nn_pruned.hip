@@ -417,6 +417,8 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     // (yhist's words are staging space again from phase 6 on; the histogram proper is the first NBINS words)
     const int ncol = SS * SS;
     auto col_start = [&](int q) { return (q * ncol + H - 1) / H; };  // first column of slice q (H slices of equal column count)
+    const int cs1 = H > 1 ? col_start(1) : 0x7FFFFFFF, cs2 = H > 2 ? col_start(2) : 0x7FFFFFFF,
+              cs3 = H > 3 ? col_start(3) : 0x7FFFFFFF;  // (uniform; the divisions stay out of the per-point loop)
     const unsigned kbase = (unsigned)col_start(half) << 9;
     const int nb_local = (col_start(half + 1) - col_start(half)) << 9;
 #else
@@ -456,9 +458,7 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
         const int col = slab * SS + (int)stripmap[slab * HB + axis_bin(py[k], fl[1], fs[1])];
         const unsigned zq = zmap[axis_bin(pz[k], fl[2], fs[2])];
         const unsigned key = ((unsigned)col << 9) | ((col & 1) ? 511u - zq : zq);
-        int slice = 0;
-#pragma unroll
-        for (int q = 1; q < 4; q++) slice += (q < H && col >= col_start(q)) ? 1 : 0;
+        const int slice = (col >= cs1) + (col >= cs2) + (col >= cs3);
         const bool own = valid && slice == half;
         pk[k] = own ? key - kbase : 0xFFFFFFFFu;
 #else
