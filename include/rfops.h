@@ -112,7 +112,11 @@ int rf_nn_distance_sorted(int b, int n, int m, const void *sorted1, const void *
 /* NnDistance followed by NnDistanceGrad on its own indices (what one training step of the
  * reference's Chamfer bench does, tf_ops/CD/tf_nndistance.py:35-61) in ONE call on caller-owned
  * buffers: one FFI crossing per step, nothing allocated.  Equivalent to rf_nn_distance +
- * rf_nn_distance_grad(..., grad_dist1, idx1, grad_dist2, idx2, ...). */
+ * rf_nn_distance_grad(..., grad_dist1, idx1, grad_dist2, idx2, ...): forward outputs bit-identical, gradients
+ * within the backward's tolerance (fp32 add order of a scatter).  On shapes that take the culled sweep the
+ * forward also leaves, in the workspace and in sorted query order, every query's winner position and own
+ * gradient term, and the backward runs in sorted index space (nnp_grad_sorted_kernel): the
+ * workspace is larger than rf_nn_distance's there (rf_chamfer_step_workspace_bytes says by how much). */
 size_t rf_chamfer_step_workspace_bytes(int b, int n, int m);
 int rf_chamfer_step(int b, int n, int m, const float *xyz1, const float *xyz2,
                     const float *grad_dist1, const float *grad_dist2, float *dist1, int *idx1,
