@@ -71,6 +71,9 @@ namespace {
 #define RFP_STR 1   // order of the register-resident sort: 1 = sort-tile-recursive key (x slabs, y strips per slab, z inside a
                     // strip, boustrophedon), 0 = Hilbert curve over per-axis equalised cells (rounds 1-2)
 #endif
+#ifndef RFP_QSAMPLE
+#define RFP_QSAMPLE 3  // the quantile histograms take every (RFP_QSAMPLE + 1)-th point: 3 = a quarter of the cloud
+#endif
 #ifndef RFP_HIST
 #define RFP_HIST 0  // 1 (instrumented build): block scans by number of active lanes -> stats[10..13]
 #endif
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     // range of the cloud is sampled).
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
-        if (((k + wave) & 3) != 0) continue;
+        if (((k + wave) & RFP_QSAMPLE) != 0) continue;
         if (tid + k * STPB < n) {
             atomicAdd(&ahist[0][axis_bin(px[k], fl[0], fs[0])], 1u);
             atomicAdd(&ahist[1][axis_bin(py[k], fl[1], fs[1])], 1u);
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     // the y histogram of every slab, from the same quarter of the points
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
-        if (((k + wave) & 3) != 0) continue;
+        if (((k + wave) & RFP_QSAMPLE) != 0) continue;
         if (tid + k * STPB < n)
             atomicAdd(&yhist[(int)slabmap[axis_bin(px[k], fl[0], fs[0])] * HB + axis_bin(py[k], fl[1], fs[1])], 1u);
     }
