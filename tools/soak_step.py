@@ -1,0 +1,60 @@
+"""Soak: rf_chamfer_step (culled sweep with the emit + sorted-space backward where the size rule sends the shape there)
+against the dense sweep and the original-order backward over many random shapes / cloud kinds / upstream gradients.
+Forward outputs bit for bit, gradients within the backward's tolerance.  python tools/soak_step.py [seconds]"""
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+from rfnet_amd import _raw  # noqa: E402
+from rfnet_amd._lib import lib  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+t0 = time.time()
+case = bad = sorted_cases = 0
+while time.time() - t0 < budget:
+    rng = np.random.RandomState(987654 + case)
+    n, m = (int(v) for v in np.exp(rng.uniform(np.log(1024), np.log(18000), size=2)))
+    b = int(rng.choice([1, 2, 3, 5, 8, 17, 33]))
+    while b * n * m < (1 << 27) and b < 64:  # push most cases over the culled size rule
+        b += int(rng.randint(1, 8))
+    if b * (n + m) > 700000:
+        b = max(1, 700000 // (n + m))
+    kind = case % 6
+
+    def cloud(k):
+        if kind == 0:
+            return rng.randn(b, k, 3)
+        if kind == 1:
+            return rng.random_sample((b, k, 3))
+        if kind == 2:
+            return rng.randint(0, 6, size=(b, k, 3)) * 0.5  # lattice: ties everywhere
+        if kind == 3:
+            base = rng.randn(b, max(k // 7, 1), 3)
+            return np.take_along_axis(base, rng.randint(0, base.shape[1], (b, k))[..., None], 1)  # duplicates
+        if kind == 4:
+            x = rng.randn(b, k, 3)
+            return x / np.linalg.norm(x, axis=-1, keepdims=True)
+        c = rng.randn(b, 5, 3)
+        return c[np.arange(b)[:, None], rng.randint(0, 5, (b, k))] + 0.02 * rng.randn(b, k, 3)
+
+    a = torch.from_numpy(cloud(n).astype(np.float32)).cuda()
+    c = torch.from_numpy(cloud(m).astype(np.float32)).cuda()
+    g1 = torch.from_numpy((rng.rand(b, n) + 0.1).astype(np.float32) * rng.choice([-1.0, 1.0], (b, n)).astype(np.float32)).cuda()
+    g2 = torch.from_numpy((rng.rand(b, m) + 0.1).astype(np.float32)).cuda()
+    plan = _raw.ChamferStep(b, n, m, "cuda")
+    out = plan(a, c, g1, g2)
+    sorted_cases += int(lib.rf_chamfer_step_workspace_bytes(b, n, m) > lib.rf_nn_distance_workspace_bytes(b, n, m))
+    ref = _raw.nn_distance(a, c, mode="dense")
+    ok = all(torch.equal(x, y) for x, y in zip(ref, out[:4]))
+    r1, r2 = _raw.nn_distance_grad(a, c, g1, ref[1], g2, ref[3])
+    ok = ok and bool(torch.allclose(out[4], r1, rtol=1e-5, atol=2e-5 * float(r1.abs().max()) + 1e-12))
+    ok = ok and bool(torch.allclose(out[5], r2, rtol=1e-5, atol=2e-5 * float(r2.abs().max()) + 1e-12))
+    if not ok:
+        bad += 1
+        print("MISMATCH case", case, "b n m", b, n, m, "kind", kind, flush=True)
+    case += 1
+    del plan
+print(f"{case} cases ({sorted_cases} through the sorted-space step), {bad} mismatches, {time.time() - t0:.0f} s")
