@@ -31,6 +31,9 @@
 
 namespace {
 
+#ifndef RFA_TARGET_WAVES
+#define RFA_TARGET_WAVES 4096  // waves a level sweep is cut into at least (column segments per row block)
+#endif
 constexpr float kLog2e = 1.44269502f;  // 0x3FB8AA3B, the constant __expf multiplies by
 constexpr int TPB = 256;
 constexpr int LVG = 16;             // levels per group in the materialisation kernel
@@ -921,7 +924,7 @@ int cull_levels(const AmLayout &L, int nlevels, const LevelConsts &lc) {
 int pick_nseg(int b, int rows, int cols_pad, int rpt) {
     long base = (long)b * rf::ceil_div(rows, 64 * rpt);
     int nseg = 1;
-    const long target = 4096;
+    const long target = RFA_TARGET_WAVES;
     while (nseg < 16 && base * nseg < target && cols_pad / (nseg * 2) >= 64) nseg *= 2;
     return nseg;
 }
