@@ -1046,7 +1046,7 @@ __device__ __forceinline__ void sweep_group(
     }
 
     float best = INFINITY;  // this wave's own minimum, the block that first attained it, tie flag
-    int bblk = 0;
+    int bblk = 0, bblk2 = -1;  // the block that first attained the minimum, the second one that equalled it
     bool tie = false;
     // <= best: also what the other waves of the group have found.  -inf for lanes that take no part
     // (padding): `bound <= cull` / `cull >= bound` are then false without a separate mask.
@@ -1264,9 +1264,14 @@ __device__ __forceinline__ void sweep_group(
                 if (cm < best) {
                     best = cm;
                     bblk = blk;
+                    bblk2 = -1;
                     tie = false;
                 } else if (cm == best) {
-                    tie = true;
+                    // a SECOND block with the same minimum is remembered and simply re-scanned too (copies of one point
+                    // -- data_util.resample_pcd fills short scans with duplicates -- are neighbours in the sorted
+                    // order and straddle at most a block boundary); only a third one sends the lane to the second traversal
+                    if (bblk2 < 0) bblk2 = blk;
+                    else tie = true;
                 }
                 if (!more) break;
             }
@@ -1280,18 +1285,22 @@ __device__ __forceinline__ void sweep_group(
     traverse(std::false_type{}, glo, ghi, besti, wpos);
     __builtin_amdgcn_s_setprio(0);
 
-    // lowest original index among the exact matches of the winning block
-    {
-        const float *cp = C + (size_t)bblk * BS * 3;  // per lane
-        const int *co = Co + (size_t)bblk * BS;
+    // lowest original index among the exact matches of the winning block (and of the second block that equalled it)
+    auto rescan = [&](int wb) {
+        const float *cp = C + (size_t)wb * BS * 3;  // per lane
+        const int *co = Co + (size_t)wb * BS;
 #pragma unroll 4
         for (int u = 0; u < BS; u++) {
             const float d = rf::d2_fma(cp[u * 3 + 0] - qx, cp[u * 3 + 1] - qy, cp[u * 3 + 2] - qz);
             if constexpr (GRAD) {
-                if (d == best && (unsigned)co[u] < besti) wpos = bblk * BS + u;
+                if (d == best && (unsigned)co[u] < besti) wpos = wb * BS + u;
             }
             if (d == best) besti = min(besti, (unsigned)co[u]);  // padding carries 0xFFFFFFFF
         }
+    };
+    rescan(bblk);
+    if (__ballot(bblk2 >= 0) != 0ull) {
+        if (bblk2 >= 0) rescan(bblk2);
     }
     // queries whose minimum was attained in more than one visited block: second traversal
     const bool flagged = tie && part;
