@@ -71,6 +71,9 @@ namespace {
 #define RFP_STR 1   // order of the register-resident sort: 1 = sort-tile-recursive key (x slabs, y strips per slab, z inside a
                     // strip, boustrophedon), 0 = Hilbert curve over per-axis equalised cells (rounds 1-2)
 #endif
+#ifndef RFP_WPE
+#define RFP_WPE 7   // waves per SIMD the sweep's register allocation is held to (6: no SGPR spills, 8: spills inside the loop)
+#endif
 #ifndef RFP_QSAMPLE
 #define RFP_QSAMPLE 3  // the quantile histograms take every (RFP_QSAMPLE + 1)-th point: 3 = a quarter of the cloud
 #endif
@@ -1393,7 +1396,7 @@ __device__ __forceinline__ void sweep_group(
 // (7 waves per SIMD: the loop's 48 record + 24 box SGPRs put the kernel at 106 SGPRs = 6 waves; capping
 // it at 7 spills 16 cold ones to VGPR lanes and measures 2 % faster, capping at 8 spills into the loop)
 template <bool GRAD>
-__global__ __launch_bounds__(64 * NSH) __attribute__((amdgpu_waves_per_eu(7, 7))) void nnp_sweep_kernel(
+__global__ __launch_bounds__(64 * NSH) __attribute__((amdgpu_waves_per_eu(RFP_WPE, RFP_WPE))) void nnp_sweep_kernel(
     SweepArgs a, GradEmit ge, const float *__restrict__ xyz0, const float *__restrict__ xyz1, const int *__restrict__ orig0,
     const int *__restrict__ orig1, const float *__restrict__ b16_0, const float *__restrict__ b16_1,
     const float *__restrict__ b64_0, const float *__restrict__ b64_1, float *__restrict__ dist0,
