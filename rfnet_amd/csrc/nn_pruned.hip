@@ -9,9 +9,11 @@
 //
 //   nnp_sort_kernel   one workgroup per cloud.  Per-axis histogram equalisation (256 bins ->
 //                     32 cells of equal marginal population: far outliers cannot flatten the
-//                     grid), a 15-bit Hilbert key per point, counting sort in LDS (32768 bins =
-//                     128 KiB of the CU's 160 KiB), clouds of up to 16384 points held in registers
-//                     throughout.  Output: the cloud's coordinates (x, y, z packed: a 16-record
+//                     grid), a 15-bit key per point -- sort-tile-recursive for clouds held in
+//                     registers (up to 16384 points: equal-count x slabs, equal-count y strips per
+//                     slab, z rank inside the strip, boustrophedon), the Hilbert
+//                     curve over the equalised cells above that -- and a counting sort in LDS
+//                     (32768 bins = 128 KiB of the CU's 160 KiB).  Output: the cloud's coordinates (x, y, z packed: a 16-record
 //                     block is three aligned 64-byte scalar loads) and original indices in key
 //                     order, padded to a multiple of 64, and the axis-aligned boxes of every
 //                     16-record block and 64-record superblock.
@@ -35,11 +37,19 @@
 //
 // Lowest original index on ties (the reference's strict '<' scan order) with candidates visited
 // out of order: a lane tracks the running minimum VALUE, the first visited block that attained
-// it, and a flag raised when a later block's minimum equals it bit for bit.  Without the flag all
-// candidates attaining the minimum sit in that one block: a re-scan of its 16 records takes the
-// lowest original index among the exact matches.  With the flag (duplicated points, symmetric
-// configurations) the wave re-scans, for that one query, every superblock whose bound does not
-// exceed the minimum, lanes across candidates, and reduces the lowest matching index.
+// it, the second such block, and a flag raised when a THIRD block's minimum equals it bit for bit.
+// Without the flag all candidates attaining the minimum sit in those one or two blocks: a re-scan
+// of their 16 records takes the lowest original index among the exact matches (two blocks cover
+// every duplicated pair of points, the reference resample_pcd's case: DESIGN.md 5.1f).  With the
+// flag (points repeated 3+ times across blocks, symmetric configurations) the wave re-scans, for
+// that one query, every superblock whose bound does not exceed the minimum, lanes across
+// candidates, and reduces the lowest matching index.
+//
+//   nnp_grad_sorted_kernel  (rf_chamfer_step only) the backward of both directions in SORTED space:
+//                     the sweep's epilogue leaves each query's winner position, its own gradient
+//                     term and a 64-bit mask of the winner buckets its group touches; this kernel
+//                     accumulates the scattered halves per tile of whole buckets in LDS and writes
+//                     every gradient row once, in original order.
 #include <stdlib.h>
 
 #include <type_traits>
