@@ -109,6 +109,17 @@ def main():
         p3 = torch.from_numpy(rng.random_sample((32, 3000, 3)).astype(np.float32)).to(dev)
         timeit("FPS 32x3000->32 (model)", lambda: R.farthest_point_sample(32, p3), a.iters)
         timeit("three_nn 32x16384 vs 1024", lambda: R.three_nn(p, q), a.iters)
+    if w == "c4":
+        # BASELINE configs[3] alone (one launch shape per kernel name: what the PMC passes of tools/profile_op.sh need)
+        u = torch.from_numpy((rng.random_sample((32, 2048, 3)) - 0.5).astype(np.float32)).to(dev)
+        v = torch.from_numpy((rng.random_sample((32, 2048, 3)) - 0.5).astype(np.float32)).to(dev)
+        timeit("C4 approx_match 32x2048x2048", lambda: R.approx_match(u, v), max(3, a.iters // 4), 30 * 32 * 2048 * 2048, "exp")
+        mt = R.approx_match(u, v)
+        timeit("C4 match_cost", lambda: R.match_cost(u, v, mt), a.iters, 32 * 2048 * 2048 * 4, "B")
+        timeit("C4 match_cost_grad", lambda: R.match_cost_grad(u, v, mt), a.iters, 32 * 2048 * 2048 * 4, "B")
+        del mt
+        timeit("C4 earth_mover fused (cost only)", lambda: R.earth_mover(u, v), max(3, a.iters // 4))
+        timeit("C4 earth_mover fused (cost + grads)", lambda: R.earth_mover(u, v, with_grad=True), max(3, a.iters // 4))
     if w in ("emd", "all"):
         u = torch.from_numpy((rng.random_sample((32, 2048, 3)) - 0.5).astype(np.float32)).to(dev)
         v = torch.from_numpy((rng.random_sample((32, 2048, 3)) - 0.5).astype(np.float32)).to(dev)

@@ -9,9 +9,12 @@ from collections import defaultdict
 
 
 def short(name):
+    if "am_rowk_kernel<" in name:  # <P3, P1 mode, rows per lane>: one name per fused phase
+        return "am_rowk<" + name.split("am_rowk_kernel<")[1].split(">")[0].replace(" ", "") + ">"
     for key in ("nnp_grad_sorted", "nnp_sweep", "nnp_sort_reg", "nnp_sort", "nn_sweep", "nn_pack", "nn_rowmerge", "nn_colresolve", "nn_resolve", "nn_grad", "pack_kernel",
                 "am_rowk_kernelILb1ELb1", "am_rowk_kernelILb0ELb1", "am_rowl", "am_match", "am_init", "mcg_kernel",
-                "mc_partial", "fps_reg", "query_ball", "three_nn"):
+                "mc_partial", "mc_final", "emd_fused", "emd_pack_cols", "am_cull", "fps_reg", "query_ball_lanes", "query_ball", "three_nn",
+                "group_point_grad", "group_point", "gather_kernel"):
         if key in name:
             return key
     return name[:60]
@@ -41,13 +44,13 @@ def main(out):
             acc = defaultdict(lambda: defaultdict(list))
             for row in csv.DictReader(open(f)):
                 nm = short(row.get("Kernel_Name", ""))
-                if nm in ("nn_sweep", "nnp_sweep"):
-                    nm = "%s grid_x=%s" % (nm, row.get("Grid_Size", row.get("Grid_Size_X", "?")))
+                # per launch SHAPE: one kernel name serves several workloads in a run (C4, training size, evaluation size)
+                nm = "%s grid=%s wg=%s" % (nm[:34], row.get("Grid_Size", row.get("Grid_Size_X", "?")), row.get("Workgroup_Size", row.get("Workgroup_Size_X", "?")))
                 acc[nm][row.get("Counter_Name", "")].append(float(row.get("Counter_Value", 0)))
             print("== counters:", os.path.relpath(f, out))
             for k, cs in sorted(acc.items()):
                 for c, vals in sorted(cs.items()):
-                    print(f"  {k:30s} {c:24s} mean/dispatch={sum(vals) / len(vals):.6g} n={len(vals)}")
+                    print(f"  {k:58s} {c:24s} mean/dispatch={sum(vals) / len(vals):.6g} n={len(vals)}")
 
 
 if __name__ == "__main__":

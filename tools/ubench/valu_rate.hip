@@ -110,6 +110,26 @@ __global__ void k(float *out, int iters, unsigned long long *clk) {
             REP8(asm volatile("v_readlane_b32 s20, %0, 3\n v_writelane_b32 %1, s22, 5\n v_readlane_b32 s21, %2, 3\n v_writelane_b32 %3, s22, 5\n"
                               "v_readlane_b32 s20, %4, 3\n v_writelane_b32 %5, s22, 5\n v_readlane_b32 s21, %6, 3\n v_writelane_b32 %7, s22, 5\n"
                               : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : : "s20", "s21");)
+        } else if (MODE == 19) {  // Chamfer pair mix, candidate coordinates as DPP row_newbcast source operands (sub-wave tile form)
+            REP8(asm volatile(
+                "v_sub_f32_dpp %0, %4, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_sub_f32_dpp %1, %5, %9 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_mul_f32 %1, %1, %1\n"
+                "v_sub_f32_dpp %2, %6, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_fmac_f32 %1, %0, %0\n v_fmac_f32 %1, %2, %2\n"
+                "v_sub_f32_dpp %0, %4, %9 row_newbcast:4 row_mask:0xf bank_mask:0xf\n v_sub_f32_dpp %3, %5, %8 row_newbcast:4 row_mask:0xf bank_mask:0xf\n v_mul_f32 %3, %3, %3\n"
+                "v_sub_f32_dpp %2, %6, %9 row_newbcast:4 row_mask:0xf bank_mask:0xf\n v_fmac_f32 %3, %0, %0\n v_fmac_f32 %3, %2, %2\n"
+                "v_min3_f32 %7, %7, %1, %3\n"
+                : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "v"(a), "v"(b));)
+        } else if (MODE == 20) {  // v_sub_f32_dpp row_newbcast alone, 8 independent chains
+            REP8(asm volatile("v_sub_f32_dpp %0, %8, %9 row_newbcast:1 row_mask:0xf bank_mask:0xf\n v_sub_f32_dpp %1, %8, %9 row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+                              "v_sub_f32_dpp %2, %8, %9 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_sub_f32_dpp %3, %8, %9 row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+                              "v_sub_f32_dpp %4, %8, %9 row_newbcast:5 row_mask:0xf bank_mask:0xf\n v_sub_f32_dpp %5, %8, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n"
+                              "v_sub_f32_dpp %6, %8, %9 row_newbcast:7 row_mask:0xf bank_mask:0xf\n v_sub_f32_dpp %7, %8, %9 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
+                              : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "v"(a), "v"(b));)
+        } else if (MODE == 21) {  // v_mov_b32_dpp quad_perm broadcast (what a quad-shared query costs per exchanged value)
+            REP8(asm volatile("v_mov_b32_dpp %0, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %8 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n"
+                              "v_mov_b32_dpp %2, %8 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %8 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n"
+                              "v_mov_b32_dpp %4, %9 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n"
+                              "v_mov_b32_dpp %6, %9 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %9 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n"
+                              : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "v"(a), "v"(b));)
         }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -161,6 +181,9 @@ int main() {
         run<16>("ds_bpermute", 64, w);
         run<17>("cndmask_e32 vcc", 64, w);
         run<18>("readlane/writelane", 64, w);
+        run<19>("chamfer mix dpp-bcast", 104, w);
+        run<20>("v_sub_f32_dpp newbcast", 64, w);
+        run<21>("v_mov_dpp quad_perm", 64, w);
     }
     return 0;
 }
