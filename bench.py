@@ -66,7 +66,37 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector peak
-EMD_ISSUE_FLOOR_MS = 0.75  # approx_match at C4: issue floor of its instruction mix, measured with tools/ubench
+# VALU instructions per (row, column) pair of every launch of approx_match's reference schedule (10 levels, the last with
+# multiplier 0), counted in rfnet_amd/csrc/approxmatch.hip and confirmed by SQ_INSTS_VALU (profiles/r04_rocprofv3_summary.txt):
+# (launches, plain VALU, v_exp_f32) -- d2 is 6, an exponential term is mul + exp (+ mul by the row ratio) + fma
+EMD_LAUNCH_MIX = {
+    "am_p1 (level 0)": (1, 8, 1),
+    "am_p2, levels 0-8": (9, 8, 1),
+    "am_p2, last level (e = 1: no distance, no exp)": (1, 1, 0),
+    "am_p3p1, levels 1-8": (8, 11, 2),
+    "am_p3p1, last level (P1 without exp)": (1, 10, 1),
+    "am_match (10 levels in one pass)": (1, 35, 9),
+}
+
+
+def emd_issue_floor_ms(eb, n, m):
+    """Issue floor of approx_match's kernels: counted instructions x issue costs measured by tools/ubench/valu_rate.hip
+    (profiles/issue_costs.json: constants from a committed measurement, NOT measured in this run), over the chip's
+    1024 SIMDs.  additive: plain x vop2 + exp x v_exp; mix: x the measured non-additivity of the 9-instruction column."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "issue_costs.json")) as f:
+            ic = json.load(f)
+    except (OSError, ValueError):
+        return None
+    c = ic["cycles_per_wave_instruction_per_simd"]
+    cyc = sum(k * (p * c["vop2_f32"] + e * c["v_exp_f32"]) for k, p, e in EMD_LAUNCH_MIX.values())
+    nonadd = 9.0 * c["emd_column_mix_9_instr"] / (8.0 * c["vop2_f32"] + c["v_exp_f32"])
+    add_ms = cyc * (eb * n * m / 64.0) / 1024.0 / (ic["clock_ghz"] * 1e9) * 1e3
+    return {"additive_ms": add_ms, "mix_ms": add_ms * nonadd, "non_additivity": nonadd,
+            "valu_per_pair": sum(k * (p + e) for k, p, e in EMD_LAUNCH_MIX.values()),
+            "exp_per_pair": sum(k * e for k, p, e in EMD_LAUNCH_MIX.values()),
+            "constants": "profiles/issue_costs.json (tools/ubench/valu_rate.hip, profiles/r04_valu_rate.txt): not measured in this run"}
+
 HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: HBM3E spec peak
 
 
@@ -613,7 +643,7 @@ def main():
                    "auto_kernels_ms": am, "note": note,
                    "identical_to_dense_sweep": all(bool(torch.equal(x, y)) for x, y in zip(o_auto, o_dense))}
             if "nnp_sweep" in am and len(st) >= 8:
-                ev = 1024.0 * (st[3] + st[7])
+                ev = float((st[14] or 1024) * st[3] + (st[15] or 1024) * st[7])
                 ent.update({"forward": "culled", "evaluated_fraction_of_2BNM": ev / (2.0 * B * N * M),
                             "heaviest_wave_block_scans": [int(st[8]), int(st[9])],
                             "culled_faster_than_dense": sum(am.values()) < sum(dm.values())})
@@ -664,8 +694,23 @@ def main():
         from rfnet_amd._raw import match_cost_grad
         mg_ms, mg_k = timed(lambda: match_cost_grad(e1, e2, mt), emd_steps, fence)
         del mt
-        am_kernel_ms = sum(am_k.values())
-        lane_ops = 9.0 * 30.0 * eb * en * en  # 8 VALU + 1 transcendental per evaluation
+        # (no kernel events -- a renamed kernel, events unavailable under a tool: fall back to the wall time, never divide by 0)
+        am_kernel_ms = sum(am_k.values()) or am_ms
+        efl = emd_issue_floor_ms(eb, en, en)
+        lane_ops = (efl["valu_per_pair"] if efl else 250.0) * eb * en * en
+        # SURVEY 8(d) C4's secondary run: BASELINE's "50 Sinkhorn iters" as the 10 reference levels each repeated 5x
+        lv50 = [float(x) for x in np.repeat([-4.0 ** j for j in range(7, -2, -1)] + [0.0], 5)]
+        from rfnet_amd._raw import approx_match as approx_match_lv
+        x50_steps = max(3, emd_steps // 4)
+        for _ in range(1):
+            c50 = match_cost(e1, e2, approx_match_lv(e1, e2, levels=lv50))
+        fence()
+        t2 = time.perf_counter()
+        for _ in range(x50_steps):
+            c50 = match_cost(e1, e2, approx_match_lv(e1, e2, levels=lv50))
+        fence()
+        dt_x50 = time.perf_counter() - t2
+        x50_checksum = float(c50.double().sum().item())
         extras["per_op_roofline"] = {
             "match_cost": hbm_roof(4.0 * eb * en * en + 12.0 * eb * 2 * en, mc_k.get("mc_partial", mc_ms), "mc_partial",
                                    "4*B*n*m + 12*B*(n+m) bytes (SURVEY 8(d)): one pass over match"),
@@ -693,24 +738,28 @@ def main():
         ns_same = all(bool(torch.equal(x, y)) for x, y in zip(ns_out, ns_dense_out))
         del y1, y2, ns_out, ns_dense_out
 
-        tmax = torch.tensor([dt_emd, dt_ns, dt_emdf], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt_emd, dt_ns, dt_emdf, dt_x50], dtype=torch.float64, device=dev)
         if use_pg:
             torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        dt_emd, dt_ns, dt_emdf = (float(tmax[i].item()) for i in range(3))
+        dt_emd, dt_ns, dt_emdf, dt_x50 = (float(tmax[i].item()) for i in range(4))
         extras["emd"] = {
             "roofline": {
-                "bound": "valu+trans", "kernel": "am_p3p1 + am_p2 + am_match (approx_match, 21 launches)",
-                "lane_ops_per_pair": 9 * 30, "exp_per_pair": 30,
+                "bound": "valu+trans", "kernel": "am_p1 + am_p3p1 + am_p2 + am_match (approx_match, 21 launches)",
+                "lane_ops_per_pair": efl["valu_per_pair"] if efl else None, "exp_per_pair": efl["exp_per_pair"] if efl else None,
                 "achieved": lane_ops / (am_kernel_ms * 1e-3) / 1e12, "unit": "T lane-ops/s",
-                "issue_floor_ms": EMD_ISSUE_FLOOR_MS * (eb / 32.0) * (en / 2048.0) ** 2,
-                "frac": EMD_ISSUE_FLOOR_MS * (eb / 32.0) * (en / 2048.0) ** 2 / am_kernel_ms,
+                "issue_floor_ms": efl["mix_ms"] if efl else None,
+                "issue_floor_additive_ms": efl["additive_ms"] if efl else None,
+                "issue_floor_source": (efl["constants"] + "; counted instructions per launch: EMD_LAUNCH_MIX in bench.py") if efl else
+                                      "profiles/issue_costs.json missing",
+                "frac": (efl["mix_ms"] / am_kernel_ms) if efl else None,
+                "valu_pipe_busy_by_counters": "0.88-0.93 of the launch (SQ_ACTIVE_INST_VALU, profiles/r04_rocprofv3_summary.txt): issue-bound",
                 "frac_of_fp32_peak": 2.0 * lane_ops / (am_kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
                 "avg_kernel_sum_ms": am_kernel_ms, "approx_match_ms_wall": am_ms, "kernels_ms": am_k,
                 "mfma": "not applicable: every matrix element needs its own exp(level * d2) (8 of the 9 ops and all of the "
                         "transcendental work); d2 via the |a|^2+|b|^2-2ab GEMM is ruled out because exp(-16384 d2) amplifies "
                         "its cancellation error to ~7e-4 relative (DESIGN.md 5.5, K=4 trial recorded there)",
-                "note": "frac = measured issue floor of the instruction mix / measured kernel time; frac_of_fp32_peak counts "
-                        "2 flop per lane-op against the 157.3 TFLOP/s vector peak"},
+                "note": "frac = issue floor derived from counted instructions x measured issue costs / measured kernel time; "
+                        "frac_of_fp32_peak counts 2 flop per lane-op against the 157.3 TFLOP/s vector peak"},
             "metric": "EMD iters/sec (approx_match + match_cost batch calls)",
             "value": world * emd_steps / dt_emd, "unit": "calls/s", "ms_per_call": dt_emd / emd_steps * 1e3,
             "level_sweeps_per_s": world * emd_steps * 30 / dt_emd,
@@ -718,6 +767,11 @@ def main():
             "workload": f"B={eb} per GPU, {en} vs {en}, reference 10-level schedule "
                         "(BASELINE.json configs[3]); uniform(-0.5,0.5) seed 100",
             "steps": emd_steps, "checksum": emd_checksum,
+            "extended_50": {"metric": "approx_match (50-level schedule: the 10 reference levels x 5) + match_cost batch calls",
+                            "value": world * x50_steps / dt_x50, "unit": "calls/s", "ms_per_call": dt_x50 / x50_steps * 1e3,
+                            "level_sweeps_per_s": world * x50_steps * 150 / dt_x50, "steps": x50_steps, "checksum": x50_checksum,
+                            "parity": "tests/test_gpu_emd.py::test_extended_schedule_50_levels_c4_size (one sample vs the oracle "
+                                      "on the same schedule; no reference counterpart: SURVEY 8(d) C4)"},
             "fused": {"op": "rf_earth_mover (same cost, match never written to HBM)",
                       "value": world * emd_steps / dt_emdf, "unit": "calls/s",
                       "ms_per_call": dt_emdf / emd_steps * 1e3, "checksum": emd_fused_checksum},
@@ -730,7 +784,7 @@ def main():
             "kernels_ms": ns_auto_ms, "dense_kernels_ms": ns_dense_ms,
         }
         if "nnp_sweep" in ns_auto_ms and len(ns_stats) >= 8:
-            ev = 1024.0 * (ns_stats[3] + ns_stats[7])
+            ev = float((ns_stats[14] or 1024) * ns_stats[3] + (ns_stats[15] or 1024) * ns_stats[7])
             t_sw = ns_auto_ms["nnp_sweep"] * 1e-3
             extras["north_star_16384sq"]["roofline"] = {
                 "bound": "valu", "kernel": "nnp_sweep", "achieved": 8.0 * ev / t_sw / 1e12, "peak": FP32_PEAK_TFLOPS,
@@ -766,7 +820,7 @@ def main():
             except Exception:
                 traffic = {}
         if culled and len(culled_stats) >= 8 and sweep_avg_s:
-            evaluated = 1024.0 * (culled_stats[3] + culled_stats[7])  # directed pairs: 16 x 64 per block scan
+            evaluated = float((culled_stats[14] or 1024) * culled_stats[3] + (culled_stats[15] or 1024) * culled_stats[7])  # directed pairs (unit per scan: stats[14+d])
             executed_tf = 8.0 * evaluated / sweep_avg_s / 1e12
             roof = {
                 "bound": "valu",

@@ -68,7 +68,8 @@ int rf_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2, fl
  * 65536) -- identical outputs, bit for bit, ties included.  RF_NN_AUTO (what rf_nn_distance
  * uses) picks by size.  `stats` (host pointer to 32 counters, or NULL; filled by the culled sweep
  * only): per direction d at [4d..4d+3] {waves, superblock steps, most steps of one wave, 16-candidate
- * block scans (x 1024 = directed pairs evaluated)}, [8+d] most block scans of one wave, [16..31] phase time stamps of the sort; a non-NULL
+ * block scans}, [8+d] most block scans of one wave, [14+d] directed pairs per counted block scan of direction d (1024: 64 queries x
+ * 16 candidates; 16 where a query has four lanes of its own, nn_pruned.hip sweep_tile16), [16..31] phase time stamps of the sort; a non-NULL
  * pointer synchronises the stream. */
 #define RF_NN_AUTO 0
 #define RF_NN_DENSE 1

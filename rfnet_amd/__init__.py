@@ -22,8 +22,10 @@ def enable_graph_safe_runtime():
     graph goes stale.  The runtime switch DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 costs nothing in replay time
     (measured: 8.51 vs 8.52 ms per C5 step) but only counts if it is set BEFORE the HIP runtime starts
     (`torch.cuda.is_available()` starts it).  This function sets it (unless the host already chose a value)
-    and returns True when it was set in time to matter as far as this process can tell, i.e. torch has not
-    initialised CUDA/HIP yet; `rfnet_amd._host.graph_replay_ok()` asks the running runtime itself.
+    and returns a BEST-EFFORT hint: True when torch has not initialised CUDA/HIP yet.  The hint can be falsely
+    True -- `torch.cuda.is_available()` / `device_count()` may already have started the runtime without torch
+    counting as initialised -- so never branch on it: `rfnet_amd._host.graph_replay_ok()` asks the running
+    runtime itself and is the authority (TrainStep / GraphedForward consult it and stay eager when it says no).
 
     `import rfnet_amd` does NOT call this: the binding leaves os.environ untouched.  The package's own
     entry points that capture such graphs (`python -m rfnet_amd.trainrun`, `python -m rfnet_amd.evalrun`,

@@ -139,8 +139,9 @@ def graph_replay_ok(dev=None):
     the runtime was STARTED with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0; a captured `sum` / `max` then returns
     stale or wrong values on some later replay (tools/experiments/graph_bug_probe2.py, train_graph.py) --
     not reliably on the first few, so checking a captured graph's outputs is no substitute.
-    rfnet_amd/_lib.py sets the switch at import, which works only if nothing has touched the HIP runtime
-    yet (`torch.cuda.is_available()` already does).  This asks the runtime itself: a graph of
+    Nothing in this package sets the switch at import: the host opts in with
+    `rfnet_amd.enable_graph_safe_runtime()` before anything touches the HIP runtime (`torch.cuda.is_available()`
+    already does).  This asks the runtime itself: a graph of
     [rf_probe_memset_async; += 1] replayed four times must read 1 every time (measured: True exactly when
     the switch took effect).  Callers that capture graphs holding torch reductions (trainrun.TrainStep) go
     eager when it says no.  Cached per device; not callable during a capture."""

@@ -458,8 +458,14 @@ __global__ void mc_final_kernel(const float *partial, int per_batch, float *cost
 //   phase B (thread <-> (l, 32-k slice)): re-reads q column-wise from LDS, accumulates
 //            (x2_l - x1_k)*q, 8 slices summed through LDS, one coalesced atomicAdd per (l, c).
 // grad1: 3 atomics per thread at the end (LSPLIT-way contention only).  Outputs zero-filled first.
-constexpr int MG_TL = 32;
-constexpr int MG_LSPLIT = 4;
+#ifndef RFA_MG_TL
+#define RFA_MG_TL 32
+#endif
+#ifndef RFA_MG_LSPLIT
+#define RFA_MG_LSPLIT 4
+#endif
+constexpr int MG_TL = RFA_MG_TL;
+constexpr int MG_LSPLIT = RFA_MG_LSPLIT;
 __global__ __launch_bounds__(TPB) void mcg_kernel(int n, int m, int lspan,
                                                   const float *__restrict__ xyz1,
                                                   const float *__restrict__ xyz2,
@@ -684,7 +690,7 @@ __global__ __launch_bounds__(TPB) void emd_fused_kernel(int n, int m, int mpad, 
 // threshold: v_exp_f32 returns +0 for every argument <= -160 (the true value is below half the smallest denormal:
 // whatever the denormal mode, the result is +0; tests/test_gpu_emd.py sweeps the instruction).  A pair with weight
 // 0 adds fma(0 * rl, s, acc) = acc to every sum of its level -- bit for bit nothing (ratios are finite: sums start
-// at 1e-9).  So for these levels the sweeps run over the Hilbert-sorted clouds of nn_pruned.hip: a workgroup owns 64
+// at 1e-9).  So for these levels the sweeps run over the spatially sorted (sort-tile-recursive) clouds of nn_pruned.hip: a workgroup owns 64
 // consecutive sorted rows, tests the box of every 16-record column block against the box of its rows with the
 // Chamfer sweep's bound (same instruction sequence on the per-axis gaps, hence <= the d2 of every pair between the
 // boxes), lists the blocks whose bound is below the threshold and streams only those through SGPRs.  What survives
@@ -707,7 +713,7 @@ constexpr int CULL_MIN_PTS = RFA_CULL_MIN_PTS;
 constexpr int CW = 8;                // waves per row group: each takes every 8th listed block
 constexpr int CULL_MAXBLK = rfp::kMaxPoints / 16 + 8;
 
-struct CullSet {          // one Hilbert-sorted set (rfp::Sorted) plus its size
+struct CullSet {          // one spatially sorted set (rfp::Sorted) plus its size
     const float *xyz;     // (b, npad, 3), padding = +inf
     const int *orig;      // (b, npad), padding = -1
     const float *box16;   // (b, npad / 64, 24)
@@ -879,7 +885,9 @@ constexpr int CULL_MAXLV = 8;  // at most this many leading levels are culled
 
 int round_up_i(int v, int q) { return (v + q - 1) / q * q; }
 
-AmLayout am_layout(int b, int n, int m, int nlevels) {
+// allow_cull: only the cost-only rf_earth_mover ever runs culled levels; rf_approxmatch(_levels) and the gradient form
+// must not carry the sorted sets and twin slots (about 50 MB at 32 x 16384^2) for nothing
+AmLayout am_layout(int b, int n, int m, int nlevels, bool allow_cull) {
     AmLayout L;
     L.npad = round_up_i(n, CPAD);
     L.mpad = round_up_i(m, CPAD);
@@ -890,7 +898,7 @@ AmLayout am_layout(int b, int n, int m, int nlevels) {
     off += (size_t)b * L.npad * 3 + 64;
     L.off_x2 = off;
     off += (size_t)b * L.mpad * 3 + 64;
-    L.cull_ok = n >= CULL_MIN_PTS && m >= CULL_MIN_PTS && rfp::pruned_supported(b, n, m);
+    L.cull_ok = allow_cull && n >= CULL_MIN_PTS && m >= CULL_MIN_PTS && rfp::pruned_supported(b, n, m);
     L.nsa = L.nsb = 0;
     L.Vs = L.tw_stride = L.off_sa = L.off_sb = L.off_tw = 0;
     if (L.cull_ok) {
@@ -945,7 +953,7 @@ void am_multipliers(int n, int m, float &multiL, float &multiR) {
 int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int nlevels,
                   const LevelConsts &lc, float multiL, float multiR, void *workspace, hipStream_t s,
                   bool allow_cull) {
-    const AmLayout L = am_layout(b, n, m, nlevels);
+    AmLayout L = am_layout(b, n, m, nlevels, allow_cull);
     float *w = (float *)workspace;
     float *remainL = w, *remainR = w + L.npad;          // slot 0 of the vector region
     float *ratios = w + L.V;                            // slot 1+v: [ratioL npad | ratioR mpad]
@@ -957,8 +965,9 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
     RF_LAUNCH("am_init", am_init_kernel, dim3(rf::ceil_div(L.mpad, 256), b), dim3(256), 0, s, m, L.mpad,
               multiR, xyz2, x2p, (size_t)L.mpad * 3, remainR, L.bstride);
 
-    // the leading sharp levels run culled over Hilbert-sorted copies of the clouds (am_cull_kernel)
+    // the leading sharp levels run culled over spatially sorted (sort-tile-recursive) copies of the clouds (am_cull_kernel)
     const int ncull = allow_cull ? cull_levels(L, nlevels, lc) : 0;
+    L.tw_stride = L.Vs * (size_t)(1 + ncull);  // only the twin slots this schedule touches are laid out (and zero-filled)
     CullSet SA{}, SB{};
     float *tw = w + L.off_tw;  // twins: slot 0 = [remainL_s nsa | remainR_s nsb], slot 1+v = [ratioL_s | ratioR_s]
     if (ncull > 0) {
@@ -1055,7 +1064,7 @@ int rf_probe_exp2(const float *x, float *y, int count, rf_stream_t stream) {
 size_t rf_approxmatch_workspace_bytes(int b, int n, int m, int nlevels) {
     if (b <= 0 || n <= 0 || m <= 0) return 0;
     if (nlevels <= 0) nlevels = 10;
-    return am_layout(b, n, m, nlevels).total * sizeof(float);
+    return am_layout(b, n, m, nlevels, false).total * sizeof(float);
 }
 
 int rf_approxmatch_levels(int b, int n, int m, const float *xyz1, const float *xyz2, float *match,
@@ -1083,7 +1092,7 @@ int rf_approxmatch_levels(int b, int n, int m, const float *xyz1, const float *x
         const int st = am_run_levels(b, n, m, xyz1, xyz2, nlevels, lc, multiL, multiR, workspace, s, false);
         if (st != RF_OK) return st;
     }
-    const AmLayout L = am_layout(b, n, m, nlevels);
+    const AmLayout L = am_layout(b, n, m, nlevels, false);
     const float *ratios = (const float *)workspace + L.V;
     // P3 of the last level only updates remainL, which nothing reads afterwards: not launched.
     const dim3 gm(rf::ceil_div(n, TPB), rf::ceil_div(m, LSEG), b);
@@ -1168,7 +1177,7 @@ EmdLayout emd_layout(int b, int n, int m) {
         E.off_rec = E.off_partial = 0;
         return E;
     }
-    const AmLayout L = am_layout(b, n, m, 10);
+    const AmLayout L = am_layout(b, n, m, 10, true);  // (one size for both forms of rf_earth_mover: the cost-only one culls)
     // enough workgroups to fill the chip: >= 4096 of 4 waves, l-spans of whole 32-column tiles
     const long base = (long)b * rf::ceil_div(n, TPB);
     int lsplit = 1;
@@ -1240,7 +1249,7 @@ int rf_earth_mover(int b, int n, int m, const float *xyz1, const float *xyz2, fl
         const int st = am_run_levels(b, n, m, xyz1, xyz2, nl, lc, multiL, multiR, workspace, s, !want_grad);
         if (st != RF_OK) return st;
     }
-    const AmLayout L = am_layout(b, n, m, nl);
+    const AmLayout L = am_layout(b, n, m, nl, !want_grad);
     const float *ratios = w + L.V;
     float *rec = w + E.off_rec, *partial = w + E.off_partial;
     RF_LAUNCH("emd_pack_cols", emd_pack_cols_kernel, dim3(rf::ceil_div(L.mpad, 256), b), dim3(256), 0, s, m,

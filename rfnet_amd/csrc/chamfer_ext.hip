@@ -250,8 +250,11 @@ int rf_chamfer_step(int b, int n, int m, const float *xyz1, const float *xyz2, c
         if (!xyz1 || !xyz2 || !dist1 || !idx1 || !dist2 || !idx2 || !workspace || !grad_dist1 || !grad_dist2 ||
             !grad_xyz1 || !grad_xyz2)
             return RF_EINVAL;
-        return rfp::pruned_step(b, n, m, xyz1, xyz2, grad_dist1, grad_dist2, dist1, idx1, dist2, idx2, grad_xyz1,
-                                grad_xyz2, workspace, workspace_bytes, (hipStream_t)stream);
+        // A caller that sized the workspace with rf_nn_distance_workspace_bytes (rounds 1-2: the two sizes were equal)
+        // still gets its step: the two ops back to back, same results -- not RF_EWORKSPACE.
+        if (workspace_bytes >= rfp::pruned_step_workspace_bytes(b, n, m))
+            return rfp::pruned_step(b, n, m, xyz1, xyz2, grad_dist1, grad_dist2, dist1, idx1, dist2, idx2, grad_xyz1,
+                                    grad_xyz2, workspace, workspace_bytes, (hipStream_t)stream);
     }
     if (int e = rf_nn_distance(b, n, m, xyz1, xyz2, dist1, idx1, dist2, idx2, workspace, workspace_bytes, stream))
         return e;

@@ -59,12 +59,11 @@
 
 namespace {
 
-// experiment knobs (tools/build_variant.py compiles A/B libraries with -D...; the defaults are the product)
+// tuning knobs (tools/build_variant.py compiles A/B libraries with -D...; the defaults are the product, every value gives
+// correct results).  Decided experiments -- the Hilbert order of the register sort, the heavy-direction-first grid order,
+// the timing-only ablations of the sorted-space backward -- live in tools/experiments/nn_pruned_decided_knobs.patch.txt.
 #ifndef RFP_NSH
 #define RFP_NSH 4   // waves sharing one query group when a direction has few groups
-#endif
-#ifndef RFP_ORDER
-#define RFP_ORDER 0 // 0: per batch element dir0's workgroups then dir1's; 1: all of dir0 first (heavy first)
 #endif
 #ifndef RFP_SPLIT_BELOW
 #define RFP_SPLIT_BELOW 4096
@@ -77,10 +76,6 @@ namespace {
 #ifndef RFP_SORT_SPLIT_ABOVE
 #define RFP_SORT_SPLIT_ABOVE 8192
 #endif
-#ifndef RFP_STR
-#define RFP_STR 1   // order of the register-resident sort: 1 = sort-tile-recursive key (x slabs, y strips per slab, z inside a
-                    // strip, boustrophedon), 0 = Hilbert curve over per-axis equalised cells (rounds 1-2)
-#endif
 #ifndef RFP_WPE
 #define RFP_WPE 7   // waves per SIMD the sweep's register allocation is held to (6: no SGPR spills, 8: spills inside the loop)
 #endif
@@ -90,10 +85,16 @@ namespace {
 #ifndef RFP_HIST
 #define RFP_HIST 0  // 1 (instrumented build): block scans by number of active lanes -> stats[10..13]
 #endif
-#ifndef RFP_GS_ABL
-#define RFP_GS_ABL 0  // ablation builds of the sorted-space backward (WRONG results, timing only; profiles/r03_ab_grad_sorted.txt):
-                      // 1 no group visits, 2 no LDS atomics; in the sweep's emit: 16 no upstream-gradient load, 32 no bucket
-                      // mask, 64 no winner-coordinate gather, 128 no emit stores
+#ifndef RFP_HAGG
+#define RFP_HAGG 1  // the sort's histogram loops pre-aggregate in waves whose points crowd into few bins (collapsed clouds)
+#endif
+#ifndef RFP_T16_STAMPS
+#define RFP_T16_STAMPS 0  // 1 (instrumented build): s_memtime per phase of the quad-per-query tiles, summed over waves -> stats[25..31]
+#endif
+#ifndef RFP_TILE16
+#define RFP_TILE16 1  // directions with few query groups: 1 = a wave per 16-query tile, four lanes per query, every quad walking its
+                      // OWN list of candidate blocks with gathered scans (round 4); 0 = four waves share a
+                      // 64-query group and stream every needed block through SGPRs to all 64 lanes (rounds 1-3)
 #endif
 constexpr int NSH = RFP_NSH;
 constexpr int BS = 16;             // candidates per block
@@ -173,14 +174,6 @@ __device__ __forceinline__ int axis_bin(float v, float lo, float scale) {
     return b < 0 ? 0 : (b > HB - 1 ? HB - 1 : b);
 }
 
-#if !RFP_STR
-// The same curve as hilbert15() as a state machine, one octant (3 bits) per level: entry
-// [state * 8 + octant] = next state << 3 | digit; 24 orientations (derived from, and verified
-// against, Skilling's mapping over all 32768 cells).  ~6 ALU ops + one LDS byte per level
-// instead of ~30.
-__constant__ unsigned char kHilbertLut[192] = {32, 9, 147, 2, 103, 118, 44, 5, 40, 1, 111, 126, 155, 10, 36, 13, 8, 163, 33, 18, 119, 28, 102, 21, 0, 171, 127, 20, 41, 26, 110, 29, 24, 135, 17, 142, 179, 12, 34, 37, 16, 143, 187, 4, 25, 134, 42, 45, 50, 153, 59, 176, 53, 94, 132, 79, 58, 145, 61, 86, 51, 184, 140, 71, 66, 83, 177, 152, 69, 108, 78, 95, 74, 91, 77, 100, 185, 144, 70, 87, 82, 85, 161, 62, 67, 124, 168, 55, 90, 93, 75, 116, 169, 54, 160, 63, 76, 115, 101, 98, 167, 56, 22, 137, 68, 123, 175, 48, 109, 106, 30, 129, 92, 117, 99, 114, 151, 6, 80, 121, 84, 125, 159, 14, 107, 122, 88, 113, 52, 191, 139, 64, 133, 46, 130, 105, 60, 183, 141, 38, 131, 72, 138, 97, 166, 57, 149, 146, 23, 136, 188, 3, 174, 49, 31, 128, 157, 154, 180, 11, 150, 165, 81, 162, 7, 172, 120, 19, 158, 173, 15, 164, 89, 170, 112, 27, 190, 47, 65, 104, 181, 156, 178, 35, 182, 39, 189, 148, 73, 96, 186, 43};
-#endif
-
 __device__ __forceinline__ unsigned spread5(unsigned v) {  // bit b -> bit 3b
     v = (v | (v << 8)) & 0x100Fu;
     v = (v | (v << 4)) & 0x10C3u;
@@ -224,6 +217,55 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 }
 #undef RFP_ROW
 
+// LDS histogram increments on DEGENERATE clouds.  ds_add_u32 serialises over lanes that hit the same address: on a
+// cloud collapsed onto a few spots (the untrained RFNet's output: 16384 points on ~120 spots, 3-5 distinct bins among
+// the 64 consecutive points of a wave instruction, interleaved) the histogram phases took 2-5x their normal time
+// (quantiles 8.0 k -> 28.5 k ticks, positions 2.0 k -> 11.5 k: profiles/r04_sort_stamps.txt).  A wave that finds >= 8 of
+// its lanes in one bin at its first sample (`hist_is_dense`) runs a SEPARATE copy of each histogram loop that
+// pre-aggregates: up to HAGG_ROUNDS distinct bins are found by ballot and added once each by a leader lane, whatever is
+// left adds singly.  Normal clouds (randn: 50 distinct x bins per 64 lanes) pay one test per wave and run the loops as before.
+constexpr int HAGG_ROUNDS = 6;
+__device__ __forceinline__ bool hist_is_dense(unsigned bin, bool act) {
+    const unsigned long long todo = __builtin_amdgcn_ballot_w64(act);
+    if (todo == 0ull) return false;
+    const unsigned first = (unsigned)__builtin_amdgcn_readlane((int)bin, __builtin_ctzll(todo));
+    return __builtin_popcountll(__builtin_amdgcn_ballot_w64(act && bin == first)) >= 8;
+}
+__device__ __forceinline__ void hist_add_agg(unsigned *h, unsigned bin, bool act, int lane) {
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(act);
+#pragma unroll 1
+    for (int it = 0; it < HAGG_ROUNDS && todo; it++) {
+        const int l = __builtin_ctzll(todo);
+        const unsigned v = (unsigned)__builtin_amdgcn_readlane((int)bin, l);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(act && bin == v);
+        if (lane == l) atomicAdd(&h[v], (unsigned)__builtin_popcountll(m));
+        todo &= ~m;
+    }
+    if ((todo >> lane) & 1ull) atomicAdd(&h[bin], 1u);
+}
+// the returning form (positions inside a key, any order): rank inside the bin's lane group + the leader's old value
+__device__ __forceinline__ unsigned hist_fetch_add_agg(unsigned *h, unsigned bin, bool act, int lane) {
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(act);
+    int leader = lane;
+    unsigned rank = 0, cnt = 1;
+#pragma unroll 1
+    for (int it = 0; it < HAGG_ROUNDS && todo; it++) {
+        const int l = __builtin_ctzll(todo);
+        const unsigned v = (unsigned)__builtin_amdgcn_readlane((int)bin, l);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(act && bin == v);
+        if ((m >> lane) & 1ull) {
+            leader = l;
+            rank = (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            cnt = (unsigned)__builtin_popcountll(m);
+        }
+        todo &= ~m;
+    }
+    unsigned base = 0;
+    if (act && leader == lane) base = atomicAdd(&h[bin], cnt);
+    base = (unsigned)__builtin_amdgcn_ds_bpermute(leader << 2, (int)base);
+    return base + rank;
+}
+
 constexpr int HALF = 9216;  // records staged in LDS at a time (16 B each, over the dead histogram + 16 KiB): a
                             // split cloud's half (8192 +- the quantiles' sampling error) fits one round
 
@@ -234,15 +276,9 @@ constexpr int HALF = 9216;  // records staged in LDS at a time (16 B each, over 
 __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned hist[HALF * 4];  // NBINS bins, later HALF staged records
     __shared__ unsigned ahist[3][HB];
-#if RFP_STR
     __shared__ unsigned char slabmap[HB];        // x bin -> slab (equal mass)
     __shared__ unsigned short zmap[HB];          // z bin -> rank in 0..511 (equal mass)
     __shared__ unsigned char stripmap[16 * HB];  // (slab, y bin) -> strip of that slab (equal mass inside the slab), snaked
-#else
-    __shared__ unsigned short cellmap[3][HB];  // equalised cell, already bit-spread and shifted per axis
-    __shared__ unsigned char hlut[192];
-    __shared__ unsigned short hlut2[24 * 64];  // two octant levels per lookup, built from hlut
-#endif
     __shared__ float red[STPB / 64][6];
     __shared__ unsigned wsum[STPB / 64];
     __shared__ unsigned lowcnt[STPB / 64][3];
@@ -294,12 +330,8 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
         for (int k = 0; k < NBINS / 4 / STPB; k++) h4[tid + k * STPB] = make_uint4(0, 0, 0, 0);
     }
     if (tid < 3 * HB) (&ahist[0][0])[tid] = 0;
-#if RFP_STR
     unsigned *yhist = hist + NBINS;  // [slab][HB], in the part of `hist` that only the staging uses (dead until then)
     for (int i = tid; i < 16 * HB; i += STPB) yhist[i] = 0;
-#else
-    if (tid < 192) hlut[tid] = kHilbertLut[tid];
-#endif
 
     stamp();
     // 1. bounding box of the finite coordinates
@@ -346,32 +378,41 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     __syncthreads();
     const float fl[3] = {frame[0], frame[1], frame[2]};
     const float fs[3] = {frame[3], frame[4], frame[5]};
-#if !RFP_STR
-    // [state * 64 + (octant_hi << 3 | octant_lo)] = next state << 6 | two digits (from the
-    // one-level table, in LDS since the first barrier: no second table to fetch from memory)
-    for (int e = tid; e < 24 * 64; e += STPB) {
-        const unsigned e1 = hlut[(e >> 6) * 8 + ((e >> 3) & 7)];
-        const unsigned e2 = hlut[(e1 >> 3) * 8 + (e & 7)];
-        hlut2[e] = (unsigned short)(((e2 >> 3) << 6) | ((e1 & 7u) << 3) | (e2 & 7u));
-    }
-#endif
 
     stamp();
     // 2. per-axis histograms of a quarter of the points: the cells only need approximate
     // quantiles, and same-address LDS atomics serialise.  The choice of k is WAVE-uniform (a
     // scalar branch skips the other three quarters; wave w takes k = -w mod 4, so every index
     // range of the cloud is sampled).
+    // (wave-uniform) this wave's points crowd into few bins: decided on its first sample, k = -wave mod 4
+    bool dense;
+    {
+        const int w3 = wave & RFP_QSAMPLE;
+        const float x0 = w3 == 0 ? px[0] : (w3 == 3 ? px[1] : (w3 == 2 ? px[2] : px[3]));
+        const int k0 = (4 - w3) & 3;
+        dense = RFP_HAGG && RFP_QSAMPLE == 3 && hist_is_dense((unsigned)axis_bin(x0, fl[0], fs[0]), tid + k0 * STPB < n);
+    }
+    if (dense) {
 #pragma unroll
-    for (int k = 0; k < RPT; k++) {
-        if (((k + wave) & RFP_QSAMPLE) != 0) continue;
-        if (tid + k * STPB < n) {
-            atomicAdd(&ahist[0][axis_bin(px[k], fl[0], fs[0])], 1u);
-            atomicAdd(&ahist[1][axis_bin(py[k], fl[1], fs[1])], 1u);
-            atomicAdd(&ahist[2][axis_bin(pz[k], fl[2], fs[2])], 1u);
+        for (int k = 0; k < RPT; k++) {
+            if (((k + wave) & RFP_QSAMPLE) != 0) continue;
+            const bool act = tid + k * STPB < n;
+            hist_add_agg(ahist[0], (unsigned)axis_bin(px[k], fl[0], fs[0]), act, lane);
+            hist_add_agg(ahist[1], (unsigned)axis_bin(py[k], fl[1], fs[1]), act, lane);
+            hist_add_agg(ahist[2], (unsigned)axis_bin(pz[k], fl[2], fs[2]), act, lane);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+            if (((k + wave) & RFP_QSAMPLE) != 0) continue;
+            if (tid + k * STPB < n) {
+                atomicAdd(&ahist[0][axis_bin(px[k], fl[0], fs[0])], 1u);
+                atomicAdd(&ahist[1][axis_bin(py[k], fl[1], fs[1])], 1u);
+                atomicAdd(&ahist[2][axis_bin(pz[k], fl[2], fs[2])], 1u);
+            }
         }
     }
     __syncthreads();
-#if RFP_STR
     // Sort-tile-recursive order from histograms: SS slabs of equal mass along x (marginal x histogram), inside
     // every slab SS strips of equal mass along y (the slab's own y histogram), inside a strip the points by z
     // (rank of the z bin, 9 bits) -- tiles of 64 consecutive records are then near-cubic cells with disjoint boxes
@@ -404,11 +445,20 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     }
     __syncthreads();
     // the y histogram of every slab, from the same quarter of the points
+    if (dense) {
 #pragma unroll
-    for (int k = 0; k < RPT; k++) {
-        if (((k + wave) & RFP_QSAMPLE) != 0) continue;
-        if (tid + k * STPB < n)
-            atomicAdd(&yhist[(int)slabmap[axis_bin(px[k], fl[0], fs[0])] * HB + axis_bin(py[k], fl[1], fs[1])], 1u);
+        for (int k = 0; k < RPT; k++) {
+            if (((k + wave) & RFP_QSAMPLE) != 0) continue;
+            hist_add_agg(yhist, (unsigned)((int)slabmap[axis_bin(px[k], fl[0], fs[0])] * HB + axis_bin(py[k], fl[1], fs[1])),
+                         tid + k * STPB < n, lane);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+            if (((k + wave) & RFP_QSAMPLE) != 0) continue;
+            if (tid + k * STPB < n)
+                atomicAdd(&yhist[(int)slabmap[axis_bin(px[k], fl[0], fs[0])] * HB + axis_bin(py[k], fl[1], fs[1])], 1u);
+        }
     }
     __syncthreads();
     if (wave < SS) {  // wave <-> slab
@@ -437,31 +487,6 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
               cs3 = H > 3 ? col_start(3) : 0x7FFFFFFF;  // (uniform; the divisions stay out of the per-point loop)
     const unsigned kbase = (unsigned)col_start(half) << 9;
     const int nb_local = (col_start(half + 1) - col_start(half)) << 9;
-#else
-    if (wave < 3) {
-        unsigned c4[4], s = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            c4[k] = ahist[wave][lane * 4 + k];
-            s += c4[k];
-        }
-        const unsigned incl = wave_incl_scan(s);
-        const unsigned total = max((unsigned)__builtin_amdgcn_readlane((int)incl, 63), 1u);
-        unsigned run = incl - s;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            // cell of a bin = the 1/32-quantile its first sample falls into
-            unsigned cell = (run * 32u) / total;  // run <= 65536: no overflow
-            cell = cell > 31u ? 31u : cell;
-            cellmap[wave][lane * 4 + k] = (unsigned short)(spread5(cell) << (2 - wave));
-            run += c4[k];
-        }
-    }
-    __syncthreads();
-    const int hshift = H == 4 ? KEYBITS - 2 : (H == 2 ? KEYBITS - 1 : KEYBITS);  // (key >> KEYBITS == 0)
-    const unsigned hmask = (unsigned)(NBINS / H - 1);
-    const int nb_local = NBINS / H;
-#endif
 
     stamp();
     unsigned below[3] = {0u, 0u, 0u};  // wave-uniform counters
@@ -469,7 +494,6 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
         const bool valid = tid + k * STPB < n;
-#if RFP_STR
         const int slab = slabmap[axis_bin(px[k], fl[0], fs[0])];
         const int col = slab * SS + (int)stripmap[slab * HB + axis_bin(py[k], fl[1], fs[1])];
         const unsigned zq = zmap[axis_bin(pz[k], fl[2], fs[2])];
@@ -477,28 +501,17 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
         const int slice = (col >= cs1) + (col >= cs2) + (col >= cs3);
         const bool own = valid && slice == half;
         pk[k] = own ? key - kbase : 0xFFFFFFFFu;
-#else
-        const unsigned m = (unsigned)cellmap[0][axis_bin(px[k], fl[0], fs[0])] |
-                           (unsigned)cellmap[1][axis_bin(py[k], fl[1], fs[1])] |
-                           (unsigned)cellmap[2][axis_bin(pz[k], fl[2], fs[2])];
-        // 5 octant levels = 2 + 2 + 1 table lookups
-        const unsigned e1 = hlut2[(m >> 9) & 63u];  // state 0
-        const unsigned e2 = hlut2[(e1 >> 6) * 64 + ((m >> 3) & 63u)];
-        const unsigned e3 = hlut[(e2 >> 6) * 8 + (m & 7u)];
-        const unsigned key = ((e1 & 63u) << 9) | ((e2 & 63u) << 3) | (e3 & 7u);
-        // bins of this workgroup: the low KEYBITS-1 bits when the cloud is split; 0xFFFFFFFF marks a
-        // point of the other half (or beyond n)
-        const int slice = (int)(key >> hshift);  // H slices of the key space (H = 1: everything is slice 0)
-        const bool own = valid && slice == half;
-        pk[k] = own ? (key & hmask) : 0xFFFFFFFFu;
-#endif
-        if (own) atomicAdd(&hist[pk[k]], 1u);
+        if (own && !dense) atomicAdd(&hist[pk[k]], 1u);
         // points of the slices below this workgroup's (its segment starts behind theirs)
         if (H > 1) {
 #pragma unroll
             for (int q = 0; q < 3; q++)
                 if (q < half) below[q] += (unsigned)__builtin_popcountll(__ballot(valid && slice == q));
         }
+    }
+    if (dense) {  // (the key histogram of a crowded wave, pre-aggregated: its own loop, the keys are in registers)
+#pragma unroll 1
+        for (int k = 0; k < RPT; k++) hist_add_agg(hist, pk[k] == 0xFFFFFFFFu ? 0u : pk[k], pk[k] != 0xFFFFFFFFu, lane);
     }
     if (H > 1 && lane == 0) {
 #pragma unroll
@@ -549,9 +562,18 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
 
     stamp();
     // 5. positions (the order inside a key is whatever the atomics give: results do not depend on it)
+    if (dense) {
 #pragma unroll
-    for (int k = 0; k < RPT; k++)
-        if (pk[k] != 0xFFFFFFFFu) pk[k] = atomicAdd(&hist[pk[k]], 1u);  // position inside this half's segment
+        for (int k = 0; k < RPT; k++) {
+            const bool act = pk[k] != 0xFFFFFFFFu;
+            const unsigned pos = hist_fetch_add_agg(hist, act ? pk[k] : 0u, act, lane);
+            if (act) pk[k] = pos;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < RPT; k++)
+            if (pk[k] != 0xFFFFFFFFu) pk[k] = atomicAdd(&hist[pk[k]], 1u);  // position inside this half's segment
+    }
     __syncthreads();  // the histogram is dead from here on
 
     stamp();
@@ -1041,7 +1063,7 @@ __device__ __forceinline__ void sweep_group(
     const bool valid = qorig >= 0;
     float gq = 0.f;  // upstream gradient of this query's distance (GRAD): fetched now, used in the epilogue
     if constexpr (GRAD) {
-        if (valid && !(RFP_GS_ABL & 16)) gq = ge.gd[dir][(size_t)bi * a.n[dir] + qorig];
+        if (valid) gq = ge.gd[dir][(size_t)bi * a.n[dir] + qorig];
     }
     // A query with a NaN coordinate can never tighten its bound (every d2 is NaN): it takes no part
     // in the traversal -- it would drag its whole wave through every superblock -- and is written as
@@ -1338,6 +1360,7 @@ __device__ __forceinline__ void sweep_group(
         atomicMax(&stats[dir * 4 + 2], (unsigned long long)n_step);
         atomicAdd(&stats[dir * 4 + 3], (unsigned long long)n_scan);
         atomicMax(&stats[8 + dir], (unsigned long long)n_scan);
+        stats[14 + dir] = SB * BS;  // directed pairs per counted scan
 #if RFP_HIST
         for (int k = 0; k < 4; k++) atomicAdd(&stats[10 + k], (scan_hist >> (16 * k)) & 0xFFFFull);
 #endif
@@ -1372,27 +1395,429 @@ __device__ __forceinline__ void sweep_group(
         const EmitView ev = emit_layout(ge.base, a.b, a.npad[0], a.npad[1], dir);
         const int w = (qnan || besti == 0xFFFFFFFFu) ? p0 : wpos;
         const int wc = valid ? w : 0;
-        const float cx = (RFP_GS_ABL & 64) ? 1.f : C[(size_t)wc * 3 + 0], cy = (RFP_GS_ABL & 64) ? 1.f : C[(size_t)wc * 3 + 1],
-                    cz = (RFP_GS_ABL & 64) ? 1.f : C[(size_t)wc * 3 + 2];
+        const float cx = C[(size_t)wc * 3 + 0], cy = C[(size_t)wc * 3 + 1], cz = C[(size_t)wc * 3 + 2];
         const float g2 = gq + gq;  // the reference's arithmetic: g = gd + gd; (a - b) * g rounded on its own
         const size_t r = (size_t)bi * a.npad[dir] + g * SB + lane;
-        if (!(RFP_GS_ABL & 128) || cx == 12345.f) {
-            ev.wp[r] = valid ? w : -1;
-            float *ow = ev.own + r * 3;
-            ow[0] = (qx - cx) * g2;
-            ow[1] = (qy - cy) * g2;
-            ow[2] = (qz - cz) * g2;
-        }
+        ev.wp[r] = valid ? w : -1;
+        float *ow = ev.own + r * 3;
+        ow[0] = (qx - cx) * g2;
+        ow[1] = (qy - cy) * g2;
+        ow[2] = (qz - cz) * g2;
         // the buckets this group's winners fall into: one trip per DISTINCT bucket (a handful: the winners of 64
         // consecutive sorted queries are neighbours)
         const int bkt = w / ge.qbucket[cd];
-        unsigned long long todo = (RFP_GS_ABL & 32) ? 0ull : __builtin_amdgcn_ballot_w64(valid), gm = 0ull;
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(valid), gm = 0ull;
         while (todo) {
             const int bb = __builtin_amdgcn_readlane(bkt, __builtin_ctzll(todo));
             gm |= 1ull << bb;
             todo &= ~__builtin_amdgcn_ballot_w64(bkt == bb);
         }
         if (lane == 0) ev.mask[(size_t)bi * G + g] = gm;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Round 4: the few-groups direction (a small query set against a large candidate set: C2's 2048 queries in
+// 16384) as QUAD-PER-QUERY tiles.  In sweep_group a candidate block is streamed through SGPRs to all 64 lanes
+// whenever ONE of them needs it: 22 % of the lane x block evaluations of such a group are needed by the lane that
+// runs them (profiles/r03_str_model.txt), and no seed or order changes that (tools/experiments/seed_model.py: an
+// oracle seed still scans 55 of 68 blocks per group) -- the unit of 64 queries x 16 candidates is the limit.  Here a
+// wave owns ONE 16-record block of the sorted query set; the four lanes of a quad share a query and split a
+// candidate block's 16 records (3 x dwordx4 = 48 B gathered per lane: 2.3e12 pairs/s chip-wide from L2,
+// tools/ubench/gather_scan.hip -- the suggested DPP row-broadcast operand form costs 1.74x per pair instead,
+// tools/ubench/valu_rate.hip mode 19), and every quad keeps its OWN lists, so the 16 quads of a wave scan DIFFERENT
+// blocks at the same time: ~50 pairs per query instead of ~1100 (tools/experiments/quad_model.py).
+//   1  keys of all candidate superblocks against the tile's box (lanes = superblocks); those that overlap it (or the
+//      nearest) are the seed candidates
+//   2  seed: per query the nearest seed superblock, its nearest block, one scan -> every query starts with a minimum
+//      ~1.3x its final distance, and U = the tile's largest minimum
+//   3  the tile's superblock list: key <= U
+//   4  per query (lanes = (query, list entry)): superblocks whose box bound <= the query's minimum -> the quad's list
+//   5  per quad (lane = one of the superblock's 4 blocks): block bounds -> the quad's block list
+//   6  drain: every quad pops its next block whose bound is still <= its minimum and scans it
+// Steps 4-6 run in bounded chunks (a list that could overflow is drained first), so any input is handled by the same
+// code.  Same outputs as sweep_group: the same d2 sequence on the same pairs' survivors, bounds culled strictly, the
+// lowest original index among exact ties (two equal blocks re-scanned, a third one -> exhaustive pass).
+constexpr int T16_CAPS = 32;  // entries of a quad's superblock list
+constexpr int T16_CAPB = 32;  // entries of a quad's block list
+constexpr int T16_UN5 = 4;    // list rounds per trip of step 4 (their gathers in flight together)
+constexpr int T16_UN6 = 4;    // block-test rounds per trip of step 5
+constexpr int T16_KK = 5;     // tile keys kept in registers: candidate sets of up to 320 superblocks
+struct T16Lds {
+    unsigned short qsb[16][T16_CAPS];
+    unsigned short qbl[16][T16_CAPB];
+    float qlb[16][T16_CAPB];
+};
+
+#define RFP_QUAD(OP, PERM) asm volatile("s_nop 1\n\t" OP " %0, %0, %0 quad_perm:" PERM " row_mask:0xf bank_mask:0xf" : "+v"(v))
+__device__ __forceinline__ float quad_min_f32(float v) {  // inputs not NaN
+    RFP_QUAD("v_min_f32_dpp", "[1,0,3,2]");
+    RFP_QUAD("v_min_f32_dpp", "[2,3,0,1]");
+    return v;
+}
+__device__ __forceinline__ unsigned quad_min_u32(unsigned v) {
+    RFP_QUAD("v_min_u32_dpp", "[1,0,3,2]");
+    RFP_QUAD("v_min_u32_dpp", "[2,3,0,1]");
+    return v;
+}
+__device__ __forceinline__ int quad_max_i32(int v) {
+    RFP_QUAD("v_max_i32_dpp", "[1,0,3,2]");
+    RFP_QUAD("v_max_i32_dpp", "[2,3,0,1]");
+    return v;
+}
+#undef RFP_QUAD
+// the quad's lexicographic minimum of (value, index): every lane ends with the same pair
+template <int CTL>
+__device__ __forceinline__ void quad_lexmin_step(float &v, int &i) {
+    const float ov = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTL, 0xf, 0xf, false));
+    const int oi = __builtin_amdgcn_update_dpp(0, i, CTL, 0xf, 0xf, false);
+    if (ov < v || (ov == v && oi < i)) {
+        v = ov;
+        i = oi;
+    }
+}
+template <int CTL>
+__device__ __forceinline__ void quad_lexmin3(float &v, unsigned &i, int &p) {  // (value, index) with a payload
+    const float ov = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTL, 0xf, 0xf, false));
+    const unsigned oi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)i, CTL, 0xf, 0xf, false);
+    const int op = __builtin_amdgcn_update_dpp(0, p, CTL, 0xf, 0xf, false);
+    const bool b = ov < v || (ov == v && oi < i);
+    v = b ? ov : v;
+    i = b ? oi : i;
+    p = b ? op : p;
+}
+__device__ __forceinline__ void quad_lexmin(float &v, int &i) {
+    quad_lexmin_step<0xB1>(v, i);  // quad_perm [1,0,3,2]
+    quad_lexmin_step<0x4E>(v, i);  // quad_perm [2,3,0,1]
+}
+// LDS written by some lanes of a wave and read by others: the wave's LDS operations execute in order, the fence
+// only keeps the compiler from moving them across
+__device__ __forceinline__ void wave_lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ int lanes_below(unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+template <bool GRAD>
+__device__ __forceinline__ void sweep_tile16(
+    const SweepArgs &a, const GradEmit &ge, const int dir, const int gid, const int wib, const int lane,
+    unsigned *__restrict__ keys_dyn, T16Lds *__restrict__ tl, unsigned long long *gmsh,
+    const float *__restrict__ xyz0, const float *__restrict__ xyz1,
+    const int *__restrict__ orig0, const int *__restrict__ orig1, const float *__restrict__ b16_0,
+    const float *__restrict__ b16_1, const float *__restrict__ b64_0, const float *__restrict__ b64_1,
+    float *__restrict__ dist0, float *__restrict__ dist1, int *__restrict__ idx0, int *__restrict__ idx1,
+    unsigned long long *__restrict__ stats) {
+    const int cd = 1 - dir;
+    const int G = a.groups[dir];
+    const int bi = gid / G, g = gid - bi * G;
+    const int qi = lane >> 2, k = lane & 3;  // query of the tile, quarter of a block
+
+    const float *__restrict__ Q = (dir ? xyz1 : xyz0) + (size_t)bi * a.npad[dir] * 3;
+    const int *__restrict__ Qo = (dir ? orig1 : orig0) + (size_t)bi * a.npad[dir];
+    const float *__restrict__ C = (dir ? xyz0 : xyz1) + (size_t)bi * a.npad[cd] * 3;
+    const int *__restrict__ Co = (dir ? orig0 : orig1) + (size_t)bi * a.npad[cd];
+    const int nsb = a.npad[cd] / SB;
+    const float *__restrict__ CB16 = (dir ? b16_0 : b16_1) + (size_t)bi * nsb * B16F;
+    const float *__restrict__ CB64 = (dir ? b64_0 : b64_1) + (size_t)bi * nsb * B64F;
+
+    const int qpos = (g * SBB + wib) * BS + qi;  // sorted position of this quad's query
+    const float qx = Q[(size_t)qpos * 3 + 0], qy = Q[(size_t)qpos * 3 + 1], qz = Q[(size_t)qpos * 3 + 2];
+    const int qorig = Qo[qpos];
+    const bool valid = qorig >= 0;
+    float gq = 0.f;
+    if constexpr (GRAD) {
+        if (valid) gq = ge.gd[dir][(size_t)bi * a.n[dir] + qorig];
+    }
+    const bool qnan = qx != qx || qy != qy || qz != qz;  // (NaN, 0), as sweep_group
+    const bool part = valid && !qnan;
+    // the tile's box = the query set's own block box (padding and NaN excluded by the sort)
+    const float *tb = (dir ? b16_1 : b16_0) + ((size_t)bi * G + g) * B16F + wib * 6;  // uniform
+    const float tlo[3] = {tb[0], tb[1], tb[2]}, thi[3] = {tb[3], tb[4], tb[5]};
+
+    unsigned *__restrict__ sbl = keys_dyn + (size_t)wib * a.kstride;  // this wave's superblock list (>= nsb entries)
+    // the quad's running result: minimum, lowest original index attaining it, that candidate's sorted position.  The
+    // index travels WITH the minimum here (one more 16-byte gather per block and ~25 VALU per scan, in a loop that waits
+    // on memory): no winning-block re-scan, no tie bookkeeping -- any candidate that equals the final minimum lies in a
+    // block whose bound does not exceed it, and such blocks are never culled.
+    float best = INFINITY, cull = part ? INFINITY : -INFINITY;
+    unsigned besti = 0xFFFFFFFFu;
+    int wpos = -1, seedblk = -1;
+    unsigned n_round = 0, n_scan = 0;
+#if RFP_T16_STAMPS
+    unsigned long long tph[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+    auto stamp = [&](int ph) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        tph[ph] += now - tlast;
+        tlast = now;
+    };
+#else
+    auto stamp = [&](int) {};
+#endif
+
+    // (minimum, lowest original index, position) of the quad's query over the 16 records of block blk: each lane its
+    // 4 records, then the quad's lexicographic minimum -- every lane of the quad ends with the same triple
+    auto block_best = [&](int blk, float &dm, unsigned &im, int &pm) {
+        const float4 *p = (const float4 *)(C + (size_t)blk * (BS * 3) + k * 12);
+        const float4 r0 = p[0], r1 = p[1], r2 = p[2];
+        const int4 co = *(const int4 *)(Co + (size_t)blk * BS + k * 4);
+        const float d[4] = {rf::d2_fma(r0.x - qx, r0.y - qy, r0.z - qz), rf::d2_fma(r0.w - qx, r1.x - qy, r1.y - qz),
+                            rf::d2_fma(r1.z - qx, r1.w - qy, r2.x - qz), rf::d2_fma(r2.y - qx, r2.z - qy, r2.w - qz)};
+        const unsigned io[4] = {(unsigned)co.x, (unsigned)co.y, (unsigned)co.z, (unsigned)co.w};  // padding carries 0xFFFFFFFF
+        dm = INFINITY;
+        im = 0xFFFFFFFFu;
+        pm = -1;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {  // (a NaN distance compares false both ways: never taken)
+            const bool b = d[u] < dm || (d[u] == dm && io[u] < im);
+            dm = b ? d[u] : dm;
+            im = b ? io[u] : im;
+            pm = b ? blk * BS + k * 4 + u : pm;
+        }
+        quad_lexmin3<0xB1>(dm, im, pm);
+        quad_lexmin3<0x4E>(dm, im, pm);
+    };
+    auto take = [&](float dm, unsigned im, int pm) {
+        const bool b = dm < best || (dm == best && im < besti);
+        best = b ? dm : best;
+        besti = b ? im : besti;
+        wpos = b ? pm : wpos;
+        cull = fminf(cull, best);
+    };
+    auto sb_bound = [&](int s) {  // per lane: query against the box of superblock s
+        const float4 *cb = (const float4 *)(CB64 + (size_t)s * B64F);
+        const float4 lo = cb[0], hi = cb[1];
+        return box_bound(qx, qy, qz, lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
+    };
+    auto blk_bound = [&](int blk) {
+        const float2 *bp = (const float2 *)(CB16 + (size_t)blk * 6);
+        const float2 v0 = bp[0], v1 = bp[1], v2 = bp[2];
+        return box_bound(qx, qy, qz, v0.x, v0.y, v1.x, v1.y, v2.x, v2.y);
+    };
+    auto tile_key = [&](int s) {  // lanes = superblocks: box-to-box bound against the tile
+        const float4 *cb = (const float4 *)(CB64 + (size_t)s * B64F);
+        return boxbox_bound(tlo, thi, cb[0], cb[1]);
+    };
+    auto nibble = [&](bool pred) { return (unsigned)(__builtin_amdgcn_ballot_w64(pred) >> (lane & ~3)) & 0xFu; };
+
+    if (__builtin_amdgcn_ballot_w64(part) != 0ull) {
+        // 1. superblocks that overlap the tile box -> sbl[0 .. n0), at most 64 (they only seed); else the nearest
+        int n0 = 0;
+        unsigned kmin = 0xFFFFFFFFu;
+        // (up to 320 superblocks -- every cloud of the register-resident sort -- the keys stay in registers for step 3
+        // and their loads are all in flight together)
+        const bool inreg = nsb <= 64 * T16_KK;  // uniform
+        float kk[T16_KK];
+        if (inreg) {
+#pragma unroll
+            for (int c = 0; c < T16_KK; c++) kk[c] = (c * 64 < nsb && c * 64 + lane < nsb) ? tile_key(c * 64 + lane) : INFINITY;
+        }
+        auto seed_cand = [&](int s, float lb) {
+            const bool z = lb == 0.f;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(z);
+            const int pos = n0 + lanes_below(m);
+            if (z && pos < 64) sbl[pos] = (unsigned)s;
+            n0 = min(64, n0 + __builtin_popcountll(m));
+            if (s < nsb) kmin = min(kmin, (__float_as_uint(lb) & ~IDMASK) | (unsigned)s);
+        };
+        if (inreg) {
+#pragma unroll
+            for (int c = 0; c < T16_KK; c++)
+                if (c * 64 < nsb) seed_cand(c * 64 + lane, kk[c]);
+        } else {
+            for (int s0 = 0; s0 < nsb; s0 += 64) seed_cand(s0 + lane, s0 + lane < nsb ? tile_key(s0 + lane) : INFINITY);
+        }
+        if (n0 == 0) {  // uniform
+            kmin = wave_min_u32(kmin);
+            if (lane == 0) sbl[0] = kmin & IDMASK;
+            n0 = 1;
+        }
+        wave_lds_order();
+        stamp(0);
+        // 2. seed: per query the NEAREST BLOCK among the blocks of the seed superblocks (lane k of the quad takes every
+        // 4th of them; a superblock's four block boxes are 96 contiguous bytes), then one scan of it
+        {
+            float blb = INFINITY;
+            int bblk = (int)sbl[0] * SBB;
+            for (int e = k; e < n0; e += 4) {
+                const int s = (int)sbl[e];
+                const float4 *bp = (const float4 *)(CB16 + (size_t)s * B16F);
+                const float4 f0 = bp[0], f1 = bp[1], f2 = bp[2], f3 = bp[3], f4 = bp[4], f5 = bp[5];
+                const float f[B16F] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w,
+                                       f3.x, f3.y, f3.z, f3.w, f4.x, f4.y, f4.z, f4.w, f5.x, f5.y, f5.z, f5.w};
+#pragma unroll
+                for (int j = 0; j < SBB; j++) {
+                    const float lb = box_bound(qx, qy, qz, f[j * 6 + 0], f[j * 6 + 1], f[j * 6 + 2], f[j * 6 + 3], f[j * 6 + 4], f[j * 6 + 5]);
+                    if (lb < blb) {  // (NaN query: never; it takes no part anyway)
+                        blb = lb;
+                        bblk = s * SBB + j;
+                    }
+                }
+            }
+            quad_lexmin(blb, bblk);
+            seedblk = bblk;
+            float dm;
+            unsigned im;
+            int pm;
+            block_best(seedblk, dm, im, pm);
+            if (part) take(dm, im, pm);
+            n_scan += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(part)) >> 2;
+        }
+        stamp(1);
+        // 3. the tile's superblock list: box-to-box bound <= the largest minimum of the tile's queries
+        const float U = wave_max_nonneg(part ? best : -INFINITY);
+        int nl = 0;
+        auto list_cand = [&](int s, float lb) {
+            const bool keep = s < nsb && lb <= U;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+            if (keep) sbl[nl + lanes_below(m)] = (unsigned)s;
+            nl += __builtin_popcountll(m);
+        };
+        if (inreg) {
+#pragma unroll
+            for (int c = 0; c < T16_KK; c++)
+                if (c * 64 < nsb) list_cand(c * 64 + lane, kk[c]);
+        } else {
+            for (int s0 = 0; s0 < nsb; s0 += 64) list_cand(s0 + lane, s0 + lane < nsb ? tile_key(s0 + lane) : INFINITY);
+        }
+        wave_lds_order();
+        stamp(2);
+        // 4-6. bounded chunks
+        int cntS = 0, cntB = 0;  // quad-uniform fill of the quad's two lists
+        int r5 = 0;
+        const int n5 = (nl + 3) >> 2;
+        for (;;) {
+            while (r5 < n5 && __builtin_amdgcn_ballot_w64(cntS > T16_CAPS - 4 * T16_UN5) == 0ull) {
+                int sv[T16_UN5];
+                float lbv[T16_UN5];
+#pragma unroll
+                for (int u = 0; u < T16_UN5; u++) {
+                    const int e = (r5 + u) * 4 + k;
+                    sv[u] = e < nl ? (int)sbl[e] : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < T16_UN5; u++) lbv[u] = sb_bound(sv[u] < 0 ? 0 : sv[u]);
+#pragma unroll
+                for (int u = 0; u < T16_UN5; u++) {
+                    const bool pass = sv[u] >= 0 && lbv[u] <= cull;
+                    const unsigned nib = nibble(pass);
+                    if (pass) tl->qsb[qi][cntS + __builtin_popcount(nib & ((1u << k) - 1u))] = (unsigned short)sv[u];
+                    cntS += __builtin_popcount(nib);
+                }
+                r5 += T16_UN5;
+                n_round++;
+            }
+            wave_lds_order();
+            stamp(3);
+            int r6 = 0;
+            while (__builtin_amdgcn_ballot_w64(r6 < cntS) != 0ull) {
+                while (__builtin_amdgcn_ballot_w64(r6 < cntS) != 0ull &&
+                       __builtin_amdgcn_ballot_w64(cntB > T16_CAPB - 4 * T16_UN6) == 0ull) {
+                    int bv[T16_UN6];
+                    float lbv[T16_UN6];
+#pragma unroll
+                    for (int u = 0; u < T16_UN6; u++) bv[u] = r6 + u < cntS ? (int)tl->qsb[qi][r6 + u] * SBB + k : -1;
+#pragma unroll
+                    for (int u = 0; u < T16_UN6; u++) lbv[u] = blk_bound(bv[u] < 0 ? 0 : bv[u]);
+#pragma unroll
+                    for (int u = 0; u < T16_UN6; u++) {
+                        const bool pass = bv[u] >= 0 && lbv[u] <= cull && bv[u] != seedblk;
+                        const unsigned nib = nibble(pass);
+                        if (pass) {
+                            const int pos = cntB + __builtin_popcount(nib & ((1u << k) - 1u));
+                            tl->qbl[qi][pos] = (unsigned short)bv[u];
+                            tl->qlb[qi][pos] = lbv[u];
+                        }
+                        cntB += __builtin_popcount(nib);
+                    }
+                    r6 += T16_UN6;
+                    n_round++;
+                }
+                wave_lds_order();
+                stamp(4);
+                // two list entries per round, their gathers in flight together (the second one's bound may have been
+                // overtaken by the first one's minimum: its block minimum then exceeds the new minimum and changes nothing)
+                int ptr = 0;
+                for (;;) {
+                    bool v0, v1;
+                    for (;;) {  // every quad moves on to its next pair with a block whose bound has not been overtaken
+                        const bool more = ptr < cntB;
+                        const float lb0 = more ? tl->qlb[qi][ptr] : 0.f;
+                        const float lb1 = ptr + 1 < cntB ? tl->qlb[qi][ptr + 1] : INFINITY;
+                        v0 = more && lb0 <= cull;
+                        v1 = ptr + 1 < cntB && lb1 <= cull;
+                        const bool skip = more && !v0 && !v1;
+                        if (skip) ptr += 2;
+                        if (__builtin_amdgcn_ballot_w64(skip) == 0ull) break;
+                    }
+                    if (__builtin_amdgcn_ballot_w64(v0 || v1) == 0ull) break;
+                    const int b0 = v0 ? (int)tl->qbl[qi][ptr] : seedblk, b1 = v1 ? (int)tl->qbl[qi][ptr + 1] : seedblk;
+                    float d0, d1;
+                    unsigned i0, i1;
+                    int p0, p1;
+                    block_best(b0, d0, i0, p0);
+                    block_best(b1, d1, i1, p1);
+                    if (v0) take(d0, i0, p0);
+                    if (v1) take(d1, i1, p1);
+                    if (v0 || v1) ptr += 2;
+                    n_scan += (unsigned)(__builtin_popcountll(__builtin_amdgcn_ballot_w64(v0)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(v1))) >> 2;
+                }
+                cntB = 0;
+                wave_lds_order();
+                stamp(5);
+            }
+            cntS = 0;
+            if (r5 >= n5) break;
+        }
+    }
+
+    stamp(6);
+#if RFP_T16_STAMPS
+    if (stats && lane == 0 && (gid & 15) == 0 && wib == 0)  // (one wave in 64: same-address atomics from every wave clog the memory pipe)
+        for (int i = 0; i < 7; i++) atomicAdd(&stats[25 + i], tph[i]);
+#endif
+    if (stats && lane == 0) {
+        atomicAdd(&stats[dir * 4 + 0], 1ull);
+        atomicAdd(&stats[dir * 4 + 1], (unsigned long long)n_round);
+        atomicMax(&stats[dir * 4 + 2], (unsigned long long)n_round);
+        atomicAdd(&stats[dir * 4 + 3], (unsigned long long)n_scan);
+        atomicMax(&stats[8 + dir], (unsigned long long)n_scan);
+        stats[14 + dir] = BS;  // directed pairs per counted scan: one query x 16 candidates (sweep_group: 64 x 16)
+    }
+
+    if (valid && k == 0) {
+        (dir ? dist1 : dist0)[(size_t)bi * a.n[dir] + qorig] = qnan ? NAN : best;
+        (dir ? idx1 : idx0)[(size_t)bi * a.n[dir] + qorig] = (qnan || besti == 0xFFFFFFFFu) ? 0 : (int)besti;
+    }
+    if constexpr (GRAD) {
+        const int *pos0 = (const int *)((const char *)(cd ? b64_1 : b64_0) +
+                                        emit_align((size_t)a.b * (a.npad[cd] / SB) * B64F * sizeof(float)));
+        const int p0 = pos0[bi];  // uniform
+        const EmitView ev = emit_layout(ge.base, a.b, a.npad[0], a.npad[1], dir);
+        const int w = (qnan || besti == 0xFFFFFFFFu) ? p0 : wpos;
+        const int wc = valid ? w : 0;
+        const float cx = C[(size_t)wc * 3 + 0], cy = C[(size_t)wc * 3 + 1], cz = C[(size_t)wc * 3 + 2];
+        const float g2 = gq + gq;
+        const size_t r = (size_t)bi * a.npad[dir] + qpos;
+        if (k == 0) {
+            ev.wp[r] = valid ? w : -1;
+            float *ow = ev.own + r * 3;
+            ow[0] = (qx - cx) * g2;
+            ow[1] = (qy - cy) * g2;
+            ow[2] = (qz - cz) * g2;
+        }
+        const int bkt = w / ge.qbucket[cd];
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(valid && k == 0), gm = 0ull;
+        while (todo) {
+            const int bb = __builtin_amdgcn_readlane(bkt, __builtin_ctzll(todo));
+            gm |= 1ull << bb;
+            todo &= ~__builtin_amdgcn_ballot_w64(bkt == bb);
+        }
+        // the mask is per 64-query GROUP: the workgroup's four tiles
+        if (lane == 0) gmsh[wib] = gm;
+        __syncthreads();
+        if (wib == 0 && lane == 0) ev.mask[(size_t)bi * G + g] = gmsh[0] | gmsh[1] | gmsh[2] | gmsh[3];
     }
 }
 
@@ -1417,6 +1842,7 @@ __global__ __launch_bounds__(64 * NSH) __attribute__((amdgpu_waves_per_eu(RFP_WP
     __shared__ float md[NSH][64];
     __shared__ unsigned mi[NSH][64];
     __shared__ int mp[GRAD ? NSH : 1][64];
+    __shared__ unsigned long long gmsh[NSH];
 
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1427,25 +1853,22 @@ __global__ __launch_bounds__(64 * NSH) __attribute__((amdgpu_waves_per_eu(RFP_WP
     // 145 MB of L2 misses per launch for 12 MB of clouds).
     const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (int)(blockIdx.x >> 3);
-#if RFP_ORDER == 1
-    // all of direction 0's workgroups first (batch-major), then direction 1's: with equal per-batch
-    // counts an XCD's eighth of either part covers the same batch elements
-    const int tot0 = a.b * a.wg0;
-    const int dir = logical >= tot0;
-    const int l2 = dir ? logical - tot0 : logical;
-    const int per = dir ? a.wg1 : a.wg0;
-    const int bi = l2 / per;
-    int wg = l2 - bi * per;
-#else
     const int wpc = a.wg0 + a.wg1;  // workgroups per batch element
     const int bi = logical / wpc;
     int wg = logical - bi * wpc;
     const int dir = wg >= a.wg0;
     if (dir) wg -= a.wg0;
-#endif
     if (a.nw[dir] == NSH) {
+#if RFP_TILE16
+        // (the tiles' lists live in DYNAMIC LDS behind the key lists: static arrays would be charged to every workgroup of
+        // the kernel, and the one-wave workgroups of a launch without shared groups lose a third of their residency)
+        T16Lds *t16 = (T16Lds *)(keys_dyn + (size_t)NSH * a.kstride);
+        sweep_tile16<GRAD>(a, ge, dir, bi * a.groups[dir] + wg, wib, lane, keys_dyn, &t16[wib], gmsh, xyz0, xyz1, orig0, orig1,
+                           b16_0, b16_1, b64_0, b64_1, dist0, dist1, idx0, idx1, stats);
+#else
         sweep_group<true, GRAD>(a, ge, dir, bi * a.groups[dir] + wg, wib, lane, keys_dyn, shbest, md, mi, mp, xyz0, xyz1,
                                 orig0, orig1, b16_0, b16_1, b64_0, b64_1, dist0, dist1, idx0, idx1, stats);
+#endif
     } else {
         const int g = wg * (int)(blockDim.x >> 6) + wib;
         if (g >= a.groups[dir]) return;  // (no barriers on this path)
@@ -1546,7 +1969,7 @@ __global__ __launch_bounds__(GS_TPB) void nnp_grad_sorted_kernel(GradSArgs a) {
     for (int u = 0; u < RG; u++)
         if (rr[u] & tmask) list[atomicAdd(&nlist, 1)] = (unsigned short)(tid + u * GS_TPB);
     __syncthreads();
-    const int nl = (RFP_GS_ABL & 1) ? 0 : nlist;
+    const int nl = nlist;
     for (int base = wave; base < nl; base += (GS_TPB / 64) * GS_KB) {
         int w[GS_KB];
         float v[GS_KB][3];
@@ -1588,13 +2011,9 @@ __global__ __launch_bounds__(GS_TPB) void nnp_grad_sorted_kernel(GradSArgs a) {
             RFP_SEG(0x111) RFP_SEG(0x112) RFP_SEG(0x114) RFP_SEG(0x118)
 #undef RFP_SEG
             if (key >= 0 && key != knext) {
-                if (RFP_GS_ABL & 2) {
-                    if (sx == 12345.f) acc[key * 3] = sx + sy + sz;
-                } else {
-                    atomicAdd(&acc[key * 3 + 0], sx);
-                    atomicAdd(&acc[key * 3 + 1], sy);
-                    atomicAdd(&acc[key * 3 + 2], sz);
-                }
+                atomicAdd(&acc[key * 3 + 0], sx);
+                atomicAdd(&acc[key * 3 + 1], sy);
+                atomicAdd(&acc[key * 3 + 2], sz);
             }
         }
     }
@@ -1720,22 +2139,24 @@ static int sweep_sorted_impl(int b, int n, int m, const Sorted &s0, const Sorted
         for (int k = 0; k < 2; k++) {
             if (!want[k]) continue;
             const int nsb = wa.groups[1 - k];
-            const int len = wa.nw[k] == NSH ? (nsb + NSH - 1) / NSH : nsb;
+            const int len = (wa.nw[k] == NSH && !RFP_TILE16) ? (nsb + NSH - 1) / NSH : nsb;  // (a tile's list may hold every superblock)
             longest = len > longest ? len : longest;
         }
         wa.kstride = (longest + 63) / 64 * 64;
     }
-    const int tpb = ((want[0] && wa.nw[0] == NSH) || (want[1] && wa.nw[1] == NSH)) ? 64 * NSH : 64;
+    const bool shared_groups = (want[0] && wa.nw[0] == NSH) || (want[1] && wa.nw[1] == NSH);
+    const int tpb = shared_groups ? 64 * NSH : 64;
     const int pack = tpb / 64;  // one-wave groups per workgroup
+    const size_t shmem = pack * wa.kstride * sizeof(unsigned) + ((RFP_TILE16 && shared_groups) ? NSH * sizeof(T16Lds) : 0);
     wa.wg0 = !want[0] ? 0 : (wa.nw[0] == NSH ? wa.groups[0] : rf::ceil_div(wa.groups[0], pack));
     wa.wg1 = !want[1] ? 0 : (wa.nw[1] == NSH ? wa.groups[1] : rf::ceil_div(wa.groups[1], pack));
     if (ge) {
         RF_LAUNCH("nnp_sweep", nnp_sweep_kernel<true>, dim3((unsigned)b * (wa.wg0 + wa.wg1)), dim3(tpb),
-                  pack * wa.kstride * sizeof(unsigned), s, wa, *ge, s0.xyz, s1.xyz, s0.orig, s1.orig, s0.box16,
+                  shmem, s, wa, *ge, s0.xyz, s1.xyz, s0.orig, s1.orig, s0.box16,
                   s1.box16, s0.box64, s1.box64, dist1, dist2, idx1, idx2, stats_dev);
     } else {
         RF_LAUNCH("nnp_sweep", nnp_sweep_kernel<false>, dim3((unsigned)b * (wa.wg0 + wa.wg1)), dim3(tpb),
-                  pack * wa.kstride * sizeof(unsigned), s, wa, GradEmit{}, s0.xyz, s1.xyz, s0.orig, s1.orig, s0.box16,
+                  shmem, s, wa, GradEmit{}, s0.xyz, s1.xyz, s0.orig, s1.orig, s0.box16,
                   s1.box16, s0.box64, s1.box64, dist1, dist2, idx1, idx2, stats_dev);
     }
     return RF_OK;
@@ -1747,7 +2168,7 @@ int sweep_sorted(int b, int n, int m, const Sorted &s0, const Sorted &s1, float 
 }
 
 // ---- forward + backward of one Chamfer (rf_chamfer_step) on the culled path -----------------------------
-// workspace: sorted(n) | sorted(m) | per set: rec (b, npad) int2 | own (b, npad, 3) | range (b, npad / 64) int2
+// workspace: sorted(n) | sorted(m) | per set (emit_layout): wp (b, npad) int | own (b, npad, 3) float | mask (b, npad / 64) u64
 static size_t step_set_bytes(int b, int n) { return emit_set_bytes(b, (int)npad_of(n)); }
 
 size_t pruned_step_workspace_bytes(int b, int n, int m) {

@@ -85,7 +85,9 @@ class TfAdam:
 class TrainStep:
     """`step(partial, gt) -> loss` for a fixed batch shape.  graph=True captures forward + loss + backward
     into a HIP graph (checked against the eager gradients, eager fallback with a note on stderr);
-    the gradient all-reduce over `group` and the Adam update follow eagerly."""
+    the gradient all-reduce over `group` and the Adam update follow eagerly.  The graph path is OPT-IN at
+    process level: call `rfnet_amd.enable_graph_safe_runtime()` before anything starts the HIP runtime,
+    otherwise `_host.graph_replay_ok()` reports False and every step stays eager (`self.mode` says which)."""
 
     def __init__(self, net, batch, npartial=3000, ngt=16384, graph=True, group=None, optimizer=None,
                  check_tol=1e-3):

@@ -78,7 +78,7 @@ def test_workspace_queries_are_pure_host_functions():
     assert lib.rf_nn_sort_bytes(1, 65536) > 0 and lib.rf_nn_sort_bytes(1, 65537) == 0 and lib.rf_nn_sort_bytes(0, 10) == 0
     both = lib.rf_nn_distance_dir_workspace_bytes(32, 2048, 16384, 1, 1)
     assert both > 0 and lib.rf_nn_distance_dir_workspace_bytes(32, 2048, 16384, 0, 0) == 0
-    # the one-call step on the culled path also holds the sweep's {winner, gradient} records (8 B per point)
+    # the one-call step on the culled path also holds the sweep's winner position + own gradient term (16 B per point) and bucket masks
     assert (lib.rf_chamfer_step_workspace_bytes(32, 2048, 16384)
             >= lib.rf_nn_distance_workspace_bytes(32, 2048, 16384) + 32 * (2048 + 16384) * 8 - 4096)
     assert lib.rf_chamfer_step_workspace_bytes(2, 300, 700) == lib.rf_nn_distance_workspace_bytes(2, 300, 700)

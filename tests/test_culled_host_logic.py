@@ -1,5 +1,6 @@
-"""CPU checks of the culled Chamfer sweep's host-side logic (no GPU): the Hilbert state-machine
-table compiled into nn_pruned.hip, the workspace planner and the size rule of RF_NN_AUTO."""
+"""CPU checks of the culled Chamfer sweep's host-side logic (no GPU): the workspace planner and the size rule of
+RF_NN_AUTO.  (The 24-state Hilbert table of the rounds 1-2 register sort left the product with that order:
+tools/experiments/nn_pruned_decided_knobs.patch.txt; larger clouds use Skilling's transform directly.)"""
 import os
 import re
 import sys
@@ -8,33 +9,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools", "experiments"))
-
-
-def _lut():
-    src = open(os.path.join(ROOT, "rfnet_amd", "csrc", "nn_pruned.hip")).read()
-    m = re.search(r"kHilbertLut\[192\] = \{([^}]*)\}", src)  # (the two-level table is built from it in LDS)
-    return np.array([int(v) for v in m.group(1).split(",")], dtype=np.int64).reshape(24, 8)
-
-
-def test_hilbert_table_is_skillings_curve():
-    """The 24-state octant table walks exactly Skilling's 3-D Hilbert curve (5 bits per axis): every
-    one of the 32768 cells gets the index of the reference transform, and consecutive indices are
-    face-adjacent cells (the property the culling's box tightness rests on)."""
-    from cull_model_orders import hilbert_index
-    lut = _lut()
-    g = np.stack(np.meshgrid(np.arange(32), np.arange(32), np.arange(32), indexing="ij"), -1).reshape(-1, 3)
-    st = np.zeros(len(g), np.int64)
-    key = np.zeros(len(g), np.int64)
-    for lvl in range(4, -1, -1):
-        octant = (((g[:, 0] >> lvl) & 1) << 2) | (((g[:, 1] >> lvl) & 1) << 1) | ((g[:, 2] >> lvl) & 1)
-        e = lut[st, octant]
-        key = (key << 3) | (e & 7)
-        st = e >> 3
-    ref = hilbert_index(g, 5).astype(np.int64)
-    assert np.array_equal(key, ref)
-    order = np.argsort(key)
-    assert len(np.unique(key)) == 32768
-    assert np.abs(np.diff(g[order], axis=0)).sum(1).max() == 1
 
 
 def test_workspace_planner_and_auto_rule():

@@ -115,7 +115,7 @@ def test_culled_equals_dense(orc, kind, b, n, m):
     # the sweep did cull: fewer pairs evaluated than b*n*m in each direction (not for the lattice /
     # duplicate clouds, where most boxes overlap most queries)
     if kind in ("randn", "uniform", "sphere"):
-        pairs = [stats[3] * 16 * 64, stats[7] * 16 * 64]
+        pairs = [stats[3] * (stats[14] or 1024), stats[7] * (stats[15] or 1024)]  # pairs per counted scan: stats[14 + d]
         assert pairs[0] < 0.6 * b * n * m and pairs[1] < 0.6 * b * n * m, (stats, b * n * m)
 
 

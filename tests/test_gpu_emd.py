@@ -99,6 +99,31 @@ def test_extended_schedule_50_levels(orc):
     assert_rel(got.cpu().numpy(), orc.approx_match(a, c, levels=lv), 1e-4, 1e-6)
 
 
+def test_extended_schedule_50_levels_c4_size(orc):
+    """SURVEY 8(d) C4's secondary run at ITS size: the 50-level schedule (10 reference levels x 5) at 2048 vs 2048, one
+    sample against the oracle on the same schedule (6.3e8 exp evaluations on the host), marginals on all of the
+    batch that was run.  Same bars as the 10-level C4 test: repeating a sharp level five times amplifies last-bit
+    differences no further than the reference schedule itself does (the level's clamps saturate)."""
+    from pc_distance.tf_approxmatch import approx_match_levels, match_cost
+    lv = np.repeat(orc.default_levels(), 5)
+    rng = np.random.RandomState(100)
+    a = (rng.random_sample((4, 2048, 3)) - 0.5).astype(np.float32)
+    c = (rng.random_sample((4, 2048, 3)) - 0.5).astype(np.float32)
+    ta, tc = cu(a), cu(c)
+    match = approx_match_levels(ta, tc, lv.tolist())
+    om = orc.approx_match(a[1:2], c[1:2], levels=lv)
+    gm = match[1:2].cpu().numpy()
+    strict_bar_report("C4 match, 50-level schedule, sample 1 (2048x2048)", gm, om)
+    assert np.abs(gm - om).max() < 2e-4
+    assert (np.abs(gm - om) <= 1e-6 + 1e-4 * np.abs(om)).mean() > 0.9999
+    cost = match_cost(ta, tc, match)
+    assert_rel(cost[1:2].cpu().numpy(), orc.match_cost(a[1:2], c[1:2], om), 1e-5, what="cost[1], 50 levels")
+    rows, cols = match.sum(1).cpu().numpy(), match.sum(2).cpu().numpy()
+    assert_rel(rows, np.ones_like(rows), 1e-3)
+    assert_rel(cols, np.ones_like(cols), 1e-3)
+    assert (match >= 0).all()
+
+
 def test_match_cost_autograd(orc):
     """earth_mover's use (vv_recon.py:392-399): cost.backward() scales the op gradients by
     grad_cost[:,None,None] and gives no gradient to match (tf_approxmatch.py:44-50)."""
@@ -255,7 +280,7 @@ def test_exp2_is_exactly_zero_below_the_cull_argument():
 @pytest.mark.parametrize("b,n,m", [(1, 4096, 4096), (1, 4096, 5000), (2, 6000, 4100)])
 def test_earth_mover_culled_sharp_levels(orc, b, n, m):
     """The cost-only rf_earth_mover on clouds of >= 4096 points runs the three sharpest levels as culled sweeps
-    over Hilbert-sorted copies (approxmatch.hip am_cull_kernel): same schedule, pairs whose weight is exactly 0
+    over spatially sorted (sort-tile-recursive) copies (approxmatch.hip am_cull_kernel): same schedule, pairs whose weight is exactly 0
     skipped, sums in sorted column order.  Cost against the oracle's chain (approx_match -> match_cost,
     tf_approxmatch.cu restated) within 1e-5; the gradient form and approx_match itself (the ops that hand out
     per-entry results) stay on the dense sweeps and keep their tolerances."""

@@ -54,8 +54,14 @@ def main():
     R.nn_distance(t1, t2, mode="culled", stats=st)
     for d in range(2):
         w, steps, mx, scans = st[4 * d:4 * d + 4]
+        unit = st[14 + d] or 1024
         print(f"dir{d}: waves {w} steps/wave {steps / max(w, 1):.1f} (max {mx}) block scans/wave {scans / max(w, 1):.1f} "
-              f"(max {st[8 + d]}) evaluated pairs {scans * 1024:.3e} of {B * N * M:.3e} = {scans * 1024 / (B * N * M):.4f}")
+              f"(max {st[8 + d]}; {unit} pairs each) evaluated pairs {scans * unit:.3e} of {B * N * M:.3e} = {scans * unit / (B * N * M):.4f}")
+    if any(st[25:32]):
+        names = ["keys", "seed", "tile list", "query x superblock", "quad x block", "drain", "epilogue"]
+        tot = sum(st[25:32])
+        print("quad-tile phases (s_memtime, summed over waves): " + "  ".join(f"{n} {100 * v / tot:.0f} %" for n, v in zip(names, st[25:32]))
+              + f"   | {tot / max(st[0] / 64, 1):.0f} ticks per sampled wave (1 in 64)")
     print("full culled forward:", timed(lambda: R.nn_distance(t1, t2, mode="culled")))
     h1, h2 = R.nn_sort(t1), R.nn_sort(t2)
     print("sort N alone:", timed(lambda: R.nn_sort(t1)))
