@@ -461,12 +461,24 @@ __global__ void mc_final_kernel(const float *partial, int per_batch, float *cost
 #ifndef RFA_MG_TL
 #define RFA_MG_TL 32
 #endif
+#ifndef RFA_MG_PREFETCH
+#define RFA_MG_PREFETCH 1  // match_cost_grad: the next tile's match rows in flight during the current tile's LDS phases
+#endif
+#ifndef RFA_MG_LDSCOL
+#define RFA_MG_LDSCOL 0    // (prefetch form) the tile's xyz2 rows through LDS instead of scalar loads
+#endif
+#ifndef RFA_MG_2BAR
+#define RFA_MG_2BAR 0      // (prefetch + LDSCOL form) two barriers per tile instead of three
+#endif
+#ifndef RFA_MG_ABL
+#define RFA_MG_ABL 0
+#endif
 #ifndef RFA_MG_LSPLIT
 #define RFA_MG_LSPLIT 4
 #endif
 constexpr int MG_TL = RFA_MG_TL;
 constexpr int MG_LSPLIT = RFA_MG_LSPLIT;
-__global__ __launch_bounds__(TPB) void mcg_kernel(int n, int m, int lspan,
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void mcg_kernel(int n, int m, int lspan,
                                                   const float *__restrict__ xyz1,
                                                   const float *__restrict__ xyz2,
                                                   const float *__restrict__ match,
@@ -475,6 +487,9 @@ __global__ __launch_bounds__(TPB) void mcg_kernel(int n, int m, int lspan,
     __shared__ float qs[MG_TL][TPB + 1];
     __shared__ float4 sx1[TPB];
     __shared__ float ps[TPB / MG_TL][MG_TL][3];
+#if RFA_MG_LDSCOL
+    __shared__ float4 cx2[MG_TL];  // the tile's 32 xyz2 rows: one broadcast LDS read per row in phase A
+#endif
     const int bi = blockIdx.z;
     const int t = threadIdx.x;
     const int k0 = blockIdx.x * TPB;
@@ -491,8 +506,55 @@ __global__ __launch_bounds__(TPB) void mcg_kernel(int n, int m, int lspan,
     const int lend = min(m, lbeg + lspan);
     const int bl = t & (MG_TL - 1);  // phase-B row (l) of this thread
     const int br = t / MG_TL;        // phase-B k slice: [br*32, br*32+32)
+#if RFA_MG_PREFETCH
+    // The match rows of the NEXT tile are fetched while this tile goes through its three barrier-separated phases:
+    // the LDS tile (40 KB) holds the kernel to 4 waves per SIMD whatever the register count, so the 32 rows can all
+    // stay in flight in registers -- 128 KB per CU instead of 32 KB, and no load waits behind a barrier (round 3: 8 rows
+    // at a time inside the tile, 3.6 TB/s; mc_partial streams the same tensor at 5.9).
+    // (uniform row base + ONE 32-bit lane offset; unconditional loads from clamped rows -- finite values -- masked by a
+    // multiplication: a select is compiled into exec-masked branches around every load; the tile after the last one is
+    // fetched too, from the clamped last row, and masked to nothing)
+    const unsigned koff = (unsigned)kk * 4u;
+    const float livef = live ? 1.f : 0.f;
+    float mv[MG_TL];
+#pragma unroll
+    for (int l = 0; l < MG_TL; l++)
+        mv[l] = *(const float *)((const char *)(M + (size_t)min(lbeg + l, m - 1) * n) + koff) * ((lbeg + l < lend) ? livef : 0.f);
+    // (the columns' coordinates come from LDS: as scalar loads they cost ~16 SALU instructions and a scalar-memory wait per
+    // row -- 3.5e7 SALU next to 4.4e7 VALU instructions per launch, profiles/r04_rocprofv3_summary.txt)
+#if RFA_MG_LDSCOL
+    if (t < MG_TL) {
+        const int ll = min(lbeg + t, m - 1);
+        cx2[t] = make_float4(B[ll * 3], B[ll * 3 + 1], B[ll * 3 + 2], 0.f);
+    }
+    __syncthreads();
+#endif
+#endif
     for (int l0 = lbeg; l0 < lend; l0 += MG_TL) {
         const int lc = min(MG_TL, lend - l0);
+#if RFA_MG_PREFETCH
+#pragma unroll
+        for (int l = 0; l < MG_TL; l++) {
+#if RFA_MG_LDSCOL
+            const float4 c2 = cx2[l];
+            const float dx = x1 - c2.x, dy = y1 - c2.y, dz = z1 - c2.z;
+#else
+            const int ll = min(l0 + l, m - 1);  // uniform -> scalar loads
+            const float dx = x1 - B[ll * 3], dy = y1 - B[ll * 3 + 1], dz = z1 - B[ll * 3 + 2];
+#endif
+            const float q = mv[l] * __builtin_amdgcn_rsqf(fmaxf(rf::d2_fma(dx, dy, dz), 1e-20f));
+            ax = fmaf(dx, q, ax);
+            ay = fmaf(dy, q, ay);
+            az = fmaf(dz, q, az);
+            qs[l][t] = q;
+            if ((l & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // (8 rows at a time: the scheduler otherwise hoists all 32 rows' work)
+        }
+        float nx[MG_TL];
+#pragma unroll
+        for (int l = 0; l < MG_TL; l++)
+            nx[l] = *(const float *)((const char *)(M + (size_t)min(l0 + MG_TL + l, m - 1) * n) + koff) *
+                    ((l0 + MG_TL + l < lend) ? livef : 0.f);
+#else
         // 8 rows at a time (the group loop is NOT unrolled): with all 32 rows of the tile in flight
         // the kernel needed 177 VGPRs = 2 waves per SIMD, and with three barriers per tile it is
         // occupancy that hides the latencies
@@ -514,7 +576,14 @@ __global__ __launch_bounds__(TPB) void mcg_kernel(int n, int m, int lspan,
                 qs[g + l][t] = q;
             }
         }
+#endif
         __syncthreads();
+#if RFA_MG_PREFETCH && RFA_MG_LDSCOL
+        if (t >= 128 && t < 128 + MG_TL) {  // the next tile's columns (cx2 was last read before the barrier above)
+            const int ll = min(l0 + MG_TL + (t - 128), m - 1);
+            cx2[t - 128] = make_float4(B[ll * 3], B[ll * 3 + 1], B[ll * 3 + 2], 0.f);
+        }
+#endif
         {
             const int ll = min(l0 + bl, m - 1);
             const float x2 = B[ll * 3], y2 = B[ll * 3 + 1], z2 = B[ll * 3 + 2];
@@ -539,11 +608,24 @@ __global__ __launch_bounds__(TPB) void mcg_kernel(int n, int m, int lspan,
                 float v = 0.f;
 #pragma unroll
                 for (int r = 0; r < TPB / MG_TL; r++) v += ps[r][l][c];
+#if RFA_MG_ABL == 1  // (timing-only ablation, tools/ variants: no grad2 atomics)
+                if (v == 12345.f) grad2[0] = v;
+#else
                 atomicAdd(&grad2[((size_t)bi * m + l0 + l) * 3 + c], v);
+#endif
             }
         }
+#if !(RFA_MG_PREFETCH && RFA_MG_LDSCOL && RFA_MG_2BAR)
         // qs / ps are rewritten only after the next tile's first barrier-separated phase
         __syncthreads();
+#endif
+        // (prefetch form: TWO barriers per tile.  The next tile's phase A only writes qs -- last read before this tile's
+        // second barrier -- and reads cx2, rewritten between this tile's two barriers; ps is rewritten after the next
+        // tile's first barrier, which no thread passes before its own phase C here is done)
+#if RFA_MG_PREFETCH
+#pragma unroll
+        for (int l = 0; l < MG_TL; l++) mv[l] = nx[l];
+#endif
     }
     if (live) {
         float *g = grad1 + ((size_t)bi * n + k) * 3;

@@ -86,7 +86,15 @@ namespace {
 #define RFP_HIST 0  // 1 (instrumented build): block scans by number of active lanes -> stats[10..13]
 #endif
 #ifndef RFP_HAGG
-#define RFP_HAGG 1  // the sort's histogram loops pre-aggregate in waves whose points crowd into few bins (collapsed clouds)
+#define RFP_HAGG 1  // the sort's quantile histograms sample 4x fewer lanes in waves whose points crowd into few bins (collapsed clouds)
+#endif
+#ifndef RFP_FUSE_STEP
+#define RFP_FUSE_STEP 1  // rf_chamfer_step: 1 = the backward's tiles ride in the sweep's launch and start cloud by cloud as the
+                         // cloud's sweep workgroups signal (two launches per step); 0 = sort, sweep, backward as three launches
+#endif
+#ifndef RFP_CLOUD_END
+#define RFP_CLOUD_END 0  // 1 (instrumented build): stats[c & 31] = s_memrealtime (100 MHz) at which the last workgroup of cloud c
+                         // left the sweep, INSTEAD of the counters: how far apart the clouds of one launch finish
 #endif
 #ifndef RFP_T16_STAMPS
 #define RFP_T16_STAMPS 0  // 1 (instrumented build): s_memtime per phase of the quad-per-query tiles, summed over waves -> stats[25..31]
@@ -129,6 +137,8 @@ struct SortArgs {
                    // NaN / no-candidate policy refers to, for the sorted-space backward)
     int str_s[2];  // STR order: slabs per cloud = strips per slab = round(cbrt(n / 64))
     unsigned long long *dbg;  // optional (with stats): s_memtime stamps of the sort's phases, [16..31]
+    unsigned *zero_words;     // optional: words the first workgroup clears (the fused step's work counters and tickets)
+    int nzero;
 };
 
 // Skilling's axes-to-transpose Hilbert mapping, 5 bits per axis -> 15-bit index.
@@ -219,51 +229,18 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 
 // LDS histogram increments on DEGENERATE clouds.  ds_add_u32 serialises over lanes that hit the same address: on a
 // cloud collapsed onto a few spots (the untrained RFNet's output: 16384 points on ~120 spots, 3-5 distinct bins among
-// the 64 consecutive points of a wave instruction, interleaved) the histogram phases took 2-5x their normal time
-// (quantiles 8.0 k -> 28.5 k ticks, positions 2.0 k -> 11.5 k: profiles/r04_sort_stamps.txt).  A wave that finds >= 8 of
-// its lanes in one bin at its first sample (`hist_is_dense`) runs a SEPARATE copy of each histogram loop that
-// pre-aggregates: up to HAGG_ROUNDS distinct bins are found by ballot and added once each by a leader lane, whatever is
-// left adds singly.  Normal clouds (randn: 50 distinct x bins per 64 lanes) pay one test per wave and run the loops as before.
-constexpr int HAGG_ROUNDS = 6;
+// the 64 consecutive points of a wave instruction, interleaved) the histogram phases take 2-5x their normal time
+// (quantiles 8.0 k -> 28.5 k ticks, keys 11.8 k -> 18.6 k, positions 2.0 k -> 11.5 k: profiles/r04_sort_stamps.txt).
+// The QUANTILE histograms only steer the order, so a wave that finds >= 8 of its lanes in one bin at its first sample
+// (`hist_is_dense`) feeds them from a quarter of its lanes (a sixteenth of the cloud instead of a quarter).  The key
+// histogram and the positions are exact and stay as they are: pre-aggregating them in the wave (one add per distinct
+// bin found by ballot / readlane, leader lanes, ranks by mbcnt) was built and measured SLOWER than the serialised
+// atomics -- quantiles 28.5 k -> 39.5 k ticks, keys 18.6 k -> 27.2 k, positions 11.5 k -> 13.0 k (profiles/r04_sort_stamps.txt).
 __device__ __forceinline__ bool hist_is_dense(unsigned bin, bool act) {
     const unsigned long long todo = __builtin_amdgcn_ballot_w64(act);
     if (todo == 0ull) return false;
     const unsigned first = (unsigned)__builtin_amdgcn_readlane((int)bin, __builtin_ctzll(todo));
     return __builtin_popcountll(__builtin_amdgcn_ballot_w64(act && bin == first)) >= 8;
-}
-__device__ __forceinline__ void hist_add_agg(unsigned *h, unsigned bin, bool act, int lane) {
-    unsigned long long todo = __builtin_amdgcn_ballot_w64(act);
-#pragma unroll 1
-    for (int it = 0; it < HAGG_ROUNDS && todo; it++) {
-        const int l = __builtin_ctzll(todo);
-        const unsigned v = (unsigned)__builtin_amdgcn_readlane((int)bin, l);
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(act && bin == v);
-        if (lane == l) atomicAdd(&h[v], (unsigned)__builtin_popcountll(m));
-        todo &= ~m;
-    }
-    if ((todo >> lane) & 1ull) atomicAdd(&h[bin], 1u);
-}
-// the returning form (positions inside a key, any order): rank inside the bin's lane group + the leader's old value
-__device__ __forceinline__ unsigned hist_fetch_add_agg(unsigned *h, unsigned bin, bool act, int lane) {
-    unsigned long long todo = __builtin_amdgcn_ballot_w64(act);
-    int leader = lane;
-    unsigned rank = 0, cnt = 1;
-#pragma unroll 1
-    for (int it = 0; it < HAGG_ROUNDS && todo; it++) {
-        const int l = __builtin_ctzll(todo);
-        const unsigned v = (unsigned)__builtin_amdgcn_readlane((int)bin, l);
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(act && bin == v);
-        if ((m >> lane) & 1ull) {
-            leader = l;
-            rank = (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-            cnt = (unsigned)__builtin_popcountll(m);
-        }
-        todo &= ~m;
-    }
-    unsigned base = 0;
-    if (act && leader == lane) base = atomicAdd(&h[bin], cnt);
-    base = (unsigned)__builtin_amdgcn_ds_bpermute(leader << 2, (int)base);
-    return base + rank;
 }
 
 constexpr int HALF = 9216;  // records staged in LDS at a time (16 B each, over the dead histogram + 16 KiB): a
@@ -283,11 +260,15 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     __shared__ unsigned wsum[STPB / 64];
     __shared__ unsigned lowcnt[STPB / 64][3];
     __shared__ float frame[6];  // lo[3], scale[3]
+    __shared__ unsigned ncrowded;  // waves whose points crowd into few bins
 
     // cloud-major logical order, each XCD a contiguous eighth (as the sweep: the XCD that sorts a
     // batch element is the one that sweeps it, its L2 still holding the records)
     const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (int)(blockIdx.x >> 3);
+    if (threadIdx.x == 0) ncrowded = 0;
+    if (blockIdx.x == 0 && a.zero_words)
+        for (int i = threadIdx.x; i < a.nzero; i += STPB) a.zero_words[i] = 0u;
     // A large cloud is shared by H = 2 or 4 workgroups, one per SLICE OF THE KEY SPACE (top key bits).  All
     // load the whole cloud and derive the same frame, cells and keys (no communication: the frame is a
     // pure function of the cloud); each then histograms, scans, places and writes out only the points
@@ -319,9 +300,15 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
         const int i = tid + k * STPB;
         px[k] = py[k] = pz[k] = 0.f;
         if (i < n) {
-            px[k] = src[(size_t)i * 3 + 0];
-            py[k] = src[(size_t)i * 3 + 1];
-            pz[k] = src[(size_t)i * 3 + 2];
+            // one 12-byte load per point (global_load_dwordx3: a wave's 64 consecutive points are 768 contiguous bytes);
+            // three strided dword loads walk the same 12 cache lines three times and the load phase is bound by that
+            struct P3 {
+                float x, y, z;
+            };
+            const P3 v = *(const P3 *)(src + (size_t)i * 3);
+            px[k] = v.x;
+            py[k] = v.y;
+            pz[k] = v.z;
         }
     }
     {
@@ -392,24 +379,15 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
         const int k0 = (4 - w3) & 3;
         dense = RFP_HAGG && RFP_QSAMPLE == 3 && hist_is_dense((unsigned)axis_bin(x0, fl[0], fs[0]), tid + k0 * STPB < n);
     }
-    if (dense) {
+    const bool feeds = !dense || (lane & 3) == 0;  // (a crowded wave: a quarter of its lanes feed the quantile histograms)
+    if (dense && lane == 0) atomicAdd(&ncrowded, 1u);
 #pragma unroll
-        for (int k = 0; k < RPT; k++) {
-            if (((k + wave) & RFP_QSAMPLE) != 0) continue;
-            const bool act = tid + k * STPB < n;
-            hist_add_agg(ahist[0], (unsigned)axis_bin(px[k], fl[0], fs[0]), act, lane);
-            hist_add_agg(ahist[1], (unsigned)axis_bin(py[k], fl[1], fs[1]), act, lane);
-            hist_add_agg(ahist[2], (unsigned)axis_bin(pz[k], fl[2], fs[2]), act, lane);
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < RPT; k++) {
-            if (((k + wave) & RFP_QSAMPLE) != 0) continue;
-            if (tid + k * STPB < n) {
-                atomicAdd(&ahist[0][axis_bin(px[k], fl[0], fs[0])], 1u);
-                atomicAdd(&ahist[1][axis_bin(py[k], fl[1], fs[1])], 1u);
-                atomicAdd(&ahist[2][axis_bin(pz[k], fl[2], fs[2])], 1u);
-            }
+    for (int k = 0; k < RPT; k++) {
+        if (((k + wave) & RFP_QSAMPLE) != 0) continue;
+        if (feeds && tid + k * STPB < n) {
+            atomicAdd(&ahist[0][axis_bin(px[k], fl[0], fs[0])], 1u);
+            atomicAdd(&ahist[1][axis_bin(py[k], fl[1], fs[1])], 1u);
+            atomicAdd(&ahist[2][axis_bin(pz[k], fl[2], fs[2])], 1u);
         }
     }
     __syncthreads();
@@ -445,20 +423,11 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     }
     __syncthreads();
     // the y histogram of every slab, from the same quarter of the points
-    if (dense) {
 #pragma unroll
-        for (int k = 0; k < RPT; k++) {
-            if (((k + wave) & RFP_QSAMPLE) != 0) continue;
-            hist_add_agg(yhist, (unsigned)((int)slabmap[axis_bin(px[k], fl[0], fs[0])] * HB + axis_bin(py[k], fl[1], fs[1])),
-                         tid + k * STPB < n, lane);
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < RPT; k++) {
-            if (((k + wave) & RFP_QSAMPLE) != 0) continue;
-            if (tid + k * STPB < n)
-                atomicAdd(&yhist[(int)slabmap[axis_bin(px[k], fl[0], fs[0])] * HB + axis_bin(py[k], fl[1], fs[1])], 1u);
-        }
+    for (int k = 0; k < RPT; k++) {
+        if (((k + wave) & RFP_QSAMPLE) != 0) continue;
+        if (feeds && tid + k * STPB < n)
+            atomicAdd(&yhist[(int)slabmap[axis_bin(px[k], fl[0], fs[0])] * HB + axis_bin(py[k], fl[1], fs[1])], 1u);
     }
     __syncthreads();
     if (wave < SS) {  // wave <-> slab
@@ -501,17 +470,13 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
         const int slice = (col >= cs1) + (col >= cs2) + (col >= cs3);
         const bool own = valid && slice == half;
         pk[k] = own ? key - kbase : 0xFFFFFFFFu;
-        if (own && !dense) atomicAdd(&hist[pk[k]], 1u);
+        if (own) atomicAdd(&hist[pk[k]], 1u);
         // points of the slices below this workgroup's (its segment starts behind theirs)
         if (H > 1) {
 #pragma unroll
             for (int q = 0; q < 3; q++)
                 if (q < half) below[q] += (unsigned)__builtin_popcountll(__ballot(valid && slice == q));
         }
-    }
-    if (dense) {  // (the key histogram of a crowded wave, pre-aggregated: its own loop, the keys are in registers)
-#pragma unroll 1
-        for (int k = 0; k < RPT; k++) hist_add_agg(hist, pk[k] == 0xFFFFFFFFu ? 0u : pk[k], pk[k] != 0xFFFFFFFFu, lane);
     }
     if (H > 1 && lane == 0) {
 #pragma unroll
@@ -562,18 +527,9 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
 
     stamp();
     // 5. positions (the order inside a key is whatever the atomics give: results do not depend on it)
-    if (dense) {
 #pragma unroll
-        for (int k = 0; k < RPT; k++) {
-            const bool act = pk[k] != 0xFFFFFFFFu;
-            const unsigned pos = hist_fetch_add_agg(hist, act ? pk[k] : 0u, act, lane);
-            if (act) pk[k] = pos;
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < RPT; k++)
-            if (pk[k] != 0xFFFFFFFFu) pk[k] = atomicAdd(&hist[pk[k]], 1u);  // position inside this half's segment
-    }
+    for (int k = 0; k < RPT; k++)
+        if (pk[k] != 0xFFFFFFFFu) pk[k] = atomicAdd(&hist[pk[k]], 1u);  // position inside this half's segment
     __syncthreads();  // the histogram is dead from here on
 
     stamp();
@@ -605,6 +561,11 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
         }
     }
     if (tid == 0 && pk[0] != 0xFFFFFFFFu) a.pos0[set][bi] = base + (int)pk[0];  // point 0 is thread 0's first
+    // CROWDED cloud (more than half of the waves found >= 8 of their 64 consecutive points in one x bin: the untrained
+    // network's collapsed output): as a CANDIDATE set it sends every query through hundreds of near-tied blocks, which the
+    // shared-group sweep streams to 64 lanes at the VALU rate and the quad tiles would chase one latency-bound round at a
+    // time (258 us instead of 120 at C2) -- the sweep reads this flag per cloud (all workgroups of a cloud agree: same data)
+    if (tid == 0 && half == 0) a.pos0[set][a.b + bi] = ncrowded * 2 > STPB / 64 ? 1 : 0;
     for (int h0 = 0; h0 < seglen; h0 += HALF) {
         const int cnt = min(HALF, seglen - h0);  // multiple of 64
 #pragma unroll
@@ -719,6 +680,8 @@ __global__ __launch_bounds__(STPB) void nnp_sort_kernel(SortArgs a) {
     };
 
     for (int i = tid; i < NBINS; i += STPB) hist[i] = 0;
+    if (blockIdx.x == 0 && a.zero_words)
+        for (int i = tid; i < a.nzero; i += STPB) a.zero_words[i] = 0u;
     if (tid < 3 * HB) (&ahist[0][0])[tid] = 0;
 
     // 1. bounding box of the finite coordinates
@@ -858,7 +821,10 @@ __global__ __launch_bounds__(STPB) void nnp_sort_kernel(SortArgs a) {
         if constexpr (REG) key = pkey[k];
         else key = key_of(x, y, z);
         const unsigned pos = atomicAdd(&hist[key], 1u);
-        if (i == 0) a.pos0[set][bi] = (int)pos;
+        if (i == 0) {
+            a.pos0[set][bi] = (int)pos;
+            a.pos0[set][a.b + bi] = 0;  // (crowded flag: the register-resident sort's test only)
+        }
         oxyz[(size_t)pos * 3 + 0] = x;
         oxyz[(size_t)pos * 3 + 1] = y;
         oxyz[(size_t)pos * 3 + 2] = z;
@@ -934,6 +900,7 @@ struct SweepArgs {
 
 // What the sweep of rf_chamfer_step leaves behind for the sorted-space backward (nnp_grad_sorted_kernel), per
 // query and in SORTED query order -- coalesced stores from the lane that owns the query:
+//   one 16-byte record {wp, own.x, own.y, own.z} (round 4: one store, one load per query; rounds 3: two arrays):
 //   wp   sorted position of its nearest neighbour in the other set (-1: padding)
 //   own  its own gradient term (q - winner) * 2 gd, three floats (the winner's coordinates are one gather at
 //        the end of the wave's life, hidden under the other waves' scans).  The term the query scatters into
@@ -951,23 +918,19 @@ struct GradEmit {
     int qbucket[2];  // sorted positions per bucket of set d: ceil(npad[d] / 64)
 };
 struct EmitView {
-    int *wp;       // (b, npad)
-    float *own;    // (b, npad, 3)
+    int4 *rec;                 // (b, npad) one 16-byte record per query: {wp, own.x, own.y, own.z (float bits)}
     unsigned long long *mask;  // (b, npad / 64)
 };
 __host__ __device__ inline size_t emit_align(size_t v) { return (v + 255) / 256 * 256; }
 __host__ __device__ inline size_t emit_set_bytes(int b, int npad) {
-    return emit_align((size_t)b * npad * sizeof(int)) + emit_align((size_t)b * npad * 3 * sizeof(float)) +
-           emit_align((size_t)b * (npad / 64) * sizeof(unsigned long long));
+    return emit_align((size_t)b * npad * sizeof(int4)) + emit_align((size_t)b * (npad / 64) * sizeof(unsigned long long));
 }
 __host__ __device__ inline EmitView emit_layout(char *base, int b, int npad0, int npad1, int set) {
     char *p = base + (set ? emit_set_bytes(b, npad0) : 0);
     const int npad = set ? npad1 : npad0;
     EmitView v;
-    v.wp = (int *)p;
-    p += emit_align((size_t)b * npad * sizeof(int));
-    v.own = (float *)p;
-    p += emit_align((size_t)b * npad * 3 * sizeof(float));
+    v.rec = (int4 *)p;
+    p += emit_align((size_t)b * npad * sizeof(int4));
     v.mask = (unsigned long long *)p;
     return v;
 }
@@ -1398,11 +1361,8 @@ __device__ __forceinline__ void sweep_group(
         const float cx = C[(size_t)wc * 3 + 0], cy = C[(size_t)wc * 3 + 1], cz = C[(size_t)wc * 3 + 2];
         const float g2 = gq + gq;  // the reference's arithmetic: g = gd + gd; (a - b) * g rounded on its own
         const size_t r = (size_t)bi * a.npad[dir] + g * SB + lane;
-        ev.wp[r] = valid ? w : -1;
-        float *ow = ev.own + r * 3;
-        ow[0] = (qx - cx) * g2;
-        ow[1] = (qy - cy) * g2;
-        ow[2] = (qz - cz) * g2;
+        ev.rec[r] = make_int4(valid ? w : -1, __float_as_int((qx - cx) * g2), __float_as_int((qy - cy) * g2),
+                              __float_as_int((qz - cz) * g2));
         // the buckets this group's winners fall into: one trip per DISTINCT bucket (a handful: the winners of 64
         // consecutive sorted queries are neighbours)
         const int bkt = w / ge.qbucket[cd];
@@ -1439,14 +1399,14 @@ __device__ __forceinline__ void sweep_group(
 // code.  Same outputs as sweep_group: the same d2 sequence on the same pairs' survivors, bounds culled strictly, the
 // lowest original index among exact ties (two equal blocks re-scanned, a third one -> exhaustive pass).
 constexpr int T16_CAPS = 32;  // entries of a quad's superblock list
-constexpr int T16_CAPB = 32;  // entries of a quad's block list
+constexpr int T16_CAPB = 16;  // entries of a quad's block list (the lists of a 4-tile workgroup + its key lists must stay under
+                              // 160 KB / 7: with 32 entries the launch's workgroups -- the other direction's too -- drop to 6 per CU)
 constexpr int T16_UN5 = 4;    // list rounds per trip of step 4 (their gathers in flight together)
-constexpr int T16_UN6 = 4;    // block-test rounds per trip of step 5
+constexpr int T16_UN6 = 2;    // block-test rounds per trip of step 5
 constexpr int T16_KK = 5;     // tile keys kept in registers: candidate sets of up to 320 superblocks
 struct T16Lds {
     unsigned short qsb[16][T16_CAPS];
-    unsigned short qbl[16][T16_CAPB];
-    float qlb[16][T16_CAPB];
+    float2 qe[16][T16_CAPB];  // (bound, block id): a pair of entries is one 16-byte LDS read
 };
 
 #define RFP_QUAD(OP, PERM) asm volatile("s_nop 1\n\t" OP " %0, %0, %0 quad_perm:" PERM " row_mask:0xf bank_mask:0xf" : "+v"(v))
@@ -1471,20 +1431,9 @@ template <int CTL>
 __device__ __forceinline__ void quad_lexmin_step(float &v, int &i) {
     const float ov = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTL, 0xf, 0xf, false));
     const int oi = __builtin_amdgcn_update_dpp(0, i, CTL, 0xf, 0xf, false);
-    if (ov < v || (ov == v && oi < i)) {
-        v = ov;
-        i = oi;
-    }
-}
-template <int CTL>
-__device__ __forceinline__ void quad_lexmin3(float &v, unsigned &i, int &p) {  // (value, index) with a payload
-    const float ov = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTL, 0xf, 0xf, false));
-    const unsigned oi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)i, CTL, 0xf, 0xf, false);
-    const int op = __builtin_amdgcn_update_dpp(0, p, CTL, 0xf, 0xf, false);
-    const bool b = ov < v || (ov == v && oi < i);
+    const bool b = (ov < v) | ((ov == v) & (oi < i));
     v = b ? ov : v;
     i = b ? oi : i;
-    p = b ? op : p;
 }
 __device__ __forceinline__ void quad_lexmin(float &v, int &i) {
     quad_lexmin_step<0xB1>(v, i);  // quad_perm [1,0,3,2]
@@ -1537,13 +1486,13 @@ __device__ __forceinline__ void sweep_tile16(
     const float tlo[3] = {tb[0], tb[1], tb[2]}, thi[3] = {tb[3], tb[4], tb[5]};
 
     unsigned *__restrict__ sbl = keys_dyn + (size_t)wib * a.kstride;  // this wave's superblock list (>= nsb entries)
-    // the quad's running result: minimum, lowest original index attaining it, that candidate's sorted position.  The
-    // index travels WITH the minimum here (one more 16-byte gather per block and ~25 VALU per scan, in a loop that waits
-    // on memory): no winning-block re-scan, no tie bookkeeping -- any candidate that equals the final minimum lies in a
-    // block whose bound does not exceed it, and such blocks are never culled.
+    // the quad's running minimum, the block that first attained it, the second block that equalled it, and a flag for
+    // a third (sweep_group's tie scheme: the index is resolved at the end by re-scanning one or two blocks.  Carrying
+    // (index, position) through every scan instead -- a fourth gather and a lexicographic quad reduction per block, no
+    // re-scan -- was built, is bit-exact, and measured SLOWER: 59.8 vs 54.3 us for the C2 sweep, profiles/r04_tile16.txt)
     float best = INFINITY, cull = part ? INFINITY : -INFINITY;
-    unsigned besti = 0xFFFFFFFFu;
-    int wpos = -1, seedblk = -1;
+    int bblk = 0, bblk2 = -1, seedblk = -1;
+    bool tie = false;
     unsigned n_round = 0, n_scan = 0;
 #if RFP_T16_STAMPS
     unsigned long long tph[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
@@ -1558,31 +1507,32 @@ __device__ __forceinline__ void sweep_tile16(
 
     // (minimum, lowest original index, position) of the quad's query over the 16 records of block blk: each lane its
     // 4 records, then the quad's lexicographic minimum -- every lane of the quad ends with the same triple
-    auto block_best = [&](int blk, float &dm, unsigned &im, int &pm) {
-        const float4 *p = (const float4 *)(C + (size_t)blk * (BS * 3) + k * 12);
-        const float4 r0 = p[0], r1 = p[1], r2 = p[2];
-        const int4 co = *(const int4 *)(Co + (size_t)blk * BS + k * 4);
-        const float d[4] = {rf::d2_fma(r0.x - qx, r0.y - qy, r0.z - qz), rf::d2_fma(r0.w - qx, r1.x - qy, r1.y - qz),
-                            rf::d2_fma(r1.z - qx, r1.w - qy, r2.x - qz), rf::d2_fma(r2.y - qx, r2.z - qy, r2.w - qz)};
-        const unsigned io[4] = {(unsigned)co.x, (unsigned)co.y, (unsigned)co.z, (unsigned)co.w};  // padding carries 0xFFFFFFFF
-        dm = INFINITY;
-        im = 0xFFFFFFFFu;
-        pm = -1;
-#pragma unroll
-        for (int u = 0; u < 4; u++) {  // (a NaN distance compares false both ways: never taken)
-            const bool b = d[u] < dm || (d[u] == dm && io[u] < im);
-            dm = b ? d[u] : dm;
-            im = b ? io[u] : im;
-            pm = b ? blk * BS + k * 4 + u : pm;
-        }
-        quad_lexmin3<0xB1>(dm, im, pm);
-        quad_lexmin3<0x4E>(dm, im, pm);
+    struct BlockRegs {  // a lane's quarter of a candidate block: 4 records
+        float4 r0, r1, r2;
     };
-    auto take = [&](float dm, unsigned im, int pm) {
-        const bool b = dm < best || (dm == best && im < besti);
-        best = b ? dm : best;
-        besti = b ? im : besti;
-        wpos = b ? pm : wpos;
+    auto block_load = [&](int blk) {
+        const float4 *p = (const float4 *)(C + (size_t)blk * (BS * 3) + k * 12);
+        BlockRegs g;
+        g.r0 = p[0];
+        g.r1 = p[1];
+        g.r2 = p[2];
+        return g;
+    };
+    // min d2 of the quad's query over the 16 records of a block: each lane its 4, then the quad's minimum
+    auto block_min = [&](const BlockRegs &g) {
+        const float4 r0 = g.r0, r1 = g.r1, r2 = g.r2;
+        const float d0 = rf::d2_fma(r0.x - qx, r0.y - qy, r0.z - qz), d1 = rf::d2_fma(r0.w - qx, r1.x - qy, r1.y - qz);
+        const float d2 = rf::d2_fma(r1.z - qx, r1.w - qy, r2.x - qz), d3 = rf::d2_fma(r2.y - qx, r2.z - qy, r2.w - qz);
+        float cm = min3_acc(INFINITY, d0, d1);
+        cm = min3_acc(cm, d2, d3);
+        return quad_min_f32(cm);
+    };
+    auto take = [&](bool on, float cm, int blk) {
+        const bool lt = on & (cm < best), eq = on & (cm == best);
+        tie = lt ? false : (tie | (eq & (bblk2 >= 0)));
+        bblk2 = lt ? -1 : ((eq & (bblk2 < 0)) ? blk : bblk2);
+        bblk = lt ? blk : bblk;
+        best = lt ? cm : best;
         cull = fminf(cull, best);
     };
     auto sb_bound = [&](int s) {  // per lane: query against the box of superblock s
@@ -1649,19 +1599,14 @@ __device__ __forceinline__ void sweep_tile16(
 #pragma unroll
                 for (int j = 0; j < SBB; j++) {
                     const float lb = box_bound(qx, qy, qz, f[j * 6 + 0], f[j * 6 + 1], f[j * 6 + 2], f[j * 6 + 3], f[j * 6 + 4], f[j * 6 + 5]);
-                    if (lb < blb) {  // (NaN query: never; it takes no part anyway)
-                        blb = lb;
-                        bblk = s * SBB + j;
-                    }
+                    const bool nb = lb < blb;  // (NaN query: never; it takes no part anyway)
+                    blb = nb ? lb : blb;
+                    bblk = nb ? s * SBB + j : bblk;
                 }
             }
             quad_lexmin(blb, bblk);
             seedblk = bblk;
-            float dm;
-            unsigned im;
-            int pm;
-            block_best(seedblk, dm, im, pm);
-            if (part) take(dm, im, pm);
+            take(part, block_min(block_load(seedblk)), seedblk);
             n_scan += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(part)) >> 2;
         }
         stamp(1);
@@ -1726,8 +1671,7 @@ __device__ __forceinline__ void sweep_tile16(
                         const unsigned nib = nibble(pass);
                         if (pass) {
                             const int pos = cntB + __builtin_popcount(nib & ((1u << k) - 1u));
-                            tl->qbl[qi][pos] = (unsigned short)bv[u];
-                            tl->qlb[qi][pos] = lbv[u];
+                            tl->qe[qi][pos] = make_float2(lbv[u], __int_as_float(bv[u]));
                         }
                         cntB += __builtin_popcount(nib);
                     }
@@ -1741,25 +1685,22 @@ __device__ __forceinline__ void sweep_tile16(
                 int ptr = 0;
                 for (;;) {
                     bool v0, v1;
+                    float4 e01;
                     for (;;) {  // every quad moves on to its next pair with a block whose bound has not been overtaken
                         const bool more = ptr < cntB;
-                        const float lb0 = more ? tl->qlb[qi][ptr] : 0.f;
-                        const float lb1 = ptr + 1 < cntB ? tl->qlb[qi][ptr + 1] : INFINITY;
-                        v0 = more && lb0 <= cull;
-                        v1 = ptr + 1 < cntB && lb1 <= cull;
+                        e01 = *(const float4 *)&tl->qe[qi][ptr < T16_CAPB ? ptr : 0];  // (ptr is even: entries ptr, ptr + 1)
+                        v0 = more && e01.x <= cull;
+                        v1 = ptr + 1 < cntB && e01.z <= cull;
                         const bool skip = more && !v0 && !v1;
                         if (skip) ptr += 2;
                         if (__builtin_amdgcn_ballot_w64(skip) == 0ull) break;
                     }
                     if (__builtin_amdgcn_ballot_w64(v0 || v1) == 0ull) break;
-                    const int b0 = v0 ? (int)tl->qbl[qi][ptr] : seedblk, b1 = v1 ? (int)tl->qbl[qi][ptr + 1] : seedblk;
-                    float d0, d1;
-                    unsigned i0, i1;
-                    int p0, p1;
-                    block_best(b0, d0, i0, p0);
-                    block_best(b1, d1, i1, p1);
-                    if (v0) take(d0, i0, p0);
-                    if (v1) take(d1, i1, p1);
+                    const int b0 = v0 ? __float_as_int(e01.y) : seedblk, b1 = v1 ? __float_as_int(e01.w) : seedblk;
+                    const BlockRegs g0 = block_load(b0), g1 = block_load(b1);  // (both gathers in flight before either is used)
+                    const float c0 = block_min(g0), c1 = block_min(g1);
+                    take(v0, c0, b0);
+                    take(v1, c1, b1);
                     if (v0 || v1) ptr += 2;
                     n_scan += (unsigned)(__builtin_popcountll(__builtin_amdgcn_ballot_w64(v0)) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(v1))) >> 2;
                 }
@@ -1770,6 +1711,59 @@ __device__ __forceinline__ void sweep_tile16(
             cntS = 0;
             if (r5 >= n5) break;
         }
+    }
+
+    // lowest original index among the exact matches of the winning block (and of the second block that equalled it);
+    // each lane its quarter, then the quad's minimum
+    unsigned besti = 0xFFFFFFFFu;
+    int wpos = -1;
+    auto rescan = [&](int wb, unsigned &bi_, int &wp_) {
+        const float4 *p = (const float4 *)(C + (size_t)wb * (BS * 3) + k * 12);
+        const int4 co = *(const int4 *)(Co + (size_t)wb * BS + k * 4);
+        const float4 r0 = p[0], r1 = p[1], r2 = p[2];
+        const float d[4] = {rf::d2_fma(r0.x - qx, r0.y - qy, r0.z - qz), rf::d2_fma(r0.w - qx, r1.x - qy, r1.y - qz),
+                            rf::d2_fma(r1.z - qx, r1.w - qy, r2.x - qz), rf::d2_fma(r2.y - qx, r2.z - qy, r2.w - qz)};
+        const unsigned io[4] = {(unsigned)co.x, (unsigned)co.y, (unsigned)co.z, (unsigned)co.w};  // padding carries 0xFFFFFFFF
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bool b = (d[u] == best) & (io[u] < bi_);
+            bi_ = b ? io[u] : bi_;
+            wp_ = b ? wb * BS + k * 4 + u : wp_;
+        }
+    };
+    if (part) rescan(bblk, besti, wpos);
+    if (__builtin_amdgcn_ballot_w64(part && bblk2 >= 0) != 0ull) {
+        if (part && bblk2 >= 0) rescan(bblk2, besti, wpos);
+    }
+    // a third block equalled the minimum: every block that can hold a match, exhaustively (rare: points repeated
+    // three times across blocks, symmetric configurations)
+    const bool flagged = tie && part;
+    if (__builtin_amdgcn_ballot_w64(flagged) != 0ull) {
+        unsigned besti2 = 0xFFFFFFFFu;
+        int wpos2 = -1;
+        for (int s = 0; s < nsb; s++) {
+            const float *cb = CB64 + (size_t)s * B64F;  // uniform: scalar loads
+            const float lb = box_bound(qx, qy, qz, cb[0], cb[1], cb[2], cb[4], cb[5], cb[6]);
+            const bool in = flagged && lb <= best;
+            if (__builtin_amdgcn_ballot_w64(in) == 0ull) continue;
+            const bool needk = in && blk_bound(s * SBB + k) <= best;
+            const unsigned nib = nibble(needk);
+#pragma unroll
+            for (int j = 0; j < SBB; j++) {
+                const bool nj = (nib >> j) & 1u;
+                if (__builtin_amdgcn_ballot_w64(nj) == 0ull) continue;
+                if (nj) rescan(s * SBB + j, besti2, wpos2);
+            }
+        }
+        if (flagged) {
+            besti = besti2;
+            wpos = wpos2;
+        }
+    }
+    {
+        const unsigned mi = quad_min_u32(besti);
+        wpos = quad_max_i32(besti == mi ? wpos : -1);
+        besti = mi;
     }
 
     stamp(6);
@@ -1801,11 +1795,8 @@ __device__ __forceinline__ void sweep_tile16(
         const float g2 = gq + gq;
         const size_t r = (size_t)bi * a.npad[dir] + qpos;
         if (k == 0) {
-            ev.wp[r] = valid ? w : -1;
-            float *ow = ev.own + r * 3;
-            ow[0] = (qx - cx) * g2;
-            ow[1] = (qy - cy) * g2;
-            ow[2] = (qz - cz) * g2;
+            ev.rec[r] = make_int4(valid ? w : -1, __float_as_int((qx - cx) * g2), __float_as_int((qy - cy) * g2),
+                                  __float_as_int((qz - cz) * g2));
         }
         const int bkt = w / ge.qbucket[cd];
         unsigned long long todo = __builtin_amdgcn_ballot_w64(valid && k == 0), gm = 0ull;
@@ -1860,11 +1851,20 @@ __global__ __launch_bounds__(64 * NSH) __attribute__((amdgpu_waves_per_eu(RFP_WP
     if (dir) wg -= a.wg0;
     if (a.nw[dir] == NSH) {
 #if RFP_TILE16
+        // the candidate cloud's crowded flag (written by the sort behind pos0): uniform per workgroup
+        const int cdk = 1 - dir;
+        const int *flags = (const int *)((const char *)(cdk ? b64_1 : b64_0) +
+                                         emit_align((size_t)a.b * (a.npad[cdk] / SB) * B64F * sizeof(float))) + a.b;
+        if (flags[bi]) {
+            sweep_group<true, GRAD>(a, ge, dir, bi * a.groups[dir] + wg, wib, lane, keys_dyn, shbest, md, mi, mp, xyz0, xyz1,
+                                    orig0, orig1, b16_0, b16_1, b64_0, b64_1, dist0, dist1, idx0, idx1, RFP_CLOUD_END ? nullptr : stats);
+            return;
+        }
         // (the tiles' lists live in DYNAMIC LDS behind the key lists: static arrays would be charged to every workgroup of
         // the kernel, and the one-wave workgroups of a launch without shared groups lose a third of their residency)
         T16Lds *t16 = (T16Lds *)(keys_dyn + (size_t)NSH * a.kstride);
         sweep_tile16<GRAD>(a, ge, dir, bi * a.groups[dir] + wg, wib, lane, keys_dyn, &t16[wib], gmsh, xyz0, xyz1, orig0, orig1,
-                           b16_0, b16_1, b64_0, b64_1, dist0, dist1, idx0, idx1, stats);
+                           b16_0, b16_1, b64_0, b64_1, dist0, dist1, idx0, idx1, RFP_CLOUD_END ? nullptr : stats);
 #else
         sweep_group<true, GRAD>(a, ge, dir, bi * a.groups[dir] + wg, wib, lane, keys_dyn, shbest, md, mi, mp, xyz0, xyz1,
                                 orig0, orig1, b16_0, b16_1, b64_0, b64_1, dist0, dist1, idx0, idx1, stats);
@@ -1873,8 +1873,11 @@ __global__ __launch_bounds__(64 * NSH) __attribute__((amdgpu_waves_per_eu(RFP_WP
         const int g = wg * (int)(blockDim.x >> 6) + wib;
         if (g >= a.groups[dir]) return;  // (no barriers on this path)
         sweep_group<false, GRAD>(a, ge, dir, bi * a.groups[dir] + g, wib, lane, keys_dyn, shbest, md, mi, mp, xyz0, xyz1,
-                                 orig0, orig1, b16_0, b16_1, b64_0, b64_1, dist0, dist1, idx0, idx1, stats);
+                                 orig0, orig1, b16_0, b16_1, b64_0, b64_1, dist0, dist1, idx0, idx1, RFP_CLOUD_END ? nullptr : stats);
     }
+#if RFP_CLOUD_END
+    if (stats && lane == 0) atomicMax(&stats[bi & 31], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1907,31 +1910,24 @@ struct GradSArgs {
     int b;
     int n[2], npad[2], gt[2], tiles[2];
     const int *orig[2];    // (b, npad)
-    const int *wp[2];      // (b, npad) winner's sorted position in the other set
-    const float *own[2];   // (b, npad, 3) own terms
+    const int4 *rec[2];    // (b, npad) {winner's sorted position in the other set, own term x, y, z}
     const unsigned long long *mask[2];  // (b, npad / 64) buckets of the OTHER set the group's winners fall into
     int qbucket[2];        // positions per bucket of set d; gt[d] is a multiple of it
     float *grad[2];        // (b, n, 3) original order
 };
 
-__global__ __launch_bounds__(GS_TPB) void nnp_grad_sorted_kernel(GradSArgs a) {
-    extern __shared__ float acc[];  // [gt * 3], gt = the larger of the two sets' tile sizes
-    __shared__ unsigned short list[GS_MAXG];
-    __shared__ int nlist;
-    // cloud-major logical order, each XCD a contiguous eighth (as sort and sweep): the re-reads of a cloud's
-    // records by its tiles then hit that XCD's L2 instead of crossing the fabric once per tile
-    const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
-    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (int)(blockIdx.x >> 3);
-    const int wpc = a.tiles[0] + a.tiles[1];
-    const int bi = logical / wpc;
-    int tile = logical - bi * wpc;
+// One destination tile (256 threads): `tile` in [0, tiles[0] + tiles[1]) of cloud bi.  acc: gt * 3 floats of LDS; list:
+// GS_MAXG entries; nlist_p: one LDS word.  Called by nnp_grad_sorted_kernel (its own launch) and by nnp_step_kernel
+// (the same tile inside the sweep's launch, once the cloud's sweep workgroups have all signalled).
+__device__ __forceinline__ void grad_tile(const GradSArgs &a, const int bi, int tile, float *__restrict__ acc,
+                                          unsigned short *__restrict__ list, int *nlist_p) {
+    int &nlist = *nlist_p;
     const int D = tile >= a.tiles[0];
     if (D) tile -= a.tiles[0];
     const int S = 1 - D;
     const int j0 = tile * a.gt[D], jn = min(a.gt[D], a.npad[D] - j0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int *__restrict__ sw = a.wp[S] + (size_t)bi * a.npad[S];
-    const float *__restrict__ so = a.own[S] + (size_t)bi * a.npad[S] * 3;
+    const int4 *__restrict__ sr = a.rec[S] + (size_t)bi * a.npad[S];
     const int ng = a.npad[S] / SB;
     const unsigned long long *__restrict__ rg = a.mask[S] + (size_t)bi * ng;
     // this tile's buckets (gt is a whole number of buckets, at most 64 of them per set)
@@ -1958,9 +1954,10 @@ __global__ __launch_bounds__(GS_TPB) void nnp_grad_sorted_kernel(GradSArgs a) {
         own[u][0] = own[u][1] = own[u][2] = 0.f;
         if (j < jn) {
             oo[u] = a.orig[D][(size_t)bi * a.npad[D] + j0 + j];
-            const float *ow = a.own[D] + ((size_t)bi * a.npad[D] + j0 + j) * 3;
-#pragma unroll
-            for (int c = 0; c < 3; c++) own[u][c] = ow[c];
+            const int4 rc = a.rec[D][(size_t)bi * a.npad[D] + j0 + j];
+            own[u][0] = __int_as_float(rc.y);
+            own[u][1] = __int_as_float(rc.z);
+            own[u][2] = __int_as_float(rc.w);
         }
     }
     for (int i = tid; i < jn * 3; i += GS_TPB) acc[i] = 0.f;
@@ -1979,10 +1976,11 @@ __global__ __launch_bounds__(GS_TPB) void nnp_grad_sorted_kernel(GradSArgs a) {
             w[i] = -1;
             v[i][0] = v[i][1] = v[i][2] = 0.f;
             if (li < nl) {
-                const int k = (int)list[li] * SB + lane;
-                w[i] = sw[k];
-#pragma unroll
-                for (int c = 0; c < 3; c++) v[i][c] = so[(size_t)k * 3 + c];
+                const int4 rc = sr[(int)list[li] * SB + lane];
+                w[i] = rc.x;
+                v[i][0] = __int_as_float(rc.y);
+                v[i][1] = __int_as_float(rc.z);
+                v[i][2] = __int_as_float(rc.w);
             }
         }
 #pragma unroll
@@ -2029,6 +2027,144 @@ __global__ __launch_bounds__(GS_TPB) void nnp_grad_sorted_kernel(GradSArgs a) {
     }
 }
 
+__global__ __launch_bounds__(GS_TPB) void nnp_grad_sorted_kernel(GradSArgs a) {
+    extern __shared__ float acc_dyn[];  // [gt * 3], gt = the larger of the two sets' tile sizes
+    __shared__ unsigned short list[GS_MAXG];
+    __shared__ int nlist;
+    // cloud-major logical order, each XCD a contiguous eighth (as sort and sweep): the re-reads of a cloud's
+    // records by its tiles then hit that XCD's L2 instead of crossing the fabric once per tile
+    const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (int)(blockIdx.x >> 3);
+    const int wpc = a.tiles[0] + a.tiles[1];
+    const int bi = logical / wpc;
+    grad_tile(a, bi, logical - bi * wpc, acc_dyn, list, &nlist);
+}
+
+// ------------------------------------------------------------------------------------------
+// rf_chamfer_step in TWO launches (round 4): the sort, then ONE launch that holds the sweep's workgroups AND the
+// backward's tiles.  The clouds of a sweep launch finish far apart -- the grid is 1.7 residency rounds in cloud-major
+// order: at C2 24 of the 32 clouds are done more than 10 us before the launch ends, the median one 20 us before
+// (profiles/r04_cloud_end_times.txt) -- so a cloud's backward tiles can run under the later clouds' sweeps instead of
+// waiting behind a kernel boundary for the slowest wave of the last cloud.
+//   * WORK ITEMS are pulled, not mapped from blockIdx: a workgroup takes `id = atomicAdd(ctr[h], 1)` from one of 8
+//     lists (h = blockIdx & 7 first: blocks b and b + 8 share an XCD in practice, which only matters for speed; then
+//     the other lists).  List h holds WHOLE clouds [h b / 8, (h + 1) b / 8): first all their sweep items, then all
+//     their backward tiles.  So when a tile of cloud c has been pulled, every sweep item of cloud c has been pulled
+//     before it -- by workgroups that are running or done, and that wait for nothing: the tile's wait on the cloud's
+//     ticket cannot deadlock whatever order the hardware starts workgroups in.  (Grid = number of items; every
+//     workgroup takes exactly one.)
+//   * SIGNAL: each wave of a sweep item drains its stores (s_waitcnt vmcnt(0)) and arrives at an LDS counter; the
+//     wave that arrives last publishes with an agent-scope release and one relaxed add on the cloud's ticket.
+//   * WAIT: lane 0 of a tile polls the ticket (relaxed, s_sleep between polls, bounded), then an agent-scope acquire,
+//     then the workgroup's barrier; plain loads after that (MI355X_MICROARCH.md, inter-workgroup visibility, R1).
+struct StepFuse {
+    unsigned *ctr;   // [8] items handed out per list
+    unsigned *done;  // [b] sweep workgroups of the cloud that have signalled
+    int spc;         // sweep items per cloud (= wg0 + wg1)
+    int tpc;         // backward tiles per cloud
+};
+constexpr int STEP_SPIN_CAP = 1 << 22;  // polls before a tile gives up waiting (~1 s: never in a healthy run, never a hang)
+
+__global__ __launch_bounds__(64 * NSH) __attribute__((amdgpu_waves_per_eu(RFP_WPE, RFP_WPE))) void nnp_step_kernel(
+    SweepArgs a, GradEmit ge, GradSArgs ga, StepFuse fu, const float *__restrict__ xyz0, const float *__restrict__ xyz1,
+    const int *__restrict__ orig0, const int *__restrict__ orig1, const float *__restrict__ b16_0,
+    const float *__restrict__ b16_1, const float *__restrict__ b64_0, const float *__restrict__ b64_1,
+    float *__restrict__ dist0, float *__restrict__ dist1, int *__restrict__ idx0, int *__restrict__ idx1) {
+    extern __shared__ unsigned dyn[];  // sweep item: key lists + tile lists; backward tile: the accumulators
+    __shared__ int shbest[64];
+    __shared__ float md[NSH][64];
+    __shared__ unsigned mi[NSH][64];
+    __shared__ int mp[NSH][64];
+    __shared__ unsigned long long gmsh[NSH];
+    __shared__ unsigned short glist[GS_MAXG];
+    __shared__ int nlist;
+    __shared__ int item[3];      // kind (0 sweep, 1 backward tile, -1 none), cloud, index inside the cloud
+    __shared__ unsigned arrive;  // waves of this workgroup that have finished their sweep work
+
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x == 0) {
+        arrive = 0;
+        int kind = -1, cloud = 0, idx = 0;
+        const int home = blockIdx.x & 7;
+        for (int d = 0; d < 8 && kind < 0; d++) {
+            const int h = (home + d) & 7;
+            const int c0 = (h * a.b) >> 3, nc = (((h + 1) * a.b) >> 3) - c0;
+            const int ns = nc * fu.spc, len = nc * (fu.spc + fu.tpc);
+            if (len == 0) continue;
+            const unsigned id = __hip_atomic_fetch_add(&fu.ctr[h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (id < (unsigned)ns) {
+                kind = 0;
+                cloud = c0 + (int)id / fu.spc;
+                idx = (int)id % fu.spc;
+            } else if (id < (unsigned)len) {
+                const int t = (int)id - ns;
+                kind = 1;
+                cloud = c0 + t / fu.tpc;
+                idx = t % fu.tpc;
+            }
+        }
+        item[0] = kind;
+        item[1] = cloud;
+        item[2] = idx;
+    }
+    __syncthreads();
+    const int kind = item[0], bi = item[1];
+    if (kind < 0) return;  // (uniform; cannot happen while the grid equals the number of items)
+    if (kind == 1) {
+        if (threadIdx.x == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(&fu.done[bi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)fu.spc && spins < STEP_SPIN_CAP) {
+                __builtin_amdgcn_s_sleep(16);
+                spins++;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        grad_tile(ga, bi, item[2], (float *)dyn, glist, &nlist);
+        return;
+    }
+    // ---- a sweep item: the workgroup `wg` of cloud bi, as nnp_sweep_kernel maps it
+    int wg = item[2];
+    const int dir = wg >= a.wg0;
+    if (dir) wg -= a.wg0;
+    unsigned *keys_dyn = dyn;
+    if (a.nw[dir] == NSH) {
+#if RFP_TILE16
+        const int cdk = 1 - dir;
+        const int *flags = (const int *)((const char *)(cdk ? b64_1 : b64_0) +
+                                         emit_align((size_t)a.b * (a.npad[cdk] / SB) * B64F * sizeof(float))) + a.b;
+        if (flags[bi]) {
+            sweep_group<true, true>(a, ge, dir, bi * a.groups[dir] + wg, wib, lane, keys_dyn, shbest, md, mi, mp, xyz0, xyz1,
+                                    orig0, orig1, b16_0, b16_1, b64_0, b64_1, dist0, dist1, idx0, idx1, nullptr);
+        } else {
+            T16Lds *t16 = (T16Lds *)(keys_dyn + (size_t)NSH * a.kstride);
+            sweep_tile16<true>(a, ge, dir, bi * a.groups[dir] + wg, wib, lane, keys_dyn, &t16[wib], gmsh, xyz0, xyz1, orig0,
+                               orig1, b16_0, b16_1, b64_0, b64_1, dist0, dist1, idx0, idx1, nullptr);
+        }
+#else
+        sweep_group<true, true>(a, ge, dir, bi * a.groups[dir] + wg, wib, lane, keys_dyn, shbest, md, mi, mp, xyz0, xyz1,
+                                orig0, orig1, b16_0, b16_1, b64_0, b64_1, dist0, dist1, idx0, idx1, nullptr);
+#endif
+    } else {
+        const int g = wg * (int)(blockDim.x >> 6) + wib;
+        if (g < a.groups[dir])
+            sweep_group<false, true>(a, ge, dir, bi * a.groups[dir] + g, wib, lane, keys_dyn, shbest, md, mi, mp, xyz0, xyz1,
+                                     orig0, orig1, b16_0, b16_1, b64_0, b64_1, dist0, dist1, idx0, idx1, nullptr);
+    }
+    // ---- signal: this wave's stores are complete; the wave that arrives last publishes for the whole workgroup
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned old = 0;
+    if (lane == 0) old = atomicAdd(&arrive, 1u);
+    old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+    if (old == (blockDim.x >> 6) - 1 && lane == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(&fu.done[bi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 int round_up(long v, int q) { return (int)((v + q - 1) / q * q); }
 
 size_t align256(size_t v) { return (v + 255) / 256 * 256; }
@@ -2053,7 +2189,7 @@ size_t sorted_bytes(int b, int n) {
     const size_t npad = npad_of(n);
     return align256((size_t)b * npad * 3 * sizeof(float) + 256)  // + prefetch overrun
            + align256((size_t)b * npad * sizeof(int)) + align256((size_t)b * (npad / SB) * B16F * sizeof(float)) +
-           align256((size_t)b * (npad / SB) * B64F * sizeof(float)) + align256((size_t)b * sizeof(int));
+           align256((size_t)b * (npad / SB) * B64F * sizeof(float)) + align256((size_t)2 * b * sizeof(int));  // pos0 (b) | crowded (b)
 }
 
 Sorted sorted_view(int b, int n, const void *buf) {
@@ -2080,12 +2216,14 @@ size_t pruned_workspace_bytes(int b, int n, int m) {
 
 // Sort `nsets` (1 or 2) sets of b clouds in ONE launch (one workgroup per cloud).
 int sort_sets(int b, int nsets, const int *n, const float *const *src, const Sorted *out, hipStream_t s,
-              unsigned long long *dbg) {
+              unsigned long long *dbg, unsigned *zero_words, int nzero) {
     if (b <= 0 || nsets < 1 || nsets > 2) return RF_EINVAL;
     SortArgs sa;
     sa.b = b;
     sa.nsets = nsets;
-    sa.dbg = dbg;
+    sa.dbg = RFP_CLOUD_END ? nullptr : dbg;
+    sa.zero_words = zero_words;
+    sa.nzero = zero_words ? nzero : 0;
     bool reg = true;
     for (int k = 0; k < 2; k++) {
         const int kk = k < nsets ? k : 0;
@@ -2119,7 +2257,7 @@ int sort_sets(int b, int nsets, const int *n, const float *const *src, const Sor
 // nothing: its workgroups are not launched.
 static int sweep_sorted_impl(int b, int n, int m, const Sorted &s0, const Sorted &s1, float *dist1, int *idx1,
                              float *dist2, int *idx2, int dirs, hipStream_t s, unsigned long long *stats_dev,
-                             const GradEmit *ge) {
+                             const GradEmit *ge, const GradSArgs *fuse_ga = nullptr, unsigned *fuse_words = nullptr) {
     if (!pruned_supported(b, n, m) || (dirs & 3) == 0) return RF_EINVAL;
     if (((dirs & 1) && (!dist1 || !idx1)) || ((dirs & 2) && (!dist2 || !idx2))) return RF_EINVAL;
     SweepArgs wa;
@@ -2145,11 +2283,25 @@ static int sweep_sorted_impl(int b, int n, int m, const Sorted &s0, const Sorted
         wa.kstride = (longest + 63) / 64 * 64;
     }
     const bool shared_groups = (want[0] && wa.nw[0] == NSH) || (want[1] && wa.nw[1] == NSH);
-    const int tpb = shared_groups ? 64 * NSH : 64;
+    const int tpb = (shared_groups || fuse_ga) ? 64 * NSH : 64;  // (the fused step's backward tiles are 256 threads)
     const int pack = tpb / 64;  // one-wave groups per workgroup
     const size_t shmem = pack * wa.kstride * sizeof(unsigned) + ((RFP_TILE16 && shared_groups) ? NSH * sizeof(T16Lds) : 0);
     wa.wg0 = !want[0] ? 0 : (wa.nw[0] == NSH ? wa.groups[0] : rf::ceil_div(wa.groups[0], pack));
     wa.wg1 = !want[1] ? 0 : (wa.nw[1] == NSH ? wa.groups[1] : rf::ceil_div(wa.groups[1], pack));
+    if (fuse_ga) {
+        // the sweep's workgroups and the backward's tiles in ONE launch (nnp_step_kernel)
+        StepFuse fu;
+        fu.ctr = fuse_words;
+        fu.done = fuse_words + 8;
+        fu.spc = wa.wg0 + wa.wg1;
+        fu.tpc = fuse_ga->tiles[0] + fuse_ga->tiles[1];
+        const int gtmax = fuse_ga->gt[0] > fuse_ga->gt[1] ? fuse_ga->gt[0] : fuse_ga->gt[1];
+        const size_t need_b = (size_t)gtmax * 3 * sizeof(float);
+        RF_LAUNCH("nnp_step", nnp_step_kernel, dim3((unsigned)b * (fu.spc + fu.tpc)), dim3(tpb), shmem > need_b ? shmem : need_b,
+                  s, wa, *ge, *fuse_ga, fu, s0.xyz, s1.xyz, s0.orig, s1.orig, s0.box16, s1.box16, s0.box64, s1.box64, dist1, dist2,
+                  idx1, idx2);
+        return RF_OK;
+    }
     if (ge) {
         RF_LAUNCH("nnp_sweep", nnp_sweep_kernel<true>, dim3((unsigned)b * (wa.wg0 + wa.wg1)), dim3(tpb),
                   shmem, s, wa, *ge, s0.xyz, s1.xyz, s0.orig, s1.orig, s0.box16,
@@ -2168,12 +2320,13 @@ int sweep_sorted(int b, int n, int m, const Sorted &s0, const Sorted &s1, float 
 }
 
 // ---- forward + backward of one Chamfer (rf_chamfer_step) on the culled path -----------------------------
-// workspace: sorted(n) | sorted(m) | per set (emit_layout): wp (b, npad) int | own (b, npad, 3) float | mask (b, npad / 64) u64
+// workspace: sorted(n) | sorted(m) | per set (emit_layout): rec (b, npad) int4 {wp, own} | mask (b, npad / 64) u64
 static size_t step_set_bytes(int b, int n) { return emit_set_bytes(b, (int)npad_of(n)); }
 
 size_t pruned_step_workspace_bytes(int b, int n, int m) {
     if (!pruned_supported(b, n, m)) return 0;
-    return sorted_bytes(b, n) + sorted_bytes(b, m) + step_set_bytes(b, n) + step_set_bytes(b, m);
+    return sorted_bytes(b, n) + sorted_bytes(b, m) + step_set_bytes(b, n) + step_set_bytes(b, m) +
+           align256((size_t)(8 + b) * sizeof(unsigned));  // + the fused step's 8 work counters and b tickets
 }
 
 int pruned_step(int b, int n, int m, const float *xyz1, const float *xyz2, const float *gd1, const float *gd2,
@@ -2207,11 +2360,18 @@ int pruned_step(int b, int n, int m, const float *xyz1, const float *xyz2, const
         ga.gt[k] = gt;
         ga.tiles[k] = rf::ceil_div(so[k].npad, gt);
         ga.orig[k] = so[k].orig;
-        ga.wp[k] = ev.wp;
-        ga.own[k] = ev.own;
+        ga.rec[k] = ev.rec;
         ga.mask[k] = ev.mask;
         ga.grad[k] = grads[k];
     }
+#if RFP_FUSE_STEP
+    {
+        // two launches: the sort (which also clears the work counters and the clouds' tickets), then sweep + backward
+        unsigned *words = (unsigned *)(ge.base + step_set_bytes(b, n) + step_set_bytes(b, m));
+        if (int e = sort_sets(b, 2, nn, src, so, s, nullptr, words, 8 + b)) return e;
+        return sweep_sorted_impl(b, n, m, so[0], so[1], dist1, idx1, dist2, idx2, 3, s, nullptr, &ge, &ga, words);
+    }
+#endif
     if (int e = sort_sets(b, 2, nn, src, so, s, nullptr)) return e;
     if (int e = sweep_sorted_impl(b, n, m, so[0], so[1], dist1, idx1, dist2, idx2, 3, s, nullptr, &ge)) return e;
     const int gtmax = ga.gt[0] > ga.gt[1] ? ga.gt[0] : ga.gt[1];

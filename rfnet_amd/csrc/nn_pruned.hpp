@@ -38,7 +38,7 @@ int sort_clouds(int b, int n, const float *src, void *workspace, size_t workspac
 size_t sorted_bytes(int b, int n);
 Sorted sorted_view(int b, int n, const void *buf);
 int sort_sets(int b, int nsets, const int *n, const float *const *src, const Sorted *out, hipStream_t s,
-              unsigned long long *dbg);
+              unsigned long long *dbg, unsigned *zero_words = nullptr, int nzero = 0);
 int sweep_sorted(int b, int n, int m, const Sorted &s0, const Sorted &s1, float *dist1, int *idx1, float *dist2,
                  int *idx2, int dirs, hipStream_t s, unsigned long long *stats_dev);
 
