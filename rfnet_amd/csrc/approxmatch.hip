@@ -464,6 +464,10 @@ __global__ void mc_final_kernel(const float *partial, int per_batch, float *cost
 #ifndef RFA_MG_PREFETCH
 #define RFA_MG_PREFETCH 1  // match_cost_grad: the next tile's match rows in flight during the current tile's LDS phases
 #endif
+#ifndef RFA_MG_LANECOL
+#define RFA_MG_LANECOL 1   // (prefetch form) the tile's xyz2 rows in lanes 0..31 of a prefetched vector load, read by v_readlane:
+                           // as scalar loads they are ~16 SALU instructions and a scalar-memory wait per row
+#endif
 #ifndef RFA_MG_LDSCOL
 #define RFA_MG_LDSCOL 0    // (prefetch form) the tile's xyz2 rows through LDS instead of scalar loads
 #endif
@@ -522,6 +526,15 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         mv[l] = *(const float *)((const char *)(M + (size_t)min(lbeg + l, m - 1) * n) + koff) * ((lbeg + l < lend) ? livef : 0.f);
     // (the columns' coordinates come from LDS: as scalar loads they cost ~16 SALU instructions and a scalar-memory wait per
     // row -- 3.5e7 SALU next to 4.4e7 VALU instructions per launch, profiles/r04_rocprofv3_summary.txt)
+#if RFA_MG_LANECOL
+    float cxv, cyv, czv;
+    {
+        const int ll = min(lbeg + (t & (MG_TL - 1)), m - 1);
+        cxv = B[ll * 3];
+        cyv = B[ll * 3 + 1];
+        czv = B[ll * 3 + 2];
+    }
+#endif
 #if RFA_MG_LDSCOL
     if (t < MG_TL) {
         const int ll = min(lbeg + t, m - 1);
@@ -538,6 +551,10 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #if RFA_MG_LDSCOL
             const float4 c2 = cx2[l];
             const float dx = x1 - c2.x, dy = y1 - c2.y, dz = z1 - c2.z;
+#elif RFA_MG_LANECOL
+            const float dx = x1 - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cxv), l)),
+                        dy = y1 - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cyv), l)),
+                        dz = z1 - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(czv), l));
 #else
             const int ll = min(l0 + l, m - 1);  // uniform -> scalar loads
             const float dx = x1 - B[ll * 3], dy = y1 - B[ll * 3 + 1], dz = z1 - B[ll * 3 + 2];
@@ -554,6 +571,15 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int l = 0; l < MG_TL; l++)
             nx[l] = *(const float *)((const char *)(M + (size_t)min(l0 + MG_TL + l, m - 1) * n) + koff) *
                     ((l0 + MG_TL + l < lend) ? livef : 0.f);
+#if RFA_MG_LANECOL
+        float cxn, cyn, czn;
+        {
+            const int ll = min(l0 + MG_TL + (t & (MG_TL - 1)), m - 1);
+            cxn = B[ll * 3];
+            cyn = B[ll * 3 + 1];
+            czn = B[ll * 3 + 2];
+        }
+#endif
 #else
         // 8 rows at a time (the group loop is NOT unrolled): with all 32 rows of the tile in flight
         // the kernel needed 177 VGPRs = 2 waves per SIMD, and with three barriers per tile it is
@@ -625,6 +651,11 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #if RFA_MG_PREFETCH
 #pragma unroll
         for (int l = 0; l < MG_TL; l++) mv[l] = nx[l];
+#if RFA_MG_LANECOL
+        cxv = cxn;
+        cyv = cyn;
+        czv = czn;
+#endif
 #endif
     }
     if (live) {

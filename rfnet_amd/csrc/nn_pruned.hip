@@ -88,9 +88,8 @@ namespace {
 #ifndef RFP_HAGG
 #define RFP_HAGG 1  // the sort's quantile histograms sample 4x fewer lanes in waves whose points crowd into few bins (collapsed clouds)
 #endif
-#ifndef RFP_FUSE_STEP
-#define RFP_FUSE_STEP 1  // rf_chamfer_step: 1 = the backward's tiles ride in the sweep's launch and start cloud by cloud as the
-                         // cloud's sweep workgroups signal (two launches per step); 0 = sort, sweep, backward as three launches
+#ifndef RFP_MIX
+#define RFP_MIX 0  // sweep grid: 1 = a cloud's direction-0 and direction-1 workgroups interleaved in proportion
 #endif
 #ifndef RFP_CLOUD_END
 #define RFP_CLOUD_END 0  // 1 (instrumented build): stats[c & 31] = s_memrealtime (100 MHz) at which the last workgroup of cloud c
@@ -137,8 +136,6 @@ struct SortArgs {
                    // NaN / no-candidate policy refers to, for the sorted-space backward)
     int str_s[2];  // STR order: slabs per cloud = strips per slab = round(cbrt(n / 64))
     unsigned long long *dbg;  // optional (with stats): s_memtime stamps of the sort's phases, [16..31]
-    unsigned *zero_words;     // optional: words the first workgroup clears (the fused step's work counters and tickets)
-    int nzero;
 };
 
 // Skilling's axes-to-transpose Hilbert mapping, 5 bits per axis -> 15-bit index.
@@ -267,8 +264,6 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (int)(blockIdx.x >> 3);
     if (threadIdx.x == 0) ncrowded = 0;
-    if (blockIdx.x == 0 && a.zero_words)
-        for (int i = threadIdx.x; i < a.nzero; i += STPB) a.zero_words[i] = 0u;
     // A large cloud is shared by H = 2 or 4 workgroups, one per SLICE OF THE KEY SPACE (top key bits).  All
     // load the whole cloud and derive the same frame, cells and keys (no communication: the frame is a
     // pure function of the cloud); each then histograms, scans, places and writes out only the points
@@ -680,8 +675,6 @@ __global__ __launch_bounds__(STPB) void nnp_sort_kernel(SortArgs a) {
     };
 
     for (int i = tid; i < NBINS; i += STPB) hist[i] = 0;
-    if (blockIdx.x == 0 && a.zero_words)
-        for (int i = tid; i < a.nzero; i += STPB) a.zero_words[i] = 0u;
     if (tid < 3 * HB) (&ahist[0][0])[tid] = 0;
 
     // 1. bounding box of the finite coordinates
@@ -1847,8 +1840,16 @@ __global__ __launch_bounds__(64 * NSH) __attribute__((amdgpu_waves_per_eu(RFP_WP
     const int wpc = a.wg0 + a.wg1;  // workgroups per batch element
     const int bi = logical / wpc;
     int wg = logical - bi * wpc;
+#if RFP_MIX
+    // the two directions' workgroups of a cloud INTERLEAVED in proportion (position p is direction 0 when the count of
+    // direction-0 workgroups among positions <= p steps up), instead of all of direction 0's first
+    const int c0 = (int)(((long)wg * a.wg0) / wpc), c1 = (int)(((long)(wg + 1) * a.wg0) / wpc);
+    const int dir = c1 > c0 ? 0 : 1;
+    wg = dir ? wg - c0 : c0;
+#else
     const int dir = wg >= a.wg0;
     if (dir) wg -= a.wg0;
+#endif
     if (a.nw[dir] == NSH) {
 #if RFP_TILE16
         // the candidate cloud's crowded flag (written by the sort behind pos0): uniform per workgroup
@@ -1917,8 +1918,8 @@ struct GradSArgs {
 };
 
 // One destination tile (256 threads): `tile` in [0, tiles[0] + tiles[1]) of cloud bi.  acc: gt * 3 floats of LDS; list:
-// GS_MAXG entries; nlist_p: one LDS word.  Called by nnp_grad_sorted_kernel (its own launch) and by nnp_step_kernel
-// (the same tile inside the sweep's launch, once the cloud's sweep workgroups have all signalled).
+// GS_MAXG entries; nlist_p: one LDS word.  (A device function since round 4's fused-step experiment ran the same tile
+// inside the sweep's launch: tools/experiments/fused_step.patch.txt)
 __device__ __forceinline__ void grad_tile(const GradSArgs &a, const int bi, int tile, float *__restrict__ acc,
                                           unsigned short *__restrict__ list, int *nlist_p) {
     int &nlist = *nlist_p;
@@ -2040,131 +2041,6 @@ __global__ __launch_bounds__(GS_TPB) void nnp_grad_sorted_kernel(GradSArgs a) {
     grad_tile(a, bi, logical - bi * wpc, acc_dyn, list, &nlist);
 }
 
-// ------------------------------------------------------------------------------------------
-// rf_chamfer_step in TWO launches (round 4): the sort, then ONE launch that holds the sweep's workgroups AND the
-// backward's tiles.  The clouds of a sweep launch finish far apart -- the grid is 1.7 residency rounds in cloud-major
-// order: at C2 24 of the 32 clouds are done more than 10 us before the launch ends, the median one 20 us before
-// (profiles/r04_cloud_end_times.txt) -- so a cloud's backward tiles can run under the later clouds' sweeps instead of
-// waiting behind a kernel boundary for the slowest wave of the last cloud.
-//   * WORK ITEMS are pulled, not mapped from blockIdx: a workgroup takes `id = atomicAdd(ctr[h], 1)` from one of 8
-//     lists (h = blockIdx & 7 first: blocks b and b + 8 share an XCD in practice, which only matters for speed; then
-//     the other lists).  List h holds WHOLE clouds [h b / 8, (h + 1) b / 8): first all their sweep items, then all
-//     their backward tiles.  So when a tile of cloud c has been pulled, every sweep item of cloud c has been pulled
-//     before it -- by workgroups that are running or done, and that wait for nothing: the tile's wait on the cloud's
-//     ticket cannot deadlock whatever order the hardware starts workgroups in.  (Grid = number of items; every
-//     workgroup takes exactly one.)
-//   * SIGNAL: each wave of a sweep item drains its stores (s_waitcnt vmcnt(0)) and arrives at an LDS counter; the
-//     wave that arrives last publishes with an agent-scope release and one relaxed add on the cloud's ticket.
-//   * WAIT: lane 0 of a tile polls the ticket (relaxed, s_sleep between polls, bounded), then an agent-scope acquire,
-//     then the workgroup's barrier; plain loads after that (MI355X_MICROARCH.md, inter-workgroup visibility, R1).
-struct StepFuse {
-    unsigned *ctr;   // [8] items handed out per list
-    unsigned *done;  // [b] sweep workgroups of the cloud that have signalled
-    int spc;         // sweep items per cloud (= wg0 + wg1)
-    int tpc;         // backward tiles per cloud
-};
-constexpr int STEP_SPIN_CAP = 1 << 22;  // polls before a tile gives up waiting (~1 s: never in a healthy run, never a hang)
-
-__global__ __launch_bounds__(64 * NSH) __attribute__((amdgpu_waves_per_eu(RFP_WPE, RFP_WPE))) void nnp_step_kernel(
-    SweepArgs a, GradEmit ge, GradSArgs ga, StepFuse fu, const float *__restrict__ xyz0, const float *__restrict__ xyz1,
-    const int *__restrict__ orig0, const int *__restrict__ orig1, const float *__restrict__ b16_0,
-    const float *__restrict__ b16_1, const float *__restrict__ b64_0, const float *__restrict__ b64_1,
-    float *__restrict__ dist0, float *__restrict__ dist1, int *__restrict__ idx0, int *__restrict__ idx1) {
-    extern __shared__ unsigned dyn[];  // sweep item: key lists + tile lists; backward tile: the accumulators
-    __shared__ int shbest[64];
-    __shared__ float md[NSH][64];
-    __shared__ unsigned mi[NSH][64];
-    __shared__ int mp[NSH][64];
-    __shared__ unsigned long long gmsh[NSH];
-    __shared__ unsigned short glist[GS_MAXG];
-    __shared__ int nlist;
-    __shared__ int item[3];      // kind (0 sweep, 1 backward tile, -1 none), cloud, index inside the cloud
-    __shared__ unsigned arrive;  // waves of this workgroup that have finished their sweep work
-
-    const int lane = threadIdx.x & 63;
-    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (threadIdx.x == 0) {
-        arrive = 0;
-        int kind = -1, cloud = 0, idx = 0;
-        const int home = blockIdx.x & 7;
-        for (int d = 0; d < 8 && kind < 0; d++) {
-            const int h = (home + d) & 7;
-            const int c0 = (h * a.b) >> 3, nc = (((h + 1) * a.b) >> 3) - c0;
-            const int ns = nc * fu.spc, len = nc * (fu.spc + fu.tpc);
-            if (len == 0) continue;
-            const unsigned id = __hip_atomic_fetch_add(&fu.ctr[h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (id < (unsigned)ns) {
-                kind = 0;
-                cloud = c0 + (int)id / fu.spc;
-                idx = (int)id % fu.spc;
-            } else if (id < (unsigned)len) {
-                const int t = (int)id - ns;
-                kind = 1;
-                cloud = c0 + t / fu.tpc;
-                idx = t % fu.tpc;
-            }
-        }
-        item[0] = kind;
-        item[1] = cloud;
-        item[2] = idx;
-    }
-    __syncthreads();
-    const int kind = item[0], bi = item[1];
-    if (kind < 0) return;  // (uniform; cannot happen while the grid equals the number of items)
-    if (kind == 1) {
-        if (threadIdx.x == 0) {
-            int spins = 0;
-            while (__hip_atomic_load(&fu.done[bi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)fu.spc && spins < STEP_SPIN_CAP) {
-                __builtin_amdgcn_s_sleep(16);
-                spins++;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-        grad_tile(ga, bi, item[2], (float *)dyn, glist, &nlist);
-        return;
-    }
-    // ---- a sweep item: the workgroup `wg` of cloud bi, as nnp_sweep_kernel maps it
-    int wg = item[2];
-    const int dir = wg >= a.wg0;
-    if (dir) wg -= a.wg0;
-    unsigned *keys_dyn = dyn;
-    if (a.nw[dir] == NSH) {
-#if RFP_TILE16
-        const int cdk = 1 - dir;
-        const int *flags = (const int *)((const char *)(cdk ? b64_1 : b64_0) +
-                                         emit_align((size_t)a.b * (a.npad[cdk] / SB) * B64F * sizeof(float))) + a.b;
-        if (flags[bi]) {
-            sweep_group<true, true>(a, ge, dir, bi * a.groups[dir] + wg, wib, lane, keys_dyn, shbest, md, mi, mp, xyz0, xyz1,
-                                    orig0, orig1, b16_0, b16_1, b64_0, b64_1, dist0, dist1, idx0, idx1, nullptr);
-        } else {
-            T16Lds *t16 = (T16Lds *)(keys_dyn + (size_t)NSH * a.kstride);
-            sweep_tile16<true>(a, ge, dir, bi * a.groups[dir] + wg, wib, lane, keys_dyn, &t16[wib], gmsh, xyz0, xyz1, orig0,
-                               orig1, b16_0, b16_1, b64_0, b64_1, dist0, dist1, idx0, idx1, nullptr);
-        }
-#else
-        sweep_group<true, true>(a, ge, dir, bi * a.groups[dir] + wg, wib, lane, keys_dyn, shbest, md, mi, mp, xyz0, xyz1,
-                                orig0, orig1, b16_0, b16_1, b64_0, b64_1, dist0, dist1, idx0, idx1, nullptr);
-#endif
-    } else {
-        const int g = wg * (int)(blockDim.x >> 6) + wib;
-        if (g < a.groups[dir])
-            sweep_group<false, true>(a, ge, dir, bi * a.groups[dir] + g, wib, lane, keys_dyn, shbest, md, mi, mp, xyz0, xyz1,
-                                     orig0, orig1, b16_0, b16_1, b64_0, b64_1, dist0, dist1, idx0, idx1, nullptr);
-    }
-    // ---- signal: this wave's stores are complete; the wave that arrives last publishes for the whole workgroup
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned old = 0;
-    if (lane == 0) old = atomicAdd(&arrive, 1u);
-    old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
-    if (old == (blockDim.x >> 6) - 1 && lane == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(&fu.done[bi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
 int round_up(long v, int q) { return (int)((v + q - 1) / q * q); }
 
 size_t align256(size_t v) { return (v + 255) / 256 * 256; }
@@ -2216,14 +2092,12 @@ size_t pruned_workspace_bytes(int b, int n, int m) {
 
 // Sort `nsets` (1 or 2) sets of b clouds in ONE launch (one workgroup per cloud).
 int sort_sets(int b, int nsets, const int *n, const float *const *src, const Sorted *out, hipStream_t s,
-              unsigned long long *dbg, unsigned *zero_words, int nzero) {
+              unsigned long long *dbg) {
     if (b <= 0 || nsets < 1 || nsets > 2) return RF_EINVAL;
     SortArgs sa;
     sa.b = b;
     sa.nsets = nsets;
     sa.dbg = RFP_CLOUD_END ? nullptr : dbg;
-    sa.zero_words = zero_words;
-    sa.nzero = zero_words ? nzero : 0;
     bool reg = true;
     for (int k = 0; k < 2; k++) {
         const int kk = k < nsets ? k : 0;
@@ -2257,7 +2131,7 @@ int sort_sets(int b, int nsets, const int *n, const float *const *src, const Sor
 // nothing: its workgroups are not launched.
 static int sweep_sorted_impl(int b, int n, int m, const Sorted &s0, const Sorted &s1, float *dist1, int *idx1,
                              float *dist2, int *idx2, int dirs, hipStream_t s, unsigned long long *stats_dev,
-                             const GradEmit *ge, const GradSArgs *fuse_ga = nullptr, unsigned *fuse_words = nullptr) {
+                             const GradEmit *ge) {
     if (!pruned_supported(b, n, m) || (dirs & 3) == 0) return RF_EINVAL;
     if (((dirs & 1) && (!dist1 || !idx1)) || ((dirs & 2) && (!dist2 || !idx2))) return RF_EINVAL;
     SweepArgs wa;
@@ -2283,25 +2157,11 @@ static int sweep_sorted_impl(int b, int n, int m, const Sorted &s0, const Sorted
         wa.kstride = (longest + 63) / 64 * 64;
     }
     const bool shared_groups = (want[0] && wa.nw[0] == NSH) || (want[1] && wa.nw[1] == NSH);
-    const int tpb = (shared_groups || fuse_ga) ? 64 * NSH : 64;  // (the fused step's backward tiles are 256 threads)
+    const int tpb = shared_groups ? 64 * NSH : 64;
     const int pack = tpb / 64;  // one-wave groups per workgroup
     const size_t shmem = pack * wa.kstride * sizeof(unsigned) + ((RFP_TILE16 && shared_groups) ? NSH * sizeof(T16Lds) : 0);
     wa.wg0 = !want[0] ? 0 : (wa.nw[0] == NSH ? wa.groups[0] : rf::ceil_div(wa.groups[0], pack));
     wa.wg1 = !want[1] ? 0 : (wa.nw[1] == NSH ? wa.groups[1] : rf::ceil_div(wa.groups[1], pack));
-    if (fuse_ga) {
-        // the sweep's workgroups and the backward's tiles in ONE launch (nnp_step_kernel)
-        StepFuse fu;
-        fu.ctr = fuse_words;
-        fu.done = fuse_words + 8;
-        fu.spc = wa.wg0 + wa.wg1;
-        fu.tpc = fuse_ga->tiles[0] + fuse_ga->tiles[1];
-        const int gtmax = fuse_ga->gt[0] > fuse_ga->gt[1] ? fuse_ga->gt[0] : fuse_ga->gt[1];
-        const size_t need_b = (size_t)gtmax * 3 * sizeof(float);
-        RF_LAUNCH("nnp_step", nnp_step_kernel, dim3((unsigned)b * (fu.spc + fu.tpc)), dim3(tpb), shmem > need_b ? shmem : need_b,
-                  s, wa, *ge, *fuse_ga, fu, s0.xyz, s1.xyz, s0.orig, s1.orig, s0.box16, s1.box16, s0.box64, s1.box64, dist1, dist2,
-                  idx1, idx2);
-        return RF_OK;
-    }
     if (ge) {
         RF_LAUNCH("nnp_sweep", nnp_sweep_kernel<true>, dim3((unsigned)b * (wa.wg0 + wa.wg1)), dim3(tpb),
                   shmem, s, wa, *ge, s0.xyz, s1.xyz, s0.orig, s1.orig, s0.box16,
@@ -2325,8 +2185,7 @@ static size_t step_set_bytes(int b, int n) { return emit_set_bytes(b, (int)npad_
 
 size_t pruned_step_workspace_bytes(int b, int n, int m) {
     if (!pruned_supported(b, n, m)) return 0;
-    return sorted_bytes(b, n) + sorted_bytes(b, m) + step_set_bytes(b, n) + step_set_bytes(b, m) +
-           align256((size_t)(8 + b) * sizeof(unsigned));  // + the fused step's 8 work counters and b tickets
+    return sorted_bytes(b, n) + sorted_bytes(b, m) + step_set_bytes(b, n) + step_set_bytes(b, m);
 }
 
 int pruned_step(int b, int n, int m, const float *xyz1, const float *xyz2, const float *gd1, const float *gd2,
@@ -2364,14 +2223,6 @@ int pruned_step(int b, int n, int m, const float *xyz1, const float *xyz2, const
         ga.mask[k] = ev.mask;
         ga.grad[k] = grads[k];
     }
-#if RFP_FUSE_STEP
-    {
-        // two launches: the sort (which also clears the work counters and the clouds' tickets), then sweep + backward
-        unsigned *words = (unsigned *)(ge.base + step_set_bytes(b, n) + step_set_bytes(b, m));
-        if (int e = sort_sets(b, 2, nn, src, so, s, nullptr, words, 8 + b)) return e;
-        return sweep_sorted_impl(b, n, m, so[0], so[1], dist1, idx1, dist2, idx2, 3, s, nullptr, &ge, &ga, words);
-    }
-#endif
     if (int e = sort_sets(b, 2, nn, src, so, s, nullptr)) return e;
     if (int e = sweep_sorted_impl(b, n, m, so[0], so[1], dist1, idx1, dist2, idx2, 3, s, nullptr, &ge)) return e;
     const int gtmax = ga.gt[0] > ga.gt[1] ? ga.gt[0] : ga.gt[1];

@@ -38,11 +38,11 @@ int sort_clouds(int b, int n, const float *src, void *workspace, size_t workspac
 size_t sorted_bytes(int b, int n);
 Sorted sorted_view(int b, int n, const void *buf);
 int sort_sets(int b, int nsets, const int *n, const float *const *src, const Sorted *out, hipStream_t s,
-              unsigned long long *dbg, unsigned *zero_words = nullptr, int nzero = 0);
+              unsigned long long *dbg);
 int sweep_sorted(int b, int n, int m, const Sorted &s0, const Sorted &s1, float *dist1, int *idx1, float *dist2,
                  int *idx2, int dirs, hipStream_t s, unsigned long long *stats_dev);
 
-// rf_chamfer_step on the culled path: sort, sweep (which also leaves {winner position, upstream gradient}
+// rf_chamfer_step on the culled path: sort, sweep (which also leaves {winner position, own gradient term}
 // records in sorted order) and the backward in sorted index space.  gd1 (b, n), gd2 (b, m) upstream gradients.
 size_t pruned_step_workspace_bytes(int b, int n, int m);
 int pruned_step(int b, int n, int m, const float *xyz1, const float *xyz2, const float *gd1, const float *gd2,

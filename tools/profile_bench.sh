@@ -5,7 +5,7 @@
 # (--no-extras), and a kernel-trace of the C5 forward.
 # usage (on the GPU box, from the repo root): bash tools/profile_bench.sh <tag>
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
