@@ -20,7 +20,7 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
   * rank 0 prints ONE JSON line.  `value` = B*N*M*K*world / seconds (pairs/s, whole job).
   * "roofline": the forward is fp32-VALU bound: NOT HBM (20*B*(N+M) bytes) and
     NOT MFMA ((b-a)^2 is not a product of a row and a column factor).  The dominant kernel is
-    nnp_sweep, the culled exact sweep (nn_pruned.hip: Hilbert sort + box-bound culling,
+    nnp_sweep, the culled exact sweep (nn_pruned.hip: sort-tile-recursive sort + box-bound culling,
     bit-identical outputs).  `achieved`/`frac` are what the VALU EXECUTED: 8 flop x the directed
     pairs the kernel evaluated (its own counters) / its average launch duration (hipEvents on
     the launch stream during the timed steps) against the 157.3 TFLOP/s fp32 vector peak -- a

@@ -637,10 +637,10 @@ Plan make_plan(int b, int n, int m, int dirs = 3) {
 // b*n*m at 2.5-6e12 pairs/s.  Thresholds from tools/ab_modes.py + tools/ab_culled.py on MI355X
 // (randn clouds), e.g. 1 x 4096^2 1.2x, 32 x 3000 x 1024 1.1x, 4 x 3000 x 16384 1.5x, 8 x 8192^2
 // 2.2x, 32 x 2048 x 16384 2.2x, 32 x 16384^2 8x, 1 x 65536^2 2.8x; dense stays ahead at
-// 128 x 1024^2, 32 x 512 x 16384, 2 x 65536 x 4096.
+// 128 x 1024^2, 16 x 700 x 20000, 2 x 65536 x 4096 (round 4: 32 x 512 x 16384 now goes to the culled sweep).
 bool culled_pays(int b, int n, int m) {
     const int lo = n < m ? n : m, hi = n < m ? m : n;
-    if (!rfp::pruned_supported(b, n, m) || lo < 1024 || (long)n * m < (1L << 21)) return false;
+    if (!rfp::pruned_supported(b, n, m) || lo < 512 || (long)n * m < (1L << 21)) return false;  // (round 4: 512, was 1024 -- 32 x 512 x 16384 culled 0.060 vs dense 0.083 ms)
     const long pairs = (long)b * n * m;
     if (hi <= 4096) return pairs >= (1L << 24);
     if (hi <= 16384) return pairs >= (1L << 27);

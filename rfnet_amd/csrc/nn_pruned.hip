@@ -88,8 +88,15 @@ namespace {
 #ifndef RFP_HAGG
 #define RFP_HAGG 1  // the sort's quantile histograms sample 4x fewer lanes in waves whose points crowd into few bins (collapsed clouds)
 #endif
+#ifndef RFP_STR_SMALL_N
+#define RFP_STR_SMALL_N 4096
+#endif
+#ifndef RFP_STR_SMALL_LEAF
+#define RFP_STR_SMALL_LEAF 32
+#endif
 #ifndef RFP_MIX
-#define RFP_MIX 0  // sweep grid: 1 = a cloud's direction-0 and direction-1 workgroups interleaved in proportion
+#define RFP_MIX 0  // sweep grid, per cloud: 0 = direction 0's workgroups then direction 1's; 1 = interleaved in proportion (measured
+                   // slower: 56.2 vs 52.2 us at C2); 2 = direction 1's first
 #endif
 #ifndef RFP_CLOUD_END
 #define RFP_CLOUD_END 0  // 1 (instrumented build): stats[c & 31] = s_memrealtime (100 MHz) at which the last workgroup of cloud c
@@ -1840,7 +1847,11 @@ __global__ __launch_bounds__(64 * NSH) __attribute__((amdgpu_waves_per_eu(RFP_WP
     const int wpc = a.wg0 + a.wg1;  // workgroups per batch element
     const int bi = logical / wpc;
     int wg = logical - bi * wpc;
-#if RFP_MIX
+#if RFP_MIX == 2
+    // direction 1's workgroups of the cloud first, then direction 0's
+    const int dir = wg < a.wg1 ? 1 : 0;
+    if (!dir) wg -= a.wg1;
+#elif RFP_MIX
     // the two directions' workgroups of a cloud INTERLEAVED in proportion (position p is direction 0 when the count of
     // direction-0 workgroups among positions <= p steps up), instead of all of direction 0's first
     const int c0 = (int)(((long)wg * a.wg0) / wpc), c1 = (int)(((long)(wg + 1) * a.wg0) / wpc);
@@ -2113,7 +2124,12 @@ int sort_sets(int b, int nsets, const int *n, const float *const *src, const Sor
         reg = reg && n[kk] <= RPT * STPB;
         sa.split[k] = sort_split_of(n[kk]);
         {
-            int ss = (int)lround(cbrt((double)n[kk] / SB));
+            // slabs per axis for leaves of 64 records; clouds of up to RFP_STR_SMALL_N points (the side that is swept as
+            // 16-query tiles) get leaves of RFP_STR_SMALL_LEAF: their 16-record blocks are then less flat -- the model
+            // (tools/experiments, round 4) gives a 2048-point set 25 instead of 36 superblocks per tile list as queries
+            // and 9.5 instead of 11.3 block scans per 64-query group as candidates
+            const int leaf = n[kk] <= RFP_STR_SMALL_N ? RFP_STR_SMALL_LEAF : SB;
+            int ss = (int)lround(cbrt((double)n[kk] / leaf));
             sa.str_s[k] = ss < 1 ? 1 : (ss > 16 ? 16 : ss);
         }
     }

@@ -31,8 +31,8 @@ def test_workspace_planner_and_auto_rule():
     assert ws(1, 70000, 100, CULLED) == 0  # beyond the culled sweep's 65536-point limit
     assert ws(0, 5, 5, AUTO) == 0
     for shape in [(32, 2048, 16384), (32, 16384, 16384), (1, 4096, 4096), (4, 3000, 16384), (32, 3000, 1024),
-                  (1, 65536, 65536), (256, 2048, 2048)]:
+                  (1, 65536, 65536), (256, 2048, 2048), (32, 512, 16384)]:  # (the last one since round 4: 0.060 vs 0.083 ms)
         assert takes_culled(*shape), shape
-    for shape in [(4, 1024, 1024), (128, 1024, 1024), (32, 512, 16384), (2, 65536, 4096), (32, 3000, 64),
+    for shape in [(4, 1024, 1024), (128, 1024, 1024), (32, 400, 16384), (2, 65536, 4096), (32, 3000, 64),
                   (1, 70000, 3000), (16, 700, 20000)]:
         assert not takes_culled(*shape), shape
