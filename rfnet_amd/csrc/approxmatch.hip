@@ -603,16 +603,25 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             }
         }
 #endif
+#if RFA_MG_ABL < 3
         __syncthreads();
+#endif
 #if RFA_MG_PREFETCH && RFA_MG_LDSCOL
         if (t >= 128 && t < 128 + MG_TL) {  // the next tile's columns (cx2 was last read before the barrier above)
             const int ll = min(l0 + MG_TL + (t - 128), m - 1);
             cx2[t - 128] = make_float4(B[ll * 3], B[ll * 3 + 1], B[ll * 3 + 2], 0.f);
         }
 #endif
+#if RFA_MG_ABL < 2
         {
+#if RFA_MG_PREFETCH && RFA_MG_LANECOL
+            // (this thread's phase-B row is l0 + (t & 31): exactly the column record its lane already holds -- loading it
+            // here put a dependent global round trip behind the barrier of every tile)
+            const float x2 = cxv, y2 = cyv, z2 = czv;
+#else
             const int ll = min(l0 + bl, m - 1);
             const float x2 = B[ll * 3], y2 = B[ll * 3 + 1], z2 = B[ll * 3 + 2];
+#endif
             float sx = 0.f, sy = 0.f, sz = 0.f;
 #pragma unroll 8
             for (int j = 0; j < MG_TL; j++) {
@@ -627,8 +636,11 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             ps[br][bl][1] = sy;
             ps[br][bl][2] = sz;
         }
+#endif
+#if RFA_MG_ABL < 3
         __syncthreads();
-        if (t < MG_TL * 3) {
+#endif
+        if (RFA_MG_ABL < 2 && t < MG_TL * 3) {
             const int l = t / 3, c = t - l * 3;
             if (l < lc) {
                 float v = 0.f;
@@ -641,7 +653,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #endif
             }
         }
-#if !(RFA_MG_PREFETCH && RFA_MG_LDSCOL && RFA_MG_2BAR)
+#if !(RFA_MG_PREFETCH && RFA_MG_LDSCOL && RFA_MG_2BAR) && RFA_MG_ABL < 3
         // qs / ps are rewritten only after the next tile's first barrier-separated phase
         __syncthreads();
 #endif
