@@ -94,6 +94,9 @@ namespace {
 #ifndef RFP_STR_SMALL_LEAF
 #define RFP_STR_SMALL_LEAF 32
 #endif
+#ifndef RFP_FORCE_PACK4
+#define RFP_FORCE_PACK4 0  // (experiment) one-wave groups packed 4 to a workgroup even when the launch holds nothing else
+#endif
 #ifndef RFP_MIX
 #define RFP_MIX 0  // sweep grid, per cloud: 0 = direction 0's workgroups then direction 1's; 1 = interleaved in proportion (measured
                    // slower: 56.2 vs 52.2 us at C2); 2 = direction 1's first
@@ -2173,7 +2176,7 @@ static int sweep_sorted_impl(int b, int n, int m, const Sorted &s0, const Sorted
         wa.kstride = (longest + 63) / 64 * 64;
     }
     const bool shared_groups = (want[0] && wa.nw[0] == NSH) || (want[1] && wa.nw[1] == NSH);
-    const int tpb = shared_groups ? 64 * NSH : 64;
+    const int tpb = (shared_groups || RFP_FORCE_PACK4) ? 64 * NSH : 64;
     const int pack = tpb / 64;  // one-wave groups per workgroup
     const size_t shmem = pack * wa.kstride * sizeof(unsigned) + ((RFP_TILE16 && shared_groups) ? NSH * sizeof(T16Lds) : 0);
     wa.wg0 = !want[0] ? 0 : (wa.nw[0] == NSH ? wa.groups[0] : rf::ceil_div(wa.groups[0], pack));
