@@ -470,7 +470,11 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
         const bool valid = tid + k * STPB < n;
         const int slab = slabmap[axis_bin(px[k], fl[0], fs[0])];
         const int col = slab * SS + (int)stripmap[slab * HB + axis_bin(py[k], fl[1], fs[1])];
-        const unsigned zq = zmap[axis_bin(pz[k], fl[2], fs[2])];
+        unsigned zq = zmap[axis_bin(pz[k], fl[2], fs[2])];
+        // a crowded wave (near-copies on a few spots) spreads its points over 16 adjacent z ranks by lane: the key
+        // histogram and the positions are exact and their same-address LDS atomics serialise -- 46 of 64 lanes on one
+        // bin otherwise; copies of one spot are the same place, so the ORDER among them is free and culling loses nothing
+        if (dense) zq = (zq & ~15u) | (unsigned)(lane & 15);
         const unsigned key = ((unsigned)col << 9) | ((col & 1) ? 511u - zq : zq);
         const int slice = (col >= cs1) + (col >= cs2) + (col >= cs3);
         const bool own = valid && slice == half;
@@ -566,11 +570,12 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
         }
     }
     if (tid == 0 && pk[0] != 0xFFFFFFFFu) a.pos0[set][bi] = base + (int)pk[0];  // point 0 is thread 0's first
-    // CROWDED cloud (more than half of the waves found >= 8 of their 64 consecutive points in one x bin: the untrained
+    // CROWDED cloud (more than a quarter of the waves found >= 8 of their 64 consecutive points in one x bin -- a test that
+    // waves of ordinary clouds practically never pass, so a low bar costs nothing and misses fewer half-crowded clouds: the untrained
     // network's collapsed output): as a CANDIDATE set it sends every query through hundreds of near-tied blocks, which the
     // shared-group sweep streams to 64 lanes at the VALU rate and the quad tiles would chase one latency-bound round at a
     // time (258 us instead of 120 at C2) -- the sweep reads this flag per cloud (all workgroups of a cloud agree: same data)
-    if (tid == 0 && half == 0) a.pos0[set][a.b + bi] = ncrowded * 2 > STPB / 64 ? 1 : 0;
+    if (tid == 0 && half == 0) a.pos0[set][a.b + bi] = ncrowded * 4 > STPB / 64 ? 1 : 0;
     for (int h0 = 0; h0 < seglen; h0 += HALF) {
         const int cnt = min(HALF, seglen - h0);  // multiple of 64
 #pragma unroll

@@ -84,7 +84,7 @@ def test_degenerate_geometry_vs_oracle(orc):
     _check_vs_oracle(orc, tiny[:, :150], tiny[:, 150:])
 
 
-@pytest.mark.parametrize("kind", ["randn", "uniform", "sphere", "lattice", "dup"])
+@pytest.mark.parametrize("kind", ["randn", "uniform", "sphere", "lattice", "dup", "collapsed"])
 # (80 x 3500^2: one wave per group in both directions, one-wave workgroups; 70 x 700 x 5000: shared
 # groups in one direction, single-wave groups packed 4 to a workgroup in the other)
 @pytest.mark.parametrize("b,n,m", [(4, 2048, 16384), (2, 16384, 16384), (40, 1000, 3000), (80, 3500, 3500),
@@ -103,6 +103,12 @@ def test_culled_equals_dense(orc, kind, b, n, m):
             return (x / np.linalg.norm(x, axis=-1, keepdims=True)).astype(np.float32)
         if kind == "lattice":
             return rng.randint(0, 12, size=(b, k, 3)).astype(np.float32)
+        if kind == "collapsed":  # ~120 spots of near-copies (the untrained network's output): the sort's crowded flag sends the
+            # few-groups direction against such a candidate cloud through the shared-group sweep instead of the quad tiles
+            # (consecutive points mostly share a spot, as the network's outputs do: that coherence is what the sort's test sees)
+            spots = rng.random_sample((b, 120, 3)) - 0.5
+            sid = np.where(rng.random_sample((b, k)) < 0.95, (np.arange(k) * 120 // k)[None], rng.randint(0, 120, (b, k)))
+            return (spots[np.arange(b)[:, None], sid] + 6e-6 * rng.randn(b, k, 3)).astype(np.float32)
         base = rng.randn(b, max(k // 5, 1), 3).astype(np.float32)
         return np.take_along_axis(base, rng.randint(0, base.shape[1], size=(b, k, 1)), 1)
 
@@ -114,6 +120,11 @@ def test_culled_equals_dense(orc, kind, b, n, m):
     assert np.array_equal(got[0][0, :200], e[0][0]) and np.array_equal(got[1][0, :200], e[1][0])
     # the sweep did cull: fewer pairs evaluated than b*n*m in each direction (not for the lattice /
     # duplicate clouds, where most boxes overlap most queries)
+    if (b, n, m) == (4, 2048, 16384):
+        # both directions have few groups here: quad-per-query tiles (16 pairs per counted scan) -- unless the CANDIDATE
+        # cloud is crowded, which the sort flags and the sweep answers with the shared-group path (1024 pairs per scan)
+        # (direction 0's candidates are the 16384-point cloud; a 2048-point cloud feeds the sort's test from too few waves to be flagged)
+        assert stats[14] == (1024 if kind == "collapsed" else 16) and stats[15] in (16, 1024), (kind, stats[14], stats[15])
     if kind in ("randn", "uniform", "sphere"):
         pairs = [stats[3] * (stats[14] or 1024), stats[7] * (stats[15] or 1024)]  # pairs per counted scan: stats[14 + d]
         assert pairs[0] < 0.6 * b * n * m and pairs[1] < 0.6 * b * n * m, (stats, b * n * m)

@@ -35,6 +35,13 @@ def make(kind, seed, b, n, m):
         a = ca[np.arange(b)[:, None], rng.randint(0, 8, (b, n))] + 0.01 * rng.randn(b, n, 3)
         c = ca[np.arange(b)[:, None], rng.randint(0, 8, (b, m))] + 0.05 * rng.randn(b, m, 3)
         return a.astype(np.float32), c.astype(np.float32)
+    if kind == "collapsed":  # the untrained network's output: the large cloud sits on ~120 spots (near-copies, no exact ties);
+        # the sort flags it as crowded and the sweep's few-groups direction takes the shared-group path for it
+        a = (rng.rand(b, n, 3) - 0.5).astype(np.float32)
+        spots = (rng.rand(b, 120, 3) - 0.5)
+        sid = np.where(rng.rand(b, m) < 0.95, (np.arange(m) * 120 // m)[None], rng.randint(0, 120, (b, m)))  # coherent runs
+        c = spots[np.arange(b)[:, None], sid] + 6e-6 * rng.randn(b, m, 3)
+        return a, c.astype(np.float32)
     if kind == "same":  # the same cloud on both sides: every winner at distance 0, one source per destination
         a = rng.randn(b, n, 3).astype(np.float32)
         return a, (a[:, rng.permutation(n)[:m]] if m <= n else np.concatenate([a] * (m // n + 1), 1)[:, :m].copy())
@@ -85,7 +92,7 @@ def test_step_randn(orc, b, n, m):
     check(orc, a, c)
 
 
-@pytest.mark.parametrize("kind", ["uniform", "dup", "lattice", "clustered", "same"])
+@pytest.mark.parametrize("kind", ["uniform", "dup", "lattice", "clustered", "same", "collapsed"])
 @pytest.mark.parametrize("b,n,m", [(4, 2048, 4096), (3, 3000, 16384)])
 def test_step_distributions(orc, kind, b, n, m):
     a, c = make(kind, 7, b, n, m)
@@ -139,3 +146,28 @@ def test_small_shapes_keep_the_two_op_step(orc):
     """Below the culled sweep's sizes rf_chamfer_step is the dense forward + the original-order backward."""
     from rfnet_amd._lib import lib
     assert lib.rf_chamfer_step_workspace_bytes(2, 300, 700) == lib.rf_nn_distance_workspace_bytes(2, 300, 700)
+
+
+def test_step_accepts_the_forward_workspace_size():
+    """A caller that sizes the workspace with rf_nn_distance_workspace_bytes (what rounds 1-2 documented) on a shape that
+    takes the culled sweep gets the two ops back to back -- same results, not RF_EWORKSPACE (chamfer_ext.hip)."""
+    from rfnet_amd import _raw as R
+    from rfnet_amd._lib import lib
+    b, n, m = 4, 2048, 4096
+    small, big = lib.rf_nn_distance_workspace_bytes(b, n, m), lib.rf_chamfer_step_workspace_bytes(b, n, m)
+    assert 0 < small < big
+    a, c = make("randn", 5, b, n, m)
+    gd1, gd2 = np.ones((b, n), np.float32), np.ones((b, m), np.float32)
+    ta, tc, tg1, tg2 = cu(a), cu(c), cu(gd1), cu(gd2)
+    ref = R.ChamferStep(b, n, m, "cuda")(ta, tc, tg1, tg2)
+    ref = [t.clone() for t in ref]
+    out = [torch.empty_like(t) for t in ref]
+    ws = torch.empty(small, dtype=torch.uint8, device="cuda")
+    st = lib.rf_chamfer_step(b, n, m, ta.data_ptr(), tc.data_ptr(), tg1.data_ptr(), tg2.data_ptr(), *[t.data_ptr() for t in out],
+                             ws.data_ptr(), small, torch.cuda.current_stream().cuda_stream)
+    assert st == 0
+    torch.cuda.synchronize()
+    for x, y in zip(out[:4], ref[:4]):
+        assert torch.equal(x, y)
+    for x, y in zip(out[4:], ref[4:]):
+        assert torch.allclose(x, y, rtol=1e-5, atol=1e-5 * float(y.abs().max()))
