@@ -91,6 +91,9 @@ namespace {
 #ifndef RFP_STR_SMALL_N
 #define RFP_STR_SMALL_N 4096
 #endif
+#ifndef RFP_STR_LARGE_LEAF
+#define RFP_STR_LARGE_LEAF 48
+#endif
 #ifndef RFP_STR_SMALL_LEAF
 #define RFP_STR_SMALL_LEAF 32
 #endif
@@ -2132,11 +2135,12 @@ int sort_sets(int b, int nsets, const int *n, const float *const *src, const Sor
         reg = reg && n[kk] <= RPT * STPB;
         sa.split[k] = sort_split_of(n[kk]);
         {
-            // slabs per axis for leaves of 64 records; clouds of up to RFP_STR_SMALL_N points (the side that is swept as
+            // slabs per axis = cbrt(n / leaf): leaves of RFP_STR_LARGE_LEAF = 48 records (round 4: 7 slabs instead of 6 at 16384
+            // points measured step 91.6 -> 90.2 us; 32 and 96 measured like 64); clouds of up to RFP_STR_SMALL_N points (the side that is swept as
             // 16-query tiles) get leaves of RFP_STR_SMALL_LEAF: their 16-record blocks are then less flat -- the model
             // (tools/experiments, round 4) gives a 2048-point set 25 instead of 36 superblocks per tile list as queries
             // and 9.5 instead of 11.3 block scans per 64-query group as candidates
-            const int leaf = n[kk] <= RFP_STR_SMALL_N ? RFP_STR_SMALL_LEAF : SB;
+            const int leaf = n[kk] <= RFP_STR_SMALL_N ? RFP_STR_SMALL_LEAF : RFP_STR_LARGE_LEAF;
             int ss = (int)lround(cbrt((double)n[kk] / leaf));
             sa.str_s[k] = ss < 1 ? 1 : (ss > 16 ? 16 : ss);
         }

@@ -124,7 +124,9 @@ def test_culled_equals_dense(orc, kind, b, n, m):
         # both directions have few groups here: quad-per-query tiles (16 pairs per counted scan) -- unless the CANDIDATE
         # cloud is crowded, which the sort flags and the sweep answers with the shared-group path (1024 pairs per scan)
         # (direction 0's candidates are the 16384-point cloud; a 2048-point cloud feeds the sort's test from too few waves to be flagged)
-        assert stats[14] == (1024 if kind == "collapsed" else 16) and stats[15] in (16, 1024), (kind, stats[14], stats[15])
+        # (the lattice / duplicate clouds may or may not be flagged -- 12 values per axis crowd a wave's x bins too; either path is exact)
+        if kind in ("randn", "uniform", "sphere", "collapsed"):
+            assert stats[14] == (1024 if kind == "collapsed" else 16) and stats[15] in (16, 1024), (kind, stats[14], stats[15])
     if kind in ("randn", "uniform", "sphere"):
         pairs = [stats[3] * (stats[14] or 1024), stats[7] * (stats[15] or 1024)]  # pairs per counted scan: stats[14 + d]
         assert pairs[0] < 0.6 * b * n * m and pairs[1] < 0.6 * b * n * m, (stats, b * n * m)
