@@ -91,6 +91,12 @@ namespace {
 #ifndef RFP_STR_SMALL_N
 #define RFP_STR_SMALL_N 4096
 #endif
+#ifndef RFP_CROWD_DIV
+#define RFP_CROWD_DIV 4  // a cloud is flagged crowded when more than 1 / RFP_CROWD_DIV of its sort's waves are
+#endif
+#ifndef RFP_ZSPREAD
+#define RFP_ZSPREAD 1    // crowded waves spread a spot's copies over 16 adjacent z ranks
+#endif
 #ifndef RFP_STR_LARGE_LEAF
 #define RFP_STR_LARGE_LEAF 48
 #endif
@@ -477,7 +483,7 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
         // a crowded wave (near-copies on a few spots) spreads its points over 16 adjacent z ranks by lane: the key
         // histogram and the positions are exact and their same-address LDS atomics serialise -- 46 of 64 lanes on one
         // bin otherwise; copies of one spot are the same place, so the ORDER among them is free and culling loses nothing
-        if (dense) zq = (zq & ~15u) | (unsigned)(lane & 15);
+        if (RFP_ZSPREAD && dense) zq = (zq & ~15u) | (unsigned)(lane & 15);
         const unsigned key = ((unsigned)col << 9) | ((col & 1) ? 511u - zq : zq);
         const int slice = (col >= cs1) + (col >= cs2) + (col >= cs3);
         const bool own = valid && slice == half;
@@ -578,7 +584,7 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     // network's collapsed output): as a CANDIDATE set it sends every query through hundreds of near-tied blocks, which the
     // shared-group sweep streams to 64 lanes at the VALU rate and the quad tiles would chase one latency-bound round at a
     // time (258 us instead of 120 at C2) -- the sweep reads this flag per cloud (all workgroups of a cloud agree: same data)
-    if (tid == 0 && half == 0) a.pos0[set][a.b + bi] = ncrowded * 4 > STPB / 64 ? 1 : 0;
+    if (tid == 0 && half == 0) a.pos0[set][a.b + bi] = ncrowded * RFP_CROWD_DIV > STPB / 64 ? 1 : 0;
     for (int h0 = 0; h0 < seglen; h0 += HALF) {
         const int cnt = min(HALF, seglen - h0);  // multiple of 64
 #pragma unroll

@@ -50,8 +50,13 @@ while time.time() - t0 < budget:
     ref = _raw.nn_distance(a, c, mode="dense")
     ok = all(torch.equal(x, y) for x, y in zip(ref, out[:4]))
     r1, r2 = _raw.nn_distance_grad(a, c, g1, ref[1], g2, ref[3])
-    ok = ok and bool(torch.allclose(out[4], r1, rtol=1e-5, atol=2e-5 * float(r1.abs().max()) + 1e-12))
-    ok = ok and bool(torch.allclose(out[5], r2, rtol=1e-5, atol=2e-5 * float(r2.abs().max()) + 1e-12))
+    # the gradient bar of the tests: rel 1e-5 + 1e-5 of the LARGEST TERM (fp32 add order of a scatter).  The largest term, not the
+    # largest result: on the lattice clouds with signed upstream gradients hundreds of O(1) terms cancel to O(0.03) in every
+    # entry, and an output-relative floor (what this soak used until round 4) flags 1e-6 of summation noise there (case 176:
+    # 10 x 11977 x 1668, one entry 1.1-1.5e-6 off in some runs, with every build back to round 3's order)
+    term = 2.0 * max(float(g1.abs().max()), float(g2.abs().max())) * float(max(ref[0].max(), ref[2].max())) ** 0.5
+    ok = ok and bool(torch.allclose(out[4], r1, rtol=1e-5, atol=1e-5 * term + 1e-12))
+    ok = ok and bool(torch.allclose(out[5], r2, rtol=1e-5, atol=1e-5 * term + 1e-12))
     if not ok:
         bad += 1
         print("MISMATCH case", case, "b n m", b, n, m, "kind", kind, flush=True)
