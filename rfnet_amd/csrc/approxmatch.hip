@@ -483,9 +483,22 @@ __global__ void mc_final_kernel(const float *partial, int per_batch, float *cost
 #ifndef RFA_MG_LSPLIT
 #define RFA_MG_LSPLIT 4
 #endif
+#ifndef RFA_MG_ROLL
+#define RFA_MG_ROLL 1      // (prefetch + LANECOL form) ROLLING prefetch: a row's register is reloaded with the next tile's row as soon as
+                           // phase A has consumed it -- no second register array, loads in flight during phase A as well, and the
+                           // rows fetched behind the last tile are the workgroup's own last row (cache hits) instead of the next
+                           // workgroup's first tile (+5 % FETCH_SIZE by the counters)
+#endif
+#ifndef RFA_MG_SCOL
+#define RFA_MG_SCOL 0      // (rolling form) whole tiles take the columns' coordinates by scalar loads, 8 rows (24 dwords) at a time, instead of
+                           // 96 v_readlane per tile
+#endif
+#ifndef RFA_MG_WPE
+#define RFA_MG_WPE 4       // waves per SIMD the register allocation is held to (the 40 KB LDS tile of TL = 32 allows 4)
+#endif
 constexpr int MG_TL = RFA_MG_TL;
 constexpr int MG_LSPLIT = RFA_MG_LSPLIT;
-__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void mcg_kernel(int n, int m, int lspan,
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RFA_MG_WPE, RFA_MG_WPE))) void mcg_kernel(int n, int m, int lspan,
                                                   const float *__restrict__ xyz1,
                                                   const float *__restrict__ xyz2,
                                                   const float *__restrict__ match,
@@ -523,13 +536,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // fetched too, from the clamped last row, and masked to nothing)
     const unsigned koff = (unsigned)kk * 4u;
     const float livef = live ? 1.f : 0.f;
-    float mv[MG_TL];
-#pragma unroll
-    for (int l = 0; l < MG_TL; l++)
-        mv[l] = *(const float *)((const char *)(M + (size_t)min(lbeg + l, m - 1) * n) + koff) * ((lbeg + l < lend) ? livef : 0.f);
-    // (the columns' coordinates come from LDS: as scalar loads they cost ~16 SALU instructions and a scalar-memory wait per
-    // row -- 3.5e7 SALU next to 4.4e7 VALU instructions per launch, profiles/r04_rocprofv3_summary.txt)
-#if RFA_MG_LANECOL
+#if RFA_MG_LANECOL  // (before the rows: the oldest load in flight, as inside the loop -- the wait at the loop head then lets the rows stay in flight)
     float cxv, cyv, czv;
     {
         const int ll = min(lbeg + (t & (MG_TL - 1)), m - 1);
@@ -537,7 +544,21 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         cyv = B[ll * 3 + 1];
         czv = B[ll * 3 + 2];
     }
+    __builtin_amdgcn_sched_barrier(0);
 #endif
+    float mv[MG_TL];
+#if RFA_MG_ROLL && RFA_MG_LANECOL
+    // (rolling form: raw rows; a row outside the range is masked when it is consumed, a dead lane by x1 = +inf: rsq(inf) = 0)
+    const float x1a = live ? x1 : INFINITY;
+#pragma unroll
+    for (int l = 0; l < MG_TL; l++) mv[l] = *(const float *)((const char *)(M + (size_t)min(lbeg + l, lend - 1) * n) + koff);
+#else
+#pragma unroll
+    for (int l = 0; l < MG_TL; l++)
+        mv[l] = *(const float *)((const char *)(M + (size_t)min(lbeg + l, m - 1) * n) + koff) * ((lbeg + l < lend) ? livef : 0.f);
+#endif
+    // (the columns' coordinates come from LDS: as scalar loads they cost ~16 SALU instructions and a scalar-memory wait per
+    // row -- 3.5e7 SALU next to 4.4e7 VALU instructions per launch, profiles/r04_rocprofv3_summary.txt)
 #if RFA_MG_LDSCOL
     if (t < MG_TL) {
         const int ll = min(lbeg + t, m - 1);
@@ -548,7 +569,60 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #endif
     for (int l0 = lbeg; l0 < lend; l0 += MG_TL) {
         const int lc = min(MG_TL, lend - l0);
-#if RFA_MG_PREFETCH
+#if RFA_MG_PREFETCH && RFA_MG_ROLL && RFA_MG_LANECOL
+        // the next tile's column records first: they are the oldest loads in flight when the next phase A needs them
+        float cxn, cyn, czn;
+        {
+            const int ll = min(l0 + MG_TL + (t & (MG_TL - 1)), m - 1);
+            cxn = B[ll * 3];
+            cyn = B[ll * 3 + 1];
+            czn = B[ll * 3 + 2];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // (a full tile -- all but the last of a range whose length is no multiple of 32 -- needs no row mask: one multiplication
+        // per element less in a kernel whose VALU pipe is 70 % busy, profiles/r04_rocprofv3_summary.txt (B))
+#define RFA_MCG_PHASE_A(MASKED)                                                                                          \
+    _Pragma("unroll") for (int g = 0; g < MG_TL; g += 8) {                                                               \
+        if (RFA_MG_SCOL && !MASKED) {                                                                                    \
+            /* uniform addresses: scalar loads (the tile is whole: in bounds), one group ahead; scalar loads return out  \
+               of order, so the wait for this group's records is lgkmcnt(0) and comes BEFORE the next group's issue */   \
+            __builtin_amdgcn_s_waitcnt(0xC07F);                                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                                           \
+            if (g + 8 < MG_TL) {                                                                                         \
+                const float *bp = B + (size_t)(l0 + g + 8) * 3;                                                          \
+                _Pragma("unroll") for (int i = 0; i < 24; i++) scb[((g >> 3) + 1) & 1][i] = bp[i];                       \
+            }                                                                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                                           \
+        }                                                                                                                \
+        const float(&sc)[24] = scb[(g >> 3) & 1];                                                                        \
+        _Pragma("unroll") for (int l = g; l < g + 8; l++) {                                                              \
+            const float dx = x1a - ((RFA_MG_SCOL && !MASKED) ? sc[(l - g) * 3 + 0] : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cxv), l))),   \
+                        dy = y1 - ((RFA_MG_SCOL && !MASKED) ? sc[(l - g) * 3 + 1] : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cyv), l))),    \
+                        dz = z1 - ((RFA_MG_SCOL && !MASKED) ? sc[(l - g) * 3 + 2] : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(czv), l)));    \
+            const float mvl = MASKED ? mv[l] * ((l0 + l < lend) ? 1.f : 0.f) : mv[l];                                    \
+            const float q = mvl * __builtin_amdgcn_rsqf(fmaxf(rf::d2_fma(dx, dy, dz), 1e-20f));                          \
+            ax = fmaf(dx, q, ax);                                                                                        \
+            ay = fmaf(dy, q, ay);                                                                                        \
+            az = fmaf(dz, q, az);                                                                                        \
+            qs[l][t] = q;                                                                                                \
+        }                                                                                                                \
+        _Pragma("unroll") for (int l = g; l < g + 8; l++)                                                                \
+            mv[l] = *(const float *)((const char *)(M + (size_t)min(l0 + MG_TL + l, lend - 1) * n) + koff);              \
+        __builtin_amdgcn_sched_barrier(0); /* 8 rows at a time: the scheduler otherwise hoists all 32 rows' work */      \
+    }
+        float scb[2][24];
+        if (lc == MG_TL) {  // (uniform)
+            if (RFA_MG_SCOL) {
+                const float *bp = B + (size_t)l0 * 3;
+#pragma unroll
+                for (int i = 0; i < 24; i++) scb[0][i] = bp[i];
+            }
+            RFA_MCG_PHASE_A(false)
+        } else {
+            RFA_MCG_PHASE_A(true)
+        }
+#undef RFA_MCG_PHASE_A
+#elif RFA_MG_PREFETCH
 #pragma unroll
         for (int l = 0; l < MG_TL; l++) {
 #if RFA_MG_LDSCOL
@@ -663,7 +737,11 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // (prefetch form: TWO barriers per tile.  The next tile's phase A only writes qs -- last read before this tile's
         // second barrier -- and reads cx2, rewritten between this tile's two barriers; ps is rewritten after the next
         // tile's first barrier, which no thread passes before its own phase C here is done)
-#if RFA_MG_PREFETCH
+#if RFA_MG_PREFETCH && RFA_MG_ROLL && RFA_MG_LANECOL
+        cxv = cxn;
+        cyv = cyn;
+        czv = czn;
+#elif RFA_MG_PREFETCH
 #pragma unroll
         for (int l = 0; l < MG_TL; l++) mv[l] = nx[l];
 #if RFA_MG_LANECOL

@@ -117,11 +117,19 @@ namespace {
 #ifndef RFP_T16_STAMPS
 #define RFP_T16_STAMPS 0  // 1 (instrumented build): s_memtime per phase of the quad-per-query tiles, summed over waves -> stats[25..31]
 #endif
+#ifndef RFP_SG_STAMPS
+#define RFP_SG_STAMPS 0  // 1 (instrumented build): s_memtime per phase of the one-wave groups (sweep_group), summed over one wave in 64
+                         // -> stats[16..23] INSTEAD of the sort's stamps: prologue, step heads (key minimum, box load, block tests), block scans,
+                         // re-scans, second traversal, outputs + emit
+#endif
 #ifndef RFP_TILE16
 #define RFP_TILE16 1  // directions with few query groups: 1 = a wave per 16-query tile, four lanes per query, every quad walking its
                       // OWN list of candidate blocks with gathered scans (round 4); 0 = four waves share a
                       // 64-query group and stream every needed block through SGPRs to all 64 lanes (rounds 1-3)
 #endif
+// (the phase-stamp builds leave the per-wave counters out: five same-address atomics from each of 12 000 waves serialise at ~25 ns
+// each and the launch then measures its own atomics -- round 4's first stamps did, profiles/r04_rescan.txt)
+constexpr bool kStampBuild = RFP_SG_STAMPS || RFP_T16_STAMPS;
 constexpr int NSH = RFP_NSH;
 constexpr int BS = 16;             // candidates per block
 constexpr int SBB = 4;             // blocks per superblock
@@ -1022,6 +1030,10 @@ __device__ __forceinline__ void sweep_group(
     const float *__restrict__ b16_1, const float *__restrict__ b64_0, const float *__restrict__ b64_1,
     float *__restrict__ dist0, float *__restrict__ dist1, int *__restrict__ idx0, int *__restrict__ idx1,
     unsigned long long *__restrict__ stats) {
+#if RFP_SG_STAMPS
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_wave0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int cd = 1 - dir;
     constexpr bool shared4 = SHARED4;
     const int G = a.groups[dir];
@@ -1070,6 +1082,16 @@ __device__ __forceinline__ void sweep_group(
 #if RFP_HIST
     unsigned long long scan_hist = 0;
 #endif
+#if RFP_SG_STAMPS
+    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = t_entry;
+    auto stamp = [&](int ph) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        tph[ph] += now - tlast;
+        tlast = now;
+    };
+#else
+    auto stamp = [&](int) {};
+#endif
 
     // One traversal of the candidate superblocks in ascending order of a lower bound, for the lanes
     // with `part` set, whose box is [blo, bhi].
@@ -1117,6 +1139,7 @@ __device__ __forceinline__ void sweep_group(
             }
         }
         int nact_ref = 64;  // active lanes when the keys were last (re)computed
+        stamp(TRACK ? 4 : 0);
         for (;;) {
             // the step's serial chain (reduction, box load, tests) goes ahead of other waves' scans:
             // -3 % at 16384^2, nothing at C2; the opposite priority is 3 % slower
@@ -1201,6 +1224,7 @@ __device__ __forceinline__ void sweep_group(
                                            bx[j * 6 + 4], bx[j * 6 + 5]);
                 if (__builtin_amdgcn_ballot_w64(lb <= cull) != 0ull) need |= 1u << j;
             }
+            stamp(TRACK ? 4 : 1);
             if (need == 0) continue;
             if constexpr (TRACK) {
                 while (need) {
@@ -1292,6 +1316,7 @@ __device__ __forceinline__ void sweep_group(
             }
             cull = fminf(cull, best);
             if (shared4) atomicMin(&shbest[lane], __float_as_int(cull));
+            stamp(2);
         }
     };
 
@@ -1299,24 +1324,61 @@ __device__ __forceinline__ void sweep_group(
     int wpos = -1;  // (GRAD) sorted position of the winner in the candidate set
     traverse(std::false_type{}, glo, ghi, besti, wpos);
     __builtin_amdgcn_s_setprio(0);
+    stamp(1);
 
-    // lowest original index among the exact matches of the winning block (and of the second block that equalled it)
+    // lowest original index among the exact matches of the winning block (and of the second block that equalled it).
+    // Per lane gathers, 8 records at a time: 6 + 2 sixteen-byte loads issued TOGETHER, then the arithmetic.  (Rounds 1-3 wrote
+    // this as a loop over the records with the index load inside `if (d == best)`: the compiler kept that load
+    // conditional -- it may not speculate it -- and the 16 records became 32 dependent memory round trips, 74 % of a
+    // one-wave group's lifetime at C2 by s_memtime stamps, profiles/r04_rescan.txt.)
     auto rescan = [&](int wb) {
-        const float *cp = C + (size_t)wb * BS * 3;  // per lane
-        const int *co = Co + (size_t)wb * BS;
-#pragma unroll 4
-        for (int u = 0; u < BS; u++) {
-            const float d = rf::d2_fma(cp[u * 3 + 0] - qx, cp[u * 3 + 1] - qy, cp[u * 3 + 2] - qz);
-            if constexpr (GRAD) {
-                if (d == best && (unsigned)co[u] < besti) wpos = wb * BS + u;
+        constexpr int RB = shared4 ? 4 : 8;  // records per batch (the shared-group form holds more state: 8 spill there)
+        const float4 *cp4 = (const float4 *)(C + (size_t)wb * BS * 3);  // per lane; a block is 192 aligned bytes
+        const int4 *co4 = (const int4 *)(Co + (size_t)wb * BS);
+#pragma unroll 1  // (all 16 records in flight at once need 64 registers: spills at the kernel's 72)
+        for (int h = 0; h < BS / RB; h++) {
+            float4 r4[RB * 3 / 4];
+            int4 o4[RB / 4];
+#pragma unroll
+            for (int i = 0; i < RB * 3 / 4; i++) r4[i] = cp4[h * (RB * 3 / 4) + i];
+#pragma unroll
+            for (int i = 0; i < RB / 4; i++) o4[i] = co4[h * (RB / 4) + i];
+            float r[RB * 3];
+            int o[RB];
+#pragma unroll
+            for (int i = 0; i < RB * 3 / 4; i++) {
+                r[i * 4 + 0] = r4[i].x;
+                r[i * 4 + 1] = r4[i].y;
+                r[i * 4 + 2] = r4[i].z;
+                r[i * 4 + 3] = r4[i].w;
             }
-            if (d == best) besti = min(besti, (unsigned)co[u]);  // padding carries 0xFFFFFFFF
+#pragma unroll
+            for (int i = 0; i < RB / 4; i++) {
+                o[i * 4 + 0] = o4[i].x;
+                o[i * 4 + 1] = o4[i].y;
+                o[i * 4 + 2] = o4[i].z;
+                o[i * 4 + 3] = o4[i].w;
+            }
+#pragma unroll
+            for (int u = 0; u < RB; u++) {
+                const float d = rf::d2_fma(r[u * 3 + 0] - qx, r[u * 3 + 1] - qy, r[u * 3 + 2] - qz);
+                const bool m = d == best;
+                if constexpr (GRAD) {
+                    const bool better = m && (unsigned)o[u] < besti;
+                    wpos = better ? wb * BS + h * RB + u : wpos;
+                }
+                besti = m ? min(besti, (unsigned)o[u]) : besti;  // padding carries 0xFFFFFFFF
+            }
         }
     };
     rescan(bblk);
     if (__ballot(bblk2 >= 0) != 0ull) {
         if (bblk2 >= 0) rescan(bblk2);
     }
+#if RFP_SG_STAMPS
+    if (__ballot(besti == 0x12345u) == ~0ull) return;  // (never true: makes the stamp wait for the re-scan's loads)
+#endif
+    stamp(3);
     // queries whose minimum was attained in more than one visited block: second traversal
     const bool flagged = tie && part;
     if (__ballot(flagged) != 0ull) {
@@ -1334,7 +1396,8 @@ __device__ __forceinline__ void sweep_group(
         }
     }
 
-    if (stats && lane == 0) {
+    stamp(4);
+    if (stats && lane == 0 && !kStampBuild) {
         atomicAdd(&stats[dir * 4 + 0], 1ull);
         atomicAdd(&stats[dir * 4 + 1], (unsigned long long)n_step);
         atomicMax(&stats[dir * 4 + 2], (unsigned long long)n_step);
@@ -1364,8 +1427,13 @@ __device__ __forceinline__ void sweep_group(
         }
     }
     if (valid) {
+#if RFP_SG_STAMPS == 2  // (instrumented build, tools/experiments/wave_timeline.py: the outputs carry the wave's start and end, 10 ns units)
+        (dir ? dist1 : dist0)[(size_t)bi * a.n[dir] + qorig] = __uint_as_float((unsigned)__builtin_amdgcn_s_memrealtime());
+        (dir ? idx1 : idx0)[(size_t)bi * a.n[dir] + qorig] = (int)(unsigned)t_wave0;
+#else
         (dir ? dist1 : dist0)[(size_t)bi * a.n[dir] + qorig] = qnan ? NAN : best;
         (dir ? idx1 : idx0)[(size_t)bi * a.n[dir] + qorig] = (qnan || besti == 0xFFFFFFFFu) ? 0 : (int)besti;
+#endif
     }
     if constexpr (GRAD) {
         // index 0 of the NaN / no-match policy above = the candidate set's point with ORIGINAL index 0
@@ -1375,6 +1443,7 @@ __device__ __forceinline__ void sweep_group(
         const EmitView ev = emit_layout(ge.base, a.b, a.npad[0], a.npad[1], dir);
         const int w = (qnan || besti == 0xFFFFFFFFu) ? p0 : wpos;
         const int wc = valid ? w : 0;
+        // (keeping the winner's coordinates from the re-scan instead of this gather: same time, 87.7 vs 88.0 us per step, and a scratch slot)
         const float cx = C[(size_t)wc * 3 + 0], cy = C[(size_t)wc * 3 + 1], cz = C[(size_t)wc * 3 + 2];
         const float g2 = gq + gq;  // the reference's arithmetic: g = gd + gd; (a - b) * g rounded on its own
         const size_t r = (size_t)bi * a.npad[dir] + g * SB + lane;
@@ -1391,6 +1460,14 @@ __device__ __forceinline__ void sweep_group(
         }
         if (lane == 0) ev.mask[(size_t)bi * G + g] = gm;
     }
+#if RFP_SG_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);  // (the outputs' stores and the emit's gathers count for the last phase)
+    stamp(5);
+    if (!shared4 && stats && lane == 0 && (gid & 63) == 0) {
+        for (int i = 0; i < 6; i++) atomicAdd(&stats[16 + i], tph[i]);
+        atomicAdd(&stats[22], 1ull);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1475,6 +1552,9 @@ __device__ __forceinline__ void sweep_tile16(
     const float *__restrict__ b16_1, const float *__restrict__ b64_0, const float *__restrict__ b64_1,
     float *__restrict__ dist0, float *__restrict__ dist1, int *__restrict__ idx0, int *__restrict__ idx1,
     unsigned long long *__restrict__ stats) {
+#if RFP_SG_STAMPS == 2
+    const unsigned long long t_wave0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int cd = 1 - dir;
     const int G = a.groups[dir];
     const int bi = gid / G, g = gid - bi * G;
@@ -1786,9 +1866,12 @@ __device__ __forceinline__ void sweep_tile16(
     stamp(6);
 #if RFP_T16_STAMPS
     if (stats && lane == 0 && (gid & 15) == 0 && wib == 0)  // (one wave in 64: same-address atomics from every wave clog the memory pipe)
+    {
         for (int i = 0; i < 7; i++) atomicAdd(&stats[25 + i], tph[i]);
+        atomicAdd(&stats[24], 1ull);
+    }
 #endif
-    if (stats && lane == 0) {
+    if (stats && lane == 0 && !kStampBuild) {
         atomicAdd(&stats[dir * 4 + 0], 1ull);
         atomicAdd(&stats[dir * 4 + 1], (unsigned long long)n_round);
         atomicMax(&stats[dir * 4 + 2], (unsigned long long)n_round);
@@ -1798,8 +1881,13 @@ __device__ __forceinline__ void sweep_tile16(
     }
 
     if (valid && k == 0) {
+#if RFP_SG_STAMPS == 2  // (instrumented build, tools/experiments/wave_timeline.py: the outputs carry the wave's start and end, 10 ns units)
+        (dir ? dist1 : dist0)[(size_t)bi * a.n[dir] + qorig] = __uint_as_float((unsigned)__builtin_amdgcn_s_memrealtime());
+        (dir ? idx1 : idx0)[(size_t)bi * a.n[dir] + qorig] = (int)(unsigned)t_wave0;
+#else
         (dir ? dist1 : dist0)[(size_t)bi * a.n[dir] + qorig] = qnan ? NAN : best;
         (dir ? idx1 : idx0)[(size_t)bi * a.n[dir] + qorig] = (qnan || besti == 0xFFFFFFFFu) ? 0 : (int)besti;
+#endif
     }
     if constexpr (GRAD) {
         const int *pos0 = (const int *)((const char *)(cd ? b64_1 : b64_0) +
@@ -2125,7 +2213,7 @@ int sort_sets(int b, int nsets, const int *n, const float *const *src, const Sor
     SortArgs sa;
     sa.b = b;
     sa.nsets = nsets;
-    sa.dbg = RFP_CLOUD_END ? nullptr : dbg;
+    sa.dbg = (RFP_CLOUD_END || kStampBuild) ? nullptr : dbg;
     bool reg = true;
     for (int k = 0; k < 2; k++) {
         const int kk = k < nsets ? k : 0;

@@ -50,9 +50,14 @@ def main():
         np.save(os.path.join("gpurun_out", "rfnet_in_sample.npy"), part[:2].cpu().numpy())
     t1 = torch.from_numpy(x1.astype(np.float32)).cuda()
     t2 = torch.from_numpy(x2.astype(np.float32)).cuda()
+    for _ in range(3):  # (warm: the first launch of a process runs several times longer, and the phase stamps of the instrumented builds with it)
+        R.nn_distance(t1, t2, mode="culled")
+    torch.cuda.synchronize()
     st = []
     R.nn_distance(t1, t2, mode="culled", stats=st)
     for d in range(2):
+        if not st[4 * d]:
+            continue  # (a phase-stamp build: no per-wave counters)
         w, steps, mx, scans = st[4 * d:4 * d + 4]
         unit = st[14 + d] or 1024
         print(f"dir{d}: waves {w} steps/wave {steps / max(w, 1):.1f} (max {mx}) block scans/wave {scans / max(w, 1):.1f} "
@@ -61,7 +66,12 @@ def main():
         names = ["keys", "seed", "tile list", "query x superblock", "quad x block", "drain", "epilogue"]
         tot = sum(st[25:32])
         print("quad-tile phases (s_memtime, summed over waves): " + "  ".join(f"{n} {100 * v / tot:.0f} %" for n, v in zip(names, st[25:32]))
-              + f"   | {tot / max(st[0] / 64, 1):.0f} ticks per sampled wave (1 in 64)")
+              + f"   | {tot / max(st[24], 1):.0f} ticks per sampled wave ({st[24]} waves; 2.4 ticks per ns)")
+    if len(st) > 22 and st[22] and st[22] < 1 << 20 and not any(st[25:32]):  # (RFP_SG_STAMPS build: one-wave groups, one wave in 64)
+        names = ["prologue + keys", "step heads (key min, box load, block tests)", "block scans", "re-scans", "second traversal", "outputs + emit"]
+        tot = sum(st[16:22])
+        print("one-wave-group phases (s_memtime, summed over sampled waves): " + "  ".join(f"{n} {100 * v / tot:.0f} %" for n, v in zip(names, st[16:22]))
+              + f"   | {tot / st[22]:.0f} ticks per sampled wave ({st[22]} waves; 2.4 ticks per ns)")
     print("full culled forward:", timed(lambda: R.nn_distance(t1, t2, mode="culled")))
     h1, h2 = R.nn_sort(t1), R.nn_sort(t2)
     print("sort N alone:", timed(lambda: R.nn_sort(t1)))

@@ -1,6 +1,12 @@
 #!/usr/bin/env bash
+# scratch GPU call of round 4 (edited per experiment)
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-cd "$R"; mkdir -p gpurun_out/r04z
-for lib in "" nozs div2 nohagg l64; do echo "=== $lib"; if [ -n "$lib" ]; then export RFOPS_LIB=rfnet_amd/variants/librfops_$lib.so; fi; timeout 200 python3 tools/experiments/soak_step_case.py 176 2>&1 | grep -v amdgpu | head -24; done > gpurun_out/r04z/case176.txt 2>&1
-cat gpurun_out/r04z/case176.txt
+cd "$R"; O=gpurun_out/r04z; mkdir -p $O
+timeout 900 python3 -m pytest tests/test_gpu_chamfer_culled.py tests/test_gpu_chamfer_step_sorted.py -x -q 2>&1 | tail -3 > $O/pytest_ch.txt; cat $O/pytest_ch.txt
+timeout 600 python3 tools/ab_step.py base nobx > $O/ab_step.txt 2>&1; cat $O/ab_step.txt
+timeout 600 python3 tools/ab_step.py --shape 32,16384,16384 base nobx > $O/ab_step_ns.txt 2>&1; cat $O/ab_step_ns.txt
+RFOPS_LIB=rfnet_amd/variants/librfops_sgst.so timeout 300 python3 tools/culled_stats.py > $O/sg_stamps.txt 2>&1; head -2 $O/sg_stamps.txt
+RFOPS_LIB=rfnet_amd/variants/librfops_tl.so timeout 300 python3 tools/experiments/wave_timeline.py > $O/timeline.txt 2>&1; cat $O/timeline.txt
+timeout 300 python3 tools/soak_culled.py 60 > $O/soak_culled.txt 2>&1; tail -2 $O/soak_culled.txt
+timeout 300 python3 tools/soak_step.py 60 > $O/soak_step.txt 2>&1; tail -2 $O/soak_step.txt

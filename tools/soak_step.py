@@ -55,8 +55,10 @@ while time.time() - t0 < budget:
     # entry, and an output-relative floor (what this soak used until round 4) flags 1e-6 of summation noise there (case 176:
     # 10 x 11977 x 1668, one entry 1.1-1.5e-6 off in some runs, with every build back to round 3's order)
     term = 2.0 * max(float(g1.abs().max()), float(g2.abs().max())) * float(max(ref[0].max(), ref[2].max())) ** 0.5
-    ok = ok and bool(torch.allclose(out[4], r1, rtol=1e-5, atol=1e-5 * term + 1e-12))
-    ok = ok and bool(torch.allclose(out[5], r2, rtol=1e-5, atol=1e-5 * term + 1e-12))
+    # (and never below the tests' output-relative floor: a candidate chosen by thousands of near-copies -- kind 5 -- sums
+    # thousands of same-sign terms, and the noise scales with that sum)
+    ok = ok and bool(torch.allclose(out[4], r1, rtol=1e-5, atol=1e-5 * max(term, float(r1.abs().max())) + 1e-12))
+    ok = ok and bool(torch.allclose(out[5], r2, rtol=1e-5, atol=1e-5 * max(term, float(r2.abs().max())) + 1e-12))
     if not ok:
         bad += 1
         print("MISMATCH case", case, "b n m", b, n, m, "kind", kind, flush=True)
