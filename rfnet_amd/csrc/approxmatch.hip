@@ -490,7 +490,7 @@ __global__ void mc_final_kernel(const float *partial, int per_batch, float *cost
                            // workgroup's first tile (+5 % FETCH_SIZE by the counters)
 #endif
 #ifndef RFA_MG_SCOL
-#define RFA_MG_SCOL 0      // (rolling form) whole tiles take the columns' coordinates by scalar loads, 8 rows (24 dwords) at a time, instead of
+#define RFA_MG_SCOL 1      // (rolling form) whole tiles take the columns' coordinates by scalar loads, 8 rows (24 dwords) at a time, instead of
                            // 96 v_readlane per tile
 #endif
 #ifndef RFA_MG_WPE

@@ -1122,13 +1122,22 @@ __device__ __forceinline__ void sweep_group(
             return (__float_as_uint(lb) & ~IDMASK) | (unsigned)s;
         };
         unsigned lmin = 0xFFFFFFFFu;
-        if (inreg) {
+        if (nmine <= 64) {  // uniform: one entry per lane
+            kk[0] = lane < nmine ? entry_key(lane, blo, bhi) : 0xFFFFFFFFu;
+            lmin = kk[0];
+        } else if (inreg) {
+            // (clamped entries, select afterwards: under `e < nmine` every round is a branch with its own wait -- five dependent
+            // round trips for a 16384-point candidate cloud)
 #pragma unroll
-            for (int i = 0; i < KK; i++)
-                if (i * 64 < nmine) {  // uniform
-                    const int e = lane + 64 * i;
-                    kk[i] = e < nmine ? entry_key(e, blo, bhi) : 0xFFFFFFFFu;
+            for (int i = 0; i < KK; i++) {
+                const int e = lane + 64 * i;
+                if constexpr (TRACK) {  // (the rare second traversal keeps the round-by-round form: it holds more state, the batch spills)
+                    if (i * 64 < nmine) kk[i] = e < nmine ? entry_key(e, blo, bhi) : 0xFFFFFFFFu;
+                } else {
+                    const unsigned key = entry_key(min(e, nmine - 1), blo, bhi);
+                    kk[i] = e < nmine ? key : 0xFFFFFFFFu;
                 }
+            }
             lmin = kk_min();
         } else {
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
@@ -1658,7 +1667,12 @@ __device__ __forceinline__ void sweep_tile16(
         float kk[T16_KK];
         if (inreg) {
 #pragma unroll
-            for (int c = 0; c < T16_KK; c++) kk[c] = (c * 64 < nsb && c * 64 + lane < nsb) ? tile_key(c * 64 + lane) : INFINITY;
+            for (int c = 0; c < T16_KK; c++) {
+                // (clamped index, select afterwards: a load under `c * 64 + lane < nsb` is a branch with its own wait per round -- five
+                // dependent round trips for a 16384-point candidate cloud, a quarter of a tile wave's life by the stamps)
+                const float key = tile_key(min(c * 64 + lane, nsb - 1));
+                kk[c] = c * 64 + lane < nsb ? key : INFINITY;
+            }
         }
         auto seed_cand = [&](int s, float lb) {
             const bool z = lb == 0.f;
@@ -1950,9 +1964,38 @@ __global__ __launch_bounds__(64 * NSH) __attribute__((amdgpu_waves_per_eu(RFP_WP
     const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (int)(blockIdx.x >> 3);
     const int wpc = a.wg0 + a.wg1;  // workgroups per batch element
-    const int bi = logical / wpc;
+    int bi = logical / wpc;
     int wg = logical - bi * wpc;
-#if RFP_MIX == 2
+#if RFP_MIX >= 3
+    // per XCD (b a multiple of 8: every XCD holds b / 8 whole clouds): direction 0's workgroups of ALL its clouds first, then direction
+    // 1's -- the quad tiles are the waves with the long-tailed durations (p99 26 us, max 37 against 15 +- 4 for the one-wave groups,
+    // profiles/r04_rescan.txt), and cloud-major order starts the last cloud's tiles 19 us into a 44 us launch.  4: direction 1's
+    // workgroups dealt round-robin over the XCD's clouds instead of cloud by cloud
+    int dir;
+    if ((a.b & 7) == 0 && a.wg0 && a.wg1) {
+        const int ncl = a.b >> 3, local = (int)(blockIdx.x >> 3);
+        int cl;
+        if (local < ncl * a.wg0) {
+            dir = 0;
+            cl = local / a.wg0;
+            wg = local - cl * a.wg0;
+        } else {
+            const int l2 = local - ncl * a.wg0;
+            dir = 1;
+            if (RFP_MIX == 4) {
+                wg = l2 / ncl;
+                cl = l2 - wg * ncl;
+            } else {
+                cl = l2 / a.wg1;
+                wg = l2 - cl * a.wg1;
+            }
+        }
+        bi = xcd * ncl + cl;
+    } else {
+        dir = wg >= a.wg0;
+        if (dir) wg -= a.wg0;
+    }
+#elif RFP_MIX == 2
     // direction 1's workgroups of the cloud first, then direction 0's
     const int dir = wg < a.wg1 ? 1 : 0;
     if (!dir) wg -= a.wg1;
