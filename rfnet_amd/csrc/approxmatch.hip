@@ -455,50 +455,32 @@ __global__ void mc_final_kernel(const float *partial, int per_batch, float *cost
 //  grad2[l] = sum_k match[l][k] (x2_l - x1_k) * rsqrt(max(d2,1e-20))     (:229-269)
 // The reference reads match twice and tree-reduces 256 threads per l.  Here a workgroup owns
 // 256 k x an l-range and walks it in tiles of 32 l:
-//   phase A (thread <-> k): 32 coalesced row loads of match, q = match*rsq kept in an LDS tile
-//            [32][257] (stride 257: conflict-free by rows and by columns), grad1 accumulated in
-//            registers over the whole l-range (x2_l comes by scalar loads: it is wave-uniform);
-//   phase B (thread <-> (l, 32-k slice)): re-reads q column-wise from LDS, accumulates
-//            (x2_l - x1_k)*q, 8 slices summed through LDS, one coalesced atomicAdd per (l, c).
+//   phase A (thread <-> k): the tile's 32 match rows are ALREADY in registers (below); q = match*rsq goes to an LDS
+//            tile [32][257] (stride 257: conflict-free by rows and by columns), grad1 accumulates in registers over
+//            the whole l-range;
+//   phase B (thread <-> (l, 32-k slice)): re-reads q column-wise from LDS, accumulates (x2_l - x1_k)*q;
+//   phase C: the 8 slices summed through LDS, one coalesced atomicAdd per (l, c).
 // grad1: 3 atomics per thread at the end (LSPLIT-way contention only).  Outputs zero-filled first.
-#ifndef RFA_MG_TL
-#define RFA_MG_TL 32
-#endif
-#ifndef RFA_MG_PREFETCH
-#define RFA_MG_PREFETCH 1  // match_cost_grad: the next tile's match rows in flight during the current tile's LDS phases
-#endif
-#ifndef RFA_MG_LANECOL
-#define RFA_MG_LANECOL 1   // (prefetch form) the tile's xyz2 rows in lanes 0..31 of a prefetched vector load, read by v_readlane:
-                           // as scalar loads they are ~16 SALU instructions and a scalar-memory wait per row
-#endif
-#ifndef RFA_MG_LDSCOL
-#define RFA_MG_LDSCOL 0    // (prefetch form) the tile's xyz2 rows through LDS instead of scalar loads
-#endif
-#ifndef RFA_MG_2BAR
-#define RFA_MG_2BAR 0      // (prefetch + LDSCOL form) two barriers per tile instead of three
-#endif
-#ifndef RFA_MG_ABL
-#define RFA_MG_ABL 0
-#endif
+// Round 4 (profiles/r04_opbench.txt; every step measured same-device, tools/ab_mcg.py):
+//   * ROLLING prefetch: a row's register is reloaded with the next tile's row as soon as phase A has consumed it (uniform
+//     row base + one 32-bit lane offset, 8 rows per scheduling group): the loads are in flight through phases A, B and C
+//     -- the 40 KB LDS tile holds the kernel to 4 waves per SIMD whatever the register count, so 32 rows per lane cost
+//     no residency -- and the rows requested behind the last tile are the workgroup's own last row (cache hits; the
+//     first prefetch form read the next workgroup's first tile: +5 % FETCH_SIZE by the counters).
+//   * whole tiles (all but the last of a range whose length is no multiple of 32) take no row mask and fetch the columns'
+//     coordinates by scalar loads, 8 rows = 24 dwords one group ahead; a partial tile masks rows by a multiplication and
+//     reads the columns from lanes 0..31 of a clamped vector load by v_readlane.  A dead lane (k >= n) runs with
+//     x1 = +inf: rsq(inf) = 0 zeroes its q.
+//   * TWO barriers per tile: the next phase A only writes qs, last read before this tile's second barrier; ps is
+//     rewritten behind the next tile's first barrier, which no thread passes before its own phase C is done.
+// The knob version this came from (non-prefetch form, columns through LDS or v_readlane only, three barriers, timing
+// ablations) is tools/experiments/mcg_knobs.patch.txt.
 #ifndef RFA_MG_LSPLIT
 #define RFA_MG_LSPLIT 4
 #endif
-#ifndef RFA_MG_ROLL
-#define RFA_MG_ROLL 1      // (prefetch + LANECOL form) ROLLING prefetch: a row's register is reloaded with the next tile's row as soon as
-                           // phase A has consumed it -- no second register array, loads in flight during phase A as well, and the
-                           // rows fetched behind the last tile are the workgroup's own last row (cache hits) instead of the next
-                           // workgroup's first tile (+5 % FETCH_SIZE by the counters)
-#endif
-#ifndef RFA_MG_SCOL
-#define RFA_MG_SCOL 1      // (rolling form) whole tiles take the columns' coordinates by scalar loads, 8 rows (24 dwords) at a time, instead of
-                           // 96 v_readlane per tile
-#endif
-#ifndef RFA_MG_WPE
-#define RFA_MG_WPE 4       // waves per SIMD the register allocation is held to (the 40 KB LDS tile of TL = 32 allows 4)
-#endif
-constexpr int MG_TL = RFA_MG_TL;
+constexpr int MG_TL = 32;
 constexpr int MG_LSPLIT = RFA_MG_LSPLIT;
-__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RFA_MG_WPE, RFA_MG_WPE))) void mcg_kernel(int n, int m, int lspan,
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void mcg_kernel(int n, int m, int lspan,
                                                   const float *__restrict__ xyz1,
                                                   const float *__restrict__ xyz2,
                                                   const float *__restrict__ match,
@@ -507,9 +489,6 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RFA_MG_WPE,
     __shared__ float qs[MG_TL][TPB + 1];
     __shared__ float4 sx1[TPB];
     __shared__ float ps[TPB / MG_TL][MG_TL][3];
-#if RFA_MG_LDSCOL
-    __shared__ float4 cx2[MG_TL];  // the tile's 32 xyz2 rows: one broadcast LDS read per row in phase A
-#endif
     const int bi = blockIdx.z;
     const int t = threadIdx.x;
     const int k0 = blockIdx.x * TPB;
@@ -521,22 +500,15 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RFA_MG_WPE,
     const float *__restrict__ M = match + (size_t)bi * n * m;
     const float x1 = A[kk * 3], y1 = A[kk * 3 + 1], z1 = A[kk * 3 + 2];
     sx1[t] = make_float4(x1, y1, z1, 0.f);
+    const float x1a = live ? x1 : INFINITY;  // (phase A only: a dead lane's q = match * rsq(inf) = 0)
     float ax = 0.f, ay = 0.f, az = 0.f;
     const int lbeg = blockIdx.y * lspan;
     const int lend = min(m, lbeg + lspan);
     const int bl = t & (MG_TL - 1);  // phase-B row (l) of this thread
     const int br = t / MG_TL;        // phase-B k slice: [br*32, br*32+32)
-#if RFA_MG_PREFETCH
-    // The match rows of the NEXT tile are fetched while this tile goes through its three barrier-separated phases:
-    // the LDS tile (40 KB) holds the kernel to 4 waves per SIMD whatever the register count, so the 32 rows can all
-    // stay in flight in registers -- 128 KB per CU instead of 32 KB, and no load waits behind a barrier (round 3: 8 rows
-    // at a time inside the tile, 3.6 TB/s; mc_partial streams the same tensor at 5.9).
-    // (uniform row base + ONE 32-bit lane offset; unconditional loads from clamped rows -- finite values -- masked by a
-    // multiplication: a select is compiled into exec-masked branches around every load; the tile after the last one is
-    // fetched too, from the clamped last row, and masked to nothing)
     const unsigned koff = (unsigned)kk * 4u;
-    const float livef = live ? 1.f : 0.f;
-#if RFA_MG_LANECOL  // (before the rows: the oldest load in flight, as inside the loop -- the wait at the loop head then lets the rows stay in flight)
+    // this thread's phase-B row is l0 + (t & 31): the column record its lane holds (before the rows: the oldest load in
+    // flight, as inside the loop -- the wait at the loop head then lets the rows stay in flight)
     float cxv, cyv, czv;
     {
         const int ll = min(lbeg + (t & (MG_TL - 1)), m - 1);
@@ -545,31 +517,12 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RFA_MG_WPE,
         czv = B[ll * 3 + 2];
     }
     __builtin_amdgcn_sched_barrier(0);
-#endif
-    float mv[MG_TL];
-#if RFA_MG_ROLL && RFA_MG_LANECOL
-    // (rolling form: raw rows; a row outside the range is masked when it is consumed, a dead lane by x1 = +inf: rsq(inf) = 0)
-    const float x1a = live ? x1 : INFINITY;
+    float mv[MG_TL];  // raw rows; unconditional loads from clamped rows (finite values)
 #pragma unroll
     for (int l = 0; l < MG_TL; l++) mv[l] = *(const float *)((const char *)(M + (size_t)min(lbeg + l, lend - 1) * n) + koff);
-#else
-#pragma unroll
-    for (int l = 0; l < MG_TL; l++)
-        mv[l] = *(const float *)((const char *)(M + (size_t)min(lbeg + l, m - 1) * n) + koff) * ((lbeg + l < lend) ? livef : 0.f);
-#endif
-    // (the columns' coordinates come from LDS: as scalar loads they cost ~16 SALU instructions and a scalar-memory wait per
-    // row -- 3.5e7 SALU next to 4.4e7 VALU instructions per launch, profiles/r04_rocprofv3_summary.txt)
-#if RFA_MG_LDSCOL
-    if (t < MG_TL) {
-        const int ll = min(lbeg + t, m - 1);
-        cx2[t] = make_float4(B[ll * 3], B[ll * 3 + 1], B[ll * 3 + 2], 0.f);
-    }
-    __syncthreads();
-#endif
-#endif
+    float scb[2][24];  // column records of 8 rows (whole tiles), ping-pong
     for (int l0 = lbeg; l0 < lend; l0 += MG_TL) {
         const int lc = min(MG_TL, lend - l0);
-#if RFA_MG_PREFETCH && RFA_MG_ROLL && RFA_MG_LANECOL
         // the next tile's column records first: they are the oldest loads in flight when the next phase A needs them
         float cxn, cyn, czn;
         {
@@ -579,11 +532,9 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RFA_MG_WPE,
             czn = B[ll * 3 + 2];
         }
         __builtin_amdgcn_sched_barrier(0);
-        // (a full tile -- all but the last of a range whose length is no multiple of 32 -- needs no row mask: one multiplication
-        // per element less in a kernel whose VALU pipe is 70 % busy, profiles/r04_rocprofv3_summary.txt (B))
-#define RFA_MCG_PHASE_A(MASKED)                                                                                          \
+#define RFA_MCG_PHASE_A(WHOLE)                                                                                           \
     _Pragma("unroll") for (int g = 0; g < MG_TL; g += 8) {                                                               \
-        if (RFA_MG_SCOL && !MASKED) {                                                                                    \
+        if (WHOLE) {                                                                                                     \
             /* uniform addresses: scalar loads (the tile is whole: in bounds), one group ahead; scalar loads return out  \
                of order, so the wait for this group's records is lgkmcnt(0) and comes BEFORE the next group's issue */   \
             __builtin_amdgcn_s_waitcnt(0xC07F);                                                                          \
@@ -596,10 +547,10 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RFA_MG_WPE,
         }                                                                                                                \
         const float(&sc)[24] = scb[(g >> 3) & 1];                                                                        \
         _Pragma("unroll") for (int l = g; l < g + 8; l++) {                                                              \
-            const float dx = x1a - ((RFA_MG_SCOL && !MASKED) ? sc[(l - g) * 3 + 0] : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cxv), l))),   \
-                        dy = y1 - ((RFA_MG_SCOL && !MASKED) ? sc[(l - g) * 3 + 1] : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cyv), l))),    \
-                        dz = z1 - ((RFA_MG_SCOL && !MASKED) ? sc[(l - g) * 3 + 2] : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(czv), l)));    \
-            const float mvl = MASKED ? mv[l] * ((l0 + l < lend) ? 1.f : 0.f) : mv[l];                                    \
+            const float dx = x1a - (WHOLE ? sc[(l - g) * 3 + 0] : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cxv), l))), \
+                        dy = y1 - (WHOLE ? sc[(l - g) * 3 + 1] : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cyv), l))),  \
+                        dz = z1 - (WHOLE ? sc[(l - g) * 3 + 2] : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(czv), l)));  \
+            const float mvl = WHOLE ? mv[l] : mv[l] * ((l0 + l < lend) ? 1.f : 0.f);                                     \
             const float q = mvl * __builtin_amdgcn_rsqf(fmaxf(rf::d2_fma(dx, dy, dz), 1e-20f));                          \
             ax = fmaf(dx, q, ax);                                                                                        \
             ay = fmaf(dy, q, ay);                                                                                        \
@@ -610,95 +561,18 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RFA_MG_WPE,
             mv[l] = *(const float *)((const char *)(M + (size_t)min(l0 + MG_TL + l, lend - 1) * n) + koff);              \
         __builtin_amdgcn_sched_barrier(0); /* 8 rows at a time: the scheduler otherwise hoists all 32 rows' work */      \
     }
-        float scb[2][24];
         if (lc == MG_TL) {  // (uniform)
-            if (RFA_MG_SCOL) {
-                const float *bp = B + (size_t)l0 * 3;
+            const float *bp = B + (size_t)l0 * 3;
 #pragma unroll
-                for (int i = 0; i < 24; i++) scb[0][i] = bp[i];
-            }
-            RFA_MCG_PHASE_A(false)
-        } else {
+            for (int i = 0; i < 24; i++) scb[0][i] = bp[i];
             RFA_MCG_PHASE_A(true)
+        } else {
+            RFA_MCG_PHASE_A(false)
         }
 #undef RFA_MCG_PHASE_A
-#elif RFA_MG_PREFETCH
-#pragma unroll
-        for (int l = 0; l < MG_TL; l++) {
-#if RFA_MG_LDSCOL
-            const float4 c2 = cx2[l];
-            const float dx = x1 - c2.x, dy = y1 - c2.y, dz = z1 - c2.z;
-#elif RFA_MG_LANECOL
-            const float dx = x1 - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cxv), l)),
-                        dy = y1 - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cyv), l)),
-                        dz = z1 - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(czv), l));
-#else
-            const int ll = min(l0 + l, m - 1);  // uniform -> scalar loads
-            const float dx = x1 - B[ll * 3], dy = y1 - B[ll * 3 + 1], dz = z1 - B[ll * 3 + 2];
-#endif
-            const float q = mv[l] * __builtin_amdgcn_rsqf(fmaxf(rf::d2_fma(dx, dy, dz), 1e-20f));
-            ax = fmaf(dx, q, ax);
-            ay = fmaf(dy, q, ay);
-            az = fmaf(dz, q, az);
-            qs[l][t] = q;
-            if ((l & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // (8 rows at a time: the scheduler otherwise hoists all 32 rows' work)
-        }
-        float nx[MG_TL];
-#pragma unroll
-        for (int l = 0; l < MG_TL; l++)
-            nx[l] = *(const float *)((const char *)(M + (size_t)min(l0 + MG_TL + l, m - 1) * n) + koff) *
-                    ((l0 + MG_TL + l < lend) ? livef : 0.f);
-#if RFA_MG_LANECOL
-        float cxn, cyn, czn;
-        {
-            const int ll = min(l0 + MG_TL + (t & (MG_TL - 1)), m - 1);
-            cxn = B[ll * 3];
-            cyn = B[ll * 3 + 1];
-            czn = B[ll * 3 + 2];
-        }
-#endif
-#else
-        // 8 rows at a time (the group loop is NOT unrolled): with all 32 rows of the tile in flight
-        // the kernel needed 177 VGPRs = 2 waves per SIMD, and with three barriers per tile it is
-        // occupancy that hides the latencies
-        constexpr int MG_G = 8;
-#pragma unroll 1
-        for (int g = 0; g < MG_TL; g += MG_G) {
-            float mv[MG_G];
-#pragma unroll
-            for (int l = 0; l < MG_G; l++)
-                mv[l] = (live && g + l < lc) ? M[(size_t)(l0 + g + l) * n + kk] : 0.f;
-#pragma unroll
-            for (int l = 0; l < MG_G; l++) {
-                const int ll = min(l0 + g + l, m - 1);  // uniform -> scalar loads
-                const float dx = x1 - B[ll * 3], dy = y1 - B[ll * 3 + 1], dz = z1 - B[ll * 3 + 2];
-                const float q = mv[l] * __builtin_amdgcn_rsqf(fmaxf(rf::d2_fma(dx, dy, dz), 1e-20f));
-                ax = fmaf(dx, q, ax);
-                ay = fmaf(dy, q, ay);
-                az = fmaf(dz, q, az);
-                qs[g + l][t] = q;
-            }
-        }
-#endif
-#if RFA_MG_ABL < 3
         __syncthreads();
-#endif
-#if RFA_MG_PREFETCH && RFA_MG_LDSCOL
-        if (t >= 128 && t < 128 + MG_TL) {  // the next tile's columns (cx2 was last read before the barrier above)
-            const int ll = min(l0 + MG_TL + (t - 128), m - 1);
-            cx2[t - 128] = make_float4(B[ll * 3], B[ll * 3 + 1], B[ll * 3 + 2], 0.f);
-        }
-#endif
-#if RFA_MG_ABL < 2
         {
-#if RFA_MG_PREFETCH && RFA_MG_LANECOL
-            // (this thread's phase-B row is l0 + (t & 31): exactly the column record its lane already holds -- loading it
-            // here put a dependent global round trip behind the barrier of every tile)
             const float x2 = cxv, y2 = cyv, z2 = czv;
-#else
-            const int ll = min(l0 + bl, m - 1);
-            const float x2 = B[ll * 3], y2 = B[ll * 3 + 1], z2 = B[ll * 3 + 2];
-#endif
             float sx = 0.f, sy = 0.f, sz = 0.f;
 #pragma unroll 8
             for (int j = 0; j < MG_TL; j++) {
@@ -713,43 +587,19 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RFA_MG_WPE,
             ps[br][bl][1] = sy;
             ps[br][bl][2] = sz;
         }
-#endif
-#if RFA_MG_ABL < 3
         __syncthreads();
-#endif
-        if (RFA_MG_ABL < 2 && t < MG_TL * 3) {
+        if (t < MG_TL * 3) {
             const int l = t / 3, c = t - l * 3;
             if (l < lc) {
                 float v = 0.f;
 #pragma unroll
                 for (int r = 0; r < TPB / MG_TL; r++) v += ps[r][l][c];
-#if RFA_MG_ABL == 1  // (timing-only ablation, tools/ variants: no grad2 atomics)
-                if (v == 12345.f) grad2[0] = v;
-#else
                 atomicAdd(&grad2[((size_t)bi * m + l0 + l) * 3 + c], v);
-#endif
             }
         }
-#if !(RFA_MG_PREFETCH && RFA_MG_LDSCOL && RFA_MG_2BAR) && RFA_MG_ABL < 3
-        // qs / ps are rewritten only after the next tile's first barrier-separated phase
-        __syncthreads();
-#endif
-        // (prefetch form: TWO barriers per tile.  The next tile's phase A only writes qs -- last read before this tile's
-        // second barrier -- and reads cx2, rewritten between this tile's two barriers; ps is rewritten after the next
-        // tile's first barrier, which no thread passes before its own phase C here is done)
-#if RFA_MG_PREFETCH && RFA_MG_ROLL && RFA_MG_LANECOL
         cxv = cxn;
         cyv = cyn;
         czv = czn;
-#elif RFA_MG_PREFETCH
-#pragma unroll
-        for (int l = 0; l < MG_TL; l++) mv[l] = nx[l];
-#if RFA_MG_LANECOL
-        cxv = cxn;
-        cyv = cyn;
-        czv = czn;
-#endif
-#endif
     }
     if (live) {
         float *g = grad1 + ((size_t)bi * n + k) * 3;

@@ -103,13 +103,6 @@ namespace {
 #ifndef RFP_STR_SMALL_LEAF
 #define RFP_STR_SMALL_LEAF 32
 #endif
-#ifndef RFP_FORCE_PACK4
-#define RFP_FORCE_PACK4 0  // (experiment) one-wave groups packed 4 to a workgroup even when the launch holds nothing else
-#endif
-#ifndef RFP_MIX
-#define RFP_MIX 0  // sweep grid, per cloud: 0 = direction 0's workgroups then direction 1's; 1 = interleaved in proportion (measured
-                   // slower: 56.2 vs 52.2 us at C2); 2 = direction 1's first
-#endif
 #ifndef RFP_CLOUD_END
 #define RFP_CLOUD_END 0  // 1 (instrumented build): stats[c & 31] = s_memrealtime (100 MHz) at which the last workgroup of cloud c
                          // left the sweep, INSTEAD of the counters: how far apart the clouds of one launch finish
@@ -1507,6 +1500,12 @@ constexpr int T16_CAPB = 16;  // entries of a quad's block list (the lists of a 
 constexpr int T16_UN5 = 4;    // list rounds per trip of step 4 (their gathers in flight together)
 constexpr int T16_UN6 = 2;    // block-test rounds per trip of step 5
 constexpr int T16_KK = 5;     // tile keys kept in registers: candidate sets of up to 320 superblocks
+struct SharedLds {  // sweep_group<true>: the group's shared minima and the four waves' results
+    int shbest[64];
+    float md[RFP_NSH][64];
+    unsigned mi[RFP_NSH][64];
+    int mp[RFP_NSH][64];
+};
 struct T16Lds {
     unsigned short qsb[16][T16_CAPS];
     float2 qe[16][T16_CAPB];  // (bound, block id): a pair of entries is one 16-byte LDS read
@@ -1947,12 +1946,17 @@ __global__ __launch_bounds__(64 * NSH) __attribute__((amdgpu_waves_per_eu(RFP_WP
     const float *__restrict__ b64_0, const float *__restrict__ b64_1, float *__restrict__ dist0,
     float *__restrict__ dist1, int *__restrict__ idx0, int *__restrict__ idx1,
     unsigned long long *__restrict__ stats) {
-    extern __shared__ unsigned keys_dyn[];  // [waves][kstride]: each wave's list of superblock keys
-    __shared__ int shbest[64];
-    __shared__ float md[NSH][64];
-    __shared__ unsigned mi[NSH][64];
-    __shared__ int mp[GRAD ? NSH : 1][64];
+    extern __shared__ unsigned keys_dyn[];  // [waves][kstride]: each wave's list of superblock keys, then SharedLds | T16Lds[NSH]
     __shared__ unsigned long long gmsh[NSH];
+    // The shared-group form's exchange arrays live in DYNAMIC LDS too, over the tiles' lists (a workgroup is one or the other):
+    // as static arrays their 3.3 KB were charged to every workgroup, 20.3 KB in all = 7 workgroups per CU = exactly the 28 wave
+    // slots -- and a workgroup's LDS is held until its LAST wave ends (18 us for the slowest of four against 15 on average).
+    // With 17 KB, 9 fit: the wave slots bind, and a new workgroup starts as soon as any four are free.
+    SharedLds *shl = (SharedLds *)(keys_dyn + (size_t)(blockDim.x >> 6) * a.kstride);
+    int *shbest = shl->shbest;
+    float(*md)[64] = shl->md;
+    unsigned(*mi)[64] = shl->mi;
+    int(*mp)[64] = shl->mp;
 
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1964,51 +1968,12 @@ __global__ __launch_bounds__(64 * NSH) __attribute__((amdgpu_waves_per_eu(RFP_WP
     const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (int)(blockIdx.x >> 3);
     const int wpc = a.wg0 + a.wg1;  // workgroups per batch element
-    int bi = logical / wpc;
+    const int bi = logical / wpc;
     int wg = logical - bi * wpc;
-#if RFP_MIX >= 3
-    // per XCD (b a multiple of 8: every XCD holds b / 8 whole clouds): direction 0's workgroups of ALL its clouds first, then direction
-    // 1's -- the quad tiles are the waves with the long-tailed durations (p99 26 us, max 37 against 15 +- 4 for the one-wave groups,
-    // profiles/r04_rescan.txt), and cloud-major order starts the last cloud's tiles 19 us into a 44 us launch.  4: direction 1's
-    // workgroups dealt round-robin over the XCD's clouds instead of cloud by cloud
-    int dir;
-    if ((a.b & 7) == 0 && a.wg0 && a.wg1) {
-        const int ncl = a.b >> 3, local = (int)(blockIdx.x >> 3);
-        int cl;
-        if (local < ncl * a.wg0) {
-            dir = 0;
-            cl = local / a.wg0;
-            wg = local - cl * a.wg0;
-        } else {
-            const int l2 = local - ncl * a.wg0;
-            dir = 1;
-            if (RFP_MIX == 4) {
-                wg = l2 / ncl;
-                cl = l2 - wg * ncl;
-            } else {
-                cl = l2 / a.wg1;
-                wg = l2 - cl * a.wg1;
-            }
-        }
-        bi = xcd * ncl + cl;
-    } else {
-        dir = wg >= a.wg0;
-        if (dir) wg -= a.wg0;
-    }
-#elif RFP_MIX == 2
-    // direction 1's workgroups of the cloud first, then direction 0's
-    const int dir = wg < a.wg1 ? 1 : 0;
-    if (!dir) wg -= a.wg1;
-#elif RFP_MIX
-    // the two directions' workgroups of a cloud INTERLEAVED in proportion (position p is direction 0 when the count of
-    // direction-0 workgroups among positions <= p steps up), instead of all of direction 0's first
-    const int c0 = (int)(((long)wg * a.wg0) / wpc), c1 = (int)(((long)(wg + 1) * a.wg0) / wpc);
-    const int dir = c1 > c0 ? 0 : 1;
-    wg = dir ? wg - c0 : c0;
-#else
+    // (other grid orders -- direction 1 first, the two interleaved per cloud, per XCD all of direction 0's workgroups first -- all measured
+    // slower: tools/experiments/sweep_grid_orders.patch.txt)
     const int dir = wg >= a.wg0;
     if (dir) wg -= a.wg0;
-#endif
     if (a.nw[dir] == NSH) {
 #if RFP_TILE16
         // the candidate cloud's crowded flag (written by the sort behind pos0): uniform per workgroup
@@ -2322,9 +2287,10 @@ static int sweep_sorted_impl(int b, int n, int m, const Sorted &s0, const Sorted
         wa.kstride = (longest + 63) / 64 * 64;
     }
     const bool shared_groups = (want[0] && wa.nw[0] == NSH) || (want[1] && wa.nw[1] == NSH);
-    const int tpb = (shared_groups || RFP_FORCE_PACK4) ? 64 * NSH : 64;
+    const int tpb = shared_groups ? 64 * NSH : 64;
     const int pack = tpb / 64;  // one-wave groups per workgroup
-    const size_t shmem = pack * wa.kstride * sizeof(unsigned) + ((RFP_TILE16 && shared_groups) ? NSH * sizeof(T16Lds) : 0);
+    const size_t aux = !shared_groups ? 0 : (RFP_TILE16 && NSH * sizeof(T16Lds) > sizeof(SharedLds) ? NSH * sizeof(T16Lds) : sizeof(SharedLds));
+    const size_t shmem = pack * wa.kstride * sizeof(unsigned) + aux;
     wa.wg0 = !want[0] ? 0 : (wa.nw[0] == NSH ? wa.groups[0] : rf::ceil_div(wa.groups[0], pack));
     wa.wg1 = !want[1] ? 0 : (wa.nw[1] == NSH ? wa.groups[1] : rf::ceil_div(wa.groups[1], pack));
     if (ge) {
