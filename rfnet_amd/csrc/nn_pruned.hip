@@ -1046,10 +1046,6 @@ __device__ __forceinline__ void sweep_group(
     const float qz = Q[(size_t)(g * SB + lane) * 3 + 2];
     const int qorig = Qo[g * SB + lane];
     const bool valid = qorig >= 0;
-    float gq = 0.f;  // upstream gradient of this query's distance (GRAD): fetched now, used in the epilogue
-    if constexpr (GRAD) {
-        if (valid) gq = ge.gd[dir][(size_t)bi * a.n[dir] + qorig];
-    }
     // A query with a NaN coordinate can never tighten its bound (every d2 is NaN): it takes no part
     // in the traversal -- it would drag its whole wave through every superblock -- and is written as
     // (NaN, 0), what the reference returns for it (tf_nndistance_g.cu:27-31).
@@ -1373,6 +1369,13 @@ __device__ __forceinline__ void sweep_group(
             }
         }
     };
+    // upstream gradient of this query's distance (GRAD): requested with the re-scan's gathers, used by the emit.  (At the top of
+    // the function its address waits for the query's original index, and every load behind it in program order -- the
+    // candidate boxes of the keys -- waited with it: one more round trip at the head of every wave.)
+    float gq = 0.f;
+    if constexpr (GRAD) {
+        if (valid) gq = ge.gd[dir][(size_t)bi * a.n[dir] + qorig];
+    }
     rescan(bblk);
     if (__ballot(bblk2 >= 0) != 0ull) {
         if (bblk2 >= 0) rescan(bblk2);
@@ -1580,10 +1583,6 @@ __device__ __forceinline__ void sweep_tile16(
     const float qx = Q[(size_t)qpos * 3 + 0], qy = Q[(size_t)qpos * 3 + 1], qz = Q[(size_t)qpos * 3 + 2];
     const int qorig = Qo[qpos];
     const bool valid = qorig >= 0;
-    float gq = 0.f;
-    if constexpr (GRAD) {
-        if (valid) gq = ge.gd[dir][(size_t)bi * a.n[dir] + qorig];
-    }
     const bool qnan = qx != qx || qy != qy || qz != qz;  // (NaN, 0), as sweep_group
     const bool part = valid && !qnan;
     // the tile's box = the query set's own block box (padding and NaN excluded by the sort)
@@ -1656,23 +1655,24 @@ __device__ __forceinline__ void sweep_tile16(
     };
     auto nibble = [&](bool pred) { return (unsigned)(__builtin_amdgcn_ballot_w64(pred) >> (lane & ~3)) & 0xFu; };
 
+    // (up to 320 superblocks -- every cloud of the register-resident sort -- the keys stay in registers for step 3 and their
+    // loads are all in flight together, AHEAD of the branch on `part`: behind it they were issued only once the query's own
+    // loads had come back)
+    const bool inreg = nsb <= 64 * T16_KK;  // uniform
+    float kk[T16_KK];
+    if (inreg) {
+#pragma unroll
+        for (int c = 0; c < T16_KK; c++) {
+            // (clamped index, select afterwards: a load under `c * 64 + lane < nsb` is a branch with its own wait per round -- five
+            // dependent round trips for a 16384-point candidate cloud, a quarter of a tile wave's life by the stamps)
+            const float key = tile_key(min(c * 64 + lane, nsb - 1));
+            kk[c] = c * 64 + lane < nsb ? key : INFINITY;
+        }
+    }
     if (__builtin_amdgcn_ballot_w64(part) != 0ull) {
         // 1. superblocks that overlap the tile box -> sbl[0 .. n0), at most 64 (they only seed); else the nearest
         int n0 = 0;
         unsigned kmin = 0xFFFFFFFFu;
-        // (up to 320 superblocks -- every cloud of the register-resident sort -- the keys stay in registers for step 3
-        // and their loads are all in flight together)
-        const bool inreg = nsb <= 64 * T16_KK;  // uniform
-        float kk[T16_KK];
-        if (inreg) {
-#pragma unroll
-            for (int c = 0; c < T16_KK; c++) {
-                // (clamped index, select afterwards: a load under `c * 64 + lane < nsb` is a branch with its own wait per round -- five
-                // dependent round trips for a 16384-point candidate cloud, a quarter of a tile wave's life by the stamps)
-                const float key = tile_key(min(c * 64 + lane, nsb - 1));
-                kk[c] = c * 64 + lane < nsb ? key : INFINITY;
-            }
-        }
         auto seed_cand = [&](int s, float lb) {
             const bool z = lb == 0.f;
             const unsigned long long m = __builtin_amdgcn_ballot_w64(z);
@@ -1841,6 +1841,10 @@ __device__ __forceinline__ void sweep_tile16(
             wp_ = b ? wb * BS + k * 4 + u : wp_;
         }
     };
+    float gq = 0.f;  // (GRAD) upstream gradient of the query's distance: requested with the re-scan's gathers (see sweep_group)
+    if constexpr (GRAD) {
+        if (valid) gq = ge.gd[dir][(size_t)bi * a.n[dir] + qorig];
+    }
     if (part) rescan(bblk, besti, wpos);
     if (__builtin_amdgcn_ballot_w64(part && bblk2 >= 0) != 0ull) {
         if (part && bblk2 >= 0) rescan(bblk2, besti, wpos);

@@ -7,9 +7,9 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetchsize" -- python3 "$R/tools/run_step_once.py" > /dev/null 2> "$OUT/f.err"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$R/tools/run_step_once.py" > /dev/null 2> "$OUT/w.err"
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_sq" -- python3 "$R/tools/run_step_once.py" > /dev/null 2> "$OUT/h.err"
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetchsize" -- python3 "$R/tools/run_step_once.py" > /dev/null 2> "$OUT/f.err"
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$R/tools/run_step_once.py" > /dev/null 2> "$OUT/w.err"
+timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_sq" -- python3 "$R/tools/run_step_once.py" > /dev/null 2> "$OUT/h.err"
 python3 - "$OUT" <<'PY'
 import csv, glob, os, sys
 from collections import defaultdict
