@@ -404,6 +404,7 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
             atomicAdd(&ahist[1][axis_bin(py[k], fl[1], fs[1])], 1u);
             atomicAdd(&ahist[2][axis_bin(pz[k], fl[2], fs[2])], 1u);
         }
+        __builtin_amdgcn_sched_barrier(0);  // (one sample at a time: interleaved, their temporaries push the kernel past its 128 registers)
     }
     __syncthreads();
     // Sort-tile-recursive order from histograms: SS slabs of equal mass along x (marginal x histogram), inside

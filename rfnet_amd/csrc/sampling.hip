@@ -121,6 +121,8 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, const float *
 #pragma unroll
     for (int s = 0; s < PPT; s++) {
         int k = (t & 511) + 512 * (s * HALVES + (t >> 9));
+        // (these loads are PPT branches with a wait each -- ~15 us at the head of a 1.12 ms launch at C3.  As clamped loads with selects
+        // they are one batch, and the KERNEL is slower, 1.208 vs 1.124 ms: the register allocation of the iteration loop changes)
         if (k < n) {
             px[s] = P[k * 3 + 0];
             py[s] = P[k * 3 + 1];
