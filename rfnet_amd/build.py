@@ -30,6 +30,10 @@ HIPCC_FLAGS = [
     "-Wall",
     "-Wno-unused-function",
 ]
+# per-kernel register / scratch / LDS figures of every compile, kept next to the objects (csrc/build/*.resources.txt) and read
+# by kernel_resources(): tests/test_kernel_resources.py holds the hot kernels to "no scratch, the occupancy they were tuned for"
+# (round 4 found a re-scan batch and a histogram loop that spilled without anyone noticing)
+RESOURCE_FLAG = "-Rpass-analysis=kernel-resource-usage"
 
 
 def _hipcc():
@@ -58,8 +62,8 @@ def build_library(force=False, verbose=False):
     for s in srcs:
         o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
-        if force or _newer(o, [s] + hdrs):
-            jobs.append([hipcc] + HIPCC_FLAGS + ["-c", s, "-o", o])
+        if force or _newer(o, [s] + hdrs) or not os.path.exists(o[:-2] + ".resources.txt"):
+            jobs.append([hipcc] + HIPCC_FLAGS + [RESOURCE_FLAG, "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -71,12 +75,36 @@ def build_library(force=False, verbose=False):
 
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
-            for out in ex.map(run, jobs):
-                if verbose and out.strip():
-                    print(out)
+            for cmd, out in zip(jobs, ex.map(run, jobs)):
+                remarks = [ln for ln in out.splitlines() if "kernel-resource-usage" in ln]
+                with open(cmd[-1][:-2] + ".resources.txt", "w") as f:
+                    f.write("\n".join(remarks) + "\n")
+                rest = "\n".join(ln for ln in out.splitlines() if "kernel-resource-usage" not in ln and not ln.startswith(("   ", "      |")))
+                if verbose and rest.strip():
+                    print(rest)
     if force or jobs or _newer(LIB, objs):
         run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB
+
+
+def kernel_resources():
+    """{mangled kernel name: {"sgprs", "vgprs", "agprs", "scratch", "occupancy", "sgpr_spill", "vgpr_spill", "lds"}} of the
+    library as last compiled (hipcc's kernel-resource-usage remarks; builds the library if a report is missing)."""
+    build_library()
+    keys = {"TotalSGPRs": "sgprs", "VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scratch",
+            "Occupancy [waves/SIMD]": "occupancy", "SGPRs Spill": "sgpr_spill", "VGPRs Spill": "vgpr_spill",
+            "LDS Size [bytes/block]": "lds"}
+    res, cur = {}, None
+    for path in sorted(glob.glob(os.path.join(OBJ, "*.resources.txt"))):
+        for ln in open(path):
+            body = ln.split("remark:", 1)[-1].rsplit("[-Rpass", 1)[0].strip()
+            if body.startswith("Function Name:"):
+                cur = res.setdefault(body.split(":", 1)[1].strip(), {})
+            elif cur is not None and ":" in body:
+                k, v = body.rsplit(":", 1)
+                if k.strip() in keys and v.strip().lstrip("-").isdigit():
+                    cur[keys[k.strip()]] = int(v)
+    return res
 
 
 if __name__ == "__main__":
