@@ -1501,11 +1501,17 @@ __device__ __forceinline__ void sweep_group(
 // Steps 4-6 run in bounded chunks (a list that could overflow is drained first), so any input is handled by the same
 // code.  Same outputs as sweep_group: the same d2 sequence on the same pairs' survivors, bounds culled strictly, the
 // lowest original index among exact ties (two equal blocks re-scanned, a third one -> exhaustive pass).
+#ifndef RFP_T16_CAPB
+#define RFP_T16_CAPB 16
+#endif
+#ifndef RFP_T16_UN6
+#define RFP_T16_UN6 2
+#endif
 constexpr int T16_CAPS = 32;  // entries of a quad's superblock list
-constexpr int T16_CAPB = 16;  // entries of a quad's block list (the lists of a 4-tile workgroup + its key lists must stay under
+constexpr int T16_CAPB = RFP_T16_CAPB;  // entries of a quad's block list (the lists of a 4-tile workgroup + its key lists must stay under
                               // 160 KB / 7: with 32 entries the launch's workgroups -- the other direction's too -- drop to 6 per CU)
 constexpr int T16_UN5 = 4;    // list rounds per trip of step 4 (their gathers in flight together)
-constexpr int T16_UN6 = 2;    // block-test rounds per trip of step 5
+constexpr int T16_UN6 = RFP_T16_UN6;    // block-test rounds per trip of step 5
 constexpr int T16_KK = 5;     // tile keys kept in registers: candidate sets of up to 320 superblocks
 struct SharedLds {  // sweep_group<true>: the group's shared minima and the four waves' results
     int shbest[64];
