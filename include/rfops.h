@@ -20,7 +20,12 @@
  *     exception is the opt-in measurement hook at the end of this file (rf_profile_*), which is
  *     process-global, thread-safe and off by default;
  *   - every call that launches work first checks that the calling thread's current HIP device
- *     is a gfx950 (the only code objects in the library) and returns RF_ENODEVICE otherwise.
+ *     is a gfx950 (the only code objects in the library) and returns RF_ENODEVICE otherwise;
+ *   - `workspace` buffers and sorted-set handles (rf_nn_sort) must be 16-byte aligned -- the kernels read
+ *     them with 16-byte vector loads at 256-byte-multiple offsets; any hipMalloc pointer is.  A misaligned
+ *     one is RF_EINVAL (culled Chamfer paths, approx_match, earth_mover), not a fault inside a kernel.
+ *     Tensor arguments need their element's natural alignment (4 bytes), except rf_point_affine's
+ *     (16 bytes: rows of c % 4 == 0 floats).
  *
  * Status codes: 0 = success; > 0 = the hipError_t of the failing HIP call;
  *               < 0 = RF_EINVAL-style argument errors below.
@@ -38,7 +43,7 @@ extern "C" {
 #endif
 
 #define RF_OK 0
-#define RF_EINVAL (-1)     /* negative size, NULL pointer with non-zero size, bad attribute */
+#define RF_EINVAL (-1)     /* negative size, NULL pointer with non-zero size, bad attribute, misaligned workspace */
 #define RF_EWORKSPACE (-2) /* workspace smaller than rf_*_workspace_bytes() says            */
 #define RF_ENODEVICE (-3)  /* no gfx950 device / code object could not be loaded            */
 

@@ -1132,7 +1132,7 @@ int rf_approxmatch_levels(int b, int n, int m, const float *xyz1, const float *x
     if (b < 0 || b > MAX_BATCH || n < 0 || m < 0 || nlevels <= 0 || nlevels > MAX_LEVELS || !levels_host)
         return RF_EINVAL;
     if (b == 0 || n == 0 || m == 0) return RF_OK;
-    if (!xyz1 || !xyz2 || !match || !workspace) return RF_EINVAL;
+    if (!xyz1 || !xyz2 || !match || !workspace || !rf::aligned16(workspace)) return RF_EINVAL;
     if (workspace_bytes < rf_approxmatch_workspace_bytes(b, n, m, nlevels)) return RF_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     float multiL, multiR;
@@ -1273,7 +1273,7 @@ int rf_earth_mover(int b, int n, int m, const float *xyz1, const float *xyz2, fl
         RF_ZERO(cost, sizeof(float) * b, s);
         return RF_OK;
     }
-    if (!xyz1 || !xyz2 || !workspace) return RF_EINVAL;
+    if (!xyz1 || !xyz2 || !workspace || !rf::aligned16(workspace)) return RF_EINVAL;
     if (workspace_bytes < rf_earth_mover_workspace_bytes(b, n, m)) return RF_EWORKSPACE;
     const EmdLayout E = emd_layout(b, n, m);
     float *w = (float *)workspace;

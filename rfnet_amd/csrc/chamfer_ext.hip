@@ -171,6 +171,7 @@ int run_forward(int b, int n, int m, const float *xyz1, const float *xyz2, const
                 hipStream_t s) {
     const FwdPlan p = plan_forward(b, n, m, dirs, sorted1 != nullptr, sorted2 != nullptr);
     if (workspace_bytes < p.bytes || (p.bytes && !workspace)) return RF_EWORKSPACE;
+    if (!rf::aligned16(workspace) || !rf::aligned16(sorted1) || !rf::aligned16(sorted2)) return RF_EINVAL;
     char *w = (char *)workspace;
     if (!p.culled)
         return rfd::dense_nn_distance(b, n, m, xyz1, xyz2, dist1, idx1, dist2, idx2, w + p.off_dense,
@@ -217,7 +218,7 @@ int rf_nn_distance_dir(int b, int n, int m, const float *xyz1, const float *xyz2
 size_t rf_nn_sort_bytes(int b, int n) { return rfp::sorted_bytes(b, n); }
 
 int rf_nn_sort(int b, int n, const float *xyz, void *sorted, size_t sorted_bytes, rf_stream_t stream) {
-    if (b <= 0 || n <= 0 || n > rfp::kMaxPoints || !xyz || !sorted) return RF_EINVAL;
+    if (b <= 0 || n <= 0 || n > rfp::kMaxPoints || !xyz || !sorted || !rf::aligned16(sorted)) return RF_EINVAL;
     if (sorted_bytes < rfp::sorted_bytes(b, n)) return RF_EWORKSPACE;
     const rfp::Sorted v = rfp::sorted_view(b, n, sorted);
     return rfp::sort_sets(b, 1, &n, &xyz, &v, (hipStream_t)stream, nullptr);
@@ -225,7 +226,7 @@ int rf_nn_sort(int b, int n, const float *xyz, void *sorted, size_t sorted_bytes
 
 int rf_nn_distance_sorted(int b, int n, int m, const void *sorted1, const void *sorted2, float *dist1, int *idx1,
                           float *dist2, int *idx2, rf_stream_t stream) {
-    if (!rfp::pruned_supported(b, n, m) || !sorted1 || !sorted2) return RF_EINVAL;
+    if (!rfp::pruned_supported(b, n, m) || !sorted1 || !sorted2 || !rf::aligned16(sorted1) || !rf::aligned16(sorted2)) return RF_EINVAL;
     const int dirs = dirs_of(dist1 && idx1, dist2 && idx2);
     if (!dirs) return RF_EINVAL;
     return rfp::sweep_sorted(b, n, m, rfp::sorted_view(b, n, sorted1), rfp::sorted_view(b, m, sorted2),

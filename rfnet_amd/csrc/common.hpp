@@ -39,6 +39,11 @@ int require_device();
 // Returns an RF_* / hipError status (runtime.hip).
 int zero_async(void *p, size_t bytes, hipStream_t s);
 
+// Workspaces and sorted-set handles are read with 16-byte vector loads at offsets that are multiples of 256: the pointer the
+// caller hands over must be 16-byte aligned (include/rfops.h; anything hipMalloc returns is).  Checked at the boundary -- a
+// misaligned sub-allocation would otherwise be a memory fault inside a kernel.
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
 }  // namespace rf
 
 #define RF_HIP(expr)                            \

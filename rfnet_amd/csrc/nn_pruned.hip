@@ -2336,7 +2336,7 @@ size_t pruned_step_workspace_bytes(int b, int n, int m) {
 int pruned_step(int b, int n, int m, const float *xyz1, const float *xyz2, const float *gd1, const float *gd2,
                 float *dist1, int *idx1, float *dist2, int *idx2, float *grad_xyz1, float *grad_xyz2, void *workspace,
                 size_t workspace_bytes, hipStream_t s) {
-    if (!pruned_supported(b, n, m) || !gd1 || !gd2 || !grad_xyz1 || !grad_xyz2) return RF_EINVAL;
+    if (!pruned_supported(b, n, m) || !gd1 || !gd2 || !grad_xyz1 || !grad_xyz2 || !rf::aligned16(workspace)) return RF_EINVAL;
     if (workspace_bytes < pruned_step_workspace_bytes(b, n, m)) return RF_EWORKSPACE;
     char *w = (char *)workspace;
     const Sorted so[2] = {sorted_view(b, n, w), sorted_view(b, m, w + sorted_bytes(b, n))};
@@ -2379,7 +2379,7 @@ int pruned_step(int b, int n, int m, const float *xyz1, const float *xyz2, const
 int pruned_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist1, int *idx1,
                        float *dist2, int *idx2, void *workspace, size_t workspace_bytes, hipStream_t s,
                        unsigned long long *stats_out, int dirs) {
-    if (!pruned_supported(b, n, m)) return RF_EINVAL;
+    if (!pruned_supported(b, n, m) || !rf::aligned16(workspace)) return RF_EINVAL;
     if (workspace_bytes < pruned_workspace_bytes(b, n, m)) return RF_EWORKSPACE;
     char *w = (char *)workspace;
     const Sorted so[2] = {sorted_view(b, n, w), sorted_view(b, m, w + sorted_bytes(b, n))};
@@ -2402,7 +2402,7 @@ int pruned_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2
 size_t sort_workspace_bytes(int b, int n) { return sorted_bytes(b, n); }
 
 int sort_clouds(int b, int n, const float *src, void *workspace, size_t workspace_bytes, hipStream_t s, Sorted *out) {
-    if (b <= 0 || n <= 0 || n > kMaxPoints || !src || !workspace || !out) return RF_EINVAL;
+    if (b <= 0 || n <= 0 || n > kMaxPoints || !src || !workspace || !out || !rf::aligned16(workspace)) return RF_EINVAL;
     if (workspace_bytes < sorted_bytes(b, n)) return RF_EWORKSPACE;
     *out = sorted_view(b, n, workspace);
     return sort_sets(b, 1, &n, &src, out, s, nullptr);

@@ -92,6 +92,22 @@ def test_workspace_queries_are_pure_host_functions():
     assert lib.rf_device_check() in (0, -3)  # RF_OK on the MI355X box, RF_ENODEVICE here
 
 
+def test_misaligned_workspace_is_an_argument_error():
+    """include/rfops.h: workspaces and sorted-set handles must be 16-byte aligned (the kernels read them with 16-byte vector
+    loads); a misaligned one is RF_EINVAL at the boundary -- checked before anything touches a device or the pointers."""
+    from rfnet_amd._lib import lib
+    p = 0x10000  # never dereferenced: every call below must return at its argument checks
+    ws = 0x200000
+    big = 1 << 32
+    b, n, m = 32, 2048, 16384  # a culled shape
+    assert lib.rf_chamfer_step(b, n, m, p, p, p, p, p, p, p, p, p, p, ws + 4, big, None) == -1
+    assert lib.rf_nn_distance(b, n, m, p, p, p, p, p, p, ws + 8, big, None) == -1
+    assert lib.rf_nn_sort(1, 4096, p, ws + 4, big, None) == -1
+    assert lib.rf_nn_distance_sorted(1, 4096, 4096, ws + 4, ws, p, p, p, p, None) == -1
+    assert lib.rf_approxmatch(1, 300, 300, p, p, p, ws + 12, big, None) == -1
+    assert lib.rf_earth_mover(1, 300, 300, p, p, p, None, None, ws + 4, big, None) == -1
+
+
 def test_reference_module_paths_and_names():
     """vv_recon.py:8-20 imports these modules and calls these names."""
     import pc_distance.tf_approxmatch as am
