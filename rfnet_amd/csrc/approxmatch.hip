@@ -404,9 +404,13 @@ __global__ __launch_bounds__(TPB) void mc_partial_kernel(int n, int m, const flo
                                                          float *partial) {
     __shared__ float cxyz[MC_L][4];
     __shared__ float wsum[TPB / 64];
-    const int bi = blockIdx.z;
+    // The batch elements LAST first, and of each its rows last first: match_cost follows approx_match, whose am_match wrote `match`
+    // (512 MiB at C4) in dispatch order, and what the 256 MB memory-side cache still holds is the END of the tensor.  Inside the
+    // sequence approx_match -> match_cost this kernel takes 112 us walking backwards and 131 us walking forwards (alone in a loop:
+    // 90 either way; tools/experiments/match_order.py); it ends at the head of the tensor, where match_cost_grad starts.
+    const int bi = gridDim.z - 1 - blockIdx.z;
+    const int l0 = (gridDim.y - 1 - blockIdx.y) * MC_L;
     const int k = blockIdx.x * TPB + threadIdx.x;
-    const int l0 = blockIdx.y * MC_L;
     const int lcnt = min(MC_L, m - l0);
     xyz1 += (size_t)bi * n * 3;
     xyz2 += (size_t)bi * m * 3;
@@ -432,7 +436,7 @@ __global__ __launch_bounds__(TPB) void mc_partial_kernel(int n, int m, const flo
     __syncthreads();
     if (threadIdx.x == 0) {
         float s = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
-        partial[((size_t)bi * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
+        partial[((size_t)bi * gridDim.y + l0 / MC_L) * gridDim.x + blockIdx.x] = s;
     }
 }
 
