@@ -2,7 +2,11 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"; O=gpurun_out/r04z; mkdir -p $O
-for rnd in 0 1; do
-timeout 300 python3 tools/experiments/match_order.py 2>&1 | grep -v amdgpu | sed 's/^/base  /'
-RFOPS_LIB=rfnet_amd/variants/librfops_mcfwd.so timeout 300 python3 tools/experiments/match_order.py 2>&1 | grep -v amdgpu | sed 's/^/mcfwd /'
-done > $O/match_order.txt; cat $O/match_order.txt
+timeout 1200 python3 -m pytest tests -m gpu -x -q 2>&1 | tail -3 > $O/pytest_all.txt; cat $O/pytest_all.txt
+python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+( time python3 bench.py --steps 100 --warmup 10 ) > $O/bench_last.json 2> $O/bench_last.err; tail -3 $O/bench_last.err
+python3 - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r04z/bench_last.json').read().strip().split('\n')[-1])
+print(d['value'], d['ms_per_step'], d['emd']['value'], d['emd']['ms_per_call'], d['per_op_roofline']['match_cost_grad']['frac'])
+PY
