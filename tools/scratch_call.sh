@@ -2,11 +2,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"; O=gpurun_out/r04z; mkdir -p $O
-timeout 1200 python3 -m pytest tests -m gpu -x -q 2>&1 | tail -3 > $O/pytest_all.txt; cat $O/pytest_all.txt
-python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-( time python3 bench.py --steps 100 --warmup 10 ) > $O/bench_last.json 2> $O/bench_last.err; tail -3 $O/bench_last.err
-python3 - <<'PY'
-import json
-d=json.loads(open('gpurun_out/r04z/bench_last.json').read().strip().split('\n')[-1])
-print(d['value'], d['ms_per_step'], d['emd']['value'], d['emd']['ms_per_call'], d['per_op_roofline']['match_cost_grad']['frac'])
-PY
+timeout 900 python3 -m pytest tests/test_gpu_chamfer_culled.py tests/test_gpu_chamfer_step_sorted.py tests/test_gpu_fuzz.py -x -q 2>&1 | tail -2
+timeout 600 python3 tools/ab_step.py base prev > $O/ab_step_bbox.txt 2>&1; cat $O/ab_step_bbox.txt
+timeout 200 python3 tools/experiments/sort_stamps.py 2>&1 | grep -v amdgpu
+timeout 200 python3 tools/soak_culled.py 60 | tail -1
