@@ -612,14 +612,19 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
         for (int p = cown - h0 + tid; p < cnt; p += STPB)  // padding records live at positions >= cown
             if (p >= 0) stg[p] = make_float4(INFINITY, INFINITY, INFINITY, __int_as_float(-1));
         __syncthreads();
-        // boxes: one thread per 16-record block, a quad of lanes per superblock (cnt/16 is a
-        // multiple of 4: quads are complete and inside one wave).  Record (u + t) % 16 at step u:
-        // lanes t and t+16 share banks, 4-way instead of 64-way conflicts.
-        if (tid < cnt / BS) {
+        stamp();
+        // boxes: TWO threads per 16-record block (8 records each), an octet of lanes per superblock (cnt / 16 is a multiple of 4:
+        // octets are complete and inside one wave).  Record (u + block + 4 half) % 8 of the half at step u: the two halves of a
+        // block and blocks 8 apart would otherwise meet in the same banks.  (One thread per block left half the workgroup idle
+        // behind a chain of 16 dependent-issue LDS reads: 3.8 k of the sort's 48 k cycles.)
+        // (a split half may hold up to HALF = 9216 records: 1152 half-blocks for 1024 threads -- a second trip for the first lanes)
+#pragma unroll 1
+        for (int t2 = tid; t2 < cnt / BS * 2; t2 += STPB) {
+            const int blk = t2 >> 1, hf = t2 & 1;
             float l[3] = {INFINITY, INFINITY, INFINITY}, hh[3] = {-INFINITY, -INFINITY, -INFINITY};
-#pragma unroll 4
-            for (int u = 0; u < BS; u++) {
-                const int r = tid * BS + ((u + tid) & (BS - 1));
+#pragma unroll 4  // (the points' 64 registers stay live across a staging round: 8 records in flight spill)
+            for (int u = 0; u < BS / 2; u++) {
+                const int r = blk * BS + hf * (BS / 2) + ((u + blk + 4 * hf) & (BS / 2 - 1));
                 const float4 v = stg[r];
                 if (h0 + r < cown) {  // padding excluded; NaN coordinates drop out of fminf/fmaxf
                     l[0] = fminf(l[0], v.x); hh[0] = fmaxf(hh[0], v.x);
@@ -627,22 +632,29 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
                     l[2] = fminf(l[2], v.z); hh[2] = fmaxf(hh[2], v.z);
                 }
             }
-            const int gblk = (base + h0) / BS + tid;
-            float *o = b16 + (size_t)(gblk >> 2) * B16F + (gblk & 3) * 6;
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                o[c] = l[c];
-                o[3 + c] = hh[c];
+                l[c] = fminf(l[c], __shfl_xor(l[c], 1, 64));
+                hh[c] = fmaxf(hh[c], __shfl_xor(hh[c], 1, 64));
+            }
+            const int gblk = (base + h0) / BS + blk;
+            if (hf == 0) {
+                float *o = b16 + (size_t)(gblk >> 2) * B16F + (gblk & 3) * 6;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    o[c] = l[c];
+                    o[3 + c] = hh[c];
+                }
             }
 #pragma unroll
-            for (int x = 1; x <= 2; x <<= 1) {
+            for (int x = 2; x <= 4; x <<= 1) {
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
                     l[c] = fminf(l[c], __shfl_xor(l[c], x, 64));
                     hh[c] = fmaxf(hh[c], __shfl_xor(hh[c], x, 64));
                 }
             }
-            if ((gblk & 3) == 0) {
+            if ((gblk & 3) == 0 && hf == 0) {
                 float *o64 = b64 + (size_t)(gblk >> 2) * B64F;
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
@@ -652,16 +664,20 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
                 o64[3] = o64[7] = 0.f;
             }
         }
+        stamp();
         {
-            // (16-byte stores instead -- a lane leaving with 4 consecutive floats of the packed stream and 4 consecutive indices, 8 store
-            // instructions per thread instead of 32 -- measured SLOWER: staging 17.0 k vs 13.5 k ticks, sort 28.3 vs 26.4 us: the LDS
-            // reads that feed them are strided by 16 / 3 and by 16 words and conflict, the dword form reads LDS conflict-free)
-            const float *sf = (const float *)stg;
-            for (int j = tid; j < cnt * 3; j += STPB) {
-                const int r = j / 3, c = j - r * 3;
-                oxyz[(size_t)(base + h0) * 3 + j] = sf[r * 4 + c];
+            // write-out: one 16-byte LDS read per record (consecutive lanes, consecutive records: conflict-free), out as a 12-byte
+            // store into the packed (x, y, z) stream -- a wave's 64 records are 768 contiguous bytes, as on the load side -- and a
+            // 4-byte store of the original index: 8 reads + 16 stores per thread.  (Per dword it was 32 + 32: 4.4 k cycles; as
+            // 16-byte stores of 4 consecutive floats the LDS reads are strided by 16 / 3 words and conflict: slower still.)
+            struct P3 {
+                float x, y, z;
+            };
+            for (int j = tid; j < cnt; j += STPB) {
+                const float4 v = stg[j];
+                *(P3 *)(oxyz + (size_t)(base + h0 + j) * 3) = P3{v.x, v.y, v.z};
+                oorig[base + h0 + j] = __float_as_int(v.w);
             }
-            for (int j = tid; j < cnt; j += STPB) oorig[base + h0 + j] = __float_as_int(sf[j * 4 + 3]);
         }
         __syncthreads();
         stamp();

@@ -6,7 +6,7 @@ from rfnet_amd import _raw as R
 rng = np.random.RandomState(100)
 a = torch.from_numpy(rng.randn(32, 2048, 3).astype(np.float32)).cuda()
 c = torch.from_numpy(rng.randn(32, 16384, 3).astype(np.float32)).cuda()
-names = ["start", "loads issued+zeroed", "bbox+tables", "quantiles", "keys+hist", "scan", "positions", "staging round 1", "staging round 2"]
+names = ["start", "loads issued+zeroed", "bbox+tables", "quantiles", "keys+hist", "scan", "positions", "staging: scatter to LDS", "staging: boxes", "staging: write-out", "round 2: scatter", "round 2: boxes", "round 2: write-out"]
 acc = []
 for _ in range(5):
     st = []
@@ -16,5 +16,5 @@ for _ in range(5):
 k = min(len(x) for x in acc)
 s = np.median(np.array([x[:k] for x in acc], dtype=np.float64), 0)
 for i in range(1, len(s)):
-    print(f"{names[i]:16s} {int(s[i] - s[i - 1]):8d} ticks")
+    print(f"{names[i]:26s} {int(s[i] - s[i - 1]):8d} ticks")
 print("total", int(s[-1] - s[0]), "shader-clock ticks (the last workgroup of the launch: second half of the last 16384-point cloud)")
