@@ -195,10 +195,12 @@ __device__ __forceinline__ unsigned hilbert15(unsigned x, unsigned y, unsigned z
 // bin of a coordinate: (v - lo) * scale clamped to [0, HB-1].  One v_med3_f32 does the clamp; a NaN
 // (NaN input, or inf * 0 when the axis has no extent) leaves it as NaN or a bound and converts to
 // 0 or a bound -- any bin is acceptable, the keys only steer the order.
-__device__ __forceinline__ int axis_bin(float v, float lo, float scale) {
-    const float f = __builtin_amdgcn_fmed3f((v - lo) * scale, 0.f, (float)(HB - 1));
-    const int b = (int)f;
-    return b < 0 ? 0 : (b > HB - 1 ? HB - 1 : b);
+// (`off` = -lo * scale: one fma, one float clamp, one conversion -- the clamp leaves [0, HB - 1] or, for a NaN, whatever
+// v_med3_f32 makes of it, which v_cvt_i32_f32 turns into 0 or a bound; as (v - lo) * scale with an integer clamp behind the
+// conversion it was six instructions, 15 times per point of the sort)
+__device__ __forceinline__ int axis_bin(float v, float off, float scale) {
+    const int b = (int)__builtin_amdgcn_fmed3f(fmaf(v, scale, off), 0.f, (float)(HB - 1));
+    return b & (HB - 1);  // (free insurance: a table index stays inside its table whatever the conversion returned)
 }
 
 __device__ __forceinline__ unsigned spread5(unsigned v) {  // bit b -> bit 3b
@@ -388,8 +390,8 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
         frame[3 + tid] = ok ? (float)HB / ext : 0.f;
     }
     __syncthreads();
-    const float fl[3] = {frame[0], frame[1], frame[2]};
     const float fs[3] = {frame[3], frame[4], frame[5]};
+    const float fl[3] = {-frame[0] * fs[0], -frame[1] * fs[1], -frame[2] * fs[2]};  // axis_bin's offsets
 
     stamp();
     // 2. per-axis histograms of a quarter of the points: the cells only need approximate
@@ -776,8 +778,8 @@ __global__ __launch_bounds__(STPB) void nnp_sort_kernel(SortArgs a) {
         frame[3 + tid] = ok ? (float)HB / ext : 0.f;
     }
     __syncthreads();
-    const float fl[3] = {frame[0], frame[1], frame[2]};
     const float fs[3] = {frame[3], frame[4], frame[5]};
+    const float fl[3] = {-frame[0] * fs[0], -frame[1] * fs[1], -frame[2] * fs[2]};  // axis_bin's offsets
 
     // 2. per-axis histograms of a quarter of the points (every 4th, staggered over the threads:
     // the cells only need approximate quantiles, and same-address LDS atomics serialise)
