@@ -412,8 +412,9 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     for (int k = 0; k < RPT; k++) {
         if (((k + wave) & RFP_QSAMPLE) != 0) continue;
         if (feeds && tid + k * STPB < n) {
+            // (x for the slabs, z for the ranks; y is histogrammed per slab below -- the marginal y histogram of the Hilbert
+            // order's cells was still being filled here until late in round 4, a third of this pass's atomics for nothing)
             atomicAdd(&ahist[0][axis_bin(px[k], fl[0], fs[0])], 1u);
-            atomicAdd(&ahist[1][axis_bin(py[k], fl[1], fs[1])], 1u);
             atomicAdd(&ahist[2][axis_bin(pz[k], fl[2], fs[2])], 1u);
         }
         __builtin_amdgcn_sched_barrier(0);  // (one sample at a time: interleaved, their temporaries push the kernel past its 128 registers)
@@ -503,7 +504,8 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
         // bin otherwise; copies of one spot are the same place, so the ORDER among them is free and culling loses nothing
         if (RFP_ZSPREAD && dense) zq = (zq & ~15u) | (unsigned)(lane & 15);
         const unsigned key = ((unsigned)col << 9) | ((col & 1) ? 511u - zq : zq);
-        const int slice = (col >= cs1) + (col >= cs2) + (col >= cs3);
+        int slice = col >= cs1;  // (two workgroups per cloud, the product's split: one comparison)
+        if (H > 2) slice += (col >= cs2) + (col >= cs3);  // (uniform)
         const bool own = valid && slice == half;
         pk[k] = own ? key - kbase : 0xFFFFFFFFu;
         if (own) atomicAdd(&hist[pk[k]], 1u);
