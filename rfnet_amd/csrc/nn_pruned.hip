@@ -2194,8 +2194,12 @@ __device__ __forceinline__ void grad_tile(const GradSArgs &a, const int bi, int 
     for (int u = 0; u < OWN; u++) {
         const int j = tid + u * GS_TPB;
         if (j < jn && oo[u] >= 0) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) out[(size_t)oo[u] * 3 + c] = own[u][c] + acc[j * 3 + c];
+            // (one 12-byte store per row: the rows leave in ORIGINAL order, every lane another cache line -- three dword stores were
+            // three transactions per row)
+            struct P3 {
+                float x, y, z;
+            };
+            *(P3 *)(out + (size_t)oo[u] * 3) = P3{own[u][0] + acc[j * 3 + 0], own[u][1] + acc[j * 3 + 1], own[u][2] + acc[j * 3 + 2]};
         }
     }
 }
