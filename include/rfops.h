@@ -163,6 +163,16 @@ size_t rf_farthestpointsampling_temp_floats(int b, int n);
 int rf_farthestpointsampling(int b, int n, int m, const float *inp, float *temp, int *out,
                              rf_stream_t stream);
 
+/* The same op (same indices, bit for bit) with every cloud spread over a cluster of k = 2, 4 or 8 workgroups that
+ * exchange their per-iteration winners through `state` (rf_fps_cluster_state_bytes(b) bytes of caller scratch,
+ * 16-byte aligned, zeroed by the call).  n <= 16384.  static_map != 0 keys membership on the block index instead
+ * of the arrival order (measurement aid: needs b % 8 == 0 and the whole grid of b*k workgroups resident).  After the
+ * stream has drained, word 1 of `state` is non-zero if a member gave up waiting (the output is then invalid).
+ * Measured against the one-workgroup form in DESIGN.md 5.3b; rf_farthestpointsampling does not use it. */
+size_t rf_fps_cluster_state_bytes(int b);
+int rf_farthestpointsampling_cluster(int b, int n, int m, int k, int static_map, const float *inp, void *state,
+                                     int *out, rf_stream_t stream);
+
 /* Replaces gatherpointLauncher (tf_sampling.cpp:125, tf_sampling_g.cu:206-208). */
 int rf_gatherpoint(int b, int n, int m, const float *inp, const int *idx, float *out,
                    rf_stream_t stream);
@@ -185,6 +195,19 @@ int rf_queryballpoint(int b, int n, int m, float radius, int nsample, const floa
 int rf_queryballpoint_dev(int b, int n, int m, const float *radius_dev, int nsample,
                           const float *xyz1, const float *xyz2, int *idx, int *pts_cnt,
                           rf_stream_t stream);
+
+/* The same op (same idx and pts_cnt, bit for bit) for datasets of 64 .. 65536 points and nsample <= 64, with
+ * caller scratch: the dataset is put in sort-tile-recursive order once (or comes as an rf_nn_sort handle in
+ * `sorted1`, NULL otherwise) and every query tests only the 64-record blocks whose box lies within the radius,
+ * then keeps the nsample lowest ORIGINAL indices in ascending order (tf_grouping_g.cu:18-33); queries whose ball
+ * reaches a large share of the cloud, non-finite queries and clouds with a non-finite point walk the cloud in index
+ * order inside the same launch.  radius_dev: NULL (use `radius`) or the reference's device scalar (then `radius` is
+ * ignored).  RF_EINVAL outside that domain: use rf_queryballpoint there.  A TF-side binder allocates the scratch
+ * with allocate_temp, as tf_sampling.cpp:115 does for FPS. */
+size_t rf_queryballpoint_boxes_workspace_bytes(int b, int n);
+int rf_queryballpoint_boxes(int b, int n, int m, float radius, const float *radius_dev, int nsample,
+                            const float *xyz1, const float *xyz2, const void *sorted1, int *idx, int *pts_cnt,
+                            void *workspace, size_t workspace_bytes, rf_stream_t stream);
 
 /* Replaces groupPointLauncher / groupPointGradLauncher (tf_grouping.cpp:146,177,208).
  * points (b,n,c); idx (b,m,nsample); out / grad_out (b,m,nsample,c); grad_points (b,n,c)

@@ -60,10 +60,14 @@ SIGNATURES = {
     "rf_matchcost_grad": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rf_farthestpointsampling_temp_floats": (_sz, [_i, _i]),
     "rf_farthestpointsampling": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "rf_fps_cluster_state_bytes": (_sz, [_i]),
+    "rf_farthestpointsampling_cluster": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "rf_gatherpoint": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "rf_scatteraddpoint": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "rf_queryballpoint": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),
     "rf_queryballpoint_dev": (_i, [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rf_queryballpoint_boxes_workspace_bytes": (_sz, [_i, _i]),
+    "rf_queryballpoint_boxes": (_i, [_i, _i, _i, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rf_grouppoint": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "rf_grouppoint_grad": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "rf_threenn": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -105,8 +109,8 @@ def _load():
             fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         except AttributeError:
             # the product library must export everything; an A/B variant named by RFOPS_LIB (tools/ab_*.py loading
-            # an OLDER build) may lack the diagnostic probes added since -- calling a missing one then raises there
-            if _VARIANT and name.startswith("rf_probe_"):
+            # an OLDER build) may lack entry points added since -- calling a missing one then raises there
+            if _VARIANT:
                 continue
             raise
         fn.restype = res

@@ -422,6 +422,29 @@ def farthest_point_sample(npoint, inp):
 
 
 @H.on_input_device
+def farthest_point_sample_cluster(npoint, inp, k=4, static_map=False, return_state=False):
+    """farthest_point_sample with each cloud spread over k workgroups (sampling.hip fps_cluster_kernel): the same
+    indices; kept for measurement."""
+    npoint = int(npoint)
+    if npoint <= 0:
+        raise H.invalid("FarthestPointSample expects positive npoint")
+    st = H.Staged()
+    p = st.take(inp, F32)
+    if not _shape3(p, 3):
+        raise H.invalid("FarthestPointSample expects (batch_size,num_points,3) inp shape")
+    b, n = p.shape[0], p.shape[1]
+    dev = st.device_()
+    p, = st.up(p)
+    out = H.empty((b, npoint), I32, dev)
+    state = H.empty(((lib.rf_fps_cluster_state_bytes(b) + 3) // 4,), I32, dev)
+    check(lib.rf_farthestpointsampling_cluster(b, n, npoint, int(k), int(bool(static_map)), H.ptr(p), H.ptr(state),
+                                               H.ptr(out), H.stream(dev)), "rf_farthestpointsampling_cluster")
+    if return_state:
+        return st.give(out), state
+    return st.give(out)
+
+
+@H.on_input_device
 def gather_point(inp, idx):
     """GatherPointGpuOp, tf_sampling.cpp:126-148 -> (b,m,3)."""
     st = H.Staged()
@@ -460,12 +483,17 @@ def gather_point_grad(inp, idx, out_g):
 
 
 # ------------------------------------------------------------------ grouping ---------------
+QB_BOXES_MIN_N = 2048  # datasets from this size on take the boxed kernel (its sort costs ~20 us whatever the size)
+
+
 @H.on_input_device
-def query_ball_point(radius, nsample, xyz1, xyz2):
+def query_ball_point(radius, nsample, xyz1, xyz2, sorted1=None, form="auto"):
     """QueryBallPointGpuOp, tf_ops/grouping/tf_grouping.cpp:68-110 -> idx (b,m,nsample), pts_cnt (b,m).
 
     Rows whose ball is empty are not written by the kernel (as in the reference, whose output
     buffer is then uninitialised); this wrapper allocates idx zero-filled so they read 0.
+    form: "auto" (the boxed kernel for datasets of QB_BOXES_MIN_N points and more, the scan below that), "boxes",
+    "scan" -- same results; sorted1: an rf_nn_sort handle of xyz1 (nn_sort), skips the boxed form's own sort.
     """
     nsample = int(nsample)
     if nsample <= 0:
@@ -481,15 +509,28 @@ def query_ball_point(radius, nsample, xyz1, xyz2):
     d, q = st.up(d, q)
     idx = H.zeros((b, m, nsample), I32, dev)
     cnt = H.empty((b, m), I32, dev)
+    rt = None
     if isinstance(radius, torch.Tensor) and radius.is_cuda:
         # the reference's form: radius is an op input tensor on the device (tf_grouping.cpp:18,93-95)
         if radius.device != dev:
             raise ValueError(f"all GPU inputs of one op must live on the same device: got {dev} and {radius.device}")
         rt = radius.detach().reshape(-1)[:1].to(F32).contiguous()
+        r = 0.0
+    else:
+        r = float(np.float32(float(radius)))
+    wsz = lib.rf_queryballpoint_boxes_workspace_bytes(b, n) if nsample <= 64 and b <= 65535 else 0
+    boxes = form == "boxes" or (form == "auto" and n >= QB_BOXES_MIN_N)
+    if form == "boxes" and not wsz:
+        raise H.invalid("QueryBallPoint: the boxed form takes datasets of 64..65536 points and nsample <= 64")
+    if boxes and wsz and b * m > 0:
+        ws = H.empty((wsz // 4,), F32, dev)
+        check(lib.rf_queryballpoint_boxes(b, n, m, r, H.ptr(rt), nsample, H.ptr(d), H.ptr(q),
+                                          H.ptr(sorted1) if sorted1 is not None else None, H.ptr(idx), H.ptr(cnt),
+                                          H.ptr(ws), wsz, H.stream(dev)), "rf_queryballpoint_boxes")
+    elif rt is not None:
         check(lib.rf_queryballpoint_dev(b, n, m, H.ptr(rt), nsample, H.ptr(d), H.ptr(q), H.ptr(idx),
                                         H.ptr(cnt), H.stream(dev)), "rf_queryballpoint_dev")
     else:
-        r = float(np.float32(float(radius)))
         check(lib.rf_queryballpoint(b, n, m, r, nsample, H.ptr(d), H.ptr(q), H.ptr(idx), H.ptr(cnt),
                                     H.stream(dev)), "rf_queryballpoint")
     return st.give(idx), st.give(cnt)

@@ -245,7 +245,35 @@ struct LevelConsts {
 // NLV > 0: exactly NLV levels starting at level 0, fully unrolled with no per-level branch (the
 // reference schedule is NLV = 10); NLV = 0: generic group of up to LVG levels, predicated.
 // LASTZERO: level NLV-1 has multiplier 0 (e = 1.0 exactly): its exponential is not evaluated.
-template <int NLV, bool LASTZERO = false>
+// SQ: every odd level below the last has exactly four times the multiplier of the level after it (the reference
+// schedule: levels -4^7 ... -4^-1, 0: tf_approxmatch.cu:36), so d2*c[v] == 4*(d2*c[v+1]) exactly and its weight is the
+// next level's squared twice -- two multiplies (4.9 issue cycles) instead of a multiply and a v_exp_f32 (10.6).  Never
+// a chain of two such steps: a weight is at most 5 ulp from v_exp_f32's, 3e-7 relative in a match entry that is a sum of
+// such terms (the op's tolerance: rel 1e-4).  ONLY here and in emd_fused_kernel, where the weights go straight into the
+// output: in the phase sweeps the same trick is 9 % faster and NOT taken -- there the weights feed remainL -= sum, whose
+// cancellation amplifies 5 ulp past the tolerance (tools/experiments/emd_p3p1_square_pingpong.patch.txt).
+template <int NLV, bool LASTZERO, bool SQ>
+__device__ __forceinline__ void level_weights(float d2, const float (&cl)[NLV > 0 ? NLV : 1], float (&e)[NLV > 0 ? NLV : 1]) {
+#pragma unroll
+    for (int v = NLV - 1; v >= 0; v--) {
+        if (LASTZERO && v == NLV - 1) {
+            e[v] = 1.0f;
+        } else if (SQ && (v & 1) && v + 1 < NLV - (LASTZERO ? 1 : 0)) {
+            const float q = e[v + 1] * e[v + 1];
+            e[v] = q * q;
+        } else {
+            e[v] = fast_exp2(d2 * cl[v]);
+        }
+    }
+}
+// does the schedule allow SQ?  (host)
+inline bool quarter_chain(const float *c, int nlv, bool lastzero) {
+    for (int v = 1; v + 1 < nlv - (lastzero ? 1 : 0); v += 2)
+        if (c[v] != 4.0f * c[v + 1] || c[v + 1] == 0.0f) return false;
+    return true;
+}
+
+template <int NLV, bool LASTZERO = false, bool SQ = false>
 __global__ __launch_bounds__(TPB) void am_match_kernel(int n, int m, const float *xyz1,
                                                        const float *xyz2, const float *ratios,
                                                        size_t lv_stride, size_t b_stride, int roff,
@@ -283,12 +311,11 @@ __global__ __launch_bounds__(TPB) void am_match_kernel(int n, int m, const float
         }
         for (int l = 0; l < lcnt; l++) {
             const float d2 = rf::d2_fma(cxyz[l][0] - x1, cxyz[l][1] - y1, cxyz[l][2] - z1);
+            float e[NLV > 0 ? NLV : 1];
+            level_weights<NLV, LASTZERO, SQ>(d2, cl, e);
             float acc = 0.f;
 #pragma unroll
-            for (int v = 0; v < NLV; v++) {
-                const float e = (LASTZERO && v == NLV - 1) ? 1.0f : fast_exp2(d2 * cl[v]);
-                acc = fmaf(rl[v] * e, crr[l][v], acc);
-            }
+            for (int v = 0; v < NLV; v++) acc = fmaf(rl[v] * e[v], crr[l][v], acc);
             match[(size_t)(l0 + l) * n + k] = acc;
         }
         return;
@@ -642,7 +669,7 @@ __global__ void emd_pack_cols_kernel(int m, int mpad, int nlv, const float *__re
     for (int i = 0; i < EF_REC / 4; i++) q[i] = make_float4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
 }
 
-template <int NLV, bool GRAD, bool LASTZERO>
+template <int NLV, bool GRAD, bool LASTZERO, bool SQ>
 __global__ __launch_bounds__(TPB) void emd_fused_kernel(int n, int m, int mpad, int lspan,
                                                         const float *__restrict__ xyz1,
                                                         const float *__restrict__ rec,
@@ -684,12 +711,11 @@ __global__ __launch_bounds__(TPB) void emd_fused_kernel(int n, int m, int mpad, 
             const float rr[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
             const float dx = cx.x - x1, dy = cx.y - y1, dz = cx.z - z1;  // xyz2 - xyz1, as :207
             const float d2 = rf::d2_fma(dx, dy, dz);
+            float e[NLV];
+            level_weights<NLV, LASTZERO, SQ>(d2, cl, e);
             float acc = 0.f;
 #pragma unroll
-            for (int v = 0; v < NLV; v++) {
-                const float e = (LASTZERO && v == NLV - 1) ? 1.0f : fast_exp2(d2 * cl[v]);
-                acc = fmaf(rl[v] * e, rr[v], acc);
-            }
+            for (int v = 0; v < NLV; v++) acc = fmaf(rl[v] * e[v], rr[v], acc);
             csum = fmaf(sqrtf(d2), acc, csum);
             if (GRAD) {
                 const float q = acc * __builtin_amdgcn_rsqf(fmaxf(d2, 1e-20f));
@@ -1159,7 +1185,10 @@ int rf_approxmatch_levels(int b, int n, int m, const float *xyz1, const float *x
     const float *ratios = (const float *)workspace + L.V;
     // P3 of the last level only updates remainL, which nothing reads afterwards: not launched.
     const dim3 gm(rf::ceil_div(n, TPB), rf::ceil_div(m, LSEG), b);
-    if (nlevels == 10 && lc.c[9] == 0.0f) {  // the reference schedule
+    if (nlevels == 10 && lc.c[9] == 0.0f && quarter_chain(lc.c, 10, true)) {  // the reference schedule
+        RF_LAUNCH("am_match", (am_match_kernel<10, true, true>), gm, dim3(TPB), 0, s, n, m, xyz1, xyz2,
+                  (const float *)ratios, L.V, L.bstride, L.npad, 0, 10, lc, match);
+    } else if (nlevels == 10 && lc.c[9] == 0.0f) {
         RF_LAUNCH("am_match", (am_match_kernel<10, true>), gm, dim3(TPB), 0, s, n, m, xyz1, xyz2,
                   (const float *)ratios, L.V, L.bstride, L.npad, 0, 10, lc, match);
     } else if (nlevels == 10) {
@@ -1318,11 +1347,18 @@ int rf_earth_mover(int b, int n, int m, const float *xyz1, const float *xyz2, fl
     RF_LAUNCH("emd_pack_cols", emd_pack_cols_kernel, dim3(rf::ceil_div(L.mpad, 256), b), dim3(256), 0, s, m,
               L.mpad, nl, xyz2, ratios, L.V, L.bstride, L.npad, rec);
     const dim3 g(rf::ceil_div(n, TPB), E.lsplit, b);
-    if (want_grad) {
-        RF_LAUNCH("emd_fused_grad", (emd_fused_kernel<10, true, true>), g, dim3(TPB), 0, s, n, m, L.mpad, E.lspan,
+    const bool sq = quarter_chain(lc.c, 10, true);
+    if (want_grad && sq) {
+        RF_LAUNCH("emd_fused_grad", (emd_fused_kernel<10, true, true, true>), g, dim3(TPB), 0, s, n, m, L.mpad, E.lspan,
                   xyz1, (const float *)rec, ratios, L.V, L.bstride, lc, partial, grad1, grad2);
+    } else if (want_grad) {
+        RF_LAUNCH("emd_fused_grad", (emd_fused_kernel<10, true, true, false>), g, dim3(TPB), 0, s, n, m, L.mpad, E.lspan,
+                  xyz1, (const float *)rec, ratios, L.V, L.bstride, lc, partial, grad1, grad2);
+    } else if (sq) {
+        RF_LAUNCH("emd_fused", (emd_fused_kernel<10, false, true, true>), g, dim3(TPB), 0, s, n, m, L.mpad, E.lspan, xyz1,
+                  (const float *)rec, ratios, L.V, L.bstride, lc, partial, grad1, grad2);
     } else {
-        RF_LAUNCH("emd_fused", (emd_fused_kernel<10, false, true>), g, dim3(TPB), 0, s, n, m, L.mpad, E.lspan, xyz1,
+        RF_LAUNCH("emd_fused", (emd_fused_kernel<10, false, true, false>), g, dim3(TPB), 0, s, n, m, L.mpad, E.lspan, xyz1,
                   (const float *)rec, ratios, L.V, L.bstride, lc, partial, grad1, grad2);
     }
     RF_LAUNCH("mc_final", mc_final_kernel, dim3(b), dim3(256), 0, s, (const float *)partial,

@@ -24,6 +24,7 @@
 #include <stdlib.h>
 
 #include "common.hpp"
+#include "nn_pruned.hpp"
 
 namespace {
 
@@ -271,6 +272,193 @@ __global__ __launch_bounds__(64 * QS) void query_ball_lanes_kernel(int n, int m,
     }
 }
 
+
+// ---- query_ball_point over the sorted cloud's boxes (round 5) -------------------------------------
+// The scans above test every dataset point against every query: B*n*m pair tests (5.4e8 at C3) for balls that hold
+// 0.4 % of the cloud.  Here the dataset is first put in sort-tile-recursive order (rfp::sort_clouds, the Chamfer
+// sweep's sort: 64-record superblocks with their boxes) and ONE WAVE owns one query:
+//   1. lanes <-> superblocks: the box's lower bound on d2 (the per-axis gaps through the same fma chain as a pair's
+//      d2, so it never exceeds the d2 of a point inside the box) against the exact threshold T -- a superblock with
+//      bound >= T holds no hit;
+//   2. lanes <-> the 64 records of each surviving superblock: the reference's predicate on every record
+//      (!(d2 >= T): a NaN d2 is a hit, tf_grouping_g.cu:24-27 through fmaxf), hits set their ORIGINAL index's bit in
+//      a per-wave LDS bitmap -- the reference keeps the nsample LOWEST original indices in ascending order, and a
+//      bitmap orders any number of hits for the price of one LDS atomic each;
+//   3. the bitmap is walked from index 0 (64 words per step, popcounts prefix-summed by DPP row shifts) until
+//      nsample hits are placed; the row is staged in LDS and written as one coalesced store, padded with the first
+//      hit (tf_grouping_g.cu:26-29); pts_cnt = min(hits, nsample); a row without hits is not written.
+// A ball that reaches more than 1/8 of the superblocks, a query with a non-finite coordinate and a cloud with a
+// non-finite point (its box cannot bound a NaN) take the other exact route inside the same kernel: the wave walks the
+// ORIGINAL cloud in index order, 64 points per step, and stops at nsample hits -- which is soon, a ball that wide holds
+// a good share of the points.  So every query runs the reference's predicate on every point that can satisfy it,
+// whatever the radius: results are bit-identical to the scan kernels' (tests/test_gpu_sampling_grouping.py).
+constexpr int QX_WPB = 4;     // waves (queries) per workgroup
+constexpr int QX_LIST = 128;  // surviving superblocks a boxed query may hold: max(16, G / 8) <= 128 for G <= 1024
+constexpr int QX_STAGE = 64;  // nsample <= 64
+#ifndef RFG_QX_BATCH
+#define RFG_QX_BATCH 4
+#endif
+constexpr int QX_BATCH = RFG_QX_BATCH;  // surviving superblocks whose records are fetched together
+
+struct QxP3 {  // one packed record of the sorted cloud (12 bytes, 4-byte aligned): ONE global_load_dwordx3
+    float x, y, z;
+};
+// max(a, b, 0) as the one instruction it is (fmaxf chains are wrapped in canonicalising v_max x,x under -fno-fast-math;
+// the operands here are never NaN: finite query, box bounds finite or +-inf)
+__device__ __forceinline__ float qx_gap(float a, float b) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+template <int N>
+__device__ __forceinline__ int dpp_row_shr(int v) {  // lane - N inside its row of 16, 0 where there is none
+    return __builtin_amdgcn_update_dpp(0, v, 0x110 + N, 0xf, 0xf, false);
+}
+// inclusive prefix sum over the wave's 64 lanes
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+    v += dpp_row_shr<1>(v);
+    v += dpp_row_shr<2>(v);
+    v += dpp_row_shr<4>(v);
+    v += dpp_row_shr<8>(v);
+    const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31),
+              r2 = __builtin_amdgcn_readlane(v, 47);
+    const int row = lane >> 4;
+    return v + (row >= 1 ? r0 : 0) + (row >= 2 ? r1 : 0) + (row >= 3 ? r2 : 0);
+}
+
+__global__ __launch_bounds__(64 * QX_WPB) void query_ball_boxes_kernel(
+    int n, int m, int npad, int words /* bitmap words per wave, a multiple of 128 */, float thresh,
+    const float *__restrict__ radius_dev, int nsample, const float *__restrict__ xyz1,
+    const float *__restrict__ xyz2, const float *__restrict__ sxyz, const int *__restrict__ sorig,
+    const float *__restrict__ box64, const int *__restrict__ nonfinite, int *__restrict__ idx,
+    int *__restrict__ pts_cnt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned qx_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bi = blockIdx.y;
+    const int q = blockIdx.x * QX_WPB + wib;
+    if (q >= m) return;  // (uniform per wave; no workgroup barrier below)
+    unsigned *__restrict__ bm = qx_lds + (size_t)wib * (words + QX_LIST + QX_STAGE);
+    int *__restrict__ list = (int *)(bm + words);
+    int *__restrict__ stage = list + QX_LIST;
+    if (radius_dev) thresh = ball_threshold_dev(radius_dev[0]);  // uniform
+    const float *__restrict__ Q = xyz2 + ((size_t)bi * m + q) * 3;
+    const float qx = Q[0], qy = Q[1], qz = Q[2];
+    int *__restrict__ I = idx + ((size_t)bi * m + q) * nsample;
+    const int G = npad >> 6;
+    const float *__restrict__ SX = sxyz + (size_t)bi * npad * 3;
+    const int *__restrict__ SO = sorig + (size_t)bi * npad;
+    const float *__restrict__ BX = box64 + (size_t)bi * G * 8;
+    if (!(thresh > 0.f)) {  // the radius does not exceed the 1e-20 clamp: nothing is ever inside
+        if (lane == 0) pts_cnt[(size_t)bi * m + q] = 0;
+        return;
+    }
+    const bool qfinite = isfinite(qx) && isfinite(qy) && isfinite(qz);
+    bool by_index = !qfinite || nonfinite[bi] != 0;  // (uniform)
+    int total = 0;  // hits (uniform)
+    int S = 0;      // surviving superblocks (uniform)
+    if (!by_index) {
+        // 1. lanes <-> superblocks, four rounds of 64 at a time with all eight box loads in flight; survivors are appended to
+        //    the wave's list
+        for (int r0 = 0; r0 < G; r0 += 256) {
+            float4 lo[4], hi[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int g = min(r0 + u * 64 + lane, G - 1);
+                lo[u] = *(const float4 *)(BX + (size_t)g * 8);
+                hi[u] = *(const float4 *)(BX + (size_t)g * 8 + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int g = r0 + u * 64 + lane;
+                const float gx = qx_gap(lo[u].x - qx, qx - hi[u].x);
+                const float gy = qx_gap(lo[u].y - qy, qy - hi[u].y);
+                const float gz = qx_gap(lo[u].z - qz, qz - hi[u].z);
+                const bool live = g < G && rf::d2_fma(gx, gy, gz) < thresh;
+                const unsigned long long mask = __ballot(live);
+                const int pos = S + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                if (live && pos < QX_LIST) list[pos] = g;
+                S += __builtin_popcountll(mask);
+            }
+        }
+        by_index = S > max(16, G >> 3);  // a wide ball: by index instead (S <= QX_LIST otherwise)
+    }
+    if (!by_index) {
+        for (int w = lane * 4; w < words; w += 256) *(uint4 *)(bm + w) = make_uint4(0u, 0u, 0u, 0u);
+        // 2. lanes <-> records, up to QX_BATCH surviving superblocks at a time (their loads in flight together); a batch
+        //    slot beyond the list is skipped by a scalar branch, not padded
+        int hit_any = 0;
+        const QxP3 *__restrict__ RP = (const QxP3 *)SX + lane;
+        const int *__restrict__ OP = SO + lane;
+        for (int i = 0; i < S; i += QX_BATCH) {
+            QxP3 p[QX_BATCH];
+            int o[QX_BATCH];
+#pragma unroll
+            for (int u = 0; u < QX_BATCH; u++) {
+                if (i + u < S) {  // (uniform)
+                    const int sb = __builtin_amdgcn_readfirstlane(list[i + u]);
+                    p[u] = RP[sb * 64];
+                    o[u] = OP[sb * 64];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < QX_BATCH; u++) {
+                if (i + u < S) {  // (uniform)
+                    const float d2 = rf::d2_fma(qx - p[u].x, qy - p[u].y, qz - p[u].z);
+                    if (!(d2 >= thresh) && o[u] >= 0) {  // padding records carry orig = -1
+                        atomicOr(&bm[o[u] >> 5], 1u << (o[u] & 31));
+                        hit_any = 1;
+                    }
+                }
+            }
+        }
+        if (__ballot(hit_any != 0) == 0ull) {  // empty ball: the row is left untouched
+            if (lane == 0) pts_cnt[(size_t)bi * m + q] = 0;
+            return;
+        }
+        // 3. the bitmap in index order, 128 words per step (two per lane)
+        int placed = 0;  // (uniform)
+        for (int w0 = 0; w0 < words && placed < nsample; w0 += 128) {
+            const uint2 v2 = *(const uint2 *)(bm + w0 + 2 * lane);
+            unsigned long long val = ((unsigned long long)v2.y << 32) | v2.x;
+            const int c = __builtin_popcountll(val);
+            const int incl = wave_incl_scan(c, lane);
+            int p = placed + incl - c;
+            while (val != 0ull && p < nsample) {
+                stage[p] = (w0 + 2 * lane) * 32 + __builtin_ctzll(val);
+                val &= val - 1ull;
+                p++;
+            }
+            placed += __builtin_amdgcn_readlane(incl, 63);
+        }
+        total = placed;  // >= 1; may exceed nsample by the last step's surplus
+    } else {
+        // the cloud in index order, 64 points per step, until nsample hits
+        const float *__restrict__ D = xyz1 + (size_t)bi * n * 3;
+        for (int k0 = 0; k0 < n && total < nsample; k0 += 64) {
+            const int k = k0 + lane;
+            const int kk = min(k, n - 1);
+            const float d2 = rf::d2_fma(qx - D[(size_t)kk * 3], qy - D[(size_t)kk * 3 + 1], qz - D[(size_t)kk * 3 + 2]);
+            const bool hit = !(d2 >= thresh) && k < n;
+            const unsigned long long mask = __ballot(hit);
+            if (mask == 0ull) continue;
+            const int pos = total + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+            if (hit && pos < nsample) stage[pos] = k;
+            total += __builtin_popcountll(mask);
+        }
+        if (total == 0) {
+            if (lane == 0) pts_cnt[(size_t)bi * m + q] = 0;
+            return;
+        }
+    }
+    const int cnt = min(total, nsample);
+    // (the wave's own LDS writes are visible to it without a barrier: in-order LDS queue)
+    const int first = stage[0];
+    for (int l = lane; l < nsample; l += 64) I[l] = l < cnt ? stage[l] : first;
+    if (lane == 0) pts_cnt[(size_t)bi * m + q] = cnt;
+}
+
 __global__ void group_point_kernel(int n, int c, long per_batch /* m*nsample */, long total,
                                    const float *__restrict__ points, const int *__restrict__ idx,
                                    float *__restrict__ out) {
@@ -367,6 +555,41 @@ int rf_queryballpoint_dev(int b, int n, int m, const float *radius_dev, int nsam
                           const float *xyz2, int *idx, int *pts_cnt, rf_stream_t stream) {
     if (!radius_dev) return RF_EINVAL;
     return queryball_impl(b, n, m, 0.f, radius_dev, nsample, xyz1, xyz2, idx, pts_cnt, stream);
+}
+
+
+// ---- the boxed form: needs scratch (the sorted copy of the dataset unless the caller hands a rf_nn_sort handle over)
+size_t rf_queryballpoint_boxes_workspace_bytes(int b, int n) {
+    if (b <= 0 || n < 64 || !rfp::pruned_supported(b, n, n)) return 0;
+    return rfp::sorted_bytes(b, n);
+}
+
+int rf_queryballpoint_boxes(int b, int n, int m, float radius, const float *radius_dev, int nsample, const float *xyz1,
+                            const float *xyz2, const void *sorted1, int *idx, int *pts_cnt, void *workspace,
+                            size_t workspace_bytes, rf_stream_t stream) {
+    if (b < 0 || n < 0 || m < 0 || nsample <= 0) return RF_EINVAL;
+    if ((long)b * m == 0) return RF_OK;
+    if (n < 64 || nsample > 64 || b > 65535 || !rfp::pruned_supported(b, n, n)) return RF_EINVAL;  // the scan kernels' domain
+    if (!xyz1 || !xyz2 || !idx || !pts_cnt || !workspace || !rf::aligned16(workspace)) return RF_EINVAL;
+    if (sorted1 && !rf::aligned16(sorted1)) return RF_EINVAL;
+    if (workspace_bytes < rf_queryballpoint_boxes_workspace_bytes(b, n)) return RF_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    rfp::Sorted so;
+    if (sorted1) {
+        so = rfp::sorted_view(b, n, sorted1);
+    } else {
+        so = rfp::sorted_view(b, n, workspace);
+        const int nn[1] = {n};
+        const float *src[1] = {xyz1};
+        if (int e = rfp::sort_sets(b, 1, nn, src, &so, s, nullptr)) return e;
+    }
+    const float thresh = radius_dev ? 0.f : ball_threshold(radius);
+    const int words = ((n + 31) / 32 + 127) / 128 * 128;
+    const size_t shmem = sizeof(unsigned) * (size_t)QX_WPB * (words + QX_LIST + QX_STAGE);
+    RF_LAUNCH("query_ball_boxes", query_ball_boxes_kernel, dim3(rf::ceil_div(m, QX_WPB), b), dim3(64 * QX_WPB), shmem, s,
+              n, m, so.npad, words, radius_dev ? 1.f : thresh, radius_dev, nsample, xyz1, xyz2, so.xyz, so.orig, so.box64,
+              so.pos0 + 2 * b, idx, pts_cnt);
+    return RF_OK;
 }
 
 int rf_grouppoint(int b, int n, int c, int m, int nsample, const float *points, const int *idx,

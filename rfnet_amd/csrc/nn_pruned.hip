@@ -280,6 +280,7 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     __shared__ unsigned lowcnt[STPB / 64][3];
     __shared__ float frame[6];  // lo[3], scale[3]
     __shared__ unsigned ncrowded;  // waves whose points crowd into few bins
+    __shared__ unsigned badw[STPB / 64];  // per wave: a NaN or infinite coordinate among its points (query_ball_boxes reads the cloud's flag)
 
     // cloud-major logical order, each XCD a contiguous eighth (as the sweep: the XCD that sorts a
     // batch element is the one that sweeps it, its L2 still holding the records)
@@ -376,6 +377,14 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
                 red[wave][3 + c] = hi[c];
             }
         }
+        // any NaN or infinite coordinate in the cloud?  (v * 0 is NaN exactly then; absent points hold 0.)  The boxes below
+        // exclude such points, which is all the Chamfer sweep needs; the ball query must know, because a NaN distance IS inside
+        // every ball (grouping.hip).  3 VALU per point here instead of a launch of its own there.
+        float nf = 0.f;
+#pragma unroll
+        for (int k = 0; k < RPT; k++) nf = fmaf(pz[k], 0.f, fmaf(py[k], 0.f, fmaf(px[k], 0.f, nf)));
+        const unsigned long long bad_lanes = __ballot(nf != nf);  // (by the whole wave: not inside the lane-0 branch)
+        if (lane == 0) badw[wave] = bad_lanes != 0ull ? 1u : 0u;  // (read behind the barriers below)
     }
     __syncthreads();
     if (tid < 3) {
@@ -607,7 +616,12 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
     // network's collapsed output): as a CANDIDATE set it sends every query through hundreds of near-tied blocks, which the
     // shared-group sweep streams to 64 lanes at the VALU rate and the quad tiles would chase one latency-bound round at a
     // time (258 us instead of 120 at C2) -- the sweep reads this flag per cloud (all workgroups of a cloud agree: same data)
-    if (tid == 0 && half == 0) a.pos0[set][a.b + bi] = ncrowded * RFP_CROWD_DIV > STPB / 64 ? 1 : 0;
+    if (tid == 0 && half == 0) {
+        a.pos0[set][a.b + bi] = ncrowded * RFP_CROWD_DIV > STPB / 64 ? 1 : 0;
+        unsigned nbad = 0;
+        for (int w = 0; w < STPB / 64; w++) nbad |= badw[w];
+        a.pos0[set][2 * a.b + bi] = nbad != 0u ? 1 : 0;
+    }
     for (int h0 = 0; h0 < seglen; h0 += HALF) {
         const int cnt = min(HALF, seglen - h0);  // multiple of 64
 #pragma unroll
@@ -701,12 +715,14 @@ __global__ __launch_bounds__(STPB) void nnp_sort_kernel(SortArgs a) {
     __shared__ float red[STPB / 64][6];
     __shared__ unsigned wsum[STPB / 64];
     __shared__ float frame[6];  // lo[3], scale[3]
+    __shared__ unsigned nbad;   // != 0: a NaN or infinite coordinate in the cloud (see nnp_sort_reg_kernel)
 
     // cloud-major logical order, each XCD a contiguous eighth (as the sweep: the XCD that sorts a
     // batch element is the one that sweeps it, its L2 still holding the records)
     const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (int)(blockIdx.x >> 3);
     const int bi = logical / a.nsets, set = logical - bi * a.nsets;
+    if (threadIdx.x == 0) nbad = 0;
     const int n = a.n[set], npad = a.npad[set];
     const float *__restrict__ src = a.src[set] + (size_t)bi * n * 3;
     float *__restrict__ oxyz = a.xyz[set] + (size_t)bi * npad * 3;
@@ -745,6 +761,8 @@ __global__ __launch_bounds__(STPB) void nnp_sort_kernel(SortArgs a) {
 
     // 1. bounding box of the finite coordinates
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool bad = false;
+    __syncthreads();  // nbad = 0 above
     for_points([&](int, int, float x, float y, float z) {
         const float v[3] = {x, y, z};
 #pragma unroll
@@ -752,9 +770,12 @@ __global__ __launch_bounds__(STPB) void nnp_sort_kernel(SortArgs a) {
             if (isfinite(v[c])) {
                 lo[c] = fminf(lo[c], v[c]);
                 hi[c] = fmaxf(hi[c], v[c]);
+            } else {
+                bad = true;
             }
         }
     });
+    if (__ballot(bad) != 0ull && lane == 0) nbad = 1u;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
 #pragma unroll
@@ -883,6 +904,7 @@ __global__ __launch_bounds__(STPB) void nnp_sort_kernel(SortArgs a) {
         if (i == 0) {
             a.pos0[set][bi] = (int)pos;
             a.pos0[set][a.b + bi] = 0;  // (crowded flag: the register-resident sort's test only)
+            a.pos0[set][2 * a.b + bi] = nbad != 0u ? 1 : 0;
         }
         oxyz[(size_t)pos * 3 + 0] = x;
         oxyz[(size_t)pos * 3 + 1] = y;
@@ -2254,7 +2276,7 @@ size_t sorted_bytes(int b, int n) {
     const size_t npad = npad_of(n);
     return align256((size_t)b * npad * 3 * sizeof(float) + 256)  // + prefetch overrun
            + align256((size_t)b * npad * sizeof(int)) + align256((size_t)b * (npad / SB) * B16F * sizeof(float)) +
-           align256((size_t)b * (npad / SB) * B64F * sizeof(float)) + align256((size_t)2 * b * sizeof(int));  // pos0 (b) | crowded (b)
+           align256((size_t)b * (npad / SB) * B64F * sizeof(float)) + align256((size_t)3 * b * sizeof(int));  // pos0 (b) | crowded (b) | non-finite (b)
 }
 
 Sorted sorted_view(int b, int n, const void *buf) {

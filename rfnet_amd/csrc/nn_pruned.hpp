@@ -27,7 +27,8 @@ struct Sorted {
     const int *orig;
     const float *box16;
     const float *box64;
-    const int *pos0;  // (b) sorted position of original index 0
+    const int *pos0;  // (b) sorted position of original index 0; behind it (b) the crowded flags and (b) the non-finite flags
+                      // (1: the cloud has a NaN or infinite coordinate -- its boxes exclude such points)
     int npad;
 };
 size_t sort_workspace_bytes(int b, int n);

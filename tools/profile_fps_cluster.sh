@@ -1,0 +1,13 @@
+#!/usr/bin/env bash
+# rocprofv3 kernel trace + two SQ counter passes over tools/ab_fps_cluster.py --quick (C3: fps_reg against the cluster forms).
+# usage: bash tools/profile_fps_cluster.sh <tag>   -> gpurun_out/<tag>/
+set -u
+TAG=${1:-r05_fps_cluster}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$R/tools/ab_fps_cluster.py" --quick > "$OUT/ab.txt" 2> "$OUT/stats.err"
+timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d "$OUT/pmc_sq" -- python3 "$R/tools/ab_fps_cluster.py" --quick > /dev/null 2> "$OUT/pmc_sq.err"
+timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS --output-format csv -d "$OUT/pmc_sq2" -- python3 "$R/tools/ab_fps_cluster.py" --quick > /dev/null 2> "$OUT/pmc_sq2.err"
+python3 "$R/tools/summarize_prof.py" "$OUT" > "$OUT/summary.txt" 2>&1
