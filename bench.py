@@ -783,8 +783,8 @@ def main():
             "identical_to_dense_sweep": ns_same,
             "kernels_ms": ns_auto_ms, "dense_kernels_ms": ns_dense_ms,
         }
-        if "nnp_sweep" in ns_auto_ms and len(ns_stats) >= 8:
-            ev = float((ns_stats[14] or 1024) * ns_stats[3] + (ns_stats[15] or 1024) * ns_stats[7])
+        if "nnp_sweep" in ns_auto_ms and len(ns_stats) >= 14:
+            ev = float(ns_stats[12] + ns_stats[13])  # directed pairs the sweep evaluated, summed by the kernel itself
             t_sw = ns_auto_ms["nnp_sweep"] * 1e-3
             extras["north_star_16384sq"]["roofline"] = {
                 "bound": "valu", "kernel": "nnp_sweep", "achieved": 8.0 * ev / t_sw / 1e12, "peak": FP32_PEAK_TFLOPS,
@@ -819,8 +819,8 @@ def main():
                 traffic = {k: tj.get(k, {}).get(f"{B}x{N}x{M}") for k in ("nn_sweep", "nnp_sweep")}
             except Exception:
                 traffic = {}
-        if culled and len(culled_stats) >= 8 and sweep_avg_s:
-            evaluated = float((culled_stats[14] or 1024) * culled_stats[3] + (culled_stats[15] or 1024) * culled_stats[7])  # directed pairs (unit per scan: stats[14+d])
+        if culled and len(culled_stats) >= 14 and sweep_avg_s:
+            evaluated = float(culled_stats[12] + culled_stats[13])  # directed pairs evaluated, summed by the kernel (a launch may mix 1024- and 16-pair scans)
             executed_tf = 8.0 * evaluated / sweep_avg_s / 1e12
             roof = {
                 "bound": "valu",

@@ -73,8 +73,9 @@ int rf_nn_distance(int b, int n, int m, const float *xyz1, const float *xyz2, fl
  * 65536) -- identical outputs, bit for bit, ties included.  RF_NN_AUTO (what rf_nn_distance
  * uses) picks by size.  `stats` (host pointer to 32 counters, or NULL; filled by the culled sweep
  * only): per direction d at [4d..4d+3] {waves, superblock steps, most steps of one wave, 16-candidate
- * block scans}, [8+d] most block scans of one wave, [14+d] directed pairs per counted block scan of direction d (1024: 64 queries x
- * 16 candidates; 16 where a query has four lanes of its own, nn_pruned.hip sweep_tile16), [16..31] phase time stamps of the sort; a non-NULL
+ * block scans}, [8+d] most block scans of one wave, [12+d] directed pairs evaluated (summed by the kernel), [14+d] directed pairs per
+ * counted block scan of the last wave of direction d to report (1024: 64 queries x 16 candidates; 16 where a query has four lanes of
+ * its own, nn_pruned.hip sweep_tile16; a launch may mix both), [16..31] phase time stamps of the sort; a non-NULL
  * pointer synchronises the stream. */
 #define RF_NN_AUTO 0
 #define RF_NN_DENSE 1
@@ -208,6 +209,24 @@ size_t rf_queryballpoint_boxes_workspace_bytes(int b, int n);
 int rf_queryballpoint_boxes(int b, int n, int m, float radius, const float *radius_dev, int nsample,
                             const float *xyz1, const float *xyz2, const void *sorted1, int *idx, int *pts_cnt,
                             void *workspace, size_t workspace_bytes, rf_stream_t stream);
+
+/* The set-abstraction chain of BASELINE.json configs[2] as ONE call on caller buffers:
+ *     fps_idx = farthest_point_sample(npoint, xyz)          (tf_sampling_g.cu:105-170)
+ *     new_xyz = gather_point(xyz, fps_idx)                  (tf_sampling_g.cu:172-181)
+ *     idx, pts_cnt = query_ball_point(radius, nsample, xyz, new_xyz)   (tf_grouping_g.cu:3-36)
+ *     grouped_xyz = group_point(xyz, idx)                   (tf_grouping_g.cu:40-57)
+ * with the results of the four separate entry points, bit for bit (rows of empty balls -- impossible for radius > 1e-20,
+ * every sample lies in its own ball -- are written as index 0 instead of being left untouched, because the grouping reads
+ * them).  xyz (b,n,3) with 64 <= n <= 65536, nsample <= 64; fps_idx (b,npoint) int32, new_xyz (b,npoint,3), idx
+ * (b,npoint,nsample) int32, pts_cnt (b,npoint) int32, grouped_xyz (b,npoint,nsample,3).  radius_dev: NULL or the reference's
+ * device scalar.  Two launches on `stream` (FPS writes new_xyz itself, the ball query writes grouped_xyz itself) plus the
+ * dataset's sort, which runs on `aux_stream` beside FPS when one is given (NULL: on `stream`, before FPS); the call creates
+ * and releases the two events that order the streams, keeps no state and is graph-capturable.  A TF-side op for a fused
+ * "SampleAndGroup" would bind this with its four outputs from allocate_output and the scratch from allocate_temp. */
+size_t rf_sample_and_group_workspace_bytes(int b, int n);
+int rf_sample_and_group(int b, int n, int npoint, float radius, const float *radius_dev, int nsample, const float *xyz,
+                        int *fps_idx, float *new_xyz, int *idx, int *pts_cnt, float *grouped_xyz, void *workspace,
+                        size_t workspace_bytes, rf_stream_t stream, rf_stream_t aux_stream);
 
 /* Replaces groupPointLauncher / groupPointGradLauncher (tf_grouping.cpp:146,177,208).
  * points (b,n,c); idx (b,m,nsample); out / grad_out (b,m,nsample,c); grad_points (b,n,c)

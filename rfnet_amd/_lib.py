@@ -68,6 +68,8 @@ SIGNATURES = {
     "rf_queryballpoint_dev": (_i, [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "rf_queryballpoint_boxes_workspace_bytes": (_sz, [_i, _i]),
     "rf_queryballpoint_boxes": (_i, [_i, _i, _i, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "rf_sample_and_group_workspace_bytes": (_sz, [_i, _i]),
+    "rf_sample_and_group": (_i, [_i, _i, _i, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "rf_grouppoint": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "rf_grouppoint_grad": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "rf_threenn": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

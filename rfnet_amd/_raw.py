@@ -537,6 +537,46 @@ def query_ball_point(radius, nsample, xyz1, xyz2, sorted1=None, form="auto"):
 
 
 @H.on_input_device
+def sample_and_group(npoint, radius, nsample, xyz, aux_stream=None):
+    """rf_sample_and_group: farthest_point_sample -> gather_point -> query_ball_point -> group_point(xyz) as one call
+    -> (fps_idx (b,npoint), new_xyz (b,npoint,3), idx (b,npoint,nsample), pts_cnt (b,npoint), grouped_xyz (b,npoint,nsample,3)),
+    bit-identical to the four ops.  aux_stream: a torch.cuda.Stream on which the dataset's sort runs beside FPS."""
+    npoint, nsample = int(npoint), int(nsample)
+    if npoint <= 0:
+        raise H.invalid("FarthestPointSample expects positive npoint")
+    if nsample <= 0:
+        raise H.invalid("QueryBallPoint expects positive nsample")
+    st = H.Staged()
+    p = st.take(xyz, F32)
+    if not _shape3(p, 3):
+        raise H.invalid("FarthestPointSample expects (batch_size,num_points,3) inp shape")
+    b, n = p.shape[0], p.shape[1]
+    dev = st.device_()
+    p, = st.up(p)
+    wsz = lib.rf_sample_and_group_workspace_bytes(b, n) if nsample <= 64 and b <= 65535 else 0
+    if not wsz:
+        raise H.invalid("sample_and_group takes clouds of 64..65536 points and nsample <= 64")
+    rt = None
+    if isinstance(radius, torch.Tensor) and radius.is_cuda:
+        rt = radius.detach().reshape(-1)[:1].to(F32).contiguous()
+        r = 0.0
+    else:
+        r = float(np.float32(float(radius)))
+    fi = H.empty((b, npoint), I32, dev)
+    nx = H.empty((b, npoint, 3), F32, dev)
+    gi = H.empty((b, npoint, nsample), I32, dev)
+    cnt = H.empty((b, npoint), I32, dev)
+    gx = H.empty((b, npoint, nsample, 3), F32, dev)
+    ws = H.empty((wsz // 4,), F32, dev)
+    check(lib.rf_sample_and_group(b, n, npoint, r, H.ptr(rt), nsample, H.ptr(p), H.ptr(fi), H.ptr(nx), H.ptr(gi), H.ptr(cnt),
+                                  H.ptr(gx), H.ptr(ws), wsz, H.stream(dev),
+                                  aux_stream.cuda_stream if aux_stream is not None else None), "rf_sample_and_group")
+    if aux_stream is not None:
+        ws.record_stream(aux_stream)  # the sort wrote the workspace on that stream
+    return st.give(fi), st.give(nx), st.give(gi), st.give(cnt), st.give(gx)
+
+
+@H.on_input_device
 def group_point(points, idx):
     """GroupPointGpuOp, tf_grouping.cpp:147-175 -> (b,m,nsample,c)."""
     st = H.Staged()

@@ -25,6 +25,7 @@
 
 #include "common.hpp"
 #include "nn_pruned.hpp"
+#include "group_internal.hpp"
 
 namespace {
 
@@ -292,7 +293,6 @@ __global__ __launch_bounds__(64 * QS) void query_ball_lanes_kernel(int n, int m,
 // ORIGINAL cloud in index order, 64 points per step, and stops at nsample hits -- which is soon, a ball that wide holds
 // a good share of the points.  So every query runs the reference's predicate on every point that can satisfy it,
 // whatever the radius: results are bit-identical to the scan kernels' (tests/test_gpu_sampling_grouping.py).
-constexpr int QX_WPB = 4;     // waves (queries) per workgroup
 constexpr int QX_LIST = 128;  // surviving superblocks a boxed query may hold: max(16, G / 8) <= 128 for G <= 1024
 constexpr int QX_STAGE = 64;  // nsample <= 64
 #ifndef RFG_QX_BATCH
@@ -327,31 +327,65 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
     return v + (row >= 1 ? r0 : 0) + (row >= 2 ? r1 : 0) + (row >= 3 ? r2 : 0);
 }
 
-__global__ __launch_bounds__(64 * QX_WPB) void query_ball_boxes_kernel(
+// LDS (dynamic): the cloud's superblock boxes as six arrays of gpad floats (lo.x lo.y lo.z hi.x hi.y hi.z: lanes read
+// consecutive dwords, conflict-free), staged ONCE per workgroup -- with every wave reading its 8 KB of boxes from global
+// memory the box phase alone was 20 of the launch's 36 us at C3 (the vector L1's 64 B/clk) -- then per wave its bitmap,
+// survivor list and output row.
+__global__ __launch_bounds__(1024) void query_ball_boxes_kernel(
     int n, int m, int npad, int words /* bitmap words per wave, a multiple of 128 */, float thresh,
     const float *__restrict__ radius_dev, int nsample, const float *__restrict__ xyz1,
     const float *__restrict__ xyz2, const float *__restrict__ sxyz, const int *__restrict__ sorig,
     const float *__restrict__ box64, const int *__restrict__ nonfinite, int *__restrict__ idx,
-    int *__restrict__ pts_cnt) {
+    int *__restrict__ pts_cnt, float *__restrict__ grouped /* (b, m, nsample, 3) or NULL */, int zero_empty) {
     extern __shared__ __attribute__((aligned(16))) unsigned qx_lds[];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wpb = blockDim.x >> 6;
     const int bi = blockIdx.y;
-    const int q = blockIdx.x * QX_WPB + wib;
-    if (q >= m) return;  // (uniform per wave; no workgroup barrier below)
-    unsigned *__restrict__ bm = qx_lds + (size_t)wib * (words + QX_LIST + QX_STAGE);
+    const int q = blockIdx.x * wpb + wib;
+    const int G = npad >> 6;
+    const int gpad = (G + 63) & ~63;
+    float *__restrict__ bx = (float *)qx_lds;
+    unsigned *__restrict__ bm = qx_lds + 6 * gpad + (size_t)wib * (words + QX_LIST + QX_STAGE);
     int *__restrict__ list = (int *)(bm + words);
     int *__restrict__ stage = list + QX_LIST;
+    const float *__restrict__ BX = box64 + (size_t)bi * G * 8;
+    for (int g = threadIdx.x; g < gpad; g += blockDim.x) {
+        float4 lo = make_float4(INFINITY, INFINITY, INFINITY, 0.f), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.f);
+        if (g < G) {
+            lo = *(const float4 *)(BX + (size_t)g * 8);
+            hi = *(const float4 *)(BX + (size_t)g * 8 + 4);
+        }
+        bx[g] = lo.x; bx[gpad + g] = lo.y; bx[2 * gpad + g] = lo.z;
+        bx[3 * gpad + g] = hi.x; bx[4 * gpad + g] = hi.y; bx[5 * gpad + g] = hi.z;
+    }
+    __syncthreads();  // the only workgroup barrier: from here on every wave is on its own
+    if (q >= m) return;
     if (radius_dev) thresh = ball_threshold_dev(radius_dev[0]);  // uniform
     const float *__restrict__ Q = xyz2 + ((size_t)bi * m + q) * 3;
     const float qx = Q[0], qy = Q[1], qz = Q[2];
     int *__restrict__ I = idx + ((size_t)bi * m + q) * nsample;
-    const int G = npad >> 6;
     const float *__restrict__ SX = sxyz + (size_t)bi * npad * 3;
     const int *__restrict__ SO = sorig + (size_t)bi * npad;
-    const float *__restrict__ BX = box64 + (size_t)bi * G * 8;
+    // The row leaves through here.  An EMPTY ball: pts_cnt = 0 and the row is left untouched, as the reference leaves it
+    // (tf_grouping_g.cu:18-33 writes nothing without a hit) -- unless the caller asked for defined contents (zero_empty: the
+    // one-call sample-and-group gathers through the row next): index 0 then.  With `grouped` the coordinates of the row's
+    // points go out with it (group_point of the same indices, tf_grouping_g.cu:40-57, fused: the row is in LDS).
+    auto finish = [&](int cnt) {
+        if (lane == 0) pts_cnt[(size_t)bi * m + q] = cnt;
+        if (cnt == 0 && !zero_empty) return;
+        // (the wave's own LDS writes are visible to it without a barrier: in-order LDS queue)
+        const int first = cnt > 0 ? stage[0] : 0;
+        const QxP3 *__restrict__ D3 = (const QxP3 *)(xyz1 + (size_t)bi * n * 3);
+        QxP3 *__restrict__ GR = grouped ? (QxP3 *)grouped + ((size_t)bi * m + q) * nsample : nullptr;
+        for (int l = lane; l < nsample; l += 64) {
+            const int v = l < cnt ? stage[l] : first;
+            I[l] = v;
+            if (GR) GR[l] = D3[v];
+        }
+    };
     if (!(thresh > 0.f)) {  // the radius does not exceed the 1e-20 clamp: nothing is ever inside
-        if (lane == 0) pts_cnt[(size_t)bi * m + q] = 0;
+        finish(0);
         return;
     }
     const bool qfinite = isfinite(qx) && isfinite(qy) && isfinite(qz);
@@ -359,24 +393,16 @@ __global__ __launch_bounds__(64 * QX_WPB) void query_ball_boxes_kernel(
     int total = 0;  // hits (uniform)
     int S = 0;      // surviving superblocks (uniform)
     if (!by_index) {
-        // 1. lanes <-> superblocks, four rounds of 64 at a time with all eight box loads in flight; survivors are appended to
-        //    the wave's list
-        for (int r0 = 0; r0 < G; r0 += 256) {
-            float4 lo[4], hi[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int g = min(r0 + u * 64 + lane, G - 1);
-                lo[u] = *(const float4 *)(BX + (size_t)g * 8);
-                hi[u] = *(const float4 *)(BX + (size_t)g * 8 + 4);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int g = r0 + u * 64 + lane;
-                const float gx = qx_gap(lo[u].x - qx, qx - hi[u].x);
-                const float gy = qx_gap(lo[u].y - qy, qy - hi[u].y);
-                const float gz = qx_gap(lo[u].z - qz, qz - hi[u].z);
-                const bool live = g < G && rf::d2_fma(gx, gy, gz) < thresh;
-                const unsigned long long mask = __ballot(live);
+        // 1. lanes <-> superblocks, 64 at a time from the staged boxes (an empty padding box has lo = +inf: never live);
+        //    survivors are appended to the wave's list
+        for (int r0 = 0; r0 < gpad; r0 += 64) {
+            const int g = r0 + lane;
+            const float gx = qx_gap(bx[g] - qx, qx - bx[3 * gpad + g]);
+            const float gy = qx_gap(bx[gpad + g] - qy, qy - bx[4 * gpad + g]);
+            const float gz = qx_gap(bx[2 * gpad + g] - qz, qz - bx[5 * gpad + g]);
+            const bool live = rf::d2_fma(gx, gy, gz) < thresh;
+            const unsigned long long mask = __ballot(live);
+            if (mask != 0ull) {  // (uniform)
                 const int pos = S + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
                 if (live && pos < QX_LIST) list[pos] = g;
                 S += __builtin_popcountll(mask);
@@ -413,8 +439,8 @@ __global__ __launch_bounds__(64 * QX_WPB) void query_ball_boxes_kernel(
                 }
             }
         }
-        if (__ballot(hit_any != 0) == 0ull) {  // empty ball: the row is left untouched
-            if (lane == 0) pts_cnt[(size_t)bi * m + q] = 0;
+        if (__ballot(hit_any != 0) == 0ull) {  // empty ball
+            finish(0);
             return;
         }
         // 3. the bitmap in index order, 128 words per step (two per lane)
@@ -447,16 +473,8 @@ __global__ __launch_bounds__(64 * QX_WPB) void query_ball_boxes_kernel(
             if (hit && pos < nsample) stage[pos] = k;
             total += __builtin_popcountll(mask);
         }
-        if (total == 0) {
-            if (lane == 0) pts_cnt[(size_t)bi * m + q] = 0;
-            return;
-        }
     }
-    const int cnt = min(total, nsample);
-    // (the wave's own LDS writes are visible to it without a barrier: in-order LDS queue)
-    const int first = stage[0];
-    for (int l = lane; l < nsample; l += 64) I[l] = l < cnt ? stage[l] : first;
-    if (lane == 0) pts_cnt[(size_t)bi * m + q] = cnt;
+    finish(min(total, nsample));
 }
 
 __global__ void group_point_kernel(int n, int c, long per_batch /* m*nsample */, long total,
@@ -485,8 +503,6 @@ __global__ void group_point_grad_kernel(int n, int c, long per_batch, long total
 
 }  // namespace
 
-extern "C" {
-
 // smallest float T such that max(sqrt_rn(x), 1e-20f) >= radius for every x >= T, i.e.
 // "max(sqrtf(d2),1e-20f) < radius"  <=>  "d2 < T" for d2 >= 0.  Bisection over the (monotone)
 // non-negative float bit patterns with the host's correctly rounded sqrtf.
@@ -504,6 +520,27 @@ static float ball_threshold(float radius) {
     memcpy(&t, &hi, 4);
     return t;
 }
+
+
+namespace rfi {
+// the boxed ball query on a sorted dataset (group_internal.hpp); the domain is the caller's to check
+int ball_boxes(int b, int n, int m, float radius, const float *radius_dev, int nsample, const float *xyz1, const float *xyz2,
+               const rfp::Sorted &so, int *idx, int *pts_cnt, float *grouped_xyz, int zero_empty, hipStream_t s) {
+    const float thresh = radius_dev ? 1.f : ball_threshold(radius);
+    const int words = ((n + 31) / 32 + 127) / 128 * 128;
+    const int gpad = (so.npad / 64 + 63) & ~63;
+    // queries (waves) per workgroup: as many as share one staging of the boxes without the per-wave bitmaps crowding the LDS
+    // (C3, same device: 4 / 8 / 16 queries per workgroup 33.1 / 31.9 / 34.0 us)
+    const int wpb = n <= 32768 ? 8 : 4;
+    const size_t shmem = sizeof(unsigned) * ((size_t)6 * gpad + (size_t)wpb * (words + QX_LIST + QX_STAGE));
+    RF_LAUNCH("query_ball_boxes", query_ball_boxes_kernel, dim3(rf::ceil_div(m, wpb), b), dim3(64 * wpb), shmem, s, n, m,
+              so.npad, words, thresh, radius_dev, nsample, xyz1, xyz2, so.xyz, so.orig, so.box64, so.pos0 + 2 * b, idx, pts_cnt,
+              grouped_xyz, zero_empty);
+    return RF_OK;
+}
+}  // namespace rfi
+
+extern "C" {
 
 static int queryball_impl(int b, int n, int m, float radius, const float *radius_dev, int nsample,
                           const float *xyz1, const float *xyz2, int *idx, int *pts_cnt, rf_stream_t stream) {
@@ -583,13 +620,7 @@ int rf_queryballpoint_boxes(int b, int n, int m, float radius, const float *radi
         const float *src[1] = {xyz1};
         if (int e = rfp::sort_sets(b, 1, nn, src, &so, s, nullptr)) return e;
     }
-    const float thresh = radius_dev ? 0.f : ball_threshold(radius);
-    const int words = ((n + 31) / 32 + 127) / 128 * 128;
-    const size_t shmem = sizeof(unsigned) * (size_t)QX_WPB * (words + QX_LIST + QX_STAGE);
-    RF_LAUNCH("query_ball_boxes", query_ball_boxes_kernel, dim3(rf::ceil_div(m, QX_WPB), b), dim3(64 * QX_WPB), shmem, s,
-              n, m, so.npad, words, radius_dev ? 1.f : thresh, radius_dev, nsample, xyz1, xyz2, so.xyz, so.orig, so.box64,
-              so.pos0 + 2 * b, idx, pts_cnt);
-    return RF_OK;
+    return rfi::ball_boxes(b, n, m, radius, radius_dev, nsample, xyz1, xyz2, so, idx, pts_cnt, nullptr, 0, s);
 }
 
 int rf_grouppoint(int b, int n, int c, int m, int nsample, const float *points, const int *idx,

@@ -59,9 +59,11 @@
 
 namespace {
 
-// tuning knobs (tools/build_variant.py compiles A/B libraries with -D...; the defaults are the product, every value gives
-// correct results).  Decided experiments -- the Hilbert order of the register sort, the heavy-direction-first grid order,
-// the timing-only ablations of the sorted-space backward -- live in tools/experiments/nn_pruned_decided_knobs.patch.txt.
+// tuning knobs (tools/build_variant.py compiles A/B libraries with -D...; the defaults are the product; the values a knob
+// accepts are asserted below: RFP_NSH must stay 4 while RFP_TILE16 = 1).  Decided experiments -- the Hilbert order of the register
+// sort, the heavy-direction-first grid order, the timing-only ablations of the sorted-space backward -- live in
+// tools/experiments/nn_pruned_decided_knobs.patch.txt; the instrumented builds (scan histograms, phase stamps, cloud end times) in
+// tools/experiments/nn_pruned_instrumented_builds.patch.txt.
 #ifndef RFP_NSH
 #define RFP_NSH 4   // waves sharing one query group when a direction has few groups
 #endif
@@ -82,9 +84,6 @@ namespace {
 #ifndef RFP_QSAMPLE
 #define RFP_QSAMPLE 3  // the quantile histograms take every (RFP_QSAMPLE + 1)-th point: 3 = a quarter of the cloud
 #endif
-#ifndef RFP_HIST
-#define RFP_HIST 0  // 1 (instrumented build): block scans by number of active lanes -> stats[10..13]
-#endif
 #ifndef RFP_HAGG
 #define RFP_HAGG 1  // the sort's quantile histograms sample 4x fewer lanes in waves whose points crowd into few bins (collapsed clouds)
 #endif
@@ -103,26 +102,11 @@ namespace {
 #ifndef RFP_STR_SMALL_LEAF
 #define RFP_STR_SMALL_LEAF 32
 #endif
-#ifndef RFP_CLOUD_END
-#define RFP_CLOUD_END 0  // 1 (instrumented build): stats[c & 31] = s_memrealtime (100 MHz) at which the last workgroup of cloud c
-                         // left the sweep, INSTEAD of the counters: how far apart the clouds of one launch finish
-#endif
-#ifndef RFP_T16_STAMPS
-#define RFP_T16_STAMPS 0  // 1 (instrumented build): s_memtime per phase of the quad-per-query tiles, summed over waves -> stats[25..31]
-#endif
-#ifndef RFP_SG_STAMPS
-#define RFP_SG_STAMPS 0  // 1 (instrumented build): s_memtime per phase of the one-wave groups (sweep_group), summed over one wave in 64
-                         // -> stats[16..23] INSTEAD of the sort's stamps: prologue, step heads (key minimum, box load, block tests), block scans,
-                         // re-scans, second traversal, outputs + emit
-#endif
 #ifndef RFP_TILE16
 #define RFP_TILE16 1  // directions with few query groups: 1 = a wave per 16-query tile, four lanes per query, every quad walking its
                       // OWN list of candidate blocks with gathered scans (round 4); 0 = four waves share a
                       // 64-query group and stream every needed block through SGPRs to all 64 lanes (rounds 1-3)
 #endif
-// (the phase-stamp builds leave the per-wave counters out: five same-address atomics from each of 12 000 waves serialise at ~25 ns
-// each and the launch then measures its own atomics -- round 4's first stamps did, profiles/r04_rescan.txt)
-constexpr bool kStampBuild = RFP_SG_STAMPS || RFP_T16_STAMPS;
 constexpr int NSH = RFP_NSH;
 constexpr int BS = 16;             // candidates per block
 constexpr int SBB = 4;             // blocks per superblock
@@ -133,6 +117,10 @@ constexpr int STPB = 1024;         // sort kernel threads
 constexpr int RPT = 16;            // points per thread of the register-resident sort (n <= 16384)
 constexpr int HB = 256;            // equalisation histogram bins per axis
 static_assert(rfp::kMaxPoints / SB <= 1024, "superblock id must fit the key low 10 bits");
+// sweep_tile16 gives wave `wib` of a workgroup the tile of block `wib` of its group (qpos = (g * SBB + wib) * BS, box at
+// tb + wib * 6) and merges exactly four bucket masks: with another NSH waves 4.. would run into the next group (past npad on the
+// last one) or half the queries would never be written
+static_assert(!RFP_TILE16 || NSH == SBB, "the quad-per-query tiles need one wave per 16-record block of a group: RFP_NSH = 4");
 constexpr unsigned IDMASK = 0x3FFu;
 constexpr int B16F = SBB * 6;      // floats per superblock in box16: 4 x (lo.xyz, hi.xyz)
 constexpr int B64F = 8;            // floats per superblock in box64: lo.xyz, -, hi.xyz, -
@@ -1086,10 +1074,6 @@ __device__ __forceinline__ void sweep_group(
     const float *__restrict__ b16_1, const float *__restrict__ b64_0, const float *__restrict__ b64_1,
     float *__restrict__ dist0, float *__restrict__ dist1, int *__restrict__ idx0, int *__restrict__ idx1,
     unsigned long long *__restrict__ stats) {
-#if RFP_SG_STAMPS
-    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
-    const unsigned long long t_wave0 = __builtin_amdgcn_s_memrealtime();
-#endif
     const int cd = 1 - dir;
     constexpr bool shared4 = SHARED4;
     const int G = a.groups[dir];
@@ -1131,19 +1115,7 @@ __device__ __forceinline__ void sweep_group(
     // (padding): `bound <= cull` / `cull >= bound` are then false without a separate mask.
     float cull = part ? INFINITY : -INFINITY;
     unsigned n_step = 0, n_scan = 0;
-#if RFP_HIST
-    unsigned long long scan_hist = 0;
-#endif
-#if RFP_SG_STAMPS
-    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = t_entry;
-    auto stamp = [&](int ph) {
-        const unsigned long long now = __builtin_amdgcn_s_memtime();
-        tph[ph] += now - tlast;
-        tlast = now;
-    };
-#else
     auto stamp = [&](int) {};
-#endif
 
     // One traversal of the candidate superblocks in ascending order of a lower bound, for the lanes
     // with `part` set, whose box is [blo, bhi].
@@ -1335,9 +1307,6 @@ __device__ __forceinline__ void sweep_group(
             for (;;) {
                 const int blk = s * SBB + j;
                 n_scan++;
-#if RFP_HIST
-                scan_hist += 1ull << (16 * (nact <= 4 ? 0 : nact <= 16 ? 1 : nact <= 32 ? 2 : 3));
-#endif
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 __builtin_amdgcn_sched_barrier(0);
                 if (!have_rb) {
@@ -1443,9 +1412,6 @@ __device__ __forceinline__ void sweep_group(
     if (__ballot(bblk2 >= 0) != 0ull) {
         if (bblk2 >= 0) rescan(bblk2);
     }
-#if RFP_SG_STAMPS
-    if (__ballot(besti == 0x12345u) == ~0ull) return;  // (never true: makes the stamp wait for the re-scan's loads)
-#endif
     stamp(3);
     // queries whose minimum was attained in more than one visited block: second traversal
     const bool flagged = tie && part;
@@ -1465,16 +1431,14 @@ __device__ __forceinline__ void sweep_group(
     }
 
     stamp(4);
-    if (stats && lane == 0 && !kStampBuild) {
+    if (stats && lane == 0) {
         atomicAdd(&stats[dir * 4 + 0], 1ull);
         atomicAdd(&stats[dir * 4 + 1], (unsigned long long)n_step);
         atomicMax(&stats[dir * 4 + 2], (unsigned long long)n_step);
         atomicAdd(&stats[dir * 4 + 3], (unsigned long long)n_scan);
         atomicMax(&stats[8 + dir], (unsigned long long)n_scan);
-        stats[14 + dir] = SB * BS;  // directed pairs per counted scan
-#if RFP_HIST
-        for (int k = 0; k < 4; k++) atomicAdd(&stats[10 + k], (scan_hist >> (16 * k)) & 0xFFFFull);
-#endif
+        atomicAdd(&stats[12 + dir], (unsigned long long)n_scan * (SB * BS));  // directed pairs evaluated (64 queries x 16 candidates per scan)
+        stats[14 + dir] = SB * BS;  // pairs per counted scan of the LAST wave to report (a launch may mix both forms: use [12 + dir])
     }
 
     if (shared4) {
@@ -1495,13 +1459,8 @@ __device__ __forceinline__ void sweep_group(
         }
     }
     if (valid) {
-#if RFP_SG_STAMPS == 2  // (instrumented build, tools/experiments/wave_timeline.py: the outputs carry the wave's start and end, 10 ns units)
-        (dir ? dist1 : dist0)[(size_t)bi * a.n[dir] + qorig] = __uint_as_float((unsigned)__builtin_amdgcn_s_memrealtime());
-        (dir ? idx1 : idx0)[(size_t)bi * a.n[dir] + qorig] = (int)(unsigned)t_wave0;
-#else
         (dir ? dist1 : dist0)[(size_t)bi * a.n[dir] + qorig] = qnan ? NAN : best;
         (dir ? idx1 : idx0)[(size_t)bi * a.n[dir] + qorig] = (qnan || besti == 0xFFFFFFFFu) ? 0 : (int)besti;
-#endif
     }
     if constexpr (GRAD) {
         // index 0 of the NaN / no-match policy above = the candidate set's point with ORIGINAL index 0
@@ -1528,14 +1487,6 @@ __device__ __forceinline__ void sweep_group(
         }
         if (lane == 0) ev.mask[(size_t)bi * G + g] = gm;
     }
-#if RFP_SG_STAMPS
-    __builtin_amdgcn_s_waitcnt(0);  // (the outputs' stores and the emit's gathers count for the last phase)
-    stamp(5);
-    if (!shared4 && stats && lane == 0 && (gid & 63) == 0) {
-        for (int i = 0; i < 6; i++) atomicAdd(&stats[16 + i], tph[i]);
-        atomicAdd(&stats[22], 1ull);
-    }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1580,7 +1531,7 @@ struct SharedLds {  // sweep_group<true>: the group's shared minima and the four
 };
 struct T16Lds {
     unsigned short qsb[16][T16_CAPS];
-    float2 qe[16][T16_CAPB];  // (bound, block id): a pair of entries is one 16-byte LDS read
+    alignas(16) float2 qe[16][T16_CAPB];  // (bound, block id): a pair of entries is one 16-byte LDS read
 };
 
 #define RFP_QUAD(OP, PERM) asm volatile("s_nop 1\n\t" OP " %0, %0, %0 quad_perm:" PERM " row_mask:0xf bank_mask:0xf" : "+v"(v))
@@ -1632,9 +1583,6 @@ __device__ __forceinline__ void sweep_tile16(
     const float *__restrict__ b16_1, const float *__restrict__ b64_0, const float *__restrict__ b64_1,
     float *__restrict__ dist0, float *__restrict__ dist1, int *__restrict__ idx0, int *__restrict__ idx1,
     unsigned long long *__restrict__ stats) {
-#if RFP_SG_STAMPS == 2
-    const unsigned long long t_wave0 = __builtin_amdgcn_s_memrealtime();
-#endif
     const int cd = 1 - dir;
     const int G = a.groups[dir];
     const int bi = gid / G, g = gid - bi * G;
@@ -1667,16 +1615,7 @@ __device__ __forceinline__ void sweep_tile16(
     int bblk = 0, bblk2 = -1, seedblk = -1;
     bool tie = false;
     unsigned n_round = 0, n_scan = 0;
-#if RFP_T16_STAMPS
-    unsigned long long tph[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
-    auto stamp = [&](int ph) {
-        const unsigned long long now = __builtin_amdgcn_s_memtime();
-        tph[ph] += now - tlast;
-        tlast = now;
-    };
-#else
     auto stamp = [&](int) {};
-#endif
 
     // (minimum, lowest original index, position) of the quad's query over the 16 records of block blk: each lane its
     // 4 records, then the quad's lexicographic minimum -- every lane of the quad ends with the same triple
@@ -1950,30 +1889,19 @@ __device__ __forceinline__ void sweep_tile16(
     }
 
     stamp(6);
-#if RFP_T16_STAMPS
-    if (stats && lane == 0 && (gid & 15) == 0 && wib == 0)  // (one wave in 64: same-address atomics from every wave clog the memory pipe)
-    {
-        for (int i = 0; i < 7; i++) atomicAdd(&stats[25 + i], tph[i]);
-        atomicAdd(&stats[24], 1ull);
-    }
-#endif
-    if (stats && lane == 0 && !kStampBuild) {
+    if (stats && lane == 0) {
         atomicAdd(&stats[dir * 4 + 0], 1ull);
         atomicAdd(&stats[dir * 4 + 1], (unsigned long long)n_round);
         atomicMax(&stats[dir * 4 + 2], (unsigned long long)n_round);
         atomicAdd(&stats[dir * 4 + 3], (unsigned long long)n_scan);
         atomicMax(&stats[8 + dir], (unsigned long long)n_scan);
-        stats[14 + dir] = BS;  // directed pairs per counted scan: one query x 16 candidates (sweep_group: 64 x 16)
+        atomicAdd(&stats[12 + dir], (unsigned long long)n_scan * BS);  // directed pairs evaluated (one query x 16 candidates per scan)
+        stats[14 + dir] = BS;  // pairs per counted scan of the LAST wave to report (sweep_group: 64 x 16)
     }
 
     if (valid && k == 0) {
-#if RFP_SG_STAMPS == 2  // (instrumented build, tools/experiments/wave_timeline.py: the outputs carry the wave's start and end, 10 ns units)
-        (dir ? dist1 : dist0)[(size_t)bi * a.n[dir] + qorig] = __uint_as_float((unsigned)__builtin_amdgcn_s_memrealtime());
-        (dir ? idx1 : idx0)[(size_t)bi * a.n[dir] + qorig] = (int)(unsigned)t_wave0;
-#else
         (dir ? dist1 : dist0)[(size_t)bi * a.n[dir] + qorig] = qnan ? NAN : best;
         (dir ? idx1 : idx0)[(size_t)bi * a.n[dir] + qorig] = (qnan || besti == 0xFFFFFFFFu) ? 0 : (int)besti;
-#endif
     }
     if constexpr (GRAD) {
         const int *pos0 = (const int *)((const char *)(cd ? b64_1 : b64_0) +
@@ -2024,7 +1952,7 @@ __global__ __launch_bounds__(64 * NSH) __attribute__((amdgpu_waves_per_eu(RFP_WP
     const float *__restrict__ b64_0, const float *__restrict__ b64_1, float *__restrict__ dist0,
     float *__restrict__ dist1, int *__restrict__ idx0, int *__restrict__ idx1,
     unsigned long long *__restrict__ stats) {
-    extern __shared__ unsigned keys_dyn[];  // [waves][kstride]: each wave's list of superblock keys, then SharedLds | T16Lds[NSH]
+    extern __shared__ __attribute__((aligned(16))) unsigned keys_dyn[];  // [waves][kstride]: each wave's list of superblock keys, then SharedLds | T16Lds[NSH]
     __shared__ unsigned long long gmsh[NSH];
     __shared__ unsigned gmcnt;  // (step) tile waves of the workgroup that have stored their bucket mask
     // The shared-group form's exchange arrays live in DYNAMIC LDS too, over the tiles' lists (a workgroup is one or the other):
@@ -2061,7 +1989,7 @@ __global__ __launch_bounds__(64 * NSH) __attribute__((amdgpu_waves_per_eu(RFP_WP
                                          emit_align((size_t)a.b * (a.npad[cdk] / SB) * B64F * sizeof(float))) + a.b;
         if (flags[bi]) {
             sweep_group<true, GRAD>(a, ge, dir, bi * a.groups[dir] + wg, wib, lane, keys_dyn, shbest, md, mi, mp, xyz0, xyz1,
-                                    orig0, orig1, b16_0, b16_1, b64_0, b64_1, dist0, dist1, idx0, idx1, RFP_CLOUD_END ? nullptr : stats);
+                                    orig0, orig1, b16_0, b16_1, b64_0, b64_1, dist0, dist1, idx0, idx1, stats);
             return;
         }
         // (the tiles' lists live in DYNAMIC LDS behind the key lists: static arrays would be charged to every workgroup of
@@ -2072,7 +2000,7 @@ __global__ __launch_bounds__(64 * NSH) __attribute__((amdgpu_waves_per_eu(RFP_WP
             __syncthreads();
         }
         sweep_tile16<GRAD>(a, ge, dir, bi * a.groups[dir] + wg, wib, lane, keys_dyn, &t16[wib], gmsh, &gmcnt, xyz0, xyz1, orig0, orig1,
-                           b16_0, b16_1, b64_0, b64_1, dist0, dist1, idx0, idx1, RFP_CLOUD_END ? nullptr : stats);
+                           b16_0, b16_1, b64_0, b64_1, dist0, dist1, idx0, idx1, stats);
 #else
         sweep_group<true, GRAD>(a, ge, dir, bi * a.groups[dir] + wg, wib, lane, keys_dyn, shbest, md, mi, mp, xyz0, xyz1,
                                 orig0, orig1, b16_0, b16_1, b64_0, b64_1, dist0, dist1, idx0, idx1, stats);
@@ -2081,11 +2009,8 @@ __global__ __launch_bounds__(64 * NSH) __attribute__((amdgpu_waves_per_eu(RFP_WP
         const int g = wg * (int)(blockDim.x >> 6) + wib;
         if (g >= a.groups[dir]) return;  // (no barriers on this path)
         sweep_group<false, GRAD>(a, ge, dir, bi * a.groups[dir] + g, wib, lane, keys_dyn, shbest, md, mi, mp, xyz0, xyz1,
-                                 orig0, orig1, b16_0, b16_1, b64_0, b64_1, dist0, dist1, idx0, idx1, RFP_CLOUD_END ? nullptr : stats);
+                                 orig0, orig1, b16_0, b16_1, b64_0, b64_1, dist0, dist1, idx0, idx1, stats);
     }
-#if RFP_CLOUD_END
-    if (stats && lane == 0) atomicMax(&stats[bi & 31], (unsigned long long)__builtin_amdgcn_s_memrealtime());
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2308,7 +2233,7 @@ int sort_sets(int b, int nsets, const int *n, const float *const *src, const Sor
     SortArgs sa;
     sa.b = b;
     sa.nsets = nsets;
-    sa.dbg = (RFP_CLOUD_END || kStampBuild) ? nullptr : dbg;
+    sa.dbg = dbg;
     bool reg = true;
     for (int k = 0; k < 2; k++) {
         const int kk = k < nsets ? k : 0;

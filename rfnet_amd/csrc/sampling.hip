@@ -16,6 +16,7 @@
 // (double-buffered: ONE barrier per iteration) -> every 16-lane row re-reduces the slots by
 // DPP (max d2, then min tie rank) -> the winner's xyz is re-read with a scalar load.
 #include "common.hpp"
+#include "group_internal.hpp"
 
 namespace {
 
@@ -102,9 +103,11 @@ __device__ __forceinline__ float wave_allmax(float v) {
 //   exchange  lane 0 publishes (wm, k) in the wave's LDS slot (double-buffered: ONE barrier per
 //             iteration); every 16-lane row re-reduces the <=16 slots by DPP (max d2, then
 //             min tie rank); the winner's coordinates come back by a scalar load.
-template <int NT, int PPT>
+// EMIT: the samples' coordinates go out with their indices (new_xyz = gather_point(inp, out), tf_sampling_g.cu:172-181,
+// fused: the winner's coordinates are in scalar registers at that point of every iteration).
+template <int NT, int PPT, bool EMIT>
 __global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, const float *__restrict__ inp,
-                                                     int *__restrict__ out) {
+                                                     int *__restrict__ out, float *__restrict__ new_xyz) {
     constexpr int NW = NT / 64;
     constexpr int HALVES = NT / 512;
     static_assert(NW <= 16, "slot reduction is one 16-lane DPP row");
@@ -137,9 +140,15 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, const float *
         slot_d[t >> 4][t & 15] = -2.0f;
         slot_k[t >> 4][t & 15] = 0;
     }
+    float *__restrict__ NX = EMIT ? new_xyz + (size_t)bi * m * 3 : nullptr;
     if (t == 0) O[0] = 0;
     __syncthreads();
     float ox = P[0], oy = P[1], oz = P[2];  // old = 0
+    if (EMIT && t == 0) {
+        NX[0] = ox;
+        NX[1] = oy;
+        NX[2] = oz;
+    }
     for (int j = 1; j < m; j++) {
         float mx = -1.0f;
 #pragma unroll
@@ -181,7 +190,14 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, const float *
         ox = P[gk * 3 + 0];  // uniform address: scalar loads
         oy = P[gk * 3 + 1];
         oz = P[gk * 3 + 2];
-        if (t == 0) O[j] = gk;
+        if (t == 0) {
+            O[j] = gk;
+            if (EMIT) {
+                NX[j * 3 + 0] = ox;
+                NX[j * 3 + 1] = oy;
+                NX[j * 3 + 2] = oz;
+            }
+        }
     }
 }
 
@@ -563,21 +579,18 @@ __global__ __launch_bounds__(PS_T) void prob_sample_kernel(int n, int m, const f
 
 }  // namespace
 
-extern "C" {
-
-size_t rf_farthestpointsampling_temp_floats(int b, int n) {
-    return n > FPS_MAX_REG_POINTS ? (size_t)b * n : 0;
-}
-
-int rf_farthestpointsampling(int b, int n, int m, const float *inp, float *temp, int *out,
-                             rf_stream_t stream) {
+namespace rfi {
+int fps(int b, int n, int m, const float *inp, float *temp, int *out, float *new_xyz, hipStream_t s) {
     if (b < 0 || n < 0 || m < 0) return RF_EINVAL;
     if (b == 0 || m == 0) return RF_OK;
     if (n == 0) return RF_EINVAL;  // cannot sample from an empty cloud
     if (!inp || !out) return RF_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
-#define FPS_CASE(NT, PPT)                                                                      \
-    RF_LAUNCH("fps_reg", (fps_reg_kernel<NT, PPT>), dim3(b), dim3(NT), 0, s, n, m, inp, out); \
+#define FPS_CASE(NT, PPT)                                                                                             \
+    if (new_xyz) {                                                                                                    \
+        RF_LAUNCH("fps_reg", (fps_reg_kernel<NT, PPT, true>), dim3(b), dim3(NT), 0, s, n, m, inp, out, new_xyz);     \
+    } else {                                                                                                          \
+        RF_LAUNCH("fps_reg", (fps_reg_kernel<NT, PPT, false>), dim3(b), dim3(NT), 0, s, n, m, inp, out, new_xyz);    \
+    }                                                                                                                 \
     return RF_OK
     if (n <= 512) { FPS_CASE(512, 1); }
     if (n <= 1024) { FPS_CASE(1024, 1); }
@@ -588,7 +601,24 @@ int rf_farthestpointsampling(int b, int n, int m, const float *inp, float *temp,
 #undef FPS_CASE
     if (!temp) return RF_EINVAL;
     RF_LAUNCH("fps_mem", fps_mem_kernel, dim3(b), dim3(1024), 0, s, n, m, inp, temp, out);
+    if (new_xyz) {  // (the fallback kernel keeps its form: the coordinates by the gather kernel)
+        const long total = (long)b * m;
+        RF_LAUNCH("gather_point", gather_kernel, dim3(rf::ceil_div(total, 256)), dim3(256), 0, s, n, m, total, inp,
+                  (const int *)out, new_xyz);
+    }
     return RF_OK;
+}
+}  // namespace rfi
+
+extern "C" {
+
+size_t rf_farthestpointsampling_temp_floats(int b, int n) {
+    return n > FPS_MAX_REG_POINTS ? (size_t)b * n : 0;
+}
+
+int rf_farthestpointsampling(int b, int n, int m, const float *inp, float *temp, int *out,
+                             rf_stream_t stream) {
+    return rfi::fps(b, n, m, inp, temp, out, nullptr, (hipStream_t)stream);
 }
 
 size_t rf_fps_cluster_state_bytes(int b) {

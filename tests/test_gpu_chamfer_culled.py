@@ -128,7 +128,8 @@ def test_culled_equals_dense(orc, kind, b, n, m):
         if kind in ("randn", "uniform", "sphere", "collapsed"):
             assert stats[14] == (1024 if kind == "collapsed" else 16) and stats[15] in (16, 1024), (kind, stats[14], stats[15])
     if kind in ("randn", "uniform", "sphere"):
-        pairs = [stats[3] * (stats[14] or 1024), stats[7] * (stats[15] or 1024)]  # pairs per counted scan: stats[14 + d]
+        pairs = [stats[12], stats[13]]  # directed pairs evaluated per direction, summed by the kernel
+        assert pairs[0] > 0 and pairs[1] > 0 and pairs[0] % 16 == 0 and pairs[1] % 16 == 0
         assert pairs[0] < 0.6 * b * n * m and pairs[1] < 0.6 * b * n * m, (stats, b * n * m)
 
 

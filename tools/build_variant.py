@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Build an A/B variant of librfops.so with extra compiler defines (kernel tuning knobs are
 compile-time macros: the product library reads no environment variables).
-usage: python tools/build_variant.py TAG -DRFP_NSH=8 [-D...]   ->  rfnet_amd/variants/librfops_TAG.so
+usage: python tools/build_variant.py TAG -DRFP_SPLIT_BELOW=2048 [-D...]   ->  rfnet_amd/variants/librfops_TAG.so
 Load it with RFOPS_LIB=rfnet_amd/variants/librfops_TAG.so (a Python-side switch of rfnet_amd/_lib.py)."""
 import glob
 import os

@@ -60,8 +60,9 @@ def main():
             continue  # (a phase-stamp build: no per-wave counters)
         w, steps, mx, scans = st[4 * d:4 * d + 4]
         unit = st[14 + d] or 1024
+        pairs = st[12 + d]  # summed by the kernel: exact also when a launch mixes the two scan forms
         print(f"dir{d}: waves {w} steps/wave {steps / max(w, 1):.1f} (max {mx}) block scans/wave {scans / max(w, 1):.1f} "
-              f"(max {st[8 + d]}; {unit} pairs each) evaluated pairs {scans * unit:.3e} of {B * N * M:.3e} = {scans * unit / (B * N * M):.4f}")
+              f"(max {st[8 + d]}; {unit} pairs each) evaluated pairs {pairs:.3e} of {B * N * M:.3e} = {pairs / (B * N * M):.4f}")
     if any(st[25:32]):
         names = ["keys", "seed", "tile list", "query x superblock", "quad x block", "drain", "epilogue"]
         tot = sum(st[25:32])
