@@ -75,7 +75,8 @@ EMD_LAUNCH_MIX = {
     "am_p2, last level (e = 1: no distance, no exp)": (1, 1, 0),
     "am_p3p1, levels 1-8": (8, 11, 2),
     "am_p3p1, last level (P1 without exp)": (1, 10, 1),
-    "am_match (10 levels in one pass)": (1, 35, 9),
+    # round 5: levels 1, 3, 5, 7 take their weight from the next level's by two squarings (2 mul instead of mul + exp)
+    "am_match (10 levels in one pass)": (1, 39, 5),
 }
 
 
@@ -86,12 +87,12 @@ def emd_issue_floor_ms(eb, n, m):
     try:
         with open(os.path.join(ROOT, "profiles", "issue_costs.json")) as f:
             ic = json.load(f)
-    except (OSError, ValueError):
+        c = ic["cycles_per_wave_instruction_per_simd"]
+        cyc = sum(k * (p * c["vop2_f32"] + e * c["v_exp_f32"]) for k, p, e in EMD_LAUNCH_MIX.values())
+        nonadd = 9.0 * c["emd_column_mix_9_instr"] / (8.0 * c["vop2_f32"] + c["v_exp_f32"])
+        add_ms = cyc * (eb * n * m / 64.0) / 1024.0 / (ic["clock_ghz"] * 1e9) * 1e3
+    except (OSError, ValueError, KeyError, TypeError, ZeroDivisionError):  # a missing or reshaped constants file costs the roof, not the bench
         return None
-    c = ic["cycles_per_wave_instruction_per_simd"]
-    cyc = sum(k * (p * c["vop2_f32"] + e * c["v_exp_f32"]) for k, p, e in EMD_LAUNCH_MIX.values())
-    nonadd = 9.0 * c["emd_column_mix_9_instr"] / (8.0 * c["vop2_f32"] + c["v_exp_f32"])
-    add_ms = cyc * (eb * n * m / 64.0) / 1024.0 / (ic["clock_ghz"] * 1e9) * 1e3
     return {"additive_ms": add_ms, "mix_ms": add_ms * nonadd, "non_additivity": nonadd,
             "valu_per_pair": sum(k * (p + e) for k, p, e in EMD_LAUNCH_MIX.values()),
             "exp_per_pair": sum(k * e for k, p, e in EMD_LAUNCH_MIX.values()),
@@ -292,43 +293,74 @@ def run_c3(rank, dev, fence, reps):
     query_ball_point(0.1, 32, xyz, new_xyz); group_point(xyz, idx).  Which roof binds each op: SURVEY.md 8(d)
     (FPS: serial-reduction latency, reported as us per iteration and distance updates/s; ball query: VALU scan
     with early exit, reported as pair tests/s against the scan's upper bound; gather / group: HBM)."""
-    from rfnet_amd._raw import farthest_point_sample, gather_point, group_point, query_ball_point
+    from rfnet_amd._raw import farthest_point_sample, gather_point, group_point, nn_sort, query_ball_point, sample_and_group
     B, n, m, ns, r = 32, 16384, 1024, 32, 0.1
     rng = np.random.RandomState(100 + rank)
     xyz = torch.from_numpy(rng.random_sample((B, n, 3)).astype(np.float32)).to(dev)
     idx = farthest_point_sample(m, xyz)
     new_xyz = gather_point(xyz, idx)
-    gi, cnt = query_ball_point(r, ns, xyz, new_xyz)
+    gi, cnt = query_ball_point(r, ns, xyz, new_xyz)                      # auto: the boxed kernel at this size
+    gi_scan, cnt_scan = query_ball_point(r, ns, xyz, new_xyz, form="scan")
     fps_ms, fps_k = timed(lambda: farthest_point_sample(m, xyz), max(3, reps // 2), fence)
     ga_ms, ga_k = timed(lambda: gather_point(xyz, idx), reps, fence)
     qb_ms, qb_k = timed(lambda: query_ball_point(r, ns, xyz, new_xyz), reps, fence)
+    handle = nn_sort(xyz)
+    qh_ms, qh_k = timed(lambda: query_ball_point(r, ns, xyz, new_xyz, sorted1=handle.buf), reps, fence)
+    qs_ms, qs_k = timed(lambda: query_ball_point(r, ns, xyz, new_xyz, form="scan"), reps, fence)
     gp_ms, gp_k = timed(lambda: group_point(xyz, gi), reps, fence)
+    aux = torch.cuda.Stream(device=dev)
+    one_ms, one_k = timed(lambda: sample_and_group(m, r, ns, xyz), max(3, reps // 2), fence)
+    onea_ms, _ = timed(lambda: sample_and_group(m, r, ns, xyz, aux_stream=aux), max(3, reps // 2), fence)
+    one = sample_and_group(m, r, ns, xyz, aux_stream=aux)
+    torch.cuda.synchronize()
+    one_same = (bool(torch.equal(one[0], idx)) and bool(torch.equal(one[1], new_xyz)) and bool(torch.equal(one[2], gi))
+                and bool(torch.equal(one[3], cnt)) and bool(torch.equal(one[4], group_point(xyz, gi))))
     fps_kms = fps_k.get("fps_reg", fps_k.get("fps_mem", fps_ms))
+    box_kms = qb_k.get("query_ball_boxes", qb_ms)
     updates = float(B) * n * (m - 1)
     return {
         "workload": f"B={B} per GPU, farthest_point_sample {n} -> {m} + gather_point + query_ball_point(r={r}, nsample={ns}) "
                     "+ group_point(c=3), U[0,1)^3 seed 100 (BASELINE.json configs[2])",
-        "ms_per_pass": fps_ms + ga_ms + qb_ms + gp_ms,
+        "ms_per_pass": onea_ms,
+        "ms_per_pass_is": "rf_sample_and_group: ONE C-ABI call (FPS writes new_xyz, the boxed ball query writes grouped_xyz, the "
+                          "dataset's sort beside FPS on an auxiliary stream); outputs identical to the four ops: "
+                          + str(one_same),
+        "ms_per_pass_one_stream": one_ms,
+        "ms_per_pass_four_ops": fps_ms + ga_ms + qb_ms + gp_ms,
+        "ms_per_pass_four_ops_scan_ball_query": fps_ms + ga_ms + qs_ms + gp_ms,
+        "one_call_kernels_ms": one_k,
         "farthest_point_sample": {
             "ms": fps_ms, "kernel_ms": fps_kms, "us_per_iteration": fps_kms * 1e3 / (m - 1),
             "distance_updates_per_s": updates / (fps_kms * 1e-3),
             "roofline": {"bound": "latency", "what": "serial chain of npoint-1 dependent arg-max reductions, one workgroup "
-                         "(one CU) per cloud: B of the 256 CUs busy by construction; no bandwidth or FLOP roof applies",
+                         "(one CU) per cloud: B of the 256 CUs busy by construction, and on that CU the VALU issues 53 % of every wave's "
+                         "life (343 instructions per wave and iteration at 2 waves per SIMD).  Spreading a cloud over 2/4/8 workgroups "
+                         "was built and is 1.27-1.43x SLOWER: one all-to-all exchange of the winners costs 0.5-0.9 us against the 1.09 us "
+                         "of a whole iteration (profiles/r05_fps_cluster.txt)",
                          "cus_busy": B, "valu_flops_per_s": 8.0 * updates / (fps_kms * 1e-3),
                          "frac_of_fp32_peak_on_busy_cus": 8.0 * updates / (fps_kms * 1e-3) / 1e12 / (FP32_PEAK_TFLOPS * B / 256.0)}},
         "gather_point": {"ms": ga_ms, "roofline": hbm_roof(28.0 * B * m, ga_k.get("gather_point", ga_ms), "gather_point",
-                                                            "28*B*m bytes (SURVEY 8(d)): 0.9 MB -- launch-bound, not a bandwidth test")},
+                                                            "28*B*m bytes (SURVEY 8(d)): 0.9 MB -- launch-bound, not a bandwidth test; "
+                                                            "inside rf_sample_and_group FPS writes new_xyz itself")},
         "query_ball_point": {
-            "ms": qb_ms, "kernel_ms": qb_k.get("query_ball_point", qb_ms),
-            "pair_tests_upper_bound_per_s": float(B) * n * m / (qb_k.get("query_ball_point", qb_ms) * 1e-3),
+            "ms": qb_ms, "kernels_ms": qb_k, "ms_on_a_sorted_handle": qh_ms, "ms_scan_kernel": qs_ms,
+            "form": "boxed: the dataset in sort-tile-recursive order (nnp_sort), one wave per query over the 64-record blocks whose "
+                    "box is within the radius, the nsample lowest original indices through an LDS bitmap (grouping.hip)",
+            "identical_to_scan_kernel": bool(torch.equal(gi, gi_scan)) and bool(torch.equal(cnt, cnt_scan)),
             "mean_pts_cnt": float(cnt.float().mean().item()),
-            "roofline": {"bound": "valu", "what": "scan with early exit: <= B*n*m pair tests, 6 VALU ops each (sub x3, mul, fma x2) "
-                         "+ 1 compare; achieved counts every pair as tested (upper bound on the work)",
-                         "achieved": 8.0 * B * n * m / (qb_k.get("query_ball_point", qb_ms) * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS,
-                         "unit": "TFLOP/s",
-                         "frac": 8.0 * B * n * m / (qb_k.get("query_ball_point", qb_ms) * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}},
+            "pair_tests_upper_bound_per_s": float(B) * n * m / (box_kms * 1e-3),
+            "roofline": {"bound": "valu-issue",
+                         "what": "the boxed kernel tests ~4 % of the B*n*m pairs (256 boxes + ~10 blocks of 64 records per query) and is "
+                                 "bound by instruction issue: ~600 VALU + ~310 SALU wave-instructions per query wave, 39 % of wave time "
+                                 "waiting to issue (profiles/r05_ball_query_first_pmc.txt); `achieved` prices the B*n*m pair tests of "
+                                 "the SCAN it replaces (8 flop each) against the fp32 vector peak -- an effective figure, like the "
+                                 "culled Chamfer's",
+                         "achieved": 8.0 * B * n * m / (box_kms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": 8.0 * B * n * m / (box_kms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                         "scan_kernel_frac": 8.0 * B * n * m / (qs_k.get("query_ball_point", qs_ms) * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}},
         "group_point": {"ms": gp_ms, "roofline": hbm_roof(4.0 * B * m * ns * (1 + 2 * 3), gp_k.get("group_point", gp_ms), "group_point",
-                                                          "4*B*m*nsample*(1+2c) bytes (SURVEY 8(d)): 29 MB")},
+                                                          "4*B*m*nsample*(1+2c) bytes (SURVEY 8(d)): 29 MB; inside rf_sample_and_group "
+                                                          "the ball query writes grouped_xyz itself")},
         "checksum": {"fps_idx_sum": int(idx.long().sum().item()), "ball_idx_sum": int(gi.long().sum().item())},
     }
 
@@ -642,8 +674,8 @@ def main():
             ent = {"ms_per_step": ms_step, "forward_ms_auto": sum(am.values()), "forward_ms_dense": sum(dm.values()),
                    "auto_kernels_ms": am, "note": note,
                    "identical_to_dense_sweep": all(bool(torch.equal(x, y)) for x, y in zip(o_auto, o_dense))}
-            if "nnp_sweep" in am and len(st) >= 8:
-                ev = float((st[14] or 1024) * st[3] + (st[15] or 1024) * st[7])
+            if "nnp_sweep" in am and len(st) >= 14:
+                ev = float(st[12] + st[13])  # directed pairs evaluated, summed by the kernel
                 ent.update({"forward": "culled", "evaluated_fraction_of_2BNM": ev / (2.0 * B * N * M),
                             "heaviest_wave_block_scans": [int(st[8]), int(st[9])],
                             "culled_faster_than_dense": sum(am.values()) < sum(dm.values())})
@@ -656,6 +688,27 @@ def main():
             byd[name] = measure(a, c, note)
             del a, c
         extras["by_distribution"] = byd
+        # ---- the reference's own bench shape (tf_ops/CD/tf_nndistance.py:35-61): randn(32,16384,3) vs randn(32,1024,3), fwd+bwd
+        rrng = np.random.RandomState(100 + rank)
+        ra = torch.from_numpy(rrng.randn(B, 16384, 3).astype(np.float32)).to(dev)
+        rc = torch.from_numpy(rrng.randn(B, 1024, 3).astype(np.float32)).to(dev)
+        rplan = ChamferStep(B, 16384, 1024, dev)
+        rg1, rg2 = torch.ones(B, 16384, device=dev), torch.ones(B, 1024, device=dev)
+        for _ in range(3):
+            rout = rplan(ra, rc, rg1, rg2)
+        fence()
+        tr = time.perf_counter()
+        for _ in range(dsteps):
+            rout = rplan(ra, rc, rg1, rg2)
+        fence()
+        r_ms = (time.perf_counter() - tr) / dsteps * 1e3
+        r_dense = nn_distance(ra, rc, mode="dense")
+        extras["reference_bench_shape"] = {
+            "workload": f"nn_distance fwd+bwd, B={B} per GPU, 16384 vs 1024 (the reference's own smoke/bench shape, "
+                        "tf_ops/CD/tf_nndistance.py:35-61), randn seed 100, upstream grads of ones",
+            "ms_per_step": r_ms, "value": world * float(B) * 16384 * 1024 / (r_ms * 1e-3), "unit": "pairs/s",
+            "identical_to_dense_sweep": all(bool(torch.equal(x, y)) for x, y in zip(rout[:4], r_dense))}
+        del ra, rc, rplan, rg1, rg2, rout, r_dense
 
         # ---- second half of BASELINE.json's metric string, "EMD iters/sec": one iter = one
         # approx_match + match_cost batch call on configs[3] (B=32, 2048 vs 2048, the reference's
@@ -752,7 +805,6 @@ def main():
                 "issue_floor_source": (efl["constants"] + "; counted instructions per launch: EMD_LAUNCH_MIX in bench.py") if efl else
                                       "profiles/issue_costs.json missing",
                 "frac": (efl["mix_ms"] / am_kernel_ms) if efl else None,
-                "valu_pipe_busy_by_counters": "0.88-0.93 of the launch (SQ_ACTIVE_INST_VALU, profiles/r04_rocprofv3_summary.txt): issue-bound",
                 "frac_of_fp32_peak": 2.0 * lane_ops / (am_kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
                 "avg_kernel_sum_ms": am_kernel_ms, "approx_match_ms_wall": am_ms, "kernels_ms": am_k,
                 "mfma": "not applicable: every matrix element needs its own exp(level * d2) (8 of the 9 ops and all of the "
@@ -856,6 +908,10 @@ def main():
         line = {
             "metric": "point-pairs/sec Chamfer (BxNxM)",
             "value": world * pairs_per_step * args.steps / dt,
+            "value_is": (f"effective rate: B*N*M pairs per step / time; the culled sweep evaluated "
+                         f"{100.0 * evaluated / (2.0 * B * N * M):.1f} % of the 2*B*N*M directed pairs and returns outputs "
+                         "bit-identical to the sweep that evaluates all of them (roofline.identical_to_dense_sweep)") if culled and len(culled_stats) >= 14 and sweep_avg_s
+                        else "B*N*M pairs per step / time; every pair evaluated",
             "unit": "pairs/s",
             "n_gpus": world,
             "rccl_ranks": world if use_pg else 1,
@@ -900,7 +956,9 @@ def main():
                 "atomic lanes and kernel-boundary latency, not by HBM (profiles/r03_ab_grad_sorted.txt)"),
             "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items())},
             "kernel_sum_ms_per_step": kernel_sum_ms,
-            "host_overhead_ms_per_step": dt / args.steps * 1e3 - kernel_sum_ms,
+            # (kernel_sum comes from the SECOND, hipEvent-instrumented pass over the same K steps, whose event records sit between the
+            # launches and lengthen it: ms_per_step_instrumented.  The un-instrumented step can therefore be SHORTER than that sum;
+            # no "host overhead" is derived from the two.)
             "ms_per_step_instrumented": dt_prof / args.steps * 1e3,
             "checksum": checksum,
             # how far the checker itself is pinned: the GPU path is bit-exact / in
