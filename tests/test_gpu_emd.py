@@ -74,7 +74,9 @@ def test_c4_config_full_size(orc):
     strict_bar_report("C4 match, sample 3 (32x2048x2048)", gm, om)  # the un-relaxed bar, always reported
     assert np.abs(gm - om).max() < 2e-4
     tight = np.abs(gm - om) <= 1e-6 + 1e-4 * np.abs(om)
-    assert tight.mean() > 0.9999
+    # the un-relaxed bar's own count, held where rounds 4 and 5 measured it (21 of 4 194 304 outside = 99.99950 % inside, with
+    # and without round 5's squared level weights in am_match): a change that widens it fails here, not in a warning
+    assert int((~tight).sum()) <= 32, f"{int((~tight).sum())} entries outside abs 1e-6 + rel 1e-4 (21 in rounds 4-5)"
     assert_rel(cost[3:4].cpu().numpy(), orc.match_cost(a[3:4], c[3:4], om), 1e-5, what="cost[3]")
     # doubly stochastic (n == m): every point ships and receives unit mass
     rows = match.sum(1).cpu().numpy()
