@@ -74,13 +74,25 @@ __global__ void am_init_kernel(int npts, int npad, float fill, const float *__re
 // evaluated; fma(1.0, s, acc) rounds exactly as before -> the same bits for fewer instructions;
 // 3 = present at the SAME multiplier as the P3 it is fused with (a schedule that repeats a level, e.g. the
 // 50-level schedule of BASELINE configs[3]): the two exponentials have the same argument, one is evaluated -- same bits.
-template <bool HAS_P3, int P1, int RPT>
+// SKIP (round 5, the sharp levels): the lanes' rows are taken in the SPATIAL order of their cloud (`perm`: position in the
+// sort-tile-recursive order -> original row, -1 for padding: rfp::Sorted::orig), so a wave's 64 * RPT rows sit in a small box,
+// and a column whose d2 to every one of them is >= tskip is skipped after the distance: its weights would be exactly 0
+// (tskip is the d2 beyond which v_exp_f32 returns +0 for the LESS sharp of the launch's levels), so every sum keeps its
+// bits -- the row order does not enter any sum, the column order is untouched.  At C4 a wave skips the exponentials of
+// 91 / 81 / 58 % of its columns at levels -4^7 / -4^6 / -4^5 (28 / 84 / 100 % would pass with rows in input order).
+// SKIP = 1: a column is dropped when it is beyond `tskip` (this level's cut-off) of every row; the fused P3 of the previous,
+//           sharper level is evaluated only for columns within its own cut-off `tskip_prev` (<= tskip) of some row;
+// SKIP = 2: this level is too broad to drop columns (every weight is evaluated) but the fused P3's level is not: only its part
+//           is conditional.  Both tests are wave-uniform branches on a ballot.
+template <bool HAS_P3, int P1, int RPT, int SKIP = 0>
 __global__ __launch_bounds__(1024) void am_rowk_kernel(
     int n, int seglen, const float *__restrict__ xyz1, const float *__restrict__ xyz2p,
     size_t xyz2p_stride, const float *__restrict__ ratioR_prev, const float *__restrict__ remainR,
     const float *__restrict__ ratioL_prev, float *__restrict__ remainL,
-    float *__restrict__ ratioL_out, size_t stride, float c_prev, float c_cur) {
+    float *__restrict__ ratioL_out, size_t stride, float c_prev, float c_cur, const int *__restrict__ perm,
+    int perm_stride, float tskip, float tskip_prev) {
     __shared__ float part3[16][64 * RPT], part1[16][64 * RPT];
+    static_assert(SKIP == 0 || P1 == 1, "the skipping sweeps evaluate this level's own exponential");
     const int bi = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -88,10 +100,14 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
     const int nseg = blockDim.x >> 6;
     const float *__restrict__ A = xyz1 + (size_t)bi * n * 3;
     float x1[RPT], y1[RPT], z1[RPT], rl[RPT], acc3[RPT], acc1[RPT];
+    int krow[RPT];  // the lane's rows (original indices; < 0: none)
 #pragma unroll
     for (int r = 0; r < RPT; r++) {
-        const int kk = min((int)blockIdx.x * 64 * RPT + r * 64 + lane, n - 1);
+        const int pos = (int)blockIdx.x * 64 * RPT + r * 64 + lane;
+        krow[r] = SKIP != 0 ? (pos < perm_stride ? perm[(size_t)bi * perm_stride + pos] : -1) : (pos < n ? pos : -1);
+        const int kk = krow[r] >= 0 ? krow[r] : n - 1;
         x1[r] = A[kk * 3]; y1[r] = A[kk * 3 + 1]; z1[r] = A[kk * 3 + 2];
+        if (SKIP != 0 && krow[r] < 0) x1[r] = INFINITY;  // a lane without a row never keeps a column alive (d2 = inf)
         rl[r] = HAS_P3 ? ratioL_prev[(size_t)bi * stride + kk] : 0.f;
         acc3[r] = 0.f;
         acc1[r] = (seg == 0) ? 1e-9f : 0.f;
@@ -126,15 +142,36 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < SUB; u++) {
+            float d2[RPT];
+            bool near = false, near_prev = false;
 #pragma unroll
             for (int r = 0; r < RPT; r++) {
-                const float d2 = rf::d2_fma(cb[u * 3] - x1[r], cb[u * 3 + 1] - y1[r], cb[u * 3 + 2] - z1[r]);
+                d2[r] = rf::d2_fma(cb[u * 3] - x1[r], cb[u * 3 + 1] - y1[r], cb[u * 3 + 2] - z1[r]);
+                near = near || d2[r] < tskip;
+                near_prev = near_prev || d2[r] < tskip_prev;
+            }
+            if (SKIP == 1) {
+                if (__ballot(near) == 0ull) continue;  // (uniform) every weight of this column is exactly 0 in this wave
+                asm volatile("; column kept");          // (keeps the branch a branch: see grouping.hip's hit path)
+            }
+            if (SKIP != 0 && HAS_P3) {  // the two parts under their own tests (static_assert below: P1 == 1 here)
+#pragma unroll
+                for (int r = 0; r < RPT; r++) acc1[r] = fmaf(fast_exp2(d2[r] * c_cur), s1[u], acc1[r]);
+                if (__ballot(near_prev) != 0ull) {  // (uniform)
+                    asm volatile("; previous level kept");
+#pragma unroll
+                    for (int r = 0; r < RPT; r++) acc3[r] = fmaf(rl[r] * fast_exp2(d2[r] * c_prev), s3[u], acc3[r]);
+                }
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < RPT; r++) {
                 float e3 = 0.f;
                 if (HAS_P3) {
-                    e3 = fast_exp2(d2 * c_prev);
+                    e3 = fast_exp2(d2[r] * c_prev);
                     acc3[r] = fmaf(rl[r] * e3, s3[u], acc3[r]);
                 }
-                if (HAS_P1) acc1[r] = fmaf(P1 == 2 ? 1.0f : (P1 == 3 ? e3 : fast_exp2(d2 * c_cur)), s1[u], acc1[r]);
+                if (HAS_P1) acc1[r] = fmaf(P1 == 2 ? 1.0f : (P1 == 3 ? e3 : fast_exp2(d2[r] * c_cur)), s1[u], acc1[r]);
             }
         }
     }
@@ -147,8 +184,8 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
     if (seg == 0) {
 #pragma unroll
         for (int r = 0; r < RPT; r++) {
-            const int k = blockIdx.x * 64 * RPT + r * 64 + lane;
-            if (k >= n) continue;
+            const int k = krow[r];
+            if (k < 0) continue;
             float t3 = part3[0][r * 64 + lane], t1 = part1[0][r * 64 + lane];
             for (int g = 1; g < nseg; g++) {
                 t3 += part3[g][r * 64 + lane];
@@ -168,11 +205,12 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
 //   sumr = sum_k fma(e, ratioL[k], .);  t = sumr*remainR[l];  cons = min(remainR[l]/(t+1e-9), 1)
 //   ratioR[l] = remainR[l]*cons;  remainR[l] = max(0, remainR[l]-t)
 // ZERO: the level's multiplier is 0 -> e = 1.0 exactly, no distance and no exponential (see am_rowk).
-template <int RPT, bool ZERO>
+template <int RPT, bool ZERO, bool SKIP = false>
 __global__ __launch_bounds__(1024) void am_rowl_kernel(
     int m, int seglen, const float *__restrict__ xyz2, const float *__restrict__ xyz1p,
     size_t xyz1p_stride, const float *__restrict__ ratioL, float *__restrict__ remainR,
-    float *__restrict__ ratioR_out, size_t stride, float c_cur) {
+    float *__restrict__ ratioR_out, size_t stride, float c_cur, const int *__restrict__ perm, int perm_stride,
+    float tskip) {
     __shared__ float part[16][64 * RPT];
     const int bi = blockIdx.y;
     const int lane = threadIdx.x & 63;
@@ -180,10 +218,14 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
     const int nseg = blockDim.x >> 6;
     const float *__restrict__ B = xyz2 + (size_t)bi * m * 3;
     float x2[RPT], y2[RPT], z2[RPT], acc[RPT];
+    int lrow[RPT];  // the lane's rows (original indices; < 0: none); SKIP: in the cloud's spatial order (see am_rowk_kernel)
 #pragma unroll
     for (int r = 0; r < RPT; r++) {
-        const int ll = min((int)blockIdx.x * 64 * RPT + r * 64 + lane, m - 1);
+        const int pos = (int)blockIdx.x * 64 * RPT + r * 64 + lane;
+        lrow[r] = SKIP ? (pos < perm_stride ? perm[(size_t)bi * perm_stride + pos] : -1) : (pos < m ? pos : -1);
+        const int ll = lrow[r] >= 0 ? lrow[r] : m - 1;
         x2[r] = B[ll * 3]; y2[r] = B[ll * 3 + 1]; z2[r] = B[ll * 3 + 2];
+        if (SKIP && lrow[r] < 0) x2[r] = INFINITY;
         acc[r] = 0.f;
     }
     const float *__restrict__ C = xyz1p + (size_t)bi * xyz1p_stride;
@@ -209,11 +251,19 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < SUB; u++) {
+            float d2[RPT];
+            bool near = false;
 #pragma unroll
             for (int r = 0; r < RPT; r++) {
-                const float d2 = rf::d2_fma(x2[r] - cb[u * 3], y2[r] - cb[u * 3 + 1], z2[r] - cb[u * 3 + 2]);
-                acc[r] = fmaf(ZERO ? 1.0f : fast_exp2(d2 * c_cur), sc[u], acc[r]);
+                d2[r] = rf::d2_fma(x2[r] - cb[u * 3], y2[r] - cb[u * 3 + 1], z2[r] - cb[u * 3 + 2]);
+                near = near || d2[r] < tskip;
             }
+            if (SKIP) {
+                if (__ballot(near) == 0ull) continue;  // (uniform)
+                asm volatile("; column kept");
+            }
+#pragma unroll
+            for (int r = 0; r < RPT; r++) acc[r] = fmaf(ZERO ? 1.0f : fast_exp2(d2[r] * c_cur), sc[u], acc[r]);
         }
     }
 #pragma unroll
@@ -222,8 +272,8 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
     if (seg == 0) {
 #pragma unroll
         for (int r = 0; r < RPT; r++) {
-            const int l = blockIdx.x * 64 * RPT + r * 64 + lane;
-            if (l >= m) continue;
+            const int l = lrow[r];
+            if (l < 0) continue;
             float sumr = part[0][r * 64 + lane];
             for (int g = 1; g < nseg; g++) sumr += part[g][r * 64 + lane];
             const float rem = remainR[(size_t)bi * stride + l];
@@ -962,12 +1012,18 @@ struct AmLayout {
     size_t off_x1, off_x2, total;  // in floats
     // culled sweeps (sizes known without the level values: room is reserved whenever the clouds qualify)
     bool cull_ok;
+    bool rowsort_ok;       // the dense sweeps of the sharp levels take their rows in the clouds' spatial order (am_rowk_kernel SKIP)
     int nsa, nsb;          // padded sizes of the two sorted sets
     size_t Vs;             // floats per sorted twin pair [L: nsa | R: nsb]
     size_t tw_stride;      // floats per batch element of the twin region: (1 + CULL_MAXLV) * Vs
     size_t off_sa, off_sb, off_tw;
 };
 constexpr int CULL_MAXLV = 8;  // at most this many leading levels are culled
+#ifndef RFA_ROWSORT_MIN_PAIRS
+#define RFA_ROWSORT_MIN_PAIRS 6.0e7
+#endif
+constexpr double ROWSORT_MIN_PAIRS = RFA_ROWSORT_MIN_PAIRS;
+constexpr float kSkipArg = 161.f;  // d2 * |c| >= 161 => fl(d2 * c) <= -160 => v_exp_f32 = +0 (kCullArg, with the product's rounding covered)
 
 int round_up_i(int v, int q) { return (v + q - 1) / q * q; }
 
@@ -985,19 +1041,23 @@ AmLayout am_layout(int b, int n, int m, int nlevels, bool allow_cull) {
     L.off_x2 = off;
     off += (size_t)b * L.mpad * 3 + 64;
     L.cull_ok = allow_cull && n >= CULL_MIN_PTS && m >= CULL_MIN_PTS && rfp::pruned_supported(b, n, m);
+    // (sizes alone decide; same device: 32 x 1024^2 = 3.4e7 pairs 0.324 ms with the sort against 0.316 without, 32 x 2048^2 = 1.3e8 pairs 1.026 against 1.057)
+    L.rowsort_ok = n >= 512 && m >= 512 && (double)b * n * m >= ROWSORT_MIN_PAIRS && rfp::pruned_supported(b, n, m);
     L.nsa = L.nsb = 0;
     L.Vs = L.tw_stride = L.off_sa = L.off_sb = L.off_tw = 0;
-    if (L.cull_ok) {
+    if (L.cull_ok || L.rowsort_ok) {
         L.nsa = rfp::sorted_view(b, n, nullptr).npad;
         L.nsb = rfp::sorted_view(b, m, nullptr).npad;
-        L.Vs = (size_t)L.nsa + L.nsb;
-        L.tw_stride = L.Vs * (size_t)(1 + CULL_MAXLV);
         off = (off + 63) / 64 * 64;  // 256-byte alignment of the sorted sets
         L.off_sa = off;
         off += (rfp::sorted_bytes(b, n) + 3) / 4 + 64;
         off = (off + 63) / 64 * 64;
         L.off_sb = off;
         off += (rfp::sorted_bytes(b, m) + 3) / 4 + 64;
+    }
+    if (L.cull_ok) {
+        L.Vs = (size_t)L.nsa + L.nsb;
+        L.tw_stride = L.Vs * (size_t)(1 + CULL_MAXLV);
         L.off_tw = off;
         off += (size_t)b * L.tw_stride + 64;
     }
@@ -1071,15 +1131,30 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
                   multiR, tw + L.nsa, L.tw_stride);
     }
     float *remL_s = tw, *remR_s = tw + L.nsa;
+    // the sharp levels that stay on the dense sweeps: rows in the clouds' spatial order, columns with all-zero weights skipped
+    // (am_rowk_kernel SKIP; bit-identical sums).  Level v qualifies when its weight is exactly 0 from a d2 of at most kCullMaxT on.
+    auto skip_t = [&](int v) { return (v >= 0 && v < nlevels && lc.c[v] < 0.f) ? kSkipArg / -lc.c[v] : INFINITY; };
+    const int *permA = nullptr, *permB = nullptr;
+    if (ncull == 0 && L.rowsort_ok && skip_t(0) <= kCullMaxT) {
+        const rfp::Sorted so[2] = {rfp::sorted_view(b, n, w + L.off_sa), rfp::sorted_view(b, m, w + L.off_sb)};
+        const int nn[2] = {n, m};
+        const float *src[2] = {xyz1, xyz2};
+        if (int e = rfp::sort_sets(b, 2, nn, src, so, s, nullptr)) return e;
+        permA = so[0].orig;
+        permB = so[1].orig;
+    }
 
     // 2 rows per lane (measured best of 1 / 2 / 4: longer compute per scalar prefetch covers the L2
     // latency of the s_loads without dropping below 4 waves per SIMD)
     constexpr int RPT = 2;
     const int segk = pick_nseg(b, n, L.mpad, RPT), segl = pick_nseg(b, m, L.npad, RPT);
     const dim3 gk(rf::ceil_div(n, 64 * RPT), b), gl(rf::ceil_div(m, 64 * RPT), b);
+    const dim3 gks(rf::ceil_div(L.nsa, 64 * RPT), b), gls(rf::ceil_div(L.nsb, 64 * RPT), b);  // SKIP: over the sorted positions
     for (int v = 0; v < nlevels; v++) {
         float *ratioL = ratios + (size_t)v * L.V, *ratioR = ratioL + L.npad;
         const bool zero = lc.c[v] == 0.0f;  // e = exp2(d2 * 0) = 1 exactly: no exponential needed
+        const float tsk = skip_t(v);        // (a fused P3 of level v-1 is sharper or equal wherever this one is skippable)
+        const bool skip = permA && tsk <= kCullMaxT && (v == 0 || (lc.c[v - 1] < 0.f && lc.c[v - 1] <= lc.c[v]));
         if (v < ncull) {
             float *ratL_s = tw + (size_t)(1 + v) * L.Vs, *ratR_s = ratL_s + L.nsa;
             const float Tcur = kCullArg / -lc.c[v];
@@ -1102,8 +1177,20 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
         }
 #define AM_ROWK_ARGS(pR_, pL_, cprev)                                                                 \
     n, L.mpad / segk, xyz1, (const float *)x2p, (size_t)L.mpad * 3, pR_, (const float *)remainR, pL_,  \
-        remainL, ratioL, L.bstride, cprev, lc.c[v]
-        if (v == 0) {
+        remainL, ratioL, L.bstride, cprev, lc.c[v], permA, L.nsa, tsk, skip_t(v - 1)
+        if (skip && v == 0) {
+            RF_LAUNCH("am_p1", (am_rowk_kernel<false, 1, RPT, 1>), gks, dim3(64 * segk), 0, s,
+                      AM_ROWK_ARGS((const float *)remainR, (const float *)remainL, 0.f));
+        } else if (skip && lc.c[v - 1] != lc.c[v]) {
+            const float *pL = ratios + (size_t)(v - 1) * L.V, *pR = pL + L.npad;
+            RF_LAUNCH("am_p3p1", (am_rowk_kernel<true, 1, RPT, 1>), gks, dim3(64 * segk), 0, s,
+                      AM_ROWK_ARGS(pR, pL, lc.c[v - 1]));
+        } else if (permA && v > 0 && !zero && lc.c[v] < 0.f && lc.c[v - 1] < lc.c[v] && skip_t(v - 1) <= kCullMaxT) {
+            // this level is too broad to drop columns, the fused P3's level is not
+            const float *pL = ratios + (size_t)(v - 1) * L.V, *pR = pL + L.npad;
+            RF_LAUNCH("am_p3p1", (am_rowk_kernel<true, 1, RPT, 2>), gks, dim3(64 * segk), 0, s,
+                      AM_ROWK_ARGS(pR, pL, lc.c[v - 1]));
+        } else if (v == 0) {
             if (zero) {
                 RF_LAUNCH("am_p1", (am_rowk_kernel<false, 2, RPT>), gk, dim3(64 * segk), 0, s,
                           AM_ROWK_ARGS((const float *)remainR, (const float *)remainL, 0.f));
@@ -1128,11 +1215,15 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
         if (zero) {
             RF_LAUNCH("am_p2", (am_rowl_kernel<RPT, true>), gl, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
                       (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR,
-                      L.bstride, lc.c[v]);
+                      L.bstride, lc.c[v], permB, L.nsb, tsk);
+        } else if (permB && tsk <= kCullMaxT) {
+            RF_LAUNCH("am_p2", (am_rowl_kernel<RPT, false, true>), gls, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
+                      (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR,
+                      L.bstride, lc.c[v], permB, L.nsb, tsk);
         } else {
             RF_LAUNCH("am_p2", (am_rowl_kernel<RPT, false>), gl, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
                       (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR,
-                      L.bstride, lc.c[v]);
+                      L.bstride, lc.c[v], permB, L.nsb, tsk);
         }
     }
     return RF_OK;

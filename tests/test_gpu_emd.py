@@ -304,3 +304,26 @@ def test_earth_mover_culled_sharp_levels(orc, b, n, m):
     # the dense pipeline on the same clouds gives the same cost to fp32 summation noise
     match = R.approx_match(cu(a), cu(c))
     assert_rel(R.match_cost(cu(a), cu(c), match).cpu().numpy(), oc, 1e-5, what="dense chain cost")
+
+
+def test_sharp_level_sweeps_with_sorted_rows_keep_every_bit():
+    """From 6e7 pairs per sweep on, the dense sweeps of the sharp levels take their rows in the clouds' spatial order and
+    skip, after the distance, the columns whose weights are exactly 0 for every row of the wave (approxmatch.hip
+    am_rowk_kernel SKIP).  Row order enters no sum and column order is untouched, so `match` must not change by one bit: the
+    same clouds as a batch of one (4.2e6 pairs: plain sweeps) and replicated into a batch of sixteen (6.7e7: sorted rows) --
+    also with a ragged pair of sizes, and for the fused earth_mover cost and gradients."""
+    from rfnet_amd import _raw as R
+    rng = np.random.RandomState(77)
+    for n, m in ((2048, 2048), (3000, 1400)):
+        reps = -(-60000000 // (n * m)) + 1
+        a = (rng.random_sample((1, n, 3)) - 0.5).astype(np.float32)
+        c = (rng.random_sample((1, m, 3)) - 0.5).astype(np.float32)
+        one = R.approx_match(cu(a), cu(c))
+        many = R.approx_match(cu(np.repeat(a, reps, 0)), cu(np.repeat(c, reps, 0)))
+        for i in range(reps):
+            assert torch.equal(many[i], one[0]), (n, m, i)
+        c1, g1, h1 = R.earth_mover(cu(a), cu(c), with_grad=True)
+        cm, gm, hm = R.earth_mover(cu(np.repeat(a, reps, 0)), cu(np.repeat(c, reps, 0)), with_grad=True)
+        assert torch.equal(cm, c1.expand(reps)), (n, m)
+        # (the gradients are atomic sums over workgroups: equal to fp32 summation noise, not bit for bit)
+        assert torch.allclose(gm[0], g1[0], rtol=1e-5, atol=1e-6) and torch.allclose(hm[-1], h1[0], rtol=1e-5, atol=1e-6)
