@@ -70,10 +70,20 @@ FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector peak
 # multiplier 0), counted in rfnet_amd/csrc/approxmatch.hip and confirmed by SQ_INSTS_VALU (profiles/r04_rocprofv3_summary.txt):
 # (launches, plain VALU, v_exp_f32) -- d2 is 6, an exponential term is mul + exp (+ mul by the row ratio) + fma
 EMD_LAUNCH_MIX = {
-    "am_p1 (level 0)": (1, 8, 1),
-    "am_p2, levels 0-8": (9, 8, 1),
+    # round 5: the sweeps of the three sharp levels take their rows in spatial order and drop, after the distance (6) and the
+    # test (~1), the columns whose weights are exactly 0 for the whole wave; a wave keeps 0.088 / 0.185 / 0.418 of its columns at
+    # levels -4^7 / -4^6 / -4^5 on C4's uniform clouds (profiles/r05_emd_skip_model.txt, tools/experiments/emd_skip_model.py: a
+    # model of this workload, NOT counted in this run) -- so these rows are EXECUTED instruction counts, not 8 + 1 per pair
+    "am_p1 (level 0, skipping)": (1, 7 + 0.088 * 2, 0.088),
+    "am_p2, level 0 (skipping)": (1, 7 + 0.088 * 2, 0.088),
+    "am_p2, level 1 (skipping)": (1, 7 + 0.185 * 2, 0.185),
+    "am_p2, level 2 (skipping)": (1, 7 + 0.418 * 2, 0.418),
+    "am_p2, levels 3-8": (6, 8, 1),
     "am_p2, last level (e = 1: no distance, no exp)": (1, 1, 0),
-    "am_p3p1, levels 1-8": (8, 11, 2),
+    "am_p3p1, levels 0+1 (skipping, P3 under its own test)": (1, 7 + 0.185 * 2 + 0.088 * 3, 0.185 + 0.088),
+    "am_p3p1, levels 1+2 (skipping)": (1, 7 + 0.418 * 2 + 0.185 * 3, 0.418 + 0.185),
+    "am_p3p1, levels 2+3 (only the P3 part conditional)": (1, 6.5 + 2 + 0.418 * 3, 1 + 0.418),
+    "am_p3p1, levels 4-8": (5, 11, 2),
     "am_p3p1, last level (P1 without exp)": (1, 10, 1),
     # round 5: levels 1, 3, 5, 7 take their weight from the next level's by two squarings (2 mul instead of mul + exp)
     "am_match (10 levels in one pass)": (1, 39, 5),
@@ -797,7 +807,7 @@ def main():
         dt_emd, dt_ns, dt_emdf, dt_x50 = (float(tmax[i].item()) for i in range(4))
         extras["emd"] = {
             "roofline": {
-                "bound": "valu+trans", "kernel": "am_p1 + am_p3p1 + am_p2 + am_match (approx_match, 21 launches)",
+                "bound": "valu+trans", "kernel": "am_p1 + am_p3p1 + am_p2 + am_match (approx_match, 21 launches + the row sort)",
                 "lane_ops_per_pair": efl["valu_per_pair"] if efl else None, "exp_per_pair": efl["exp_per_pair"] if efl else None,
                 "achieved": lane_ops / (am_kernel_ms * 1e-3) / 1e12, "unit": "T lane-ops/s",
                 "issue_floor_ms": efl["mix_ms"] if efl else None,
@@ -810,7 +820,11 @@ def main():
                 "mfma": "not applicable: every matrix element needs its own exp(level * d2) (8 of the 9 ops and all of the "
                         "transcendental work); d2 via the |a|^2+|b|^2-2ab GEMM is ruled out because exp(-16384 d2) amplifies "
                         "its cancellation error to ~7e-4 relative (DESIGN.md 5.5, K=4 trial recorded there)",
-                "note": "frac = issue floor derived from counted instructions x measured issue costs / measured kernel time; "
+                "dense_equivalent": {"lane_ops_per_pair": 254, "exp_per_pair": 32,
+                                     "what": "the schedule with every pair evaluated (round 5 before the skipping sweeps); the skipped "
+                                             "terms are exact zeros: match is bit-identical"},
+                "note": "frac = issue floor derived from EXECUTED instructions (counted, with the model's keep fractions for the "
+                        "skipping sweeps) x measured issue costs / measured kernel time; "
                         "frac_of_fp32_peak counts 2 flop per lane-op against the 157.3 TFLOP/s vector peak"},
             "metric": "EMD iters/sec (approx_match + match_cost batch calls)",
             "value": world * emd_steps / dt_emd, "unit": "calls/s", "ms_per_call": dt_emd / emd_steps * 1e3,
