@@ -93,6 +93,48 @@ def test_fuzz_query_ball_group(orc, seed):
     assert np.array_equal(grp.cpu().numpy(), orc.group_point(pts, oi))
 
 
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_query_ball_boxes_and_one_call(orc, seed):
+    """The boxed ball query (every dataset size from 64 up, whatever the auto rule would pick) and the one-call
+    sample-and-group on random shapes, cloud kinds (uniform / lattice ties / duplicated halves / one tight cluster) and radii
+    from "a few hits" to "every ball holds the cloud": idx, pts_cnt against the oracle; the one call against the four ops."""
+    from rfnet_amd import _raw
+    rng = np.random.RandomState(7000 + seed)
+    b = rng.randint(1, 5)
+    n, m = _logint(rng, 64, 20000), _logint(rng, 1, 400)
+    ns = [1, 7, 32, 64][seed % 4]
+    kind = seed % 4
+    if kind == 0:
+        ds = rng.rand(b, n, 3)
+    elif kind == 1:
+        ds = rng.randint(0, 7, size=(b, n, 3)) / 6.0
+    elif kind == 2:
+        ds = rng.rand(b, n, 3)
+        ds[:, n // 2:] = ds[:, : n - n // 2]
+    else:
+        ds = rng.rand(b, n, 3)
+        ds[:, : n // 3] = 0.3 + 1e-3 * rng.randn(b, n // 3, 3)
+    ds = ds.astype(np.float32)
+    q = rng.rand(b, m, 3).astype(np.float32)
+    k = min(n, m) // 2
+    q[:, :k] = ds[:, rng.permutation(n)[:k]]
+    r = float(np.exp(rng.uniform(np.log(0.01), np.log(1.5))))
+    idx, cnt = _raw.query_ball_point(r, ns, cu(ds), cu(q), form="boxes")
+    oi, oc = orc.query_ball_point(r, ns, ds, q, fill=0)
+    assert np.array_equal(cnt.cpu().numpy(), oc), f"seed {seed} b={b} n={n} m={m} ns={ns} r={r} kind={kind}"
+    assert np.array_equal(idx.cpu().numpy(), oi), f"seed {seed} b={b} n={n} m={m} ns={ns} r={r} kind={kind}"
+    npoint = rng.randint(1, min(n, 200) + 1)
+    x = cu(ds)
+    fi = _raw.farthest_point_sample(npoint, x)
+    nx = _raw.gather_point(x, fi)
+    gi, gc = _raw.query_ball_point(r, ns, x, nx, form="scan")
+    gx = _raw.group_point(x, gi)
+    one = _raw.sample_and_group(npoint, r, ns, x, aux_stream=torch.cuda.Stream() if seed % 2 else None)
+    torch.cuda.synchronize()
+    for name, w, g in zip(("fps_idx", "new_xyz", "idx", "pts_cnt", "grouped_xyz"), (fi, nx, gi, gc, gx), one):
+        assert torch.equal(w, g), f"seed {seed} {name} b={b} n={n} npoint={npoint} ns={ns} r={r} kind={kind}"
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_fuzz_three_nn_interpolate(orc, seed):
     from rfnet_amd import _raw
