@@ -86,7 +86,9 @@ EMD_LAUNCH_MIX = {
     "am_p3p1, levels 4-8": (5, 11, 2),
     "am_p3p1, last level (P1 without exp)": (1, 10, 1),
     # round 5: levels 1, 3, 5, 7 take their weight from the next level's by two squarings (2 mul instead of mul + exp)
-    "am_match (10 levels in one pass)": (1, 39, 5),
+    # ... and the sharpest level is evaluated only where some column of the wave is within its cut-off of the row (14 % of the
+    # (wave, row) pairs at C4: 1 - (1 - 0.0023)^64)
+    "am_match (10 levels in one pass)": (1, 36 + 1 + 0.14 * 3, 4 + 0.14),
 }
 
 

@@ -34,6 +34,7 @@ namespace {
 #ifndef RFA_TARGET_WAVES
 #define RFA_TARGET_WAVES 4096  // waves a level sweep is cut into at least (column segments per row block)
 #endif
+constexpr float kSkipArg = 161.f;  // d2 * |c| >= 161 => fl(d2 * c) <= -160 => v_exp_f32 = +0 (kCullArg below, with the product's rounding covered)
 constexpr float kLog2e = 1.44269502f;  // 0x3FB8AA3B, the constant __expf multiplies by
 constexpr int TPB = 256;
 constexpr int LVG = 16;             // levels per group in the materialisation kernel
@@ -80,6 +81,9 @@ __global__ void am_init_kernel(int npts, int npad, float fill, const float *__re
 // (tskip is the d2 beyond which v_exp_f32 returns +0 for the LESS sharp of the launch's levels), so every sum keeps its
 // bits -- the row order does not enter any sum, the column order is untouched.  At C4 a wave skips the exponentials of
 // 91 / 81 / 58 % of its columns at levels -4^7 / -4^6 / -4^5 (28 / 84 / 100 % would pass with rows in input order).
+// (Finite inputs: a NaN distance is not "near", so where the plain sweep would spread a NaN coordinate's NaN over a sum, this one
+// may leave the sum finite -- EMD of non-finite clouds is NaN garbage in the reference too and no caller's contract; the `<`
+// form of the test is 3 % of the launch cheaper than the NaN-keeping `!(>=)`, measured.)
 // SKIP = 1: a column is dropped when it is beyond `tskip` (this level's cut-off) of every row; the fused P3 of the previous,
 //           sharper level is evaluated only for columns within its own cut-off `tskip_prev` (<= tskip) of some row;
 // SKIP = 2: this level is too broad to drop columns (every weight is evaluated) but the fused P3's level is not: only its part
@@ -302,10 +306,10 @@ struct LevelConsts {
 // such terms (the op's tolerance: rel 1e-4).  ONLY here and in emd_fused_kernel, where the weights go straight into the
 // output: in the phase sweeps the same trick is 9 % faster and NOT taken -- there the weights feed remainL -= sum, whose
 // cancellation amplifies 5 ulp past the tolerance (tools/experiments/emd_p3p1_square_pingpong.patch.txt).
-template <int NLV, bool LASTZERO, bool SQ>
+template <int NLV, bool LASTZERO, bool SQ, int V0 = 0>
 __device__ __forceinline__ void level_weights(float d2, const float (&cl)[NLV > 0 ? NLV : 1], float (&e)[NLV > 0 ? NLV : 1]) {
 #pragma unroll
-    for (int v = NLV - 1; v >= 0; v--) {
+    for (int v = NLV - 1; v >= V0; v--) {
         if (LASTZERO && v == NLV - 1) {
             e[v] = 1.0f;
         } else if (SQ && (v & 1) && v + 1 < NLV - (LASTZERO ? 1 : 0)) {
@@ -359,13 +363,27 @@ __global__ __launch_bounds__(TPB) void am_match_kernel(int n, int m, const float
             rl[v] = ratios[(size_t)v * lv_stride + k];
             cl[v] = lc.c[v];
         }
+        const float t0 = cl[0] < 0.f ? kSkipArg / -cl[0] : INFINITY;  // (uniform)
         for (int l = 0; l < lcnt; l++) {
             const float d2 = rf::d2_fma(cxyz[l][0] - x1, cxyz[l][1] - y1, cxyz[l][2] - z1);
             float e[NLV > 0 ? NLV : 1];
-            level_weights<NLV, LASTZERO, SQ>(d2, cl, e);
             float acc = 0.f;
+            if (SQ) {
+                // the sharpest level on its own: beyond t0 its weight is exactly +0 (v_exp_f32 returns +0 below -160), and a
+                // row l is beyond t0 of ALL 64 columns of the wave in 86 % of the cases at C4 (the cut-off is 0.082) -- then
+                // fma(rl * 0, rr, 0) = +0 = the accumulator's start: skipped by a wave-uniform branch, same bits
+                level_weights<NLV, LASTZERO, SQ, 1>(d2, cl, e);
+                if (__ballot(d2 < t0) != 0ull) {
+                    asm volatile("; level 0 kept");
+                    acc = fmaf(rl[0] * fast_exp2(d2 * cl[0]), crr[l][0], 0.f);
+                }
 #pragma unroll
-            for (int v = 0; v < NLV; v++) acc = fmaf(rl[v] * e[v], crr[l][v], acc);
+                for (int v = 1; v < NLV; v++) acc = fmaf(rl[v] * e[v], crr[l][v], acc);
+            } else {
+                level_weights<NLV, LASTZERO, SQ>(d2, cl, e);
+#pragma unroll
+                for (int v = 0; v < NLV; v++) acc = fmaf(rl[v] * e[v], crr[l][v], acc);
+            }
             match[(size_t)(l0 + l) * n + k] = acc;
         }
         return;
@@ -747,6 +765,7 @@ __global__ __launch_bounds__(TPB) void emd_fused_kernel(int n, int m, int mpad, 
         rl[v] = live ? ratios[(size_t)bi * b_stride + (size_t)v * lv_stride + kk] : 0.f;
         cl[v] = lc.c[v];
     }
+    const float t0 = cl[0] < 0.f ? kSkipArg / -cl[0] : INFINITY;  // (uniform)
     if (GRAD) sx1[t] = make_float4(x1, y1, z1, 0.f);
     float ax = 0.f, ay = 0.f, az = 0.f, csum = 0.f;
     const int lbeg = blockIdx.y * lspan;
@@ -762,10 +781,20 @@ __global__ __launch_bounds__(TPB) void emd_fused_kernel(int n, int m, int mpad, 
             const float dx = cx.x - x1, dy = cx.y - y1, dz = cx.z - z1;  // xyz2 - xyz1, as :207
             const float d2 = rf::d2_fma(dx, dy, dz);
             float e[NLV];
-            level_weights<NLV, LASTZERO, SQ>(d2, cl, e);
             float acc = 0.f;
+            if (SQ) {  // the sharpest level under its own wave-uniform test (see am_match_kernel)
+                level_weights<NLV, LASTZERO, SQ, 1>(d2, cl, e);
+                if (__ballot(d2 < t0) != 0ull) {
+                    asm volatile("; level 0 kept");
+                    acc = fmaf(rl[0] * fast_exp2(d2 * cl[0]), rr[0], 0.f);
+                }
 #pragma unroll
-            for (int v = 0; v < NLV; v++) acc = fmaf(rl[v] * e[v], rr[v], acc);
+                for (int v = 1; v < NLV; v++) acc = fmaf(rl[v] * e[v], rr[v], acc);
+            } else {
+                level_weights<NLV, LASTZERO, SQ>(d2, cl, e);
+#pragma unroll
+                for (int v = 0; v < NLV; v++) acc = fmaf(rl[v] * e[v], rr[v], acc);
+            }
             csum = fmaf(sqrtf(d2), acc, csum);
             if (GRAD) {
                 const float q = acc * __builtin_amdgcn_rsqf(fmaxf(d2, 1e-20f));
@@ -1023,7 +1052,6 @@ constexpr int CULL_MAXLV = 8;  // at most this many leading levels are culled
 #define RFA_ROWSORT_MIN_PAIRS 6.0e7
 #endif
 constexpr double ROWSORT_MIN_PAIRS = RFA_ROWSORT_MIN_PAIRS;
-constexpr float kSkipArg = 161.f;  // d2 * |c| >= 161 => fl(d2 * c) <= -160 => v_exp_f32 = +0 (kCullArg, with the product's rounding covered)
 
 int round_up_i(int v, int q) { return (v + q - 1) / q * q; }
 
