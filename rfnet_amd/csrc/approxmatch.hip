@@ -43,6 +43,7 @@ constexpr int MAX_BATCH = 65535;  // the batch index is a grid y/z dimension (th
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+typedef __attribute__((address_space(4))) float cfloat;  // wave-uniform, launch-constant operands: s_load
 constexpr int SUB = 8;     // columns per scalar-load sub-chunk
 constexpr int CPAD = 128;  // column counts are padded to a multiple of this (zero scalars)
 
@@ -120,63 +121,101 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
     const float *__restrict__ S3 = ratioR_prev + (size_t)bi * stride;
     const float *__restrict__ S1 = remainR + (size_t)bi * stride;
     const int c0 = seg * seglen, c1 = c0 + seglen;  // multiples of SUB, inside the padded range
-    float nb[3 * SUB], n3[SUB], n1[SUB];
+    // one column (its coordinates and scalars wave-uniform) against the lane's RPT rows
+    auto column = [&](float cx, float cy, float cz, float s3u, float s1u) {
+        float d2[RPT];
+        bool near = false, near_prev = false;
 #pragma unroll
-    for (int i = 0; i < 3 * SUB; i++) nb[i] = C[(size_t)c0 * 3 + i];
+        for (int r = 0; r < RPT; r++) {
+            d2[r] = rf::d2_fma(cx - x1[r], cy - y1[r], cz - z1[r]);
+            near = near || d2[r] < tskip;
+            near_prev = near_prev || d2[r] < tskip_prev;
+        }
+        if (SKIP == 1) {
+            if (__ballot(near) == 0ull) return;  // (uniform) every weight of this column is exactly 0 in this wave
+            asm volatile("; column kept");        // (keeps the branch a branch: see grouping.hip's hit path)
+        }
+        if (SKIP != 0 && HAS_P3) {  // the two parts under their own tests (static_assert above: P1 == 1 here)
 #pragma unroll
-    for (int i = 0; i < SUB; i++) {
-        n3[i] = HAS_P3 ? S3[c0 + i] : 0.f;
-        n1[i] = HAS_P1 ? S1[c0 + i] : 0.f;
-    }
-    for (int c = c0; c < c1; c += SUB) {
-        float cb[3 * SUB], s3[SUB], s1[SUB];
-        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): retire the previous prefetch first
-        __builtin_amdgcn_sched_barrier(0);
+            for (int r = 0; r < RPT; r++) acc1[r] = fmaf(fast_exp2(d2[r] * c_cur), s1u, acc1[r]);
+            if (__ballot(near_prev) != 0ull) {  // (uniform)
+                asm volatile("; previous level kept");
 #pragma unroll
-        for (int i = 0; i < 3 * SUB; i++) cb[i] = nb[i];
+                for (int r = 0; r < RPT; r++) acc3[r] = fmaf(rl[r] * fast_exp2(d2[r] * c_prev), s3u, acc3[r]);
+            }
+            return;
+        }
 #pragma unroll
-        for (int i = 0; i < SUB; i++) { s3[i] = n3[i]; s1[i] = n1[i]; }
+        for (int r = 0; r < RPT; r++) {
+            float e3 = 0.f;
+            if (HAS_P3) {
+                e3 = fast_exp2(d2[r] * c_prev);
+                acc3[r] = fmaf(rl[r] * e3, s3u, acc3[r]);
+            }
+            if (HAS_P1) acc1[r] = fmaf(P1 == 2 ? 1.0f : (P1 == 3 ? e3 : fast_exp2(d2[r] * c_cur)), s1u, acc1[r]);
+        }
+    };
+    if constexpr (SKIP != 0) {
+        // The skipping sweeps issue 14 VALU per column and lane pair against ~10 scalar instructions -- and a CU has ONE scalar
+        // unit for its 16 waves: they are bound by IT (an x-only pre-test that removed 4 VALU from 50 % of the columns changed
+        // nothing).  So here the column operands go through TWO scalar register sets used in turn instead of load-then-copy (5
+        // s_mov per column gone).  For the plain sweeps, which are VALU-bound, the same form measured 5 % slower
+        // (tools/experiments/emd_p3p1_square_pingpong.patch.txt) and they keep the copy.  The operands are cast to the constant
+        // address space -- nothing in this launch writes them -- which keeps their loads on s_load in this loop shape.
+        const cfloat *Cc = (const cfloat *)C, *S3c = (const cfloat *)S3, *S1c = (const cfloat *)S1;
+        float xa[3 * SUB], a3[SUB], a1[SUB], xb[3 * SUB], b3[SUB], b1[SUB];
+#define RFA_FETCH_K(xs, t3, t1, c)                                                           \
+    do {                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 3 * SUB; i++) xs[i] = Cc[(size_t)(c) * 3 + i]; \
+        _Pragma("unroll") for (int i = 0; i < SUB; i++) {                                    \
+            t3[i] = HAS_P3 ? S3c[(c) + i] : 0.f;                                             \
+            t1[i] = HAS_P1 ? S1c[(c) + i] : 0.f;                                             \
+        }                                                                                    \
+    } while (0)
+        RFA_FETCH_K(xa, a3, a1, c0);
+        for (int c = c0; c < c1; c += 2 * SUB) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): set a has arrived
+            __builtin_amdgcn_sched_barrier(0);
+            RFA_FETCH_K(xb, b3, b1, c + SUB);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 3 * SUB; i++) nb[i] = C[(size_t)(c + SUB) * 3 + i];
+            for (int u = 0; u < SUB; u++) column(xa[u * 3], xa[u * 3 + 1], xa[u * 3 + 2], a3[u], a1[u]);
+            if (c + SUB >= c1) break;
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // set b has arrived
+            __builtin_amdgcn_sched_barrier(0);
+            RFA_FETCH_K(xa, a3, a1, c + 2 * SUB);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < SUB; u++) column(xb[u * 3], xb[u * 3 + 1], xb[u * 3 + 2], b3[u], b1[u]);
+        }
+#undef RFA_FETCH_K
+    } else {
+        float nb[3 * SUB], n3[SUB], n1[SUB];
+#pragma unroll
+        for (int i = 0; i < 3 * SUB; i++) nb[i] = C[(size_t)c0 * 3 + i];
 #pragma unroll
         for (int i = 0; i < SUB; i++) {
-            n3[i] = HAS_P3 ? S3[c + SUB + i] : 0.f;
-            n1[i] = HAS_P1 ? S1[c + SUB + i] : 0.f;
+            n3[i] = HAS_P3 ? S3[c0 + i] : 0.f;
+            n1[i] = HAS_P1 ? S1[c0 + i] : 0.f;
         }
-        __builtin_amdgcn_sched_barrier(0);
+        for (int c = c0; c < c1; c += SUB) {
+            float cb[3 * SUB], s3[SUB], s1[SUB];
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): retire the previous prefetch first
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < SUB; u++) {
-            float d2[RPT];
-            bool near = false, near_prev = false;
+            for (int i = 0; i < 3 * SUB; i++) cb[i] = nb[i];
 #pragma unroll
-            for (int r = 0; r < RPT; r++) {
-                d2[r] = rf::d2_fma(cb[u * 3] - x1[r], cb[u * 3 + 1] - y1[r], cb[u * 3 + 2] - z1[r]);
-                near = near || d2[r] < tskip;
-                near_prev = near_prev || d2[r] < tskip_prev;
+            for (int i = 0; i < SUB; i++) { s3[i] = n3[i]; s1[i] = n1[i]; }
+#pragma unroll
+            for (int i = 0; i < 3 * SUB; i++) nb[i] = C[(size_t)(c + SUB) * 3 + i];
+#pragma unroll
+            for (int i = 0; i < SUB; i++) {
+                n3[i] = HAS_P3 ? S3[c + SUB + i] : 0.f;
+                n1[i] = HAS_P1 ? S1[c + SUB + i] : 0.f;
             }
-            if (SKIP == 1) {
-                if (__ballot(near) == 0ull) continue;  // (uniform) every weight of this column is exactly 0 in this wave
-                asm volatile("; column kept");          // (keeps the branch a branch: see grouping.hip's hit path)
-            }
-            if (SKIP != 0 && HAS_P3) {  // the two parts under their own tests (static_assert below: P1 == 1 here)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int r = 0; r < RPT; r++) acc1[r] = fmaf(fast_exp2(d2[r] * c_cur), s1[u], acc1[r]);
-                if (__ballot(near_prev) != 0ull) {  // (uniform)
-                    asm volatile("; previous level kept");
-#pragma unroll
-                    for (int r = 0; r < RPT; r++) acc3[r] = fmaf(rl[r] * fast_exp2(d2[r] * c_prev), s3[u], acc3[r]);
-                }
-                continue;
-            }
-#pragma unroll
-            for (int r = 0; r < RPT; r++) {
-                float e3 = 0.f;
-                if (HAS_P3) {
-                    e3 = fast_exp2(d2[r] * c_prev);
-                    acc3[r] = fmaf(rl[r] * e3, s3[u], acc3[r]);
-                }
-                if (HAS_P1) acc1[r] = fmaf(P1 == 2 ? 1.0f : (P1 == 3 ? e3 : fast_exp2(d2[r] * c_cur)), s1[u], acc1[r]);
-            }
+            for (int u = 0; u < SUB; u++) column(cb[u * 3], cb[u * 3 + 1], cb[u * 3 + 2], s3[u], s1[u]);
         }
     }
 #pragma unroll
@@ -235,39 +274,67 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
     const float *__restrict__ C = xyz1p + (size_t)bi * xyz1p_stride;
     const float *__restrict__ S = ratioL + (size_t)bi * stride;
     const int c0 = seg * seglen, c1 = c0 + seglen;
-    float nb[3 * SUB], ns[SUB];
+    auto column = [&](float cx, float cy, float cz, float su) {
+        float d2[RPT];
+        bool near = false;
 #pragma unroll
-    for (int i = 0; i < 3 * SUB; i++) nb[i] = C[(size_t)c0 * 3 + i];
+        for (int r = 0; r < RPT; r++) {
+            d2[r] = rf::d2_fma(x2[r] - cx, y2[r] - cy, z2[r] - cz);
+            near = near || d2[r] < tskip;
+        }
+        if (SKIP) {
+            if (__ballot(near) == 0ull) return;  // (uniform)
+            asm volatile("; column kept");
+        }
 #pragma unroll
-    for (int i = 0; i < SUB; i++) ns[i] = S[c0 + i];
-    for (int c = c0; c < c1; c += SUB) {
-        float cb[3 * SUB], sc[SUB];
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int r = 0; r < RPT; r++) acc[r] = fmaf(ZERO ? 1.0f : fast_exp2(d2[r] * c_cur), su, acc[r]);
+    };
+    if constexpr (SKIP) {  // two scalar register sets in turn: the skipping sweeps are bound by the CU's scalar unit (am_rowk_kernel)
+        const cfloat *Cc = (const cfloat *)C, *Sc = (const cfloat *)S;
+        float xa[3 * SUB], sa[SUB], xb[3 * SUB], sb[SUB];
+#define RFA_FETCH_L(xs, ts, c)                                                               \
+    do {                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 3 * SUB; i++) xs[i] = Cc[(size_t)(c) * 3 + i]; \
+        _Pragma("unroll") for (int i = 0; i < SUB; i++) ts[i] = Sc[(c) + i];                 \
+    } while (0)
+        RFA_FETCH_L(xa, sa, c0);
+        for (int c = c0; c < c1; c += 2 * SUB) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_sched_barrier(0);
+            RFA_FETCH_L(xb, sb, c + SUB);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 3 * SUB; i++) cb[i] = nb[i];
+            for (int u = 0; u < SUB; u++) column(xa[u * 3], xa[u * 3 + 1], xa[u * 3 + 2], sa[u]);
+            if (c + SUB >= c1) break;
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_sched_barrier(0);
+            RFA_FETCH_L(xa, sa, c + 2 * SUB);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < SUB; i++) sc[i] = ns[i];
+            for (int u = 0; u < SUB; u++) column(xb[u * 3], xb[u * 3 + 1], xb[u * 3 + 2], sb[u]);
+        }
+#undef RFA_FETCH_L
+    } else {
+        float nb[3 * SUB], ns[SUB];
 #pragma unroll
-        for (int i = 0; i < 3 * SUB; i++) nb[i] = C[(size_t)(c + SUB) * 3 + i];
+        for (int i = 0; i < 3 * SUB; i++) nb[i] = C[(size_t)c0 * 3 + i];
 #pragma unroll
-        for (int i = 0; i < SUB; i++) ns[i] = S[c + SUB + i];
-        __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < SUB; i++) ns[i] = S[c0 + i];
+        for (int c = c0; c < c1; c += SUB) {
+            float cb[3 * SUB], sc[SUB];
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < SUB; u++) {
-            float d2[RPT];
-            bool near = false;
+            for (int i = 0; i < 3 * SUB; i++) cb[i] = nb[i];
 #pragma unroll
-            for (int r = 0; r < RPT; r++) {
-                d2[r] = rf::d2_fma(x2[r] - cb[u * 3], y2[r] - cb[u * 3 + 1], z2[r] - cb[u * 3 + 2]);
-                near = near || d2[r] < tskip;
-            }
-            if (SKIP) {
-                if (__ballot(near) == 0ull) continue;  // (uniform)
-                asm volatile("; column kept");
-            }
+            for (int i = 0; i < SUB; i++) sc[i] = ns[i];
 #pragma unroll
-            for (int r = 0; r < RPT; r++) acc[r] = fmaf(ZERO ? 1.0f : fast_exp2(d2[r] * c_cur), sc[u], acc[r]);
+            for (int i = 0; i < 3 * SUB; i++) nb[i] = C[(size_t)(c + SUB) * 3 + i];
+#pragma unroll
+            for (int i = 0; i < SUB; i++) ns[i] = S[c + SUB + i];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < SUB; u++) column(cb[u * 3], cb[u * 3 + 1], cb[u * 3 + 2], sc[u]);
         }
     }
 #pragma unroll
