@@ -14,6 +14,7 @@ from rfnet_amd._lib import lib  # noqa: E402
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 t0 = time.time()
 case = bad = sorted_cases = 0
+worst = 0.0
 while time.time() - t0 < budget:
     rng = np.random.RandomState(987654 + case)
     n, m = (int(v) for v in np.exp(rng.uniform(np.log(1024), np.log(18000), size=2)))
@@ -50,18 +51,25 @@ while time.time() - t0 < budget:
     ref = _raw.nn_distance(a, c, mode="dense")
     ok = all(torch.equal(x, y) for x, y in zip(ref, out[:4]))
     r1, r2 = _raw.nn_distance_grad(a, c, g1, ref[1], g2, ref[3])
-    # the gradient bar of the tests: rel 1e-5 + 1e-5 of the LARGEST TERM (fp32 add order of a scatter).  The largest term, not the
-    # largest result: on the lattice clouds with signed upstream gradients hundreds of O(1) terms cancel to O(0.03) in every
-    # entry, and an output-relative floor (what this soak used until round 4) flags 1e-6 of summation noise there (case 176:
-    # 10 x 11977 x 1668, one entry 1.1-1.5e-6 off in some runs, with every build back to round 3's order)
-    term = 2.0 * max(float(g1.abs().max()), float(g2.abs().max())) * float(max(ref[0].max(), ref[2].max())) ** 0.5
-    # (and never below the tests' output-relative floor: a candidate chosen by thousands of near-copies -- kind 5 -- sums
-    # thousands of same-sign terms, and the noise scales with that sum)
-    ok = ok and bool(torch.allclose(out[4], r1, rtol=1e-5, atol=1e-5 * max(term, float(r1.abs().max())) + 1e-12))
-    ok = ok and bool(torch.allclose(out[5], r2, rtol=1e-5, atol=1e-5 * max(term, float(r2.abs().max())) + 1e-12))
+    # The gradient bar, per ENTRY: 1e-5 of the sum of the ABSOLUTE values of the terms that entry is made of (fp32 add order of
+    # a scatter: the error of a sum of K terms in any order is bounded by ~K eps times that sum).  Tight where the terms are few
+    # and of one sign, and it scales by itself where hundreds of O(1) terms cancel to O(0.03) (the lattice clouds with signed
+    # upstream gradients: case 176) or thousands of same-sign terms pile up (kind 5) -- no global floor from the largest term or
+    # the largest result any more (round 4's bar; the advisor's finding).  The worst error / bound ratio seen is reported.
+    i1, i2 = ref[1].long(), ref[3].long()
+    gi1 = torch.gather(c, 1, i1[..., None].expand(-1, -1, 3))
+    gi2 = torch.gather(a, 1, i2[..., None].expand(-1, -1, 3))
+    t1 = 2.0 * g1.abs()[..., None] * (a - gi1).abs()           # own terms of xyz1 (b, n, 3)
+    t2 = 2.0 * g2.abs()[..., None] * (c - gi2).abs()           # own terms of xyz2 (b, m, 3)
+    s1 = t1 + torch.zeros_like(t1).scatter_add_(1, i2[..., None].expand(-1, -1, 3), t2)   # + what xyz2's points scatter into xyz1
+    s2 = t2 + torch.zeros_like(t2).scatter_add_(1, i1[..., None].expand(-1, -1, 3), t1)
+    e1, e2 = (out[4] - r1).abs(), (out[5] - r2).abs()
+    ratio = max(float((e1 / (1e-5 * s1 + 1e-12)).max()), float((e2 / (1e-5 * s2 + 1e-12)).max()))
+    worst = max(worst, ratio)
+    ok = ok and ratio <= 1.0
     if not ok:
         bad += 1
         print("MISMATCH case", case, "b n m", b, n, m, "kind", kind, flush=True)
     case += 1
     del plan
-print(f"{case} cases ({sorted_cases} through the sorted-space step), {bad} mismatches, {time.time() - t0:.0f} s")
+print(f"{case} cases ({sorted_cases} through the sorted-space step), {bad} mismatches, worst gradient error = {worst:.3f} of the per-entry bound (1e-5 x sum of |terms|), {time.time() - t0:.0f} s")
