@@ -363,8 +363,9 @@ def run_c3(rank, dev, fence, reps):
             "pair_tests_upper_bound_per_s": float(B) * n * m / (box_kms * 1e-3),
             "roofline": {"bound": "valu-issue",
                          "what": "the boxed kernel tests ~4 % of the B*n*m pairs (256 boxes + ~10 blocks of 64 records per query) and is "
-                                 "bound by instruction issue: ~600 VALU + ~310 SALU wave-instructions per query wave, 39 % of wave time "
-                                 "waiting to issue (profiles/r05_ball_query_first_pmc.txt); `achieved` prices the B*n*m pair tests of "
+                                 "bound by latency and instruction issue: 452 VALU + 303 SALU wave-instructions per query wave, waves parked 47 % "
+                                 "and waiting to issue 24 % of their life (profiles/r05_rocprofv3_summary.txt (C); HBM-side 71 MB per "
+                                 "launch for a 6.3 MB dataset); `achieved` prices the B*n*m pair tests of "
                                  "the SCAN it replaces (8 flop each) against the fp32 vector peak -- an effective figure, like the "
                                  "culled Chamfer's",
                          "achieved": 8.0 * B * n * m / (box_kms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",

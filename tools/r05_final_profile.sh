@@ -1,0 +1,16 @@
+#!/usr/bin/env bash
+# round 5: the evidence set at the round's final build -- full gpu suite, smoke, tools/profile_bench.sh (bench + rocprofv3 stats + PMC),
+# tools/profile_op.sh c4 (EMD counters), the C3 ball query / one-call profile, same-device A/Bs.  usage (GPU box): bash tools/r05_final_profile.sh
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r05h; mkdir -p "$O"
+cd "$R"
+( time timeout 1500 python3 -m pytest tests -m gpu -x -q ) > "$O/pytest_gpu.txt" 2>&1
+tail -4 "$O/pytest_gpu.txt"
+python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$O/smoke.txt" 2>&1; tail -1 "$O/smoke.txt"
+bash tools/profile_bench.sh r05h/prof
+bash tools/profile_op.sh c4 r05h/c4
+bash tools/profile_py.sh r05h/ball tools/run_ball_once.py 0.1
+timeout 200 python3 tools/ab_ball.py > "$O/ab_ball.txt" 2>&1; cat "$O/ab_ball.txt"
+timeout 200 python3 tools/ab_c3.py > "$O/ab_c3.txt" 2>&1; cat "$O/ab_c3.txt"
+timeout 300 python3 tools/ab_emd_kernels.py norows base > "$O/ab_emd.txt" 2>&1; cut -c1-200 "$O/ab_emd.txt"
