@@ -28,6 +28,7 @@
 
 #include "common.hpp"
 #include "nn_pruned.hpp"
+#include "emd_fgt.hpp"
 
 namespace {
 
@@ -95,8 +96,11 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
     size_t xyz2p_stride, const float *__restrict__ ratioR_prev, const float *__restrict__ remainR,
     const float *__restrict__ ratioL_prev, float *__restrict__ remainL,
     float *__restrict__ ratioL_out, size_t stride, float c_prev, float c_cur, const int *__restrict__ perm,
-    int perm_stride, float tskip, float tskip_prev) {
+    int perm_stride, float tskip, float tskip_prev, const int *__restrict__ guard, int guard_want) {
     __shared__ float part3[16][64 * RPT], part1[16][64 * RPT];
+    // (the broad levels: this sweep runs only when the expansion of emd_fgt.hip was refused for the call's clouds, or -- the
+    // P3-only form before the first expanded level -- only when it was accepted; guard = NULL: always)
+    if (guard && (*guard != 0) != (guard_want != 0)) return;
     static_assert(SKIP == 0 || P1 == 1, "the skipping sweeps evaluate this level's own exponential");
     const int bi = blockIdx.y;
     const int lane = threadIdx.x & 63;
@@ -253,7 +257,8 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
     int m, int seglen, const float *__restrict__ xyz2, const float *__restrict__ xyz1p,
     size_t xyz1p_stride, const float *__restrict__ ratioL, float *__restrict__ remainR,
     float *__restrict__ ratioR_out, size_t stride, float c_cur, const int *__restrict__ perm, int perm_stride,
-    float tskip) {
+    float tskip, const int *__restrict__ guard, int guard_want) {
+    if (guard && (*guard != 0) != (guard_want != 0)) return;  // (see am_rowk_kernel)
     __shared__ float part[16][64 * RPT];
     const int bi = blockIdx.y;
     const int lane = threadIdx.x & 63;
@@ -1109,6 +1114,8 @@ struct AmLayout {
     // culled sweeps (sizes known without the level values: room is reserved whenever the clouds qualify)
     bool cull_ok;
     bool rowsort_ok;       // the dense sweeps of the sharp levels take their rows in the clouds' spatial order (am_rowk_kernel SKIP)
+    bool fgt_ok;           // the broad levels by expansion (emd_fgt.hip): scratch reserved
+    size_t off_fgt;
     int nsa, nsb;          // padded sizes of the two sorted sets
     size_t Vs;             // floats per sorted twin pair [L: nsa | R: nsb]
     size_t tw_stride;      // floats per batch element of the twin region: (1 + CULL_MAXLV) * Vs
@@ -1119,6 +1126,10 @@ constexpr int CULL_MAXLV = 8;  // at most this many leading levels are culled
 #define RFA_ROWSORT_MIN_PAIRS 6.0e7
 #endif
 constexpr double ROWSORT_MIN_PAIRS = RFA_ROWSORT_MIN_PAIRS;
+#ifndef RFA_FGT_MIN_PAIRS
+#define RFA_FGT_MIN_PAIRS 4.0e6
+#endif
+constexpr double FGT_MIN_PAIRS = RFA_FGT_MIN_PAIRS;
 
 int round_up_i(int v, int q) { return (v + q - 1) / q * q; }
 
@@ -1155,6 +1166,14 @@ AmLayout am_layout(int b, int n, int m, int nlevels, bool allow_cull) {
         L.tw_stride = L.Vs * (size_t)(1 + CULL_MAXLV);
         L.off_tw = off;
         off += (size_t)b * L.tw_stride + 64;
+    }
+    // (from about 4e6 pairs per sweep on: below, five tiny dense sweeps are cheaper than the expansion's seven launches)
+    L.fgt_ok = n >= 512 && m >= 512 && (double)b * n * m >= FGT_MIN_PAIRS;
+    L.off_fgt = 0;
+    if (L.fgt_ok) {
+        off = (off + 63) / 64 * 64;
+        L.off_fgt = off;
+        off += (rfe::fgt_workspace_bytes(b, n > m ? n : m) + 3) / 4 + 64;
     }
     L.total = off;
     return L;
@@ -1245,9 +1264,37 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
     const int segk = pick_nseg(b, n, L.mpad, RPT), segl = pick_nseg(b, m, L.npad, RPT);
     const dim3 gk(rf::ceil_div(n, 64 * RPT), b), gl(rf::ceil_div(m, 64 * RPT), b);
     const dim3 gks(rf::ceil_div(L.nsa, 64 * RPT), b), gls(rf::ceil_div(L.nsb, 64 * RPT), b);  // SKIP: over the sorted positions
+    // The broad tail of the schedule by expansion (emd_fgt.hip): every level from vF on has sharpness a = -c ln 2 <= kFgtMaxA
+    // (the reference schedule: levels -1, -0.25, 0 -> vF = 7).  The device decides per call whether the clouds' extent allows it
+    // (the `bad` word); the dense sweeps of those levels are launched behind that word and return at once when it is clear.
+    auto sharp = [&](int v) { return (double)(-lc.c[v]) * 0.69314718055994530942; };
+    int vF = nlevels;
+    while (vF > 1 && lc.c[vF - 1] <= 0.f && sharp(vF - 1) <= (double)rfe::kFgtMaxA * 1.0001) vF--;
+    const bool fgt = L.fgt_ok && vF < nlevels && vF >= ncull + 1;
+    void *fws = fgt ? (void *)(w + L.off_fgt) : nullptr;
+    if (fgt) {
+        if (int e = rfe::fgt_prep(b, n, m, xyz1, xyz2, sharp(vF), fws, s)) return e;
+    }
     for (int v = 0; v < nlevels; v++) {
         float *ratioL = ratios + (size_t)v * L.V, *ratioR = ratioL + L.npad;
         const bool zero = lc.c[v] == 0.0f;  // e = exp2(d2 * 0) = 1 exactly: no exponential needed
+        const int *gptr = nullptr;  // (the sweeps' guard word: unused since the expansion carries its own direct fallback)
+        if (fgt && v >= vF) {
+            const float *pL = ratios + (size_t)(v - 1) * L.V, *pR = pL + L.npad;
+            if (v == vF) {
+                // the P3 of the last swept level on its own (its P1 partner is an expanded level)
+                RF_LAUNCH("am_p3", (am_rowk_kernel<true, 0, RPT>), gk, dim3(64 * segk), 0, s, n, L.mpad / segk, xyz1,
+                          (const float *)x2p, (size_t)L.mpad * 3, pR, (const float *)remainR, pL, remainL, ratioL, L.bstride,
+                          lc.c[v - 1], lc.c[v], permA, L.nsa, INFINITY, INFINITY, gptr, 0);
+            }
+            if (int e = rfe::fgt_p3p1(b, n, m, xyz1, xyz2, v > vF, v > vF ? sharp(v - 1) : 0.0, sharp(v), pR, (const float *)remainR,
+                                      pL, remainL, ratioL, L.bstride, fws, s))
+                return e;
+            if (int e = rfe::fgt_p2(b, n, m, xyz1, xyz2, sharp(v), v + 1 < nlevels ? sharp(v + 1) : -1.0, (const float *)ratioL, remainR,
+                                    ratioR, L.bstride, fws, s))
+                return e;
+            continue;
+        }
         const float tsk = skip_t(v);        // (a fused P3 of level v-1 is sharper or equal wherever this one is skippable)
         const bool skip = permA && tsk <= kCullMaxT && (v == 0 || (lc.c[v - 1] < 0.f && lc.c[v - 1] <= lc.c[v]));
         if (v < ncull) {
@@ -1272,7 +1319,7 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
         }
 #define AM_ROWK_ARGS(pR_, pL_, cprev)                                                                 \
     n, L.mpad / segk, xyz1, (const float *)x2p, (size_t)L.mpad * 3, pR_, (const float *)remainR, pL_,  \
-        remainL, ratioL, L.bstride, cprev, lc.c[v], permA, L.nsa, tsk, skip_t(v - 1)
+        remainL, ratioL, L.bstride, cprev, lc.c[v], permA, L.nsa, tsk, skip_t(v - 1), gptr, 1
         if (skip && v == 0) {
             RF_LAUNCH("am_p1", (am_rowk_kernel<false, 1, RPT, 1>), gks, dim3(64 * segk), 0, s,
                       AM_ROWK_ARGS((const float *)remainR, (const float *)remainL, 0.f));
@@ -1310,15 +1357,15 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
         if (zero) {
             RF_LAUNCH("am_p2", (am_rowl_kernel<RPT, true>), gl, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
                       (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR,
-                      L.bstride, lc.c[v], permB, L.nsb, tsk);
+                      L.bstride, lc.c[v], permB, L.nsb, tsk, gptr, 1);
         } else if (permB && tsk <= kCullMaxT) {
             RF_LAUNCH("am_p2", (am_rowl_kernel<RPT, false, true>), gls, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
                       (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR,
-                      L.bstride, lc.c[v], permB, L.nsb, tsk);
+                      L.bstride, lc.c[v], permB, L.nsb, tsk, gptr, 1);
         } else {
             RF_LAUNCH("am_p2", (am_rowl_kernel<RPT, false>), gl, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
                       (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR,
-                      L.bstride, lc.c[v], permB, L.nsb, tsk);
+                      L.bstride, lc.c[v], permB, L.nsb, tsk, gptr, 1);
         }
     }
     return RF_OK;

@@ -1,0 +1,563 @@
+// emd_fgt.hip -- the BROAD levels of approx_match's schedule (tf_approxmatch.cu:36-177: levels -1, -0.25 and 0 of
+// -4^7 ... -4^-1, 0) without their n x m sweeps.
+//
+// Every phase of a level is a row sum S[row] = sum_col w[col] * exp(-a |row - col|^2).  For a <= 1 and clouds of about unit
+// extent the kernel is smooth enough for ONE truncated Taylor expansion about the clouds' common centre O (a fast Gauss
+// transform with a single box):
+//     exp(-a |x - y|^2) = exp(-a |x|^2) exp(-a |y|^2) exp(2a x.y),      x, y relative to O
+//     exp(g x.y) = sum over multi-indices (i,j,k) of  g^(i+j+k) / (i! j! k!) * x^(ijk) * y^(ijk),   g = 2a
+// so   S[row] = exp(-a |row|^2) * sum_(ijk) coef(ijk) * row^(ijk) * M(ijk),      M(ijk) = sum_col w[col] exp(-a |col|^2) col^(ijk):
+// 455 moments (total degree <= 12) per batch element replace the 2048 x 2048 exponentials of a sweep.  Truncation error at
+// g * R_rows * R_cols = 1.32 (C4's clouds at level -1): 6e-12 relative, measured against the direct fp64 sum
+// (tools/experiments/fgt_proto.py); everything here is fp64, the state vectors stay fp32 with the dense sweeps' own update
+// formulas.  Against the reference the result moves by LESS than the dense sweeps' segment-order sums do (which sit ~1e-7 from
+// the reference's sequential fp32 sums): replacing the sums of levels 6-8 by exact ones leaves the set of `match` entries outside
+// the strict bar unchanged, entry for entry (tools/experiments/fgt_parity.py).
+//
+// Validity is checked on the device, per call: fgt_prep measures R_rows * R_cols per batch element and raises the `bad` word when
+// g_max * R_rows * R_cols > kBound (clouds much larger than the unit cube, or non-finite): every kernel here then returns at
+// once and approxmatch.hip's dense sweeps, launched behind the same word, run instead -- no host synchronisation either way.
+//
+// One launch per phase: a workgroup EVALUATES the phase for its 256 rows from the other cloud's moments (staged in LDS, the chunk
+// partials summed in a fixed order: deterministic) and then ACCUMULATES the moments its own rows contribute, as columns, to the
+// next phase (their new weights are in its registers) -- so the chain P1 -> P2 -> P3+P1 -> ... alternates between the two clouds
+// with no separate moment launches.
+#include "common.hpp"
+#include "emd_fgt.hpp"
+
+namespace {
+
+constexpr int FG_P = 12;                                            // total degree of the expansion
+constexpr int FG_NM = (FG_P + 1) * (FG_P + 2) * (FG_P + 3) / 6;     // 455 monomials
+constexpr int FG_ROWS = 256;                                        // rows (and new columns) per workgroup
+constexpr int FG_TPB = 2 * FG_ROWS;                                 // threads per workgroup: two per row (see fgt_step_kernel)
+constexpr int FG_PWS = FG_ROWS + 1;                                 // row stride of the power tables in LDS (doubles)
+constexpr size_t FG_LDS = sizeof(double) * (2 * (FG_P + 1) * (FG_P + 2) / 2 * 14 + 2 * FG_ROWS + 4 * (FG_P + 1) * (size_t)FG_PWS);
+constexpr double kBound = 2.0;                                      // g * R_rows * R_cols up to which degree 12 holds 1e-9
+
+struct Ijk {
+    unsigned char i, j, k, n;
+};
+struct MonoTable {
+    Ijk t[FG_NM];
+    constexpr MonoTable() : t{} {
+        int idx = 0;
+        for (int i = 0; i <= FG_P; i++)
+            for (int j = 0; j <= FG_P - i; j++)
+                for (int k = 0; k <= FG_P - i - j; k++) {
+                    t[idx].i = (unsigned char)i;
+                    t[idx].j = (unsigned char)j;
+                    t[idx].k = (unsigned char)k;
+                    t[idx].n = (unsigned char)(i + j + k);
+                    idx++;
+                }
+    }
+};
+__device__ constexpr MonoTable kMono{};
+// flat index of monomial (i, j, k) in that order
+constexpr int mono_index(int i, int j, int k) {
+    int idx = 0;
+    for (int a = 0; a < i; a++) idx += (FG_P - a + 1) * (FG_P - a + 2) / 2;
+    for (int c = 0; c < j; c++) idx += FG_P - i - c + 1;
+    return idx + k;
+}
+// The moment accumulation's work items: two monomials that differ by one power of x -- (i0, j, k) and (i0 + 1, j, k) -- share the
+// y^j z^k factor of every point.  252 items cover the 455 monomials.
+struct Item {
+    unsigned char i0, j, k, cnt;
+    unsigned short t0, t1;
+};
+constexpr int FG_NI = 252;
+struct ItemTable {
+    Item t[FG_NI];
+    constexpr ItemTable() : t{} {
+        int n = 0;
+        for (int j = 0; j <= FG_P; j++)
+            for (int k = 0; k <= FG_P - j; k++)
+                for (int i0 = 0; i0 <= FG_P - j - k; i0 += 2) {
+                    const bool two = i0 + 1 <= FG_P - j - k;
+                    t[n].i0 = (unsigned char)i0;
+                    t[n].j = (unsigned char)j;
+                    t[n].k = (unsigned char)k;
+                    t[n].cnt = two ? 2 : 1;
+                    t[n].t0 = (unsigned short)mono_index(i0, j, k);
+                    t[n].t1 = (unsigned short)(two ? mono_index(i0 + 1, j, k) : 0);
+                    n++;
+                }
+    }
+};
+__device__ constexpr ItemTable kItems{};
+__device__ constexpr double kInvFact[13] = {1.0, 1.0, 1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320,
+                                            1.0 / 362880, 1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600};
+
+struct Geom {  // per batch element
+    double ox, oy, oz, rarb;
+};
+
+size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+int chunks_of(int npts) { return 2 * ((npts + FG_ROWS - 1) / FG_ROWS); }  // two partials per workgroup (one per half of its threads)
+
+struct FgtWs {
+    int *bad;
+    Geom *geom;
+    double *mom[2];  // [side][(set * b + bi) * chunks + chunk][FG_NM]: side 0 = moments over xyz1 (columns of P2), 1 = over xyz2
+    int chmax;
+};
+FgtWs view(const void *ws, int b, int nmax) {
+    FgtWs v;
+    char *p = (char *)ws;
+    v.bad = (int *)p;
+    p += 256;
+    v.geom = (Geom *)p;
+    p += align256(sizeof(Geom) * (size_t)b);
+    v.chmax = chunks_of(nmax);
+    const size_t per = align256(sizeof(double) * 2 * (size_t)b * v.chmax * FG_NM);
+    v.mom[0] = (double *)p;
+    v.mom[1] = (double *)(p + per);
+    return v;
+}
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// centre = middle of the bounding box of both clouds; R1, R2 = the clouds' largest distances from it
+__global__ __launch_bounds__(1024) void fgt_prep_kernel(int n, int m, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+                                                         double a_max, Geom *__restrict__ geom, int *__restrict__ bad) {
+    __shared__ float red[16][6];
+    __shared__ float ctr[3];
+    const int bi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *A = xyz1 + (size_t)bi * n * 3, *B = xyz2 + (size_t)bi * m * 3;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool nonfinite = false;
+    for (int i = tid; i < n + m; i += 1024) {
+        const float *p = i < n ? A + (size_t)i * 3 : B + (size_t)(i - n) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float v = p[c];
+            nonfinite = nonfinite || !(fabsf(v) < INFINITY);
+            lo[c] = fminf(lo[c], v);
+            hi[c] = fmaxf(hi[c], v);
+        }
+    }
+    const bool anybad = __ballot(nonfinite) != 0ull;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        lo[c] = wave_min(lo[c]);
+        hi[c] = wave_max(hi[c]);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            red[wave][c] = lo[c];
+            red[wave][3 + c] = hi[c];
+        }
+    }
+    if (anybad && lane == 0) atomicOr(bad, 1);
+    __syncthreads();
+    if (tid < 3) {
+        float l = INFINITY, h = -INFINITY;
+        for (int w = 0; w < 16; w++) {
+            l = fminf(l, red[w][tid]);
+            h = fmaxf(h, red[w][3 + tid]);
+        }
+        ctr[tid] = 0.5f * l + 0.5f * h;
+    }
+    __syncthreads();
+    const float ox = ctr[0], oy = ctr[1], oz = ctr[2];
+    float r1 = 0.f, r2 = 0.f;
+    for (int i = tid; i < n + m; i += 1024) {
+        const float *p = i < n ? A + (size_t)i * 3 : B + (size_t)(i - n) * 3;
+        const float dx = p[0] - ox, dy = p[1] - oy, dz = p[2] - oz;
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        if (i < n) r1 = fmaxf(r1, d2); else r2 = fmaxf(r2, d2);
+    }
+    r1 = wave_max(r1);
+    r2 = wave_max(r2);
+    __syncthreads();
+    if (lane == 0) {
+        red[wave][0] = r1;
+        red[wave][1] = r2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float a = 0.f, c = 0.f;
+        for (int w = 0; w < 16; w++) {
+            a = fmaxf(a, red[w][0]);
+            c = fmaxf(c, red[w][1]);
+        }
+        const double rarb = sqrt((double)a) * sqrt((double)c);
+        geom[bi] = Geom{(double)ox, (double)oy, (double)oz, rarb};
+        if (!(2.0 * a_max * rarb <= kBound)) atomicOr(bad, 1);
+    }
+}
+
+struct Step {
+    // rows (this launch evaluates them) and, as columns of the NEXT phase, the same points
+    const float *rows;   // (b, nrows, 3)
+    int nrows;
+    // moments of the other cloud, to evaluate with: up to two sets
+    const double *min;   // [(set * b + bi) * chin + chunk][FG_NM]
+    int chin;            // chunks per batch element in `min`
+    int nin;             // 1 or 2 sets
+    double a_in[2];      // sharpness of each input set
+    int deg_in[2];       // its expansion's total degree (<= FG_P: broader levels need fewer terms)
+    // the columns behind those moments, for the direct sums of a refused call (`bad`): points and the sets' fp32 weights
+    const float *cols;   // (b, ncols, 3)
+    int ncols;
+    const float *wcol[2];
+    // moments this launch leaves for the next phase (NULL: none)
+    double *mout;        // [(set * b + bi) * chout + chunk][FG_NM]
+    int chout;
+    int nout;            // 0, 1 or 2 sets
+    double a_out[2];
+    int deg_out[2];
+    // state (fp32, `stride` floats per batch element)
+    size_t stride;
+    int mode;            // 0: moments only (w = v0 at a_out[0]); 1: P1 (+P3 when nin == 2); 2: P2
+    const float *v0;     // mode 0: the weights; mode 1: ratioL_prev (P3); mode 2: unused
+    float *rem;          // mode 1: remainL; mode 2: remainR
+    float *out;          // mode 1: ratioL_out; mode 2: ratioR_out
+    const Geom *geom;
+    const int *bad;
+    int b;
+};
+
+// sum_(ijk) Ms * x^i y^j z^k by Horner's rule in z inside y inside x.  Ms is staged as one ROW per (i, j) -- the k = 0..FG_P-i-j
+// coefficients, zero-padded to FG_RL entries -- so that every row is the same straight-line code: its 14 entries arrive by seven
+// 16-byte broadcast reads issued together, then a 13-step fma chain; the rows of one i are independent but for one fma each, so
+// the loads of the next row overlap the chain of this one.  (As one pointer walking down the unpadded table every fma waited for
+// its own LDS read: 54 us per launch; fully unrolled, the compiler hoisted all 455 reads and spilled 2.6 KB per lane.)
+constexpr int FG_NR = (FG_P + 1) * (FG_P + 2) / 2;  // 91 rows (i, j)
+constexpr int FG_RL = 14;                           // entries per row: up to FG_P + 1 = 13 coefficients, padded to an even count
+__device__ __forceinline__ int row_of(int i, int j) { return i * (FG_P + 1) - i * (i - 1) / 2 + j; }
+// istep = 1: the whole series.  istep = 2: only the powers of x with the parity of `ifirst` (Horner in x^2): a row's two threads
+// take one parity each and the series is even(x^2) + x * odd(x^2).
+__device__ __forceinline__ double eval_series(const double *__restrict__ Ms, int deg, double x, double y, double z, int ifirst,
+                                              int istep) {
+    double accx = 0.0;
+    const double xs = istep == 2 ? x * x : x;
+#pragma unroll 1
+    for (int i = ifirst; i >= 0; i -= istep) {  // (rows beyond the set's degree hold zeros and are not visited)
+        double accy = 0.0;
+        int r = row_of(i, deg - i);
+#pragma unroll 2
+        for (int j = deg - i; j >= 0; --j, --r) {
+            const double2 *mr = (const double2 *)(Ms + r * FG_RL);
+            double m[FG_RL];
+#pragma unroll
+            for (int q = 0; q < FG_RL / 2; q++) {
+                const double2 v = mr[q];
+                m[2 * q] = v.x;
+                m[2 * q + 1] = v.y;
+            }
+            double bz = m[FG_P];
+#pragma unroll
+            for (int k = FG_P - 1; k >= 0; --k) bz = fma(bz, z, m[k]);
+            accy = fma(accy, y, bz);
+        }
+        accx = fma(accx, xs, accy);
+    }
+    return accx;
+}
+
+// the direct sum of a refused call: S = sum_col w[col] exp2(d2 * c), fp32 as the dense sweeps form their terms, summed in column
+// order (the reference's own order).  Slow -- one row per lane, the columns from L2 -- and only ever run for clouds far outside
+// the unit cube at these levels or with non-finite coordinates.
+__device__ __forceinline__ float direct_sum(const float *__restrict__ C, const float *__restrict__ w, int ncols, float c_exp,
+                                            float x, float y, float z, float start) {
+    float acc = start;
+    for (int l = 0; l < ncols; l++) {
+        const float d2 = rf::d2_fma(C[l * 3] - x, C[l * 3 + 1] - y, C[l * 3 + 2] - z);
+        acc = fmaf(c_exp == 0.f ? 1.0f : __builtin_amdgcn_exp2f(d2 * c_exp), w[l], acc);
+    }
+    return acc;
+}
+
+// 512 threads for 256 rows: the chip has only b * rows / 64 = 1024 waves of rows at C4, ONE per SIMD, and both halves of this
+// kernel are latency-bound at that (fp64 fma chains in the evaluation, LDS reads in the moments: 21-39 us per launch with 256
+// threads).  So thread t and t + 256 share row t: they evaluate one input set each, and in the moment accumulation each takes
+// half of every sub-chunk's points (their partials are two separate chunk slots, summed by the next launch's staging).
+__global__ __launch_bounds__(FG_TPB) void fgt_step_kernel(Step p) {
+    // dynamic LDS (131 KB of the CU's 160: one workgroup per CU, which is all the grid has at C4):
+    //   Ms   [2][FG_NR * FG_RL]        the staged input moments
+    //   s1x  [FG_ROWS]                 what the upper half of the threads hands to the lower half
+    //   xc   [FG_ROWS]                 the rows' x coordinates
+    //   pw   [4][FG_P + 1][FG_PWS]     power tables of ALL the workgroup's rows as columns: x^e (set 0 | set 1, weights folded in) | y^e | z^e;
+    //                                  row stride FG_PWS = 257: lanes of one wave that read different exponents hit different banks
+    extern __shared__ __attribute__((aligned(16))) double fg_lds[];
+    double(*Ms)[FG_NR * FG_RL] = (double(*)[FG_NR * FG_RL])fg_lds;
+    double *s1x = fg_lds + 2 * FG_NR * FG_RL;
+    double *xc = s1x + FG_ROWS;
+    double *pw = xc + FG_ROWS;
+    const bool bad = *p.bad != 0;  // (uniform) the expansion was refused for this call: direct sums, no moments
+    const int bi = blockIdx.y, tid = threadIdx.x;
+    const int rt = tid & (FG_ROWS - 1), half = tid >> 8;  // FG_ROWS == 256
+    const int row = blockIdx.x * FG_ROWS + rt;
+    const bool live = row < p.nrows;
+    const Geom g = p.geom[bi];
+    const float *R = p.rows + ((size_t)bi * p.nrows + (live ? row : p.nrows - 1)) * 3;
+    const double x = (double)R[0] - g.ox, y = (double)R[1] - g.oy, z = (double)R[2] - g.oz;
+    const double r2 = x * x + y * y + z * z;
+    float wnew[2] = {0.f, 0.f};  // this row's weights as a column of the next phase (lower half of the threads)
+    if (p.mode == 0) {
+        wnew[0] = live ? p.v0[(size_t)bi * p.stride + row] : 0.f;
+    } else {
+        double S0 = 0.0, S1 = 0.0;
+        if (!bad) {
+            // ---- stage the input moments: chunk partials summed in a fixed order (eight loads in flight), times
+            //      coef(ijk) = g^(i+j+k) / (i! j! k!); entries beyond a set's degree stay zero
+            for (int t = tid; t < 2 * FG_NR * FG_RL; t += FG_TPB) (&Ms[0][0])[t] = 0.0;
+            __syncthreads();
+            for (int s = 0; s < p.nin; s++) {
+                const double gam = 2.0 * p.a_in[s];
+                for (int t = tid; t < FG_NM; t += FG_TPB) {
+                    const Ijk e = kMono.t[t];
+                    if (e.n > p.deg_in[s]) continue;
+                    const double *src = p.min + ((size_t)(s * p.b + bi) * p.chin) * FG_NM + t;
+                    double sum = 0.0;
+                    for (int c0 = 0; c0 < p.chin; c0 += 8) {
+                        double v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) v[u] = c0 + u < p.chin ? src[(size_t)(c0 + u) * FG_NM] : 0.0;
+#pragma unroll
+                        for (int u = 0; u < 8; u++) sum += v[u];
+                    }
+                    double gp = 1.0;
+                    for (int q = 0; q < e.n; q++) gp *= gam;
+                    Ms[s][row_of(e.i, e.j) * FG_RL + e.k] = sum * gp * kInvFact[e.i] * kInvFact[e.j] * kInvFact[e.k];
+                }
+            }
+            __syncthreads();
+            if (p.nin == 2) {  // a set each
+                if (half == 0) S0 = exp(-p.a_in[0] * r2) * eval_series(Ms[0], p.deg_in[0], x, y, z, p.deg_in[0], 1);
+                else s1x[rt] = exp(-p.a_in[1] * r2) * eval_series(Ms[1], p.deg_in[1], x, y, z, p.deg_in[1], 1);
+                __syncthreads();
+                S1 = s1x[rt];
+            } else {  // one set: the even powers of x here, the odd ones there
+                const int d = p.deg_in[0];
+                const int ifirst = half == 0 ? (d & ~1) : (d >= 1 ? ((d - 1) | 1) : -1);  // largest even / odd i <= d (none: -1)
+                const double part = eval_series(Ms[0], d, x, y, z, ifirst, 2);
+                if (half == 1) s1x[rt] = part * x;
+                __syncthreads();
+                S0 = exp(-p.a_in[0] * r2) * (part + s1x[rt]);
+            }
+        } else if (live && half == 0) {
+            const float *C = p.cols + (size_t)bi * p.ncols * 3;
+            // (a = -c ln 2 in double, so -a / ln 2 rounds back to the sweeps' own float multiplier c = level * kLog2e)
+            const float c0 = (float)(-p.a_in[0] / 0.69314718055994530942), c1 = (float)(-p.a_in[1] / 0.69314718055994530942);
+            S0 = (double)direct_sum(C, p.wcol[0] + (size_t)bi * p.stride, p.ncols, c0, R[0], R[1], R[2], 0.f);
+            if (p.nin == 2) S1 = (double)direct_sum(C, p.wcol[1] + (size_t)bi * p.stride, p.ncols, c1, R[0], R[1], R[2], 0.f);
+        }
+        if (live && half == 0) {
+            const size_t o = (size_t)bi * p.stride + row;
+            if (p.mode == 1) {  // P1 of this level (set 0: w = remainR), behind the fused P3 of the previous one (set 1: w = ratioR_prev)
+                float rem = p.rem[o];
+                if (p.nin == 2) {
+                    const float t3 = (float)((double)p.v0[o] * S1);
+                    rem = fmaxf(0.0f, rem - t3);
+                    p.rem[o] = rem;
+                }
+                const float t1 = (float)(1e-9 + S0);
+                const float ratio = rem / t1;
+                p.out[o] = ratio;
+                wnew[0] = ratio;  // P2 of this level sums ratioL over these points
+            } else {  // P2 (am_rowl_kernel's epilogue)
+                const float sumr = (float)S0;
+                const float rem = p.rem[o];
+                const float t = sumr * rem;
+                const float cons = fminf(rem / (t + 1e-9f), 1.0f);
+                const float ratioR = rem * cons;
+                const float left = fmaxf(0.0f, rem - t);
+                p.out[o] = ratioR;
+                p.rem[o] = left;
+                wnew[0] = left;    // P1 of the next level sums remainR ...
+                wnew[1] = ratioR;  // ... and its fused P3 sums this level's ratioR
+            }
+        }
+    }
+    if (p.nout == 0 || bad) return;
+    // ---- the moments these rows contribute, as columns, to the next phase.  The power tables of the workgroup's 256 points go to
+    //      LDS -- x^e once per set with the set's weight and exp(-a |col|^2) folded in, y^e and z^e shared, and the points' x --
+    //      then thread <-> (item, half of the points): an item is two monomials one power of x apart, so a point costs 5 LDS
+    //      reads for its 4 products (both sets).
+    double wt0 = 0.0, wt1 = 0.0;
+    if (half == 0 && live) {
+        wt0 = (double)wnew[0] * exp(-p.a_out[0] * r2);
+        if (p.nout == 2) wt1 = (double)wnew[1] * exp(-p.a_out[1] * r2);
+    }
+    const int dmax = p.nout == 2 ? max(p.deg_out[0], p.deg_out[1]) : p.deg_out[0];
+    const int item = rt;  // (252 of the 256 are items)
+    const Item it = kItems.t[item < FG_NI ? item : 0];
+    const bool work = item < FG_NI && (int)it.i0 + it.j + it.k <= dmax;
+    double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;  // [monomial of the item][set]
+    __syncthreads();  // (Ms / s1x are done with)
+    if (half == 0) {
+        double p0 = wt0, p1 = wt1, py = 1.0, pz = 1.0;
+        xc[rt] = x;
+        for (int e = 0; e <= dmax; e++) {
+            pw[(0 * (FG_P + 1) + e) * FG_PWS + rt] = p0;
+            pw[(1 * (FG_P + 1) + e) * FG_PWS + rt] = p1;
+            pw[(2 * (FG_P + 1) + e) * FG_PWS + rt] = py;
+            pw[(3 * (FG_P + 1) + e) * FG_PWS + rt] = pz;
+            p0 *= x;
+            p1 *= x;
+            py *= y;
+            pz *= z;
+        }
+    }
+    __syncthreads();
+    if (work) {
+        const int q0 = half * (FG_ROWS / 2);
+        const double *b0 = pw + (0 * (FG_P + 1) + it.i0) * FG_PWS + q0, *b1 = pw + (1 * (FG_P + 1) + it.i0) * FG_PWS + q0;
+        const double *ay = pw + (2 * (FG_P + 1) + it.j) * FG_PWS + q0, *az = pw + (3 * (FG_P + 1) + it.k) * FG_PWS + q0;
+        const double *xq = xc + q0;
+#pragma unroll 8
+        for (int q = 0; q < FG_ROWS / 2; q++) {
+            const double yz = ay[q] * az[q];
+            const double u0 = b0[q] * yz, u1 = b1[q] * yz;
+            a00 += u0;
+            a01 += u1;
+            a10 = fma(u0, xq[q], a10);
+            a11 = fma(u1, xq[q], a11);
+        }
+    }
+    if (item < FG_NI) {
+        double *out0 = p.mout + ((size_t)(0 * p.b + bi) * p.chout + blockIdx.x * 2 + half) * FG_NM;
+        out0[it.t0] = a00;
+        if (it.cnt == 2) out0[it.t1] = a10;
+        if (p.nout == 2) {
+            double *out1 = p.mout + ((size_t)(1 * p.b + bi) * p.chout + blockIdx.x * 2 + half) * FG_NM;
+            out1[it.t0] = a01;
+            if (it.cnt == 2) out1[it.t1] = a11;
+        }
+    }
+}
+
+int launch(const Step &p, hipStream_t s) {
+    // (per call, not once: the attribute belongs to the calling thread's current device)
+    RF_HIP(hipFuncSetAttribute((const void *)fgt_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FG_LDS));
+    RF_LAUNCH("am_fgt", fgt_step_kernel, dim3(rf::ceil_div(p.nrows, FG_ROWS), p.b), dim3(FG_TPB), FG_LDS, s, p);
+    return RF_OK;
+}
+
+}  // namespace
+
+namespace rfe {
+
+size_t fgt_workspace_bytes(int b, int nmax) {
+    if (b <= 0 || nmax <= 0) return 0;
+    return 256 + align256(sizeof(Geom) * (size_t)b) + 2 * align256(sizeof(double) * 2 * (size_t)b * chunks_of(nmax) * FG_NM);
+}
+
+const int *fgt_bad_word(const void *ws) { return (const int *)ws; }
+
+int fgt_prep(int b, int n, int m, const float *xyz1, const float *xyz2, double a_max, void *ws, hipStream_t s) {
+    FgtWs v = view(ws, b, n > m ? n : m);
+    RF_ZERO(v.bad, 256, s);
+    RF_LAUNCH("am_fgt_prep", fgt_prep_kernel, dim3(b), dim3(1024), 0, s, n, m, xyz1, xyz2, a_max, v.geom, v.bad);
+    return RF_OK;
+}
+
+// total degree for sharpness a (relative truncation error <= ~1e-11 up to the validity bound: tools/experiments/fgt_proto.py)
+static int degree_for(double a) { return a <= 1e-12 ? 0 : (a <= 0.3 ? 8 : FG_P); }
+
+// moments over xyz2 with w = remainR at a: what the first fgt_p3p1 (without a fused P3) evaluates
+static int moments_only(int b, int npts, const float *pts, const float *w, size_t stride, double a, double *mout, int chout,
+                        const FgtWs &v, hipStream_t s) {
+    Step p{};
+    p.rows = pts;
+    p.nrows = npts;
+    p.mode = 0;
+    p.v0 = w;
+    p.stride = stride;
+    p.mout = mout;
+    p.chout = chout;
+    p.nout = 1;
+    p.a_out[0] = a;
+    p.deg_out[0] = degree_for(a);
+    p.geom = v.geom;
+    p.bad = v.bad;
+    p.b = b;
+    return launch(p, s);
+}
+
+// What the workspace holds between the calls of one schedule:
+//   after fgt_p3p1(level v):  mom[0] set 0 = over xyz1, w = ratioL_v at a_v                                   (for fgt_p2(v))
+//   after fgt_p2(level v):    mom[1] set 0 = over xyz2, w = remainR at a_next; set 1 = w = ratioR_v at a_v      (for fgt_p3p1(v + 1))
+int fgt_p3p1(int b, int n, int m, const float *xyz1, const float *xyz2, bool has_p3, double a_prev, double a_cur,
+             const float *ratioR_prev, const float *remainR, const float *ratioL_prev, float *remainL, float *ratioL_out,
+             size_t stride, void *ws, hipStream_t s) {
+    FgtWs v = view(ws, b, n > m ? n : m);
+    if (!has_p3) {  // the chain starts here: the moments over xyz2 with w = remainR
+        if (int e = moments_only(b, m, xyz2, remainR, stride, a_cur, v.mom[1], chunks_of(m), v, s)) return e;
+    }
+    Step p{};
+    p.rows = xyz1;
+    p.nrows = n;
+    p.min = v.mom[1];
+    p.chin = chunks_of(m);
+    p.nin = has_p3 ? 2 : 1;
+    p.a_in[0] = a_cur;
+    p.a_in[1] = a_prev;
+    p.deg_in[0] = degree_for(a_cur);
+    p.deg_in[1] = degree_for(a_prev);
+    p.cols = xyz2;
+    p.ncols = m;
+    p.wcol[0] = remainR;
+    p.wcol[1] = ratioR_prev;
+    p.mout = v.mom[0];
+    p.chout = chunks_of(n);
+    p.nout = 1;
+    p.a_out[0] = a_cur;
+    p.deg_out[0] = degree_for(a_cur);
+    p.stride = stride;
+    p.mode = 1;
+    p.v0 = ratioL_prev;
+    p.rem = remainL;
+    p.out = ratioL_out;
+    p.geom = v.geom;
+    p.bad = v.bad;
+    p.b = b;
+    return launch(p, s);
+}
+
+int fgt_p2(int b, int n, int m, const float *xyz1, const float *xyz2, double a_cur, double a_next, const float *ratioL,
+           float *remainR, float *ratioR_out, size_t stride, void *ws, hipStream_t s) {
+    FgtWs v = view(ws, b, n > m ? n : m);
+    Step p{};
+    p.rows = xyz2;
+    p.nrows = m;
+    p.min = v.mom[0];
+    p.chin = chunks_of(n);
+    p.nin = 1;
+    p.a_in[0] = a_cur;
+    p.deg_in[0] = degree_for(a_cur);
+    p.cols = xyz1;
+    p.ncols = n;
+    p.wcol[0] = ratioL;
+    p.mout = v.mom[1];
+    p.chout = chunks_of(m);
+    p.nout = a_next >= 0.0 ? 2 : 0;
+    p.a_out[0] = a_next >= 0.0 ? a_next : 0.0;
+    p.a_out[1] = a_cur;
+    p.deg_out[0] = degree_for(p.a_out[0]);
+    p.deg_out[1] = degree_for(a_cur);
+    p.stride = stride;
+    p.mode = 2;
+    p.rem = remainR;
+    p.out = ratioR_out;
+    p.geom = v.geom;
+    p.bad = v.bad;
+    p.b = b;
+    return launch(p, s);
+}
+
+}  // namespace rfe

@@ -11,7 +11,7 @@ rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 seq=[(r["Kernel_Name"],int(r["End_Timestamp"])-int(r["Start_Timestamp"])) for r in rows]
 import re
 def short(n):
-    m=re.search(r"(am_row[kl]_kernel<[^>]*>|am_match_kernel<[^>]*>|nnp_sort\w*|mc_\w+|am_init\w*|zero_kernel|am_\w+)",n)
+    m=re.search(r"(am_row[kl]_kernel<[^>]*>|am_match_kernel<[^>]*>|fgt_\w+|nnp_sort\w*|mc_\w+|am_init\w*|zero_kernel|am_\w+)",n)
     return m.group(1) if m else n[:40]
 # take the last 40 kernels
 for n,d in seq[-30:]:
