@@ -7,8 +7,8 @@
 //     exp(-a |x - y|^2) = exp(-a |x|^2) exp(-a |y|^2) exp(2a x.y),      x, y relative to O
 //     exp(g x.y) = sum over multi-indices (i,j,k) of  g^(i+j+k) / (i! j! k!) * x^(ijk) * y^(ijk),   g = 2a
 // so   S[row] = exp(-a |row|^2) * sum_(ijk) coef(ijk) * row^(ijk) * M(ijk),      M(ijk) = sum_col w[col] exp(-a |col|^2) col^(ijk):
-// 455 moments (total degree <= 12) per batch element replace the 2048 x 2048 exponentials of a sweep.  Truncation error at
-// g * R_rows * R_cols = 1.32 (C4's clouds at level -1): 6e-12 relative, measured against the direct fp64 sum
+// 286 moments (total degree <= 10; 84 at level -0.25, one at level 0) per batch element replace the 2048 x 2048 exponentials of a
+// sweep.  Truncation error at g * R_rows * R_cols = 1.32 (C4's clouds at level -1): 7e-10 relative, measured against the direct fp64 sum
 // (tools/experiments/fgt_proto.py); everything here is fp64, the state vectors stay fp32 with the dense sweeps' own update
 // formulas.  Against the reference the result moves by LESS than the dense sweeps' segment-order sums do (which sit ~1e-7 from
 // the reference's sequential fp32 sums): replacing the sums of levels 6-8 by exact ones leaves the set of `match` entries outside
@@ -27,13 +27,13 @@
 
 namespace {
 
-constexpr int FG_P = 12;                                            // total degree of the expansion
-constexpr int FG_NM = (FG_P + 1) * (FG_P + 2) * (FG_P + 3) / 6;     // 455 monomials
+constexpr int FG_P = 10;                                            // largest total degree of an expansion
+constexpr int FG_NM = (FG_P + 1) * (FG_P + 2) * (FG_P + 3) / 6;     // 286 monomials
 constexpr int FG_ROWS = 256;                                        // rows (and new columns) per workgroup
 constexpr int FG_TPB = 2 * FG_ROWS;                                 // threads per workgroup: two per row (see fgt_step_kernel)
 constexpr int FG_PWS = FG_ROWS + 1;                                 // row stride of the power tables in LDS (doubles)
-constexpr size_t FG_LDS = sizeof(double) * (2 * (FG_P + 1) * (FG_P + 2) / 2 * 14 + 2 * FG_ROWS + 4 * (FG_P + 1) * (size_t)FG_PWS);
-constexpr double kBound = 2.0;                                      // g * R_rows * R_cols up to which degree 12 holds 1e-9
+constexpr size_t FG_LDS = sizeof(double) * (2 * (FG_P + 1) * (FG_P + 2) / 2 * 12 + 2 * FG_ROWS + 4 * (FG_P + 1) * (size_t)FG_PWS);
+constexpr double kBound = 1.5;                                      // g * R_rows * R_cols up to which degree 10 holds 3e-9 (any two clouds inside a unit cube: <= 1.5 at level -1)
 
 struct Ijk {
     unsigned char i, j, k, n;
@@ -62,12 +62,12 @@ constexpr int mono_index(int i, int j, int k) {
     return idx + k;
 }
 // The moment accumulation's work items: two monomials that differ by one power of x -- (i0, j, k) and (i0 + 1, j, k) -- share the
-// y^j z^k factor of every point.  252 items cover the 455 monomials.
+// y^j z^k factor of every point.  161 items cover the 286 monomials.
 struct Item {
     unsigned char i0, j, k, cnt;
     unsigned short t0, t1;
 };
-constexpr int FG_NI = 252;
+constexpr int FG_NI = 161;
 struct ItemTable {
     Item t[FG_NI];
     constexpr ItemTable() : t{} {
@@ -95,7 +95,7 @@ struct Geom {  // per batch element
 };
 
 size_t align256(size_t v) { return (v + 255) / 256 * 256; }
-int chunks_of(int npts) { return 2 * ((npts + FG_ROWS - 1) / FG_ROWS); }  // two partials per workgroup (one per half of its threads)
+int chunks_of(int npts) { return (npts + FG_ROWS - 1) / FG_ROWS; }  // one partial per workgroup
 
 struct FgtWs {
     int *bad;
@@ -234,16 +234,17 @@ struct Step {
 // coefficients, zero-padded to FG_RL entries -- so that every row is the same straight-line code: its 14 entries arrive by seven
 // 16-byte broadcast reads issued together, then a 13-step fma chain; the rows of one i are independent but for one fma each, so
 // the loads of the next row overlap the chain of this one.  (As one pointer walking down the unpadded table every fma waited for
-// its own LDS read: 54 us per launch; fully unrolled, the compiler hoisted all 455 reads and spilled 2.6 KB per lane.)
+// its own LDS read: 54 us per launch; fully unrolled, the compiler hoisted all the reads and spilled 2.6 KB per lane.)
 constexpr int FG_NR = (FG_P + 1) * (FG_P + 2) / 2;  // 91 rows (i, j)
-constexpr int FG_RL = 14;                           // entries per row: up to FG_P + 1 = 13 coefficients, padded to an even count
+constexpr int FG_RL = 12;                           // entries per row: up to FG_P + 1 = 11 coefficients, padded to an even count
 __device__ __forceinline__ int row_of(int i, int j) { return i * (FG_P + 1) - i * (i - 1) / 2 + j; }
 // istep = 1: the whole series.  istep = 2: only the powers of x with the parity of `ifirst` (Horner in x^2): a row's two threads
 // take one parity each and the series is even(x^2) + x * odd(x^2).
 __device__ __forceinline__ double eval_series(const double *__restrict__ Ms, int deg, double x, double y, double z, int ifirst,
                                               int istep) {
+    static_assert((FG_P & 1) == 0, "the row polynomial's even / odd split assumes an even top degree");
     double accx = 0.0;
-    const double xs = istep == 2 ? x * x : x;
+    const double xs = istep == 2 ? x * x : x, z2 = z * z;
 #pragma unroll 1
     for (int i = ifirst; i >= 0; i -= istep) {  // (rows beyond the set's degree hold zeros and are not visited)
         double accy = 0.0;
@@ -258,10 +259,13 @@ __device__ __forceinline__ double eval_series(const double *__restrict__ Ms, int
                 m[2 * q] = v.x;
                 m[2 * q + 1] = v.y;
             }
-            double bz = m[FG_P];
+            // the row's polynomial in z as even(z^2) + z * odd(z^2): two chains of six instead of one of eleven
+            double ev = m[FG_P], od = m[FG_P - 1];  // (FG_P is even)
 #pragma unroll
-            for (int k = FG_P - 1; k >= 0; --k) bz = fma(bz, z, m[k]);
-            accy = fma(accy, y, bz);
+            for (int k = FG_P - 2; k >= 0; k -= 2) ev = fma(ev, z2, m[k]);
+#pragma unroll
+            for (int k = FG_P - 3; k >= 1; k -= 2) od = fma(od, z2, m[k]);
+            accy = fma(accy, y, fma(od, z, ev));
         }
         accx = fma(accx, xs, accy);
     }
@@ -284,7 +288,7 @@ __device__ __forceinline__ float direct_sum(const float *__restrict__ C, const f
 // 512 threads for 256 rows: the chip has only b * rows / 64 = 1024 waves of rows at C4, ONE per SIMD, and both halves of this
 // kernel are latency-bound at that (fp64 fma chains in the evaluation, LDS reads in the moments: 21-39 us per launch with 256
 // threads).  So thread t and t + 256 share row t: they evaluate one input set each, and in the moment accumulation each takes
-// half of every sub-chunk's points (their partials are two separate chunk slots, summed by the next launch's staging).
+// half of the workgroup's points (their sums meet in LDS).
 __global__ __launch_bounds__(FG_TPB) void fgt_step_kernel(Step p) {
     // dynamic LDS (131 KB of the CU's 160: one workgroup per CU, which is all the grid has at C4):
     //   Ms   [2][FG_NR * FG_RL]        the staged input moments
@@ -394,7 +398,7 @@ __global__ __launch_bounds__(FG_TPB) void fgt_step_kernel(Step p) {
         if (p.nout == 2) wt1 = (double)wnew[1] * exp(-p.a_out[1] * r2);
     }
     const int dmax = p.nout == 2 ? max(p.deg_out[0], p.deg_out[1]) : p.deg_out[0];
-    const int item = rt;  // (252 of the 256 are items)
+    const int item = rt;  // (161 of the 256 are items)
     const Item it = kItems.t[item < FG_NI ? item : 0];
     const bool work = item < FG_NI && (int)it.i0 + it.j + it.k <= dmax;
     double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;  // [monomial of the item][set]
@@ -419,22 +423,45 @@ __global__ __launch_bounds__(FG_TPB) void fgt_step_kernel(Step p) {
         const double *b0 = pw + (0 * (FG_P + 1) + it.i0) * FG_PWS + q0, *b1 = pw + (1 * (FG_P + 1) + it.i0) * FG_PWS + q0;
         const double *ay = pw + (2 * (FG_P + 1) + it.j) * FG_PWS + q0, *az = pw + (3 * (FG_P + 1) + it.k) * FG_PWS + q0;
         const double *xq = xc + q0;
+        if (p.nout == 2) {
 #pragma unroll 8
-        for (int q = 0; q < FG_ROWS / 2; q++) {
-            const double yz = ay[q] * az[q];
-            const double u0 = b0[q] * yz, u1 = b1[q] * yz;
-            a00 += u0;
-            a01 += u1;
-            a10 = fma(u0, xq[q], a10);
-            a11 = fma(u1, xq[q], a11);
+            for (int q = 0; q < FG_ROWS / 2; q++) {
+                const double yz = ay[q] * az[q];
+                const double u0 = b0[q] * yz, u1 = b1[q] * yz;
+                a00 += u0;
+                a01 += u1;
+                a10 = fma(u0, xq[q], a10);
+                a11 = fma(u1, xq[q], a11);
+            }
+        } else {
+#pragma unroll 8
+            for (int q = 0; q < FG_ROWS / 2; q++) {
+                const double u0 = b0[q] * (ay[q] * az[q]);
+                a00 += u0;
+                a10 = fma(u0, xq[q], a10);
+            }
         }
     }
-    if (item < FG_NI) {
-        double *out0 = p.mout + ((size_t)(0 * p.b + bi) * p.chout + blockIdx.x * 2 + half) * FG_NM;
+    // the two halves' sums meet in LDS (the tables are done with): ONE partial per workgroup and set leaves the CU
+    __syncthreads();
+    double *xch = pw;  // [4][FG_ROWS]
+    if (half == 1) {
+        xch[0 * FG_ROWS + rt] = a00;
+        xch[1 * FG_ROWS + rt] = a01;
+        xch[2 * FG_ROWS + rt] = a10;
+        xch[3 * FG_ROWS + rt] = a11;
+    }
+    __syncthreads();
+    if (half == 0 && item < FG_NI) {
+        a00 += xch[0 * FG_ROWS + rt];
+        a01 += xch[1 * FG_ROWS + rt];
+        a10 += xch[2 * FG_ROWS + rt];
+        a11 += xch[3 * FG_ROWS + rt];
+        double *out0 = p.mout + ((size_t)(0 * p.b + bi) * p.chout + blockIdx.x) * FG_NM;
         out0[it.t0] = a00;
         if (it.cnt == 2) out0[it.t1] = a10;
         if (p.nout == 2) {
-            double *out1 = p.mout + ((size_t)(1 * p.b + bi) * p.chout + blockIdx.x * 2 + half) * FG_NM;
+            double *out1 = p.mout + ((size_t)(1 * p.b + bi) * p.chout + blockIdx.x) * FG_NM;
             out1[it.t0] = a01;
             if (it.cnt == 2) out1[it.t1] = a11;
         }
@@ -467,7 +494,7 @@ int fgt_prep(int b, int n, int m, const float *xyz1, const float *xyz2, double a
 }
 
 // total degree for sharpness a (relative truncation error <= ~1e-11 up to the validity bound: tools/experiments/fgt_proto.py)
-static int degree_for(double a) { return a <= 1e-12 ? 0 : (a <= 0.3 ? 8 : FG_P); }
+static int degree_for(double a) { return a <= 1e-12 ? 0 : (a <= 0.3 ? 6 : FG_P); }
 
 // moments over xyz2 with w = remainR at a: what the first fgt_p3p1 (without a fused P3) evaluates
 static int moments_only(int b, int npts, const float *pts, const float *w, size_t stride, double a, double *mout, int chout,
