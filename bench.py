@@ -78,13 +78,14 @@ EMD_LAUNCH_MIX = {
     "am_p2, level 0 (skipping)": (1, 7 + 0.088 * 2, 0.088),
     "am_p2, level 1 (skipping)": (1, 7 + 0.185 * 2, 0.185),
     "am_p2, level 2 (skipping)": (1, 7 + 0.418 * 2, 0.418),
-    "am_p2, levels 3-8": (6, 8, 1),
-    "am_p2, last level (e = 1: no distance, no exp)": (1, 1, 0),
+    "am_p2, levels 3-6": (4, 8, 1),
     "am_p3p1, levels 0+1 (skipping, P3 under its own test)": (1, 7 + 0.185 * 2 + 0.088 * 3, 0.185 + 0.088),
     "am_p3p1, levels 1+2 (skipping)": (1, 7 + 0.418 * 2 + 0.185 * 3, 0.418 + 0.185),
     "am_p3p1, levels 2+3 (only the P3 part conditional)": (1, 6.5 + 2 + 0.418 * 3, 1 + 0.418),
-    "am_p3p1, levels 4-8": (5, 11, 2),
-    "am_p3p1, last level (P1 without exp)": (1, 10, 1),
+    "am_p3p1, level pairs 3+4, 4+5, 5+6": (3, 11, 2),
+    # round 5, late: levels 7, 8 and 9 (-1, -0.25, 0) are not swept any more -- their row sums come from a truncated Taylor expansion
+    # about the clouds' centre (emd_fgt.hip: 7 small fp64 launches, `emd.roofline.expanded_levels`), so the P3 of level 6 runs alone
+    "am_p3 (level 6 alone)": (1, 9, 1),
     # round 5: levels 1, 3, 5, 7 take their weight from the next level's by two squarings (2 mul instead of mul + exp)
     # ... and the sharpest level is evaluated only where some column of the wave is within its cut-off of the row (14 % of the
     # (wave, row) pairs at C4: 1 - (1 - 0.0023)^64)
@@ -762,6 +763,9 @@ def main():
         del mt
         # (no kernel events -- a renamed kernel, events unavailable under a tool: fall back to the wall time, never divide by 0)
         am_kernel_ms = sum(am_k.values()) or am_ms
+        # the issue floor models the SWEPT launches (fp32 VALU + v_exp_f32) and the materialisation; the expanded levels' fp64 launches,
+        # the row sort and the init kernels are reported beside it
+        am_swept_ms = sum(v for k, v in am_k.items() if k in ("am_p1", "am_p2", "am_p3p1", "am_p3", "am_match")) or am_kernel_ms
         efl = emd_issue_floor_ms(eb, en, en)
         lane_ops = (efl["valu_per_pair"] if efl else 250.0) * eb * en * en
         # SURVEY 8(d) C4's secondary run: BASELINE's "50 Sinkhorn iters" as the 10 reference levels each repeated 5x
@@ -810,22 +814,27 @@ def main():
         dt_emd, dt_ns, dt_emdf, dt_x50 = (float(tmax[i].item()) for i in range(4))
         extras["emd"] = {
             "roofline": {
-                "bound": "valu+trans", "kernel": "am_p1 + am_p3p1 + am_p2 + am_match (approx_match, 21 launches + the row sort)",
+                "bound": "valu+trans", "kernel": "am_p1 + am_p2 + am_p3p1 + am_p3 + am_match (approx_match: 15 swept launches; + 8 launches of the expanded levels, the row sort)",
                 "lane_ops_per_pair": efl["valu_per_pair"] if efl else None, "exp_per_pair": efl["exp_per_pair"] if efl else None,
                 "achieved": lane_ops / (am_kernel_ms * 1e-3) / 1e12, "unit": "T lane-ops/s",
                 "issue_floor_ms": efl["mix_ms"] if efl else None,
                 "issue_floor_additive_ms": efl["additive_ms"] if efl else None,
                 "issue_floor_source": (efl["constants"] + "; counted instructions per launch: EMD_LAUNCH_MIX in bench.py") if efl else
                                       "profiles/issue_costs.json missing",
-                "frac": (efl["mix_ms"] / am_kernel_ms) if efl else None,
+                "frac": (efl["mix_ms"] / am_swept_ms) if efl else None,
+                "swept_kernel_sum_ms": am_swept_ms,
+                "expanded_levels": {"what": "levels -1, -0.25 and 0 of the schedule: row sums from one truncated Taylor expansion about the "
+                                            "clouds' centre (emd_fgt.hip, fp64, degree 10 / 6 / 0, <= 3e-9 of the direct sum inside a unit "
+                                            "cube; refused per call on the device for larger or non-finite clouds, which take direct sums)",
+                                    "kernels_ms": {k: v for k, v in am_k.items() if k.startswith("am_fgt")}},
                 "frac_of_fp32_peak": 2.0 * lane_ops / (am_kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
                 "avg_kernel_sum_ms": am_kernel_ms, "approx_match_ms_wall": am_ms, "kernels_ms": am_k,
                 "mfma": "not applicable: every matrix element needs its own exp(level * d2) (8 of the 9 ops and all of the "
                         "transcendental work); d2 via the |a|^2+|b|^2-2ab GEMM is ruled out because exp(-16384 d2) amplifies "
                         "its cancellation error to ~7e-4 relative (DESIGN.md 5.5, K=4 trial recorded there)",
                 "dense_equivalent": {"lane_ops_per_pair": 254, "exp_per_pair": 32,
-                                     "what": "the schedule with every pair evaluated (round 5 before the skipping sweeps); the skipped "
-                                             "terms are exact zeros: match is bit-identical"},
+                                     "what": "the schedule with every pair of every level evaluated (round 5 before the skipping sweeps "
+                                             "and the expanded levels); the skipped terms are exact zeros"},
                 "note": "frac = issue floor derived from EXECUTED instructions (counted, with the model's keep fractions for the "
                         "skipping sweeps) x measured issue costs / measured kernel time; "
                         "frac_of_fp32_peak counts 2 flop per lane-op against the 157.3 TFLOP/s vector peak"},
