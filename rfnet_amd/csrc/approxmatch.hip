@@ -1127,7 +1127,7 @@ constexpr int CULL_MAXLV = 8;  // at most this many leading levels are culled
 #endif
 constexpr double ROWSORT_MIN_PAIRS = RFA_ROWSORT_MIN_PAIRS;
 #ifndef RFA_FGT_MIN_PAIRS
-#define RFA_FGT_MIN_PAIRS 4.0e6
+#define RFA_FGT_MIN_PAIRS 8.0e7
 #endif
 constexpr double FGT_MIN_PAIRS = RFA_FGT_MIN_PAIRS;
 

@@ -272,17 +272,65 @@ __device__ __forceinline__ double eval_series(const double *__restrict__ Ms, int
     return accx;
 }
 
-// the direct sum of a refused call: S = sum_col w[col] exp2(d2 * c), fp32 as the dense sweeps form their terms, summed in column
-// order (the reference's own order).  Slow -- one row per lane, the columns from L2 -- and only ever run for clouds far outside
-// the unit cube at these levels or with non-finite coordinates.
-__device__ __forceinline__ float direct_sum(const float *__restrict__ C, const float *__restrict__ w, int ncols, float c_exp,
-                                            float x, float y, float z, float start) {
-    float acc = start;
-    for (int l = 0; l < ncols; l++) {
-        const float d2 = rf::d2_fma(C[l * 3] - x, C[l * 3 + 1] - y, C[l * 3 + 2] - z);
-        acc = fmaf(c_exp == 0.f ? 1.0f : __builtin_amdgcn_exp2f(d2 * c_exp), w[l], acc);
+// the direct sum of a refused call: S = sum_col w[col] exp2(d2 * c) over the columns [lo, hi), fp32 as the dense sweeps form their
+// terms.  One row per lane; the columns are wave-uniform and come by scalar loads, eight columns (24 + 8 dwords) per batch in two
+// register sets: the wait for a batch comes before the next batch's issue (scalar loads return out of order, so the only wait
+// there is is "all of them").  About the dense sweeps' own speed -- the path of clouds far outside the unit cube at these levels
+// (an untrained network's output) and of non-finite coordinates.
+typedef const __attribute__((address_space(4))) float cfloat;
+// TWO: both sums of a fused P3 + P1 phase from one d2 per pair (acc[1]: weights w1, multiplier c1), as am_rowk_kernel forms them.
+template <bool TWO>
+__device__ __forceinline__ void direct_sum(const float *C_, const float *w0_, const float *w1_, int lo, int hi, float c0, float c1,
+                                           float x, float y, float z, float (&acc)[2]) {
+    cfloat *C = (cfloat *)C_;
+    cfloat *w0 = (cfloat *)w0_;
+    cfloat *w1 = (cfloat *)w1_;
+    acc[0] = acc[1] = 0.f;
+    const bool one = c0 == 0.f;
+    auto term = [&](float cx, float cy, float cz, float wl0, float wl1) {
+        const float d2 = rf::d2_fma(cx - x, cy - y, cz - z);
+        acc[0] = fmaf(one ? 1.0f : __builtin_amdgcn_exp2f(d2 * c0), wl0, acc[0]);
+        if (TWO) acc[1] = fmaf(__builtin_amdgcn_exp2f(d2 * c1), wl1, acc[1]);
+    };
+    int l = lo;
+    if (!TWO && one) {  // (uniform) level 0 on its own: the sum of the weights, as am_rowl_kernel<.., ZERO> takes it
+        for (; l + 8 <= hi; l += 8) {
+            float ww[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) ww[u] = w0[l + u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc[0] = fmaf(1.0f, ww[u], acc[0]);
+        }
+        for (; l < hi; l++) acc[0] = fmaf(1.0f, w0[l], acc[0]);
+        return;
     }
-    return acc;
+    float ca[24], wa[8], va[8], cb[24], wb[8], vb[8];
+#define RFE_DS_LOAD(c, ww, vv, at)                                                              \
+    _Pragma("unroll") for (int u = 0; u < 24; u++) c[u] = C[(size_t)(at) * 3 + u];              \
+    _Pragma("unroll") for (int u = 0; u < 8; u++) ww[u] = w0[(at) + u];                         \
+    if (TWO) { _Pragma("unroll") for (int u = 0; u < 8; u++) vv[u] = w1[(at) + u]; }
+#define RFE_DS_USE(c, ww, vv) \
+    _Pragma("unroll") for (int u = 0; u < 8; u++) term(c[3 * u], c[3 * u + 1], c[3 * u + 2], ww[u], TWO ? vv[u] : 0.f);
+    if (l + 8 <= hi) {
+        RFE_DS_LOAD(ca, wa, va, l)
+        for (; l + 24 <= hi; l += 16) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_sched_barrier(0);
+            RFE_DS_LOAD(cb, wb, vb, l + 8)
+            __builtin_amdgcn_sched_barrier(0);
+            RFE_DS_USE(ca, wa, va)
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_sched_barrier(0);
+            RFE_DS_LOAD(ca, wa, va, l + 16)
+            __builtin_amdgcn_sched_barrier(0);
+            RFE_DS_USE(cb, wb, vb)
+        }
+        RFE_DS_USE(ca, wa, va)
+        l += 8;
+    }
+#undef RFE_DS_LOAD
+#undef RFE_DS_USE
+    for (; l < hi; l++) term(C[(size_t)l * 3], C[(size_t)l * 3 + 1], C[(size_t)l * 3 + 2], w0[l], TWO ? w1[l] : 0.f);
 }
 
 // 512 threads for 256 rows: the chip has only b * rows / 64 = 1024 waves of rows at C4, ONE per SIMD, and both halves of this
@@ -353,12 +401,25 @@ __global__ __launch_bounds__(FG_TPB) void fgt_step_kernel(Step p) {
                 __syncthreads();
                 S0 = exp(-p.a_in[0] * r2) * (part + s1x[rt]);
             }
-        } else if (live && half == 0) {
-            const float *C = p.cols + (size_t)bi * p.ncols * 3;
+        } else {
+            // refused: direct sums, half of the columns for each of a row's two threads
+            const int h = __builtin_amdgcn_readfirstlane(half);  // (a wave lies in one half)
+            const int mid = (p.ncols / 2) & ~7;
+            const int lo = h == 0 ? 0 : mid, hi = h == 0 ? mid : p.ncols;
             // (a = -c ln 2 in double, so -a / ln 2 rounds back to the sweeps' own float multiplier c = level * kLog2e)
             const float c0 = (float)(-p.a_in[0] / 0.69314718055994530942), c1 = (float)(-p.a_in[1] / 0.69314718055994530942);
-            S0 = (double)direct_sum(C, p.wcol[0] + (size_t)bi * p.stride, p.ncols, c0, R[0], R[1], R[2], 0.f);
-            if (p.nin == 2) S1 = (double)direct_sum(C, p.wcol[1] + (size_t)bi * p.stride, p.ncols, c1, R[0], R[1], R[2], 0.f);
+            const float *C = p.cols + (size_t)bi * p.ncols * 3;
+            const float *w0 = p.wcol[0] + (size_t)bi * p.stride;
+            float acc[2];
+            if (p.nin == 2) direct_sum<true>(C, w0, p.wcol[1] + (size_t)bi * p.stride, lo, hi, c0, c1, R[0], R[1], R[2], acc);
+            else direct_sum<false>(C, w0, w0, lo, hi, c0, c0, R[0], R[1], R[2], acc);
+            if (half == 1) {
+                s1x[rt] = (double)acc[0];
+                xc[rt] = (double)acc[1];  // (xc is not in use before the moment pass, which a refused call never reaches)
+            }
+            __syncthreads();
+            S0 = (double)(acc[0] + (float)s1x[rt]);
+            S1 = (double)(acc[1] + (float)xc[rt]);
         }
         if (live && half == 0) {
             const size_t o = (size_t)bi * p.stride + row;

@@ -311,7 +311,8 @@ def test_sharp_level_sweeps_with_sorted_rows_keep_every_bit():
     skip, after the distance, the columns whose weights are exactly 0 for every row of the wave (approxmatch.hip
     am_rowk_kernel SKIP).  Row order enters no sum and column order is untouched, so `match` must not change by one bit: the
     same clouds as a batch of one (4.2e6 pairs: plain sweeps) and replicated into a batch of sixteen (6.7e7: sorted rows) --
-    also with a ragged pair of sizes, and for the fused earth_mover cost and gradients."""
+    also with a ragged pair of sizes, and for the fused earth_mover cost and gradients.  (Both batches stay under the 8e7 pairs
+    from which the BROAD levels leave the sweeps for their expansion, emd_fgt.hip: that changes bits.)"""
     from rfnet_amd import _raw as R
     rng = np.random.RandomState(77)
     for n, m in ((2048, 2048), (3000, 1400)):
@@ -331,29 +332,32 @@ def test_sharp_level_sweeps_with_sorted_rows_keep_every_bit():
 
 @pytest.mark.parametrize("scale,what", [(1.0, "expanded"), (4.0, "refused: direct sums"), (float("nan"), "refused: a NaN coordinate")])
 def test_broad_levels_by_expansion_and_its_refusal(orc, scale, what):
-    """From 4e6 pairs on the three broadest levels of the schedule (-1, -0.25, 0) are not swept: their row sums come from one
-    truncated Taylor expansion about the clouds' centre (emd_fgt.hip, fp64, 1e-11 of the direct sum).  The device refuses the
+    """From 8e7 pairs per call on the three broadest levels of the schedule (-1, -0.25, 0) are not swept: their row sums come from
+    one truncated Taylor expansion about the clouds' centre (emd_fgt.hip, fp64, 1e-11 of the direct sum).  The device refuses the
     expansion per call when the clouds' extent breaks its error bound -- here clouds four times the unit cube -- or a coordinate
-    is not finite, and forms the sums directly instead.  Both routes against the oracle's chain.  The count of `match` entries
-    outside abs 1e-6 + rel 1e-4 is that of the all-swept build on the same inputs (tools/experiments/fgt_fallback_probe.py, same
-    device: 4 / 174 / 4 of 4.5e6 with and without the expansion -- the scaled clouds sharpen every level sixteen-fold and the
-    strays are the sharp levels' cancellations): held to those counts with a little room."""
+    is not finite, and forms the sums directly instead.  Both routes against the oracle's chain on the first and last sample of
+    a 21 x 2000 x 2000 call.  The count of `match` entries outside abs 1e-6 + rel 1e-4 is that of the all-swept build on the same
+    inputs (tools/experiments/fgt_fallback_probe.py, same device: 21 / 2485 / 21 of 8e6 with and without the expansion -- the scaled clouds sharpen
+    every level sixteen-fold and the strays are the sharp levels' cancellations): held to those counts with a little room."""
     from pc_distance.tf_approxmatch import approx_match, match_cost
     rng = np.random.RandomState(31)
-    a = (rng.random_sample((2, 1500, 3)) - 0.5).astype(np.float32)
-    c = (rng.random_sample((2, 1500, 3)) - 0.5).astype(np.float32)
+    B, N = 21, 2000  # 8.4e7 pairs: past the expansion's threshold (approxmatch.hip FGT_MIN_PAIRS = 8e7)
+    a = (rng.random_sample((B, N, 3)) - 0.5).astype(np.float32)
+    c = (rng.random_sample((B, N, 3)) - 0.5).astype(np.float32)
+    pick = [0, B - 1]
     if np.isnan(scale):
         a2 = a.copy()
-        a2[1, 7, 2] = np.nan  # sample 1 is garbage by contract; sample 0 must be what it is without the NaN next door
-        got = approx_match(cu(a2), cu(c)).cpu().numpy()
-        om = orc.approx_match(a[:1], c[:1])
-        bad = np.abs(got[:1] - om) > 1e-6 + 1e-4 * np.abs(om)
-        assert int(bad.sum()) <= 8 and np.abs(got[:1] - om).max() < 2e-4, int(bad.sum())
+        a2[1, 7, 2] = np.nan  # sample 1 is garbage by contract; the others must be what they are without the NaN next door
+        got = approx_match(cu(a2), cu(c))[pick].cpu().numpy()
+        om = orc.approx_match(a[pick], c[pick])
+        bad = np.abs(got - om) > 1e-6 + 1e-4 * np.abs(om)
+        assert int(bad.sum()) <= 32 and np.abs(got - om).max() < 2e-4, int(bad.sum())
         return
     a, c = a * np.float32(scale), c * np.float32(scale)
-    om = orc.approx_match(a, c)
-    got = approx_match(cu(a), cu(c))
-    strict_bar_report(f"1500^2 x {scale} ({what})", got.cpu().numpy(), om)
-    bad = np.abs(got.cpu().numpy() - om) > 1e-6 + 1e-4 * np.abs(om)
-    assert int(bad.sum()) <= (8 if scale == 1.0 else 260), f"{int(bad.sum())} of {bad.size} entries outside abs 1e-6 + rel 1e-4 ({what})"
-    assert_rel(match_cost(cu(a), cu(c), got).cpu().numpy(), orc.match_cost(a, c, om), 1e-5, what="cost")
+    om = orc.approx_match(a[pick], c[pick])
+    got_all = approx_match(cu(a), cu(c))
+    got = got_all[pick].cpu().numpy()
+    strict_bar_report(f"2000^2 x {scale} ({what})", got, om)
+    bad = np.abs(got - om) > 1e-6 + 1e-4 * np.abs(om)
+    assert int(bad.sum()) <= (32 if scale == 1.0 else 2800), f"{int(bad.sum())} of {bad.size} entries outside abs 1e-6 + rel 1e-4 ({what})"
+    assert_rel(match_cost(cu(a), cu(c), got_all).cpu().numpy()[pick], orc.match_cost(a[pick], c[pick], om), 1e-5, what="cost")
