@@ -780,6 +780,221 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+// ---- match_cost_grad, second form (round 5): whole rows per workgroup, no LDS tile, no barrier.
+// A lane owns FOUR consecutive k (one 16-byte load per match row: a wave reads 1 KB, a workgroup 4 KB of a row in one piece) and
+// walks an l-range; grad1 of its four k accumulates in registers over the range, as in mcg_kernel.  grad2[l] = -sum_k (x1_k - x2_l) q
+// is a sum ACROSS lanes: every lane adds its four products per row into three per-row registers, and eight rows' 24 partial sums
+// are reduced over the 64 lanes by a reduce-scatter -- v_permlane32_swap + add halves the values held per lane (24 -> 12), then
+// v_permlane16_swap + add (12 -> 6), then four DPP row rotations per value leave every lane of a 16-lane row with the row's total of
+// its six values; lane j < 6 of each row picks value j: 24 lanes hold the 24 sums and add them to grad2 with one atomic each.
+// 65 VALU per 8 rows x 4 k instead of a 6-VALU-per-entry column phase behind an LDS transpose: 18 VALU per match entry (13 for
+// q and grad1, 3 for the row sums, 2 for the reduction) against mcg_kernel's 25.  The rows a lane will need are in flight 16 deep
+// (rolling: a row's register is reloaded when its group is done); the rows' x2 are wave-uniform scalar loads.
+// Needs n % 4 == 0 and 16-byte aligned xyz1 / match (else mcg_kernel).
+constexpr int MR_KPL = 4;     // k per lane
+#ifndef RFA_MR_G
+#define RFA_MR_G 4
+#endif
+#ifndef RFA_MR_DEPTH
+#define RFA_MR_DEPTH 8
+#endif
+constexpr int MR_LSPAN_MAX = 1024;      // rows per workgroup at most (its grad2 sums live in LDS)
+constexpr int MR_G = RFA_MR_G;          // rows per reduce-scatter group (4 or 8)
+constexpr int MR_DEPTH = RFA_MR_DEPTH;  // rows in flight per lane (a multiple of MR_G)
+// one group: MR_G rows x 4 k.  xs: the rows' x2 records (wave-uniform).  TAIL: rows at or beyond `lend` are masked by a
+// multiplication (their registers hold the range's last row).
+template <bool FULL, bool TAIL, int G0>
+__device__ __forceinline__ void mr_group(const float4 (&mv)[MR_DEPTH], const float (&xs)[3 * MR_G], int lg, int lend, bool live,
+                                         float (&x1)[MR_KPL], float (&y1)[MR_KPL], float (&z1)[MR_KPL],
+                                         float (&ax)[MR_KPL], float (&ay)[MR_KPL], float (&az)[MR_KPL], float (&S)[3 * MR_G]) {
+#pragma unroll
+    for (int r = 0; r < MR_G; r++) {
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        const float x2 = xs[r * 3], y2 = xs[r * 3 + 1], z2 = xs[r * 3 + 2];
+        const float4 v4 = mv[G0 + r];
+        const float vv[MR_KPL] = {v4.x, v4.y, v4.z, v4.w};
+        const float keep = (!TAIL || lg + r < lend) ? 1.f : 0.f;  // (uniform)
+#pragma unroll
+        for (int e = 0; e < MR_KPL; e++) {
+            const float dx = x1[e] - x2, dy = y1[e] - y2, dz = z1[e] - z2;
+            float w = FULL ? vv[e] : (live ? vv[e] : 0.f);
+            if (TAIL) w *= keep;
+            const float q = w * __builtin_amdgcn_rsqf(fmaxf(rf::d2_fma(dx, dy, dz), 1e-20f));
+            ax[e] = fmaf(dx, q, ax[e]);
+            ay[e] = fmaf(dy, q, ay[e]);
+            az[e] = fmaf(dz, q, az[e]);
+            sx = fmaf(dx, q, sx);
+            sy = fmaf(dy, q, sy);
+            sz = fmaf(dz, q, sz);
+        }
+        // a row at a time: left alone the compiler opens all 16 entries of a group at once and spills (sched_barrier does not
+        // bind the order instructions are selected in); the next row's differences are made to depend on this empty statement
+#pragma unroll
+        for (int e = 0; e < MR_KPL; e++)
+            asm volatile("" : "+v"(x1[e]), "+v"(y1[e]), "+v"(z1[e]), "+v"(ax[e]), "+v"(ay[e]), "+v"(az[e]), "+v"(sx), "+v"(sy), "+v"(sz));
+        S[r * 3 + 0] = sx;
+        S[r * 3 + 1] = sy;
+        S[r * 3 + 2] = sz;
+    }
+}
+
+// the group's 3 * MR_G per-lane sums reduced over the wave's 64 lanes and added to the workgroup's grad2 sums (the rows from lg on, below lend)
+__device__ __forceinline__ void mr_reduce_emit(const float (&S)[3 * MR_G], int lane, int lg, int lend, int lbeg, float *g2s) {
+    // reduce-scatter: 3G -> 3G/2 (lanes >= 32 keep the upper half) -> 3G/4 (odd 16-lane rows keep the upper half)
+    constexpr int NH = 3 * MR_G / 2, NQ = 3 * MR_G / 4;
+    float W[NH], U[NQ];
+#pragma unroll
+    for (int i = 0; i < NH; i++) {
+        const auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(S[i]), __float_as_uint(S[i + NH]), false, false);
+        W[i] = __uint_as_float(p[0]) + __uint_as_float(p[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(W[i]), __float_as_uint(W[i + NQ]), false, false);
+        U[i] = __uint_as_float(p[0]) + __uint_as_float(p[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {  // every lane of a 16-lane row ends with the row's total (row_ror 8, 4, 2, 1)
+        U[i] += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(U[i]), 0x128, 0xf, 0xf, false));
+        U[i] += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(U[i]), 0x124, 0xf, 0xf, false));
+        U[i] += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(U[i]), 0x122, 0xf, 0xf, false));
+        U[i] += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(U[i]), 0x121, 0xf, 0xf, false));
+    }
+    const int j = lane & 15;
+    float out = U[0];
+#pragma unroll
+    for (int i = 1; i < NQ; i++) out = j == i ? U[i] : out;
+    // lane -> index into the group's 3G sums (row * 3 + component)
+    const int vi = j + ((lane & 16) ? NQ : 0) + ((lane & 32) ? NH : 0);
+    // (into the workgroup's own sums in LDS: its four waves hold different k of the same rows; one global atomic per sum at the end)
+    if (j < NQ && lg + vi / 3 < lend) __hip_atomic_fetch_add(&g2s[(lg - lbeg) * 3 + vi], -out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+#ifndef RFA_MR_WAVES
+#define RFA_MR_WAVES 4
+#endif
+template <bool FULL>
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RFA_MR_WAVES, RFA_MR_WAVES))) void mcg_rows_kernel(int n, int m, int lspan,
+                                                  const float *__restrict__ xyz1,
+                                                  const float *__restrict__ xyz2,
+                                                  const float *__restrict__ match,
+                                                  float *__restrict__ grad1,
+                                                  float *__restrict__ grad2) {
+    const int bi = blockIdx.z;
+    const int t = threadIdx.x;
+    const int k = (blockIdx.x * TPB + t) * MR_KPL;
+    const bool live = FULL || k < n;  // (n % 4 == 0: a lane's four k are all inside or all outside)
+    const int kk = live ? k : 0;
+    float x1[MR_KPL], y1[MR_KPL], z1[MR_KPL];
+    {
+        const float4 *A = (const float4 *)(xyz1 + ((size_t)bi * n + kk) * 3);
+        const float4 a0 = A[0], a1 = A[1], a2 = A[2];
+        x1[0] = a0.x, y1[0] = a0.y, z1[0] = a0.z;
+        x1[1] = a0.w, y1[1] = a1.x, z1[1] = a1.y;
+        x1[2] = a1.z, y1[2] = a1.w, z1[2] = a2.x;
+        x1[3] = a2.y, y1[3] = a2.z, z1[3] = a2.w;
+    }
+    const cfloat *B = (const cfloat *)(xyz2 + (size_t)bi * m * 3);
+    const float *__restrict__ M = match + (size_t)bi * n * m;  // (uniform: a row's base is scalar, the lane adds koff bytes)
+    const unsigned koff = (unsigned)kk * 4u;
+    float *__restrict__ g2 = grad2 + (size_t)bi * m * 3;
+    const int lbeg = blockIdx.y * lspan;
+    const int lend = min(m, lbeg + lspan);
+    float ax[MR_KPL], ay[MR_KPL], az[MR_KPL];
+#pragma unroll
+    for (int e = 0; e < MR_KPL; e++) ax[e] = ay[e] = az[e] = 0.f;
+    __shared__ float g2s[MR_LSPAN_MAX * 3];  // grad2 of the workgroup's rows, summed over its four waves
+    for (int i = t; i < (lend - lbeg) * 3; i += TPB) g2s[i] = 0.f;
+    __syncthreads();
+    // the x2 records of a group of rows: 3 * MR_G consecutive dwords by scalar loads (the base row clamped into the cloud: a
+    // prefetch behind the range loads records nobody reads)
+#define RFA_MR_LDX(d, row)                                                                 \
+    {                                                                                      \
+        const cfloat *bp_ = B + (size_t)max(0, min((row), m - MR_G)) * 3;                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < 3 * MR_G; i_++) d[i_] = bp_[i_];           \
+    }
+    float xs0[3 * MR_G], xs1[3 * MR_G];
+    RFA_MR_LDX(xs0, lbeg)
+    float4 mv[MR_DEPTH];
+#pragma unroll
+    for (int i = 0; i < MR_DEPTH; i++) mv[i] = *(const float4 *)((const char *)(M + (size_t)min(lbeg + i, lend - 1) * n) + koff);
+    const int lane = t & 63;
+    int l0 = lbeg;
+    // one group of the whole-block path.  Scalar loads return out of order: the wait for this group's records is "all", and
+    // comes before the next group's issue.  The group's rows consumed, their registers take the rows MR_DEPTH further on
+    // (behind the range: its last row).
+#define RFA_MR_BODY(G0, CUR, NXT)                                                                                          \
+    {                                                                                                                      \
+        const int lg = l0 + G0;                                                                                            \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        RFA_MR_LDX(NXT, lg + MR_G)                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        float S[3 * MR_G];                                                                                                 \
+        mr_group<FULL, false, G0>(mv, CUR, lg, lend, live, x1, y1, z1, ax, ay, az, S);                                     \
+        _Pragma("unroll") for (int r = 0; r < MR_G; r++)                                                                   \
+            mv[G0 + r] = *(const float4 *)((const char *)(M + (size_t)min(lg + MR_DEPTH + r, lend - 1) * n) + koff);       \
+        mr_reduce_emit(S, lane, lg, lend, lbeg, g2s);                                                                      \
+    }
+#define RFA_MR_TAIL(G0)                                                                                                    \
+    if (l0 + G0 < lend) {                                                                                                  \
+        const int lg = l0 + G0;                                                                                            \
+        float xt[3 * MR_G];                                                                                                \
+        _Pragma("unroll") for (int r = 0; r < MR_G; r++) {                                                                 \
+            const cfloat *bp = B + (size_t)min(lg + r, m - 1) * 3;                                                         \
+            xt[r * 3] = bp[0], xt[r * 3 + 1] = bp[1], xt[r * 3 + 2] = bp[2];                                               \
+        }                                                                                                                  \
+        float4 tv[MR_DEPTH]; /* (its own loads: the prefetch registers end their life with the loop above) */             \
+        _Pragma("unroll") for (int r = 0; r < MR_G; r++)                                                                   \
+            tv[r] = *(const float4 *)((const char *)(M + (size_t)min(lg + r, lend - 1) * n) + koff);                       \
+        float S[3 * MR_G];                                                                                                 \
+        mr_group<FULL, true, 0>(tv, xt, lg, lend, live, x1, y1, z1, ax, ay, az, S);                                        \
+        mr_reduce_emit(S, lane, lg, lend, lbeg, g2s);                                                                      \
+    }
+    static_assert(MR_DEPTH == 4 * MR_G || MR_DEPTH == 2 * MR_G, "two or four groups per block below");
+    for (; l0 + MR_DEPTH <= lend; l0 += MR_DEPTH) {
+        RFA_MR_BODY(0, xs0, xs1)
+        RFA_MR_BODY(MR_G, xs1, xs0)
+        if (MR_DEPTH == 4 * MR_G) {
+            RFA_MR_BODY((2 * MR_G) % MR_DEPTH, xs0, xs1)
+            RFA_MR_BODY((3 * MR_G) % MR_DEPTH, xs1, xs0)
+        }
+    }
+    if (l0 < lend) {  // (uniform) the range's last, partial block: rows masked, records fetched row by row
+        RFA_MR_TAIL(0)
+        RFA_MR_TAIL(MR_G)
+        if (MR_DEPTH == 4 * MR_G) {
+            RFA_MR_TAIL(2 * MR_G)
+            RFA_MR_TAIL(3 * MR_G)
+        }
+    }
+#undef RFA_MR_LDX
+#undef RFA_MR_BODY
+#undef RFA_MR_TAIL
+    // grad1 of the workgroup's 1024 k: through LDS into memory order, so that a wave's atomic covers 64 consecutive floats
+    // (added straight from the lanes -- twelve atomics of stride 48 bytes each -- these were HALF of the kernel's time: 16 l-ranges
+    // add into the same 3072 addresses and every instruction touched 48 cache lines)
+    __shared__ float gs[TPB * MR_KPL * 3];
+#pragma unroll
+    for (int e = 0; e < MR_KPL; e++) {
+        gs[(t * MR_KPL + e) * 3 + 0] = ax[e];
+        gs[(t * MR_KPL + e) * 3 + 1] = ay[e];
+        gs[(t * MR_KPL + e) * 3 + 2] = az[e];
+    }
+    __syncthreads();
+    for (int i = t; i < (lend - lbeg) * 3; i += TPB) atomicAdd(&g2[(size_t)lbeg * 3 + i], g2s[i]);
+    {
+        const int k0 = blockIdx.x * TPB * MR_KPL;
+        const int cnt = min(TPB * MR_KPL, n - k0) * 3;  // (>= 0: the grid covers n)
+        float *gp = grad1 + ((size_t)bi * n + k0) * 3;
+#pragma unroll
+        for (int i = 0; i < MR_KPL * 3; i++) {
+            const int o = i * TPB + t;
+            if (o < cnt) atomicAdd(gp + o, gs[o]);
+        }
+    }
+}
+
 // ---- earth_mover fused (row f1): cost and its gradients straight from the per-level ratio vectors;
 // `match` (4*B*n*m bytes: 512 MiB at C4, 1 GiB per sample at 16384^2) is never materialised.
 // The match entry is recomputed in registers with the same level-ordered fma chain as
@@ -1469,6 +1684,38 @@ int rf_matchcost(int b, int n, int m, const float *xyz1, const float *xyz2, cons
     return RF_OK;
 }
 
+// The gradient pass over `match` (outputs zero-filled by the caller): whole rows per workgroup where the layout allows it.
+#ifndef RFA_MCG_ROWS
+#define RFA_MCG_ROWS 1
+#endif
+#ifndef RFA_MCG_ROWS_WG
+#define RFA_MCG_ROWS_WG 1024  // workgroups the l-ranges are cut for (four per CU)
+#endif
+static int mcg_launch(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match, float *grad1,
+                       float *grad2, hipStream_t s) {
+    const int kspan = TPB * MR_KPL;
+    if (RFA_MCG_ROWS && n % MR_KPL == 0 && n >= kspan / 2 && m >= 2 * MR_DEPTH && (((uintptr_t)xyz1 | (uintptr_t)match) & 15) == 0) {
+        const int kb = rf::ceil_div(n, kspan);
+        int lsplit = rf::ceil_div(RFA_MCG_ROWS_WG, b * kb);
+        lsplit = max(1, min(lsplit, m / MR_DEPTH));
+        lsplit = max(lsplit, rf::ceil_div(m, MR_LSPAN_MAX - MR_DEPTH));
+        const int lspan = rf::ceil_div(rf::ceil_div(m, lsplit), MR_DEPTH) * MR_DEPTH;
+        dim3 g(kb, rf::ceil_div(m, lspan), b);
+        if (n % kspan == 0) {
+            RF_LAUNCH("mc_grad", (mcg_rows_kernel<true>), g, dim3(TPB), 0, s, n, m, lspan, xyz1, xyz2, match, grad1, grad2);
+        } else {
+            RF_LAUNCH("mc_grad", (mcg_rows_kernel<false>), g, dim3(TPB), 0, s, n, m, lspan, xyz1, xyz2, match, grad1, grad2);
+        }
+        return RF_OK;
+    }
+    int lsplit = MG_LSPLIT;
+    while (lsplit > 1 && m / lsplit < MG_TL) lsplit /= 2;
+    const int lspan = rf::ceil_div(rf::ceil_div(m, lsplit), MG_TL) * MG_TL;
+    dim3 g(rf::ceil_div(n, TPB), rf::ceil_div(m, lspan), b);
+    RF_LAUNCH("mc_grad", mcg_kernel, g, dim3(TPB), 0, s, n, m, lspan, xyz1, xyz2, match, grad1, grad2);
+    return RF_OK;
+}
+
 int rf_matchcost_grad(int b, int n, int m, const float *xyz1, const float *xyz2,
                       const float *match, float *grad1, float *grad2, rf_stream_t stream) {
     if (b < 0 || b > MAX_BATCH || n < 0 || m < 0) return RF_EINVAL;
@@ -1476,12 +1723,7 @@ int rf_matchcost_grad(int b, int n, int m, const float *xyz1, const float *xyz2,
     if ((size_t)b * n) RF_ZERO(grad1, sizeof(float) * 3 * (size_t)b * n, s);
     if ((size_t)b * m) RF_ZERO(grad2, sizeof(float) * 3 * (size_t)b * m, s);
     if (b == 0 || n == 0 || m == 0) return RF_OK;
-    int lsplit = MG_LSPLIT;
-    while (lsplit > 1 && m / lsplit < MG_TL) lsplit /= 2;
-    const int lspan = rf::ceil_div(rf::ceil_div(m, lsplit), MG_TL) * MG_TL;
-    dim3 g(rf::ceil_div(n, TPB), rf::ceil_div(m, lspan), b);
-    RF_LAUNCH("mc_grad", mcg_kernel, g, dim3(TPB), 0, s, n, m, lspan, xyz1, xyz2, match, grad1, grad2);
-    return RF_OK;
+    return mcg_launch(b, n, m, xyz1, xyz2, match, grad1, grad2, s);
 }
 
 // ---- row f1: earth_mover fused ------------------------------------------------------------
