@@ -361,3 +361,30 @@ def test_broad_levels_by_expansion_and_its_refusal(orc, scale, what):
     bad = np.abs(got - om) > 1e-6 + 1e-4 * np.abs(om)
     assert int(bad.sum()) <= (32 if scale == 1.0 else 2800), f"{int(bad.sum())} of {bad.size} entries outside abs 1e-6 + rel 1e-4 ({what})"
     assert_rel(match_cost(cu(a), cu(c), got_all).cpu().numpy()[pick], orc.match_cost(a[pick], c[pick], om), 1e-5, what="cost")
+
+
+@pytest.mark.parametrize("b,n,m", [(2, 768, 37), (3, 1028, 100), (1, 2048, 17), (2, 1536, 1003), (1, 4096, 2500), (2, 1024, 16),
+                                   (1, 1800, 4100), (2, 2048, 2048), (1, 3000, 64)])
+def test_match_cost_grad_whole_row_form_shapes(orc, b, n, m):
+    """match_cost_grad's whole-row form (approxmatch.hip mcg_rows_kernel: n % 4 == 0 and at least 3/4 of its 1024-k blocks alive,
+    m >= 16, 16-byte aligned operands; 3 x 1028 x 100 is a shape that stays with the tile form) over ragged shapes -- dead lanes behind n, a partial last block of rows, l-ranges cut for LDS, one and several
+    k-blocks -- with an arbitrary non-negative `match` (the op is linear in it: nothing needs it to be a transport plan),
+    against the oracle; and the same call through views whose storage is NOT 16-byte aligned (the tile form takes those):
+    same gradients to summation noise."""
+    from rfnet_amd import _raw as R
+    rng = np.random.RandomState(b * 1000 + n + m)
+    a = (rng.random_sample((b, n, 3)) - 0.5).astype(np.float32)
+    c = (rng.random_sample((b, m, 3)) - 0.5).astype(np.float32)
+    mt = (rng.random_sample((b, m, n)) ** 8).astype(np.float32) / np.float32(n)
+    c[0, 3] = a[0, 5]  # a coincident pair: rsq(max(d2, 1e-20)) * 0
+    g1, g2 = R.match_cost_grad(cu(a), cu(c), cu(mt))
+    o1, o2 = orc.match_cost_grad(a, c, mt)
+    assert_rel(g1.cpu().numpy(), o1, 1e-4, 2e-6, what="grad1")
+    assert_rel(g2.cpu().numpy(), o2, 1e-4, 2e-6, what="grad2")
+    # misaligned storage: one float into a larger buffer
+    buf = torch.empty(mt.size + 1, dtype=torch.float32, device="cuda")
+    view = buf[1:].view(b, m, n)
+    view.copy_(cu(mt))
+    assert view.data_ptr() % 16 != 0
+    h1, h2 = R.match_cost_grad(cu(a), cu(c), view)
+    assert torch.allclose(h1, g1, rtol=1e-4, atol=2e-6) and torch.allclose(h2, g2, rtol=1e-4, atol=2e-6)
