@@ -196,3 +196,26 @@ def test_fuzz_emd_chain_and_fused(orc, seed):
     o1, o2 = orc.match_cost_grad(a, c, gm)
     assert_rel(g1.cpu().numpy(), o1, 1e-4, 1e-5 * max(1, m // n), what="fused grad1")
     assert_rel(g2.cpu().numpy(), o2, 1e-4, 1e-5 * max(1, n // m), what="fused grad2")
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_match_cost_grad_both_forms(orc, seed):
+    """match_cost_grad over random shapes on both sides of its dispatch rule (approxmatch.hip mcg_launch: whole rows per workgroup
+    when n % 4 == 0 and the 1024-k blocks are at least 3/4 alive, the LDS-tile form otherwise), arbitrary non-negative `match`,
+    duplicated points (coincident pairs: rsq(max(d2, 1e-20)) * 0), against the oracle."""
+    from rfnet_amd import _raw
+    rng = np.random.RandomState(7000 + seed)
+    b = rng.randint(1, 4)
+    n = _logint(rng, 200, 3300)
+    if seed % 3:
+        n = max(4, n // 4 * 4)
+    m = _logint(rng, 2, 1500)
+    a = _cloud(rng, b, n, 0 if seed % 4 else 2) * np.float32(0.3)
+    c = _cloud(rng, b, m, 0) * np.float32(0.3)
+    if seed % 4 == 0 and m > 2:
+        c[:, 1] = a[:, 0]
+    mt = (rng.random_sample((b, m, n)) ** 6).astype(np.float32) / np.float32(n)
+    g1, g2 = _raw.match_cost_grad(cu(a), cu(c), cu(mt))
+    o1, o2 = orc.match_cost_grad(a, c, mt)
+    assert_rel(g1.cpu().numpy(), o1, 1e-4, 2e-6 * max(1, m // 256), what=f"seed {seed} {b}x{n}x{m} grad1")
+    assert_rel(g2.cpu().numpy(), o2, 1e-4, 2e-6 * max(1, n // 256), what=f"seed {seed} {b}x{n}x{m} grad2")
