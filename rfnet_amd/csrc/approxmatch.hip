@@ -1481,7 +1481,7 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
     const dim3 gks(rf::ceil_div(L.nsa, 64 * RPT), b), gls(rf::ceil_div(L.nsb, 64 * RPT), b);  // SKIP: over the sorted positions
     // The broad tail of the schedule by expansion (emd_fgt.hip): every level from vF on has sharpness a = -c ln 2 <= kFgtMaxA
     // (the reference schedule: levels -1, -0.25, 0 -> vF = 7).  The device decides per call whether the clouds' extent allows it
-    // (the `bad` word); the dense sweeps of those levels are launched behind that word and return at once when it is clear.
+    // (the `bad` word): a refused call forms the same row sums directly inside the expansion's own launches (emd_fgt.hip direct_sum).
     auto sharp = [&](int v) { return (double)(-lc.c[v]) * 0.69314718055994530942; };
     int vF = nlevels;
     while (vF > 1 && lc.c[vF - 1] <= 0.f && sharp(vF - 1) <= (double)rfe::kFgtMaxA * 1.0001) vF--;
