@@ -37,6 +37,15 @@ namespace {
 #endif
 constexpr float kSkipArg = 161.f;  // d2 * |c| >= 161 => fl(d2 * c) <= -160 => v_exp_f32 = +0 (kCullArg below, with the product's rounding covered)
 constexpr float kLog2e = 1.44269502f;  // 0x3FB8AA3B, the constant __expf multiplies by
+// am_match's stores of `match` are non-temporal: the tensor (512 MiB at C4) is twice the memory-side cache and is read next by
+// another launch; written through the caches it leaves that launch competing with the write-back of its own input
+// (approx_match + match_cost 0.987 -> 0.956 ms same-device, am_match itself 139 -> 135.5 us; non-temporal LOADS in match_cost: no gain)
+#ifndef RFA_MATCH_NT
+#define RFA_MATCH_NT 1
+#endif
+#ifndef RFA_MC_NT
+#define RFA_MC_NT 0
+#endif
 constexpr int TPB = 256;
 constexpr int LVG = 16;             // levels per group in the materialisation kernel
 constexpr int MAX_LEVELS = 64;
@@ -456,7 +465,11 @@ __global__ __launch_bounds__(TPB) void am_match_kernel(int n, int m, const float
 #pragma unroll
                 for (int v = 0; v < NLV; v++) acc = fmaf(rl[v] * e[v], crr[l][v], acc);
             }
+#if RFA_MATCH_NT
+            __builtin_nontemporal_store(acc, &match[(size_t)(l0 + l) * n + k]);
+#else
             match[(size_t)(l0 + l) * n + k] = acc;
+#endif
         }
         return;
     }
@@ -594,7 +607,11 @@ __global__ __launch_bounds__(TPB) void mc_partial_kernel(int n, int m, const flo
 #pragma unroll 8
         for (int l = 0; l < lcnt; l++) {
             float d = sqrtf(rf::d2_fma(cxyz[l][0] - x1, cxyz[l][1] - y1, cxyz[l][2] - z1));
+#if RFA_MC_NT
+            sum = fmaf(d, __builtin_nontemporal_load(&match[(size_t)(l0 + l) * n + k]), sum);
+#else
             sum = fmaf(d, match[(size_t)(l0 + l) * n + k], sum);
+#endif
         }
     }
 #pragma unroll
