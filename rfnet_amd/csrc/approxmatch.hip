@@ -666,6 +666,14 @@ __global__ void mc_final_kernel(const float *partial, int per_batch, float *cost
 #ifndef RFA_MG_LSPLIT
 #define RFA_MG_LSPLIT 4
 #endif
+#ifndef RFA_MG_NT
+#define RFA_MG_NT 1
+#endif
+#if RFA_MG_NT
+#define RFA_MG_LOAD(p) __builtin_nontemporal_load(p)  // (`match` is read once: see mr_load_row)
+#else
+#define RFA_MG_LOAD(p) (*(p))
+#endif
 constexpr int MG_TL = 32;
 constexpr int MG_LSPLIT = RFA_MG_LSPLIT;
 __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void mcg_kernel(int n, int m, int lspan,
@@ -707,7 +715,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __builtin_amdgcn_sched_barrier(0);
     float mv[MG_TL];  // raw rows; unconditional loads from clamped rows (finite values)
 #pragma unroll
-    for (int l = 0; l < MG_TL; l++) mv[l] = *(const float *)((const char *)(M + (size_t)min(lbeg + l, lend - 1) * n) + koff);
+    for (int l = 0; l < MG_TL; l++) mv[l] = RFA_MG_LOAD((const float *)((const char *)(M + (size_t)min(lbeg + l, lend - 1) * n) + koff));
     float scb[2][24];  // column records of 8 rows (whole tiles), ping-pong
     for (int l0 = lbeg; l0 < lend; l0 += MG_TL) {
         const int lc = min(MG_TL, lend - l0);
@@ -746,7 +754,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             qs[l][t] = q;                                                                                                \
         }                                                                                                                \
         _Pragma("unroll") for (int l = g; l < g + 8; l++)                                                                \
-            mv[l] = *(const float *)((const char *)(M + (size_t)min(l0 + MG_TL + l, lend - 1) * n) + koff);              \
+            mv[l] = RFA_MG_LOAD((const float *)((const char *)(M + (size_t)min(l0 + MG_TL + l, lend - 1) * n) + koff)); \
         __builtin_amdgcn_sched_barrier(0); /* 8 rows at a time: the scheduler otherwise hoists all 32 rows' work */      \
     }
         if (lc == MG_TL) {  // (uniform)
@@ -820,6 +828,20 @@ constexpr int MR_G = RFA_MR_G;          // rows per reduce-scatter group (4 or 8
 constexpr int MR_DEPTH = RFA_MR_DEPTH;  // rows in flight per lane (a multiple of MR_G)
 // one group: MR_G rows x 4 k.  xs: the rows' x2 records (wave-uniform).  TAIL: rows at or beyond `lend` are masked by a
 // multiplication (their registers hold the range's last row).
+// `match` is read once, front to back: non-temporal loads (C4 same-device: mcg_rows 104.5 -> 94.3 us, 5.1 -> 5.7 TB/s; inside
+// the sequence approx_match -> match_cost -> match_cost_grad 97 -> 90 us)
+#ifndef RFA_MR_NT
+#define RFA_MR_NT 1
+#endif
+typedef float mr_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 mr_load_row(const void *p) {
+#if RFA_MR_NT
+    const mr_v4f v = __builtin_nontemporal_load((const mr_v4f *)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *(const float4 *)p;
+#endif
+}
 template <bool FULL, bool TAIL, int G0>
 __device__ __forceinline__ void mr_group(const float4 (&mv)[MR_DEPTH], const float (&xs)[3 * MR_G], int lg, int lend, bool live,
                                          float (&x1)[MR_KPL], float (&y1)[MR_KPL], float (&z1)[MR_KPL],
@@ -934,7 +956,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RFA_MR_WAVE
     RFA_MR_LDX(xs0, lbeg)
     float4 mv[MR_DEPTH];
 #pragma unroll
-    for (int i = 0; i < MR_DEPTH; i++) mv[i] = *(const float4 *)((const char *)(M + (size_t)min(lbeg + i, lend - 1) * n) + koff);
+    for (int i = 0; i < MR_DEPTH; i++) mv[i] = mr_load_row((const char *)(M + (size_t)min(lbeg + i, lend - 1) * n) + koff);
     const int lane = t & 63;
     int l0 = lbeg;
     // one group of the whole-block path.  Scalar loads return out of order: the wait for this group's records is "all", and
@@ -950,7 +972,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RFA_MR_WAVE
         float S[3 * MR_G];                                                                                                 \
         mr_group<FULL, false, G0>(mv, CUR, lg, lend, live, x1, y1, z1, ax, ay, az, S);                                     \
         _Pragma("unroll") for (int r = 0; r < MR_G; r++)                                                                   \
-            mv[G0 + r] = *(const float4 *)((const char *)(M + (size_t)min(lg + MR_DEPTH + r, lend - 1) * n) + koff);       \
+            mv[G0 + r] = mr_load_row((const char *)(M + (size_t)min(lg + MR_DEPTH + r, lend - 1) * n) + koff);              \
         mr_reduce_emit(S, lane, lg, lend, lbeg, g2s);                                                                      \
     }
 #define RFA_MR_TAIL(G0)                                                                                                    \
@@ -963,7 +985,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RFA_MR_WAVE
         }                                                                                                                  \
         float4 tv[MR_DEPTH]; /* (its own loads: the prefetch registers end their life with the loop above) */             \
         _Pragma("unroll") for (int r = 0; r < MR_G; r++)                                                                   \
-            tv[r] = *(const float4 *)((const char *)(M + (size_t)min(lg + r, lend - 1) * n) + koff);                       \
+            tv[r] = mr_load_row((const char *)(M + (size_t)min(lg + r, lend - 1) * n) + koff);                             \
         float S[3 * MR_G];                                                                                                 \
         mr_group<FULL, true, 0>(tv, xt, lg, lend, live, x1, y1, z1, ax, ay, az, S);                                        \
         mr_reduce_emit(S, lane, lg, lend, lbeg, g2s);                                                                      \
