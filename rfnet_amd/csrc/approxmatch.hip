@@ -58,22 +58,30 @@ constexpr int SUB = 8;     // columns per scalar-load sub-chunk
 constexpr int CPAD = 128;  // column counts are padded to a multiple of this (zero scalars)
 
 // pack xyz (b,npts,3) -> (b,npad,3) zero padded, and initialise remain (padded entries = 0 so
-// that padded columns contribute e*0 = 0 to every sum; e <= 1 is always finite)
-__global__ void am_init_kernel(int npts, int npad, float fill, const float *__restrict__ xyz,
-                               float *__restrict__ xyzp, size_t xyzp_stride,
-                               float *__restrict__ remain, size_t stride) {
-    const int bi = blockIdx.y;
+// that padded columns contribute e*0 = 0 to every sum; e <= 1 is always finite).  Both clouds in one launch (blockIdx.z).
+struct AmInit {
+    int npts[2], npad[2];
+    float fill[2];
+    const float *xyz[2];
+    float *xyzp[2];
+    size_t xyzp_stride[2];
+    float *remain[2];
+    size_t stride;
+};
+__global__ void am_init_kernel(AmInit a) {
+    const int bi = blockIdx.y, c = blockIdx.z;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int npts = c ? a.npts[1] : a.npts[0], npad = c ? a.npad[1] : a.npad[0];
     if (j >= npad) return;
     float x = 0.f, y = 0.f, z = 0.f, r = 0.f;
     if (j < npts) {
-        const float *p = xyz + ((size_t)bi * npts + j) * 3;
+        const float *p = (c ? a.xyz[1] : a.xyz[0]) + ((size_t)bi * npts + j) * 3;
         x = p[0]; y = p[1]; z = p[2];
-        r = fill;
+        r = c ? a.fill[1] : a.fill[0];
     }
-    float *q = xyzp + (size_t)bi * xyzp_stride + (size_t)j * 3;
+    float *q = (c ? a.xyzp[1] : a.xyzp[0]) + (size_t)bi * (c ? a.xyzp_stride[1] : a.xyzp_stride[0]) + (size_t)j * 3;
     q[0] = x; q[1] = y; q[2] = z;
-    remain[(size_t)bi * stride + j] = r;
+    (c ? a.remain[1] : a.remain[0])[(size_t)bi * a.stride + j] = r;
 }
 
 // Rows = xyz1 points k (one per lane), columns = xyz2 points l streamed through SGPRs.
@@ -1474,10 +1482,15 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
     float *x1p = w + L.off_x1, *x2p = w + L.off_x2;
     // padded entries of every vector must read 0 (they are column scalars of padded columns)
     RF_ZERO(w, sizeof(float) * ((size_t)b * L.bstride + 64), s);
-    RF_LAUNCH("am_init", am_init_kernel, dim3(rf::ceil_div(L.npad, 256), b), dim3(256), 0, s, n, L.npad,
-              multiL, xyz1, x1p, (size_t)L.npad * 3, remainL, L.bstride);
-    RF_LAUNCH("am_init", am_init_kernel, dim3(rf::ceil_div(L.mpad, 256), b), dim3(256), 0, s, m, L.mpad,
-              multiR, xyz2, x2p, (size_t)L.mpad * 3, remainR, L.bstride);
+    {
+        AmInit ai;
+        ai.npts[0] = n, ai.npts[1] = m, ai.npad[0] = L.npad, ai.npad[1] = L.mpad;
+        ai.fill[0] = multiL, ai.fill[1] = multiR;
+        ai.xyz[0] = xyz1, ai.xyz[1] = xyz2, ai.xyzp[0] = x1p, ai.xyzp[1] = x2p;
+        ai.xyzp_stride[0] = (size_t)L.npad * 3, ai.xyzp_stride[1] = (size_t)L.mpad * 3;
+        ai.remain[0] = remainL, ai.remain[1] = remainR, ai.stride = L.bstride;
+        RF_LAUNCH("am_init", am_init_kernel, dim3(rf::ceil_div(max(L.npad, L.mpad), 256), b, 2), dim3(256), 0, s, ai);
+    }
 
     // the leading sharp levels run culled over spatially sorted (sort-tile-recursive) copies of the clouds (am_cull_kernel)
     const int ncull = allow_cull ? cull_levels(L, nlevels, lc) : 0;

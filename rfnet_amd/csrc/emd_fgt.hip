@@ -14,9 +14,10 @@
 // the reference's sequential fp32 sums): replacing the sums of levels 6-8 by exact ones leaves the set of `match` entries outside
 // the strict bar unchanged, entry for entry (tools/experiments/fgt_parity.py).
 //
-// Validity is checked on the device, per call: fgt_prep measures R_rows * R_cols per batch element and raises the `bad` word when
-// g_max * R_rows * R_cols > kBound (clouds much larger than the unit cube, or non-finite): every kernel here then returns at
-// once and approxmatch.hip's dense sweeps, launched behind the same word, run instead -- no host synchronisation either way.
+// Validity is checked on the device, per batch element: fgt_prep measures R_rows * R_cols and raises the element's `bad` flag when
+// g_max * R_rows * R_cols > kBound (clouds much larger than the unit cube) or a coordinate is not finite: the kernels here then
+// form that element's row sums directly (direct_sum: the dense sweeps' arithmetic, inside the same launches) -- no host
+// synchronisation either way, and nothing to clear before a call.
 //
 // One launch per phase: a workgroup EVALUATES the phase for its 256 rows from the other cloud's moments (staged in LDS, the chunk
 // partials summed in a fixed order: deterministic) and then ACCUMULATES the moments its own rows contribute, as columns, to the
@@ -92,13 +93,13 @@ __device__ constexpr double kInvFact[13] = {1.0, 1.0, 1.0 / 2, 1.0 / 6, 1.0 / 24
 
 struct Geom {  // per batch element
     double ox, oy, oz, rarb;
+    int bad, pad;  // bad != 0: this element's extent breaks the series' bound, or a coordinate is not finite -- direct sums
 };
 
 size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 int chunks_of(int npts) { return (npts + FG_ROWS - 1) / FG_ROWS; }  // one partial per workgroup
 
 struct FgtWs {
-    int *bad;
     Geom *geom;
     double *mom[2];  // [side][(set * b + bi) * chunks + chunk][FG_NM]: side 0 = moments over xyz1 (columns of P2), 1 = over xyz2
     int chmax;
@@ -106,8 +107,6 @@ struct FgtWs {
 FgtWs view(const void *ws, int b, int nmax) {
     FgtWs v;
     char *p = (char *)ws;
-    v.bad = (int *)p;
-    p += 256;
     v.geom = (Geom *)p;
     p += align256(sizeof(Geom) * (size_t)b);
     v.chmax = chunks_of(nmax);
@@ -130,11 +129,14 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // centre = middle of the bounding box of both clouds; R1, R2 = the clouds' largest distances from it
 __global__ __launch_bounds__(1024) void fgt_prep_kernel(int n, int m, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
-                                                         double a_max, Geom *__restrict__ geom, int *__restrict__ bad) {
+                                                         double a_max, Geom *__restrict__ geom) {
     __shared__ float red[16][6];
     __shared__ float ctr[3];
+    __shared__ int nonfin;
     const int bi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *A = xyz1 + (size_t)bi * n * 3, *B = xyz2 + (size_t)bi * m * 3;
+    if (tid == 0) nonfin = 0;
+    __syncthreads();
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     bool nonfinite = false;
     for (int i = tid; i < n + m; i += 1024) {
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(1024) void fgt_prep_kernel(int n, int m, const floa
             red[wave][3 + c] = hi[c];
         }
     }
-    if (anybad && lane == 0) atomicOr(bad, 1);
+    if (anybad && lane == 0) atomicOr(&nonfin, 1);
     __syncthreads();
     if (tid < 3) {
         float l = INFINITY, h = -INFINITY;
@@ -194,8 +196,8 @@ __global__ __launch_bounds__(1024) void fgt_prep_kernel(int n, int m, const floa
             c = fmaxf(c, red[w][1]);
         }
         const double rarb = sqrt((double)a) * sqrt((double)c);
-        geom[bi] = Geom{(double)ox, (double)oy, (double)oz, rarb};
-        if (!(2.0 * a_max * rarb <= kBound)) atomicOr(bad, 1);
+        // (every element's record is written whole by its own workgroup: nothing to clear beforehand)
+        geom[bi] = Geom{(double)ox, (double)oy, (double)oz, rarb, (nonfin != 0 || !(2.0 * a_max * rarb <= kBound)) ? 1 : 0, 0};
     }
 }
 
@@ -226,7 +228,6 @@ struct Step {
     float *rem;          // mode 1: remainL; mode 2: remainR
     float *out;          // mode 1: ratioL_out; mode 2: ratioR_out
     const Geom *geom;
-    const int *bad;
     int b;
 };
 
@@ -349,12 +350,12 @@ __global__ __launch_bounds__(FG_TPB) void fgt_step_kernel(Step p) {
     double *s1x = fg_lds + 2 * FG_NR * FG_RL;
     double *xc = s1x + FG_ROWS;
     double *pw = xc + FG_ROWS;
-    const bool bad = *p.bad != 0;  // (uniform) the expansion was refused for this call: direct sums, no moments
     const int bi = blockIdx.y, tid = threadIdx.x;
     const int rt = tid & (FG_ROWS - 1), half = tid >> 8;  // FG_ROWS == 256
     const int row = blockIdx.x * FG_ROWS + rt;
     const bool live = row < p.nrows;
     const Geom g = p.geom[bi];
+    const bool bad = g.bad != 0;  // (uniform) the expansion was refused for this batch element: direct sums, no moments
     const float *R = p.rows + ((size_t)bi * p.nrows + (live ? row : p.nrows - 1)) * 3;
     const double x = (double)R[0] - g.ox, y = (double)R[1] - g.oy, z = (double)R[2] - g.oz;
     const double r2 = x * x + y * y + z * z;
@@ -542,15 +543,12 @@ namespace rfe {
 
 size_t fgt_workspace_bytes(int b, int nmax) {
     if (b <= 0 || nmax <= 0) return 0;
-    return 256 + align256(sizeof(Geom) * (size_t)b) + 2 * align256(sizeof(double) * 2 * (size_t)b * chunks_of(nmax) * FG_NM);
+    return align256(sizeof(Geom) * (size_t)b) + 2 * align256(sizeof(double) * 2 * (size_t)b * chunks_of(nmax) * FG_NM);
 }
-
-const int *fgt_bad_word(const void *ws) { return (const int *)ws; }
 
 int fgt_prep(int b, int n, int m, const float *xyz1, const float *xyz2, double a_max, void *ws, hipStream_t s) {
     FgtWs v = view(ws, b, n > m ? n : m);
-    RF_ZERO(v.bad, 256, s);
-    RF_LAUNCH("am_fgt_prep", fgt_prep_kernel, dim3(b), dim3(1024), 0, s, n, m, xyz1, xyz2, a_max, v.geom, v.bad);
+    RF_LAUNCH("am_fgt_prep", fgt_prep_kernel, dim3(b), dim3(1024), 0, s, n, m, xyz1, xyz2, a_max, v.geom);
     return RF_OK;
 }
 
@@ -572,7 +570,6 @@ static int moments_only(int b, int npts, const float *pts, const float *w, size_
     p.a_out[0] = a;
     p.deg_out[0] = degree_for(a);
     p.geom = v.geom;
-    p.bad = v.bad;
     p.b = b;
     return launch(p, s);
 }
@@ -612,7 +609,6 @@ int fgt_p3p1(int b, int n, int m, const float *xyz1, const float *xyz2, bool has
     p.rem = remainL;
     p.out = ratioL_out;
     p.geom = v.geom;
-    p.bad = v.bad;
     p.b = b;
     return launch(p, s);
 }
@@ -643,7 +639,6 @@ int fgt_p2(int b, int n, int m, const float *xyz1, const float *xyz2, double a_c
     p.rem = remainR;
     p.out = ratioR_out;
     p.geom = v.geom;
-    p.bad = v.bad;
     p.b = b;
     return launch(p, s);
 }

@@ -13,11 +13,10 @@ constexpr float kFgtMaxA = 1.0f;
 // two sets); 256-byte aligned sizes.
 size_t fgt_workspace_bytes(int b, int nmax);
 
-// Once per call: the clouds' common centre and radii per batch element, and the validity word -- *bad != 0 when some batch
-// element's extent makes the truncated series miss its error bound for a level of sharpness a_max, or a coordinate is not finite
-// (then every fgt_* call below forms its row sums directly, column by column in fp32 -- slow, and only for such inputs).
+// Once per call: the clouds' common centre and radii per batch element, and the element's validity flag -- raised when its extent
+// makes the truncated series miss its error bound for a level of sharpness a_max, or a coordinate is not finite (then every fgt_*
+// call below forms THAT element's row sums directly, as the dense sweeps do, inside the same launches).
 int fgt_prep(int b, int n, int m, const float *xyz1, const float *xyz2, double a_max, void *ws, hipStream_t s);
-const int *fgt_bad_word(const void *ws);
 
 // The phases of a level (tf_approxmatch.cu:36-177) with their row sums S = sum_col w[col] exp(-a |row - col|^2) from the
 // expansion; state vectors as in approxmatch.hip's dense sweeps (per batch element `stride` floats apart, original order).
