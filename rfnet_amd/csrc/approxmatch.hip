@@ -57,31 +57,37 @@ typedef __attribute__((address_space(4))) float cfloat;  // wave-uniform, launch
 constexpr int SUB = 8;     // columns per scalar-load sub-chunk
 constexpr int CPAD = 128;  // column counts are padded to a multiple of this (zero scalars)
 
-// pack xyz (b,npts,3) -> (b,npad,3) zero padded, and initialise remain (padded entries = 0 so
-// that padded columns contribute e*0 = 0 to every sum; e <= 1 is always finite).  Both clouds in one launch (blockIdx.z).
+// pack xyz (b,npts,3) -> (b,npad,3) zero padded, and initialise the state vectors: remain = the cloud's multiplier, and the
+// PADDED entries of every vector slot (remain and each level's ratio) = 0, so that padded columns contribute e*0 = 0 to every sum
+// (e <= 1 is always finite) -- the entries of real points are all written by their level's sweep before anything reads them, so
+// nothing else of the state needs clearing (a memset of the whole region was 8 us per call at C4).  Both clouds in one launch.
 struct AmInit {
     int npts[2], npad[2];
     float fill[2];
     const float *xyz[2];
     float *xyzp[2];
     size_t xyzp_stride[2];
-    float *remain[2];
-    size_t stride;
+    float *vec;        // the vector region: per batch element `stride` floats = nslots slots of V = npad[0] + npad[1] floats
+    size_t stride, V;  // slot s: [cloud 0's vector (npad[0]) | cloud 1's (npad[1])]
+    int nslots, b;
 };
 __global__ void am_init_kernel(AmInit a) {
     const int bi = blockIdx.y, c = blockIdx.z;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int npts = c ? a.npts[1] : a.npts[0], npad = c ? a.npad[1] : a.npad[0];
+    if (bi == 0 && c == 0 && j < 64) a.vec[(size_t)a.b * a.stride + j] = 0.f;  // the slack behind the last element's vectors
     if (j >= npad) return;
-    float x = 0.f, y = 0.f, z = 0.f, r = 0.f;
+    float *v = a.vec + (size_t)bi * a.stride + (c ? a.npad[0] : 0) + j;
     if (j < npts) {
         const float *p = (c ? a.xyz[1] : a.xyz[0]) + ((size_t)bi * npts + j) * 3;
-        x = p[0]; y = p[1]; z = p[2];
-        r = c ? a.fill[1] : a.fill[0];
+        float *q = (c ? a.xyzp[1] : a.xyzp[0]) + (size_t)bi * (c ? a.xyzp_stride[1] : a.xyzp_stride[0]) + (size_t)j * 3;
+        q[0] = p[0]; q[1] = p[1]; q[2] = p[2];
+        v[0] = c ? a.fill[1] : a.fill[0];
+    } else {
+        float *q = (c ? a.xyzp[1] : a.xyzp[0]) + (size_t)bi * (c ? a.xyzp_stride[1] : a.xyzp_stride[0]) + (size_t)j * 3;
+        q[0] = q[1] = q[2] = 0.f;
+        for (int s = 0; s < a.nslots; s++) v[(size_t)s * a.V] = 0.f;
     }
-    float *q = (c ? a.xyzp[1] : a.xyzp[0]) + (size_t)bi * (c ? a.xyzp_stride[1] : a.xyzp_stride[0]) + (size_t)j * 3;
-    q[0] = x; q[1] = y; q[2] = z;
-    (c ? a.remain[1] : a.remain[0])[(size_t)bi * a.stride + j] = r;
 }
 
 // Rows = xyz1 points k (one per lane), columns = xyz2 points l streamed through SGPRs.
@@ -1480,15 +1486,14 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
     float *remainL = w, *remainR = w + L.npad;          // slot 0 of the vector region
     float *ratios = w + L.V;                            // slot 1+v: [ratioL npad | ratioR mpad]
     float *x1p = w + L.off_x1, *x2p = w + L.off_x2;
-    // padded entries of every vector must read 0 (they are column scalars of padded columns)
-    RF_ZERO(w, sizeof(float) * ((size_t)b * L.bstride + 64), s);
+    // (padded entries of every vector must read 0 -- they are column scalars of padded columns: am_init writes them)
     {
         AmInit ai;
         ai.npts[0] = n, ai.npts[1] = m, ai.npad[0] = L.npad, ai.npad[1] = L.mpad;
         ai.fill[0] = multiL, ai.fill[1] = multiR;
         ai.xyz[0] = xyz1, ai.xyz[1] = xyz2, ai.xyzp[0] = x1p, ai.xyzp[1] = x2p;
         ai.xyzp_stride[0] = (size_t)L.npad * 3, ai.xyzp_stride[1] = (size_t)L.mpad * 3;
-        ai.remain[0] = remainL, ai.remain[1] = remainR, ai.stride = L.bstride;
+        ai.vec = w, ai.stride = L.bstride, ai.V = L.V, ai.nslots = 1 + nlevels, ai.b = b;
         RF_LAUNCH("am_init", am_init_kernel, dim3(rf::ceil_div(max(L.npad, L.mpad), 256), b, 2), dim3(256), 0, s, ai);
     }
 

@@ -92,6 +92,23 @@ def test_calls_are_independent_of_workspace_contents(orc):
     for buf in _host._ws_cache.values():
         buf.fill_(0xFF)
     assert torch.equal(m1, R.approx_match(u, v))
+    # the EMD state vectors are not cleared as a whole (am_init writes the padded entries only): ragged sizes on every route --
+    # plain sweeps, the fused op with gradients, and a batch large enough for sorted rows + the expanded broad levels
+    e1 = [t.clone() for t in R.earth_mover(u, v, with_grad=True)]
+    for buf in _host._ws_cache.values():
+        buf.fill_(0xFF)
+    e2 = R.earth_mover(u, v, with_grad=True)
+    assert torch.equal(e1[0], e2[0]) and torch.allclose(e1[1], e2[1], rtol=1e-5, atol=1e-7) and torch.allclose(e1[2], e2[2], rtol=1e-5, atol=1e-7)
+    ub = torch.from_numpy((rng.rand(22, 2000, 3) - .5).astype(np.float32)).cuda()
+    vb = torch.from_numpy((rng.rand(22, 1900, 3) - .5).astype(np.float32)).cuda()
+    mb = R.approx_match(ub, vb).clone()
+    cb = R.earth_mover(ub, vb).clone()
+    for buf in _host._ws_cache.values():
+        buf.fill_(0xFF)
+    assert torch.equal(mb, R.approx_match(ub, vb))
+    for buf in _host._ws_cache.values():
+        buf.fill_(0xFF)
+    assert torch.equal(cb, R.earth_mover(ub, vb))
 
 
 def test_two_streams_do_not_share_scratch(orc):
