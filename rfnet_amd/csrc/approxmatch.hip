@@ -29,6 +29,7 @@
 #include "common.hpp"
 #include "nn_pruned.hpp"
 #include "emd_fgt.hpp"
+#include "emd_fgt_prep.hpp"
 
 namespace {
 
@@ -70,9 +71,16 @@ struct AmInit {
     float *vec;        // the vector region: per batch element `stride` floats = nslots slots of V = npad[0] + npad[1] floats
     size_t stride, V;  // slot s: [cloud 0's vector (npad[0]) | cloud 1's (npad[1])]
     int nslots, b;
+    rfe::Geom *geom;   // != nullptr: blocks (0, bi, 2) run the expansion's geometry pass (emd_fgt_prep.hpp) for element bi
+    double a_max;
 };
-__global__ void am_init_kernel(AmInit a) {
+constexpr int AI_TPB = 1024;  // (the geometry pass is one workgroup per batch element: 13 us with 256 threads, 8 with 1024)
+__global__ __launch_bounds__(AI_TPB) void am_init_kernel(AmInit a) {
     const int bi = blockIdx.y, c = blockIdx.z;
+    if (c == 2) {  // (uniform per workgroup)
+        if (blockIdx.x == 0) rfe::fgt_prep_block<AI_TPB>(bi, a.npts[0], a.npts[1], a.xyz[0], a.xyz[1], a.a_max, a.geom);
+        return;
+    }
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int npts = c ? a.npts[1] : a.npts[0], npad = c ? a.npad[1] : a.npad[0];
     if (bi == 0 && c == 0 && j < 64) a.vec[(size_t)a.b * a.stride + j] = 0.f;  // the slack behind the last element's vectors
@@ -1486,7 +1494,18 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
     float *remainL = w, *remainR = w + L.npad;          // slot 0 of the vector region
     float *ratios = w + L.V;                            // slot 1+v: [ratioL npad | ratioR mpad]
     float *x1p = w + L.off_x1, *x2p = w + L.off_x2;
-    // (padded entries of every vector must read 0 -- they are column scalars of padded columns: am_init writes them)
+    // the leading sharp levels run culled over spatially sorted (sort-tile-recursive) copies of the clouds (am_cull_kernel)
+    const int ncull = allow_cull ? cull_levels(L, nlevels, lc) : 0;
+    // The broad tail of the schedule by expansion (emd_fgt.hip): every level from vF on has sharpness a = -c ln 2 <= kFgtMaxA
+    // (the reference schedule: levels -1, -0.25, 0 -> vF = 7).  The device decides per batch element whether the clouds' extent
+    // allows it (Geom::bad): a refused element's row sums are formed directly inside the expansion's own launches (direct_sum).
+    auto sharp = [&](int v) { return (double)(-lc.c[v]) * 0.69314718055994530942; };
+    int vF = nlevels;
+    while (vF > 1 && lc.c[vF - 1] <= 0.f && sharp(vF - 1) <= (double)rfe::kFgtMaxA * 1.0001) vF--;
+    const bool fgt = L.fgt_ok && vF < nlevels && vF >= ncull + 1;
+    void *fws = fgt ? (void *)(w + L.off_fgt) : nullptr;
+    // (padded entries of every vector must read 0 -- they are column scalars of padded columns: am_init writes them; the same
+    // launch carries the expansion's geometry pass, one more workgroup per batch element)
     {
         AmInit ai;
         ai.npts[0] = n, ai.npts[1] = m, ai.npad[0] = L.npad, ai.npad[1] = L.mpad;
@@ -1494,11 +1513,11 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
         ai.xyz[0] = xyz1, ai.xyz[1] = xyz2, ai.xyzp[0] = x1p, ai.xyzp[1] = x2p;
         ai.xyzp_stride[0] = (size_t)L.npad * 3, ai.xyzp_stride[1] = (size_t)L.mpad * 3;
         ai.vec = w, ai.stride = L.bstride, ai.V = L.V, ai.nslots = 1 + nlevels, ai.b = b;
-        RF_LAUNCH("am_init", am_init_kernel, dim3(rf::ceil_div(max(L.npad, L.mpad), 256), b, 2), dim3(256), 0, s, ai);
+        ai.geom = fgt ? (rfe::Geom *)rfe::fgt_geom(fws, b, n > m ? n : m) : nullptr;
+        ai.a_max = fgt ? sharp(vF) : 0.0;
+        RF_LAUNCH("am_init", am_init_kernel, dim3(rf::ceil_div(max(L.npad, L.mpad), AI_TPB), b, fgt ? 3 : 2), dim3(AI_TPB), 0, s, ai);
     }
 
-    // the leading sharp levels run culled over spatially sorted (sort-tile-recursive) copies of the clouds (am_cull_kernel)
-    const int ncull = allow_cull ? cull_levels(L, nlevels, lc) : 0;
     L.tw_stride = L.Vs * (size_t)(1 + ncull);  // only the twin slots this schedule touches are laid out (and zero-filled)
     CullSet SA{}, SB{};
     float *tw = w + L.off_tw;  // twins: slot 0 = [remainL_s nsa | remainR_s nsb], slot 1+v = [ratioL_s | ratioR_s]
@@ -1536,17 +1555,6 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
     const int segk = pick_nseg(b, n, L.mpad, RPT), segl = pick_nseg(b, m, L.npad, RPT);
     const dim3 gk(rf::ceil_div(n, 64 * RPT), b), gl(rf::ceil_div(m, 64 * RPT), b);
     const dim3 gks(rf::ceil_div(L.nsa, 64 * RPT), b), gls(rf::ceil_div(L.nsb, 64 * RPT), b);  // SKIP: over the sorted positions
-    // The broad tail of the schedule by expansion (emd_fgt.hip): every level from vF on has sharpness a = -c ln 2 <= kFgtMaxA
-    // (the reference schedule: levels -1, -0.25, 0 -> vF = 7).  The device decides per call whether the clouds' extent allows it
-    // (the `bad` word): a refused call forms the same row sums directly inside the expansion's own launches (emd_fgt.hip direct_sum).
-    auto sharp = [&](int v) { return (double)(-lc.c[v]) * 0.69314718055994530942; };
-    int vF = nlevels;
-    while (vF > 1 && lc.c[vF - 1] <= 0.f && sharp(vF - 1) <= (double)rfe::kFgtMaxA * 1.0001) vF--;
-    const bool fgt = L.fgt_ok && vF < nlevels && vF >= ncull + 1;
-    void *fws = fgt ? (void *)(w + L.off_fgt) : nullptr;
-    if (fgt) {
-        if (int e = rfe::fgt_prep(b, n, m, xyz1, xyz2, sharp(vF), fws, s)) return e;
-    }
     for (int v = 0; v < nlevels; v++) {
         float *ratioL = ratios + (size_t)v * L.V, *ratioR = ratioL + L.npad;
         const bool zero = lc.c[v] == 0.0f;  // e = exp2(d2 * 0) = 1 exactly: no exponential needed

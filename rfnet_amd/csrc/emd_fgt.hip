@@ -25,8 +25,11 @@
 // with no separate moment launches.
 #include "common.hpp"
 #include "emd_fgt.hpp"
+#include "emd_fgt_prep.hpp"
 
 namespace {
+using rfe::Geom;
+using rfe::kBound;
 
 constexpr int FG_P = 10;                                            // largest total degree of an expansion
 constexpr int FG_NM = (FG_P + 1) * (FG_P + 2) * (FG_P + 3) / 6;     // 286 monomials
@@ -34,7 +37,6 @@ constexpr int FG_ROWS = 256;                                        // rows (and
 constexpr int FG_TPB = 2 * FG_ROWS;                                 // threads per workgroup: two per row (see fgt_step_kernel)
 constexpr int FG_PWS = FG_ROWS + 1;                                 // row stride of the power tables in LDS (doubles)
 constexpr size_t FG_LDS = sizeof(double) * (2 * (FG_P + 1) * (FG_P + 2) / 2 * 12 + 2 * FG_ROWS + 4 * (FG_P + 1) * (size_t)FG_PWS);
-constexpr double kBound = 1.5;                                      // g * R_rows * R_cols up to which degree 10 holds 3e-9 (any two clouds inside a unit cube: <= 1.5 at level -1)
 
 struct Ijk {
     unsigned char i, j, k, n;
@@ -91,11 +93,6 @@ __device__ constexpr ItemTable kItems{};
 __device__ constexpr double kInvFact[13] = {1.0, 1.0, 1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320,
                                             1.0 / 362880, 1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600};
 
-struct Geom {  // per batch element
-    double ox, oy, oz, rarb;
-    int bad, pad;  // bad != 0: this element's extent breaks the series' bound, or a coordinate is not finite -- direct sums
-};
-
 size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 int chunks_of(int npts) { return (npts + FG_ROWS - 1) / FG_ROWS; }  // one partial per workgroup
 
@@ -114,91 +111,6 @@ FgtWs view(const void *ws, int b, int nmax) {
     v.mom[0] = (double *)p;
     v.mom[1] = (double *)(p + per);
     return v;
-}
-
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-
-// centre = middle of the bounding box of both clouds; R1, R2 = the clouds' largest distances from it
-__global__ __launch_bounds__(1024) void fgt_prep_kernel(int n, int m, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
-                                                         double a_max, Geom *__restrict__ geom) {
-    __shared__ float red[16][6];
-    __shared__ float ctr[3];
-    __shared__ int nonfin;
-    const int bi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float *A = xyz1 + (size_t)bi * n * 3, *B = xyz2 + (size_t)bi * m * 3;
-    if (tid == 0) nonfin = 0;
-    __syncthreads();
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    bool nonfinite = false;
-    for (int i = tid; i < n + m; i += 1024) {
-        const float *p = i < n ? A + (size_t)i * 3 : B + (size_t)(i - n) * 3;
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const float v = p[c];
-            nonfinite = nonfinite || !(fabsf(v) < INFINITY);
-            lo[c] = fminf(lo[c], v);
-            hi[c] = fmaxf(hi[c], v);
-        }
-    }
-    const bool anybad = __ballot(nonfinite) != 0ull;
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        lo[c] = wave_min(lo[c]);
-        hi[c] = wave_max(hi[c]);
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            red[wave][c] = lo[c];
-            red[wave][3 + c] = hi[c];
-        }
-    }
-    if (anybad && lane == 0) atomicOr(&nonfin, 1);
-    __syncthreads();
-    if (tid < 3) {
-        float l = INFINITY, h = -INFINITY;
-        for (int w = 0; w < 16; w++) {
-            l = fminf(l, red[w][tid]);
-            h = fmaxf(h, red[w][3 + tid]);
-        }
-        ctr[tid] = 0.5f * l + 0.5f * h;
-    }
-    __syncthreads();
-    const float ox = ctr[0], oy = ctr[1], oz = ctr[2];
-    float r1 = 0.f, r2 = 0.f;
-    for (int i = tid; i < n + m; i += 1024) {
-        const float *p = i < n ? A + (size_t)i * 3 : B + (size_t)(i - n) * 3;
-        const float dx = p[0] - ox, dy = p[1] - oy, dz = p[2] - oz;
-        const float d2 = dx * dx + dy * dy + dz * dz;
-        if (i < n) r1 = fmaxf(r1, d2); else r2 = fmaxf(r2, d2);
-    }
-    r1 = wave_max(r1);
-    r2 = wave_max(r2);
-    __syncthreads();
-    if (lane == 0) {
-        red[wave][0] = r1;
-        red[wave][1] = r2;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        float a = 0.f, c = 0.f;
-        for (int w = 0; w < 16; w++) {
-            a = fmaxf(a, red[w][0]);
-            c = fmaxf(c, red[w][1]);
-        }
-        const double rarb = sqrt((double)a) * sqrt((double)c);
-        // (every element's record is written whole by its own workgroup: nothing to clear beforehand)
-        geom[bi] = Geom{(double)ox, (double)oy, (double)oz, rarb, (nonfin != 0 || !(2.0 * a_max * rarb <= kBound)) ? 1 : 0, 0};
-    }
 }
 
 struct Step {
@@ -546,11 +458,7 @@ size_t fgt_workspace_bytes(int b, int nmax) {
     return align256(sizeof(Geom) * (size_t)b) + 2 * align256(sizeof(double) * 2 * (size_t)b * chunks_of(nmax) * FG_NM);
 }
 
-int fgt_prep(int b, int n, int m, const float *xyz1, const float *xyz2, double a_max, void *ws, hipStream_t s) {
-    FgtWs v = view(ws, b, n > m ? n : m);
-    RF_LAUNCH("am_fgt_prep", fgt_prep_kernel, dim3(b), dim3(1024), 0, s, n, m, xyz1, xyz2, a_max, v.geom);
-    return RF_OK;
-}
+void *fgt_geom(void *ws, int b, int nmax) { return (void *)view(ws, b, nmax).geom; }
 
 // total degree for sharpness a (relative truncation error <= ~1e-11 up to the validity bound: tools/experiments/fgt_proto.py)
 static int degree_for(double a) { return a <= 1e-12 ? 0 : (a <= 0.3 ? 6 : FG_P); }

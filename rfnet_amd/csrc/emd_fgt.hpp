@@ -13,10 +13,12 @@ constexpr float kFgtMaxA = 1.0f;
 // two sets); 256-byte aligned sizes.
 size_t fgt_workspace_bytes(int b, int nmax);
 
-// Once per call: the clouds' common centre and radii per batch element, and the element's validity flag -- raised when its extent
-// makes the truncated series miss its error bound for a level of sharpness a_max, or a coordinate is not finite (then every fgt_*
-// call below forms THAT element's row sums directly, as the dense sweeps do, inside the same launches).
-int fgt_prep(int b, int n, int m, const float *xyz1, const float *xyz2, double a_max, void *ws, hipStream_t s);
+// Once per call, BEFORE the chain below: the clouds' common centre and radii per batch element, and the element's validity flag --
+// raised when its extent makes the truncated series miss its error bound for a level of sharpness a_max, or a coordinate is not
+// finite (then every fgt_* call below forms THAT element's row sums directly, as the dense sweeps do, inside the same launches).
+// The pass is rfe::fgt_prep_block (emd_fgt_prep.hpp), run by the caller inside a launch of its own -- one workgroup per batch
+// element writing record bi of the array this returns (an array of rfe::Geom).
+void *fgt_geom(void *ws, int b, int nmax);
 
 // The phases of a level (tf_approxmatch.cu:36-177) with their row sums S = sum_col w[col] exp(-a |row - col|^2) from the
 // expansion; state vectors as in approxmatch.hip's dense sweeps (per batch element `stride` floats apart, original order).
