@@ -489,6 +489,20 @@ __global__ void group_point_kernel(int n, int c, long per_batch /* m*nsample */,
     out[e] = points[(bi * n + ii) * c + ch];
 }
 
+// c == 3 (the model's use: coordinates): a row per lane, one 12-byte load and one 12-byte store, the batch element from the grid
+// (the general kernel spends two 64-bit divisions per ELEMENT: 13.6 us at C3 against 5 here)
+__global__ void group_point3_kernel(int n, int per_batch, const float *__restrict__ points, const int *__restrict__ idx,
+                                    float *__restrict__ out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= per_batch) return;
+    const size_t bi = blockIdx.y, js = bi * per_batch + r;
+    struct P3 {
+        float x, y, z;
+    };
+    const int ii = idx[js];
+    *(P3 *)(out + js * 3) = *(const P3 *)(points + (bi * n + ii) * 3);
+}
+
 __global__ void group_point_grad_kernel(int n, int c, long per_batch, long total,
                                         const float *__restrict__ grad_out,
                                         const int *__restrict__ idx, float *__restrict__ grad_points) {
@@ -630,6 +644,11 @@ int rf_grouppoint(int b, int n, int c, int m, int nsample, const float *points, 
     long total = (long)b * per_batch * c;
     if (total == 0) return RF_OK;
     if (!points || !idx || !out) return RF_EINVAL;
+    if (c == 3 && per_batch < (1L << 30) && b <= 65535) {
+        RF_LAUNCH("group_point", group_point3_kernel, dim3(rf::ceil_div((int)per_batch, 256), b), dim3(256), 0,
+                  (hipStream_t)stream, n, (int)per_batch, points, idx, out);
+        return RF_OK;
+    }
     RF_LAUNCH("group_point", group_point_kernel, dim3(rf::ceil_div(total, 256)), dim3(256), 0,
               (hipStream_t)stream, n, c, per_batch, total, points, idx, out);
     return RF_OK;
