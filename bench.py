@@ -328,27 +328,38 @@ def run_c3(rank, dev, fence, reps):
     torch.cuda.synchronize()
     one_same = (bool(torch.equal(one[0], idx)) and bool(torch.equal(one[1], new_xyz)) and bool(torch.equal(one[2], gi))
                 and bool(torch.equal(one[3], cnt)) and bool(torch.equal(one[4], group_point(xyz, gi))))
-    fps_kms = fps_k.get("fps_reg", fps_k.get("fps_mem", fps_ms))
+    fps_kms = fps_k.get("fps_sorted", fps_k.get("fps_reg", fps_k.get("fps_mem", fps_ms)))  # (the sampling kernel alone: its sort is in fps_k)
+    from rfnet_amd._raw import farthest_point_sample_reg
+    fpr_ms, fpr_k = timed(lambda: farthest_point_sample_reg(m, xyz), max(3, reps // 2), fence)
+    fps_same = bool(torch.equal(farthest_point_sample_reg(m, xyz), idx))
     box_kms = qb_k.get("query_ball_boxes", qb_ms)
     updates = float(B) * n * (m - 1)
     return {
         "workload": f"B={B} per GPU, farthest_point_sample {n} -> {m} + gather_point + query_ball_point(r={r}, nsample={ns}) "
                     "+ group_point(c=3), U[0,1)^3 seed 100 (BASELINE.json configs[2])",
         "ms_per_pass": onea_ms,
-        "ms_per_pass_is": "rf_sample_and_group: ONE C-ABI call (FPS writes new_xyz, the boxed ball query writes grouped_xyz, the "
-                          "dataset's sort beside FPS on an auxiliary stream); outputs identical to the four ops: "
+        "ms_per_pass_is": "rf_sample_and_group: ONE C-ABI call (one sort of the dataset serves FPS -- which runs over the sorted cloud and "
+                          "writes new_xyz -- and the boxed ball query, which writes grouped_xyz); outputs identical to the four ops: "
                           + str(one_same),
         "ms_per_pass_one_stream": one_ms,
         "ms_per_pass_four_ops": fps_ms + ga_ms + qb_ms + gp_ms,
         "ms_per_pass_four_ops_scan_ball_query": fps_ms + ga_ms + qs_ms + gp_ms,
         "one_call_kernels_ms": one_k,
         "farthest_point_sample": {
-            "ms": fps_ms, "kernel_ms": fps_kms, "us_per_iteration": fps_kms * 1e3 / (m - 1),
+            "ms": fps_ms, "kernels_ms": fps_k, "kernel_ms": fps_kms, "us_per_iteration": fps_kms * 1e3 / (m - 1),
+            "form": "over the spatially sorted cloud (nnp_sort + fps_sorted_kernel: 16 waves x 16 consecutive sorted points per lane, a wave "
+                    "re-scans only when the new sample can still lower a running minimum in one of its lanes' boxes -- 2.9 of 16 waves per "
+                    "iteration at C3); indices identical to the unsorted kernel's: " + str(fps_same),
+            "unsorted_kernel": {"ms": fpr_ms, "kernel_ms": fpr_k.get("fps_reg", fpr_ms),
+                                "us_per_iteration": fpr_k.get("fps_reg", fpr_ms) * 1e3 / (m - 1)},
             "distance_updates_per_s": updates / (fps_kms * 1e-3),
             "roofline": {"bound": "latency", "what": "serial chain of npoint-1 dependent arg-max reductions, one workgroup "
-                         "(one CU) per cloud: B of the 256 CUs busy by construction, and on that CU the VALU issues 53 % of every wave's "
-                         "life (343 instructions per wave and iteration at 2 waves per SIMD).  Spreading a cloud over 2/4/8 workgroups "
-                         "was built and is 1.27-1.43x SLOWER: one all-to-all exchange of the winners costs 0.5-0.9 us against the 1.09 us "
+                         "(one CU) per cloud: B of the 256 CUs busy by construction.  The unsorted kernel's VALU issues 53 % of every wave's "
+                         "life (343 instructions per wave and iteration); over the sorted cloud 82 % of the wave-scans are skipped and what "
+                         "is left of an iteration is its chain: box test, one lone wave's scan, wave reduction, barrier, slot reduction, "
+                         "scalar re-read of the winner.  `distance_updates_per_s` counts the reference's (npoint-1)*n updates (an effective "
+                         "figure: most are proven unnecessary and not executed).  Spreading a cloud over 2/4/8 workgroups "
+                         "was built and is 1.27-1.43x SLOWER: one all-to-all exchange of the winners costs 0.5-0.9 us against the ~1 us "
                          "of a whole iteration (profiles/r05_fps_cluster.txt)",
                          "cus_busy": B, "valu_flops_per_s": 8.0 * updates / (fps_kms * 1e-3),
                          "frac_of_fp32_peak_on_busy_cus": 8.0 * updates / (fps_kms * 1e-3) / 1e12 / (FP32_PEAK_TFLOPS * B / 256.0)}},

@@ -60,6 +60,10 @@ SIGNATURES = {
     "rf_matchcost_grad": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rf_farthestpointsampling_temp_floats": (_sz, [_i, _i]),
     "rf_farthestpointsampling": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "rf_farthestpointsampling_workspace_bytes": (_sz, [_i, _i, _i]),
+    "rf_farthestpointsampling_ws": (_i, [_i, _i, _i, _vp, _vp, _sz, _vp, _vp]),
+    "rf_farthestpointsampling_sorted_workspace_bytes": (_sz, [_i, _i]),
+    "rf_farthestpointsampling_sorted": (_i, [_i, _i, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
     "rf_fps_cluster_state_bytes": (_sz, [_i]),
     "rf_farthestpointsampling_cluster": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "rf_gatherpoint": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),

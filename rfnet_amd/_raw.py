@@ -401,8 +401,9 @@ def earth_mover(xyz1, xyz2, with_grad=False):
 
 # ------------------------------------------------------------------ sampling ---------------
 @H.on_input_device
-def farthest_point_sample(npoint, inp):
-    """FarthestPointSampleGpuOp, tf_ops/sampling/tf_sampling.cpp:95-123 -> (b,npoint) int32."""
+def farthest_point_sample(npoint, inp, _pin_reg=False):
+    """FarthestPointSampleGpuOp, tf_ops/sampling/tf_sampling.cpp:95-123 -> (b,npoint) int32.
+    (_pin_reg: the kernels of the unsorted cloud whatever the size -- rf_farthestpointsampling; a measurement aid.)"""
     npoint = int(npoint)
     if npoint <= 0:
         raise H.invalid("FarthestPointSample expects positive npoint")
@@ -414,10 +415,15 @@ def farthest_point_sample(npoint, inp):
     dev = st.device_()
     p, = st.up(p)
     out = H.empty((b, npoint), I32, dev)
-    nt = lib.rf_farthestpointsampling_temp_floats(b, n)
-    temp = H.empty((nt,), F32, dev) if nt else None
-    check(lib.rf_farthestpointsampling(b, n, npoint, H.ptr(p), H.ptr(temp), H.ptr(out),
-                                       H.stream(dev)), "rf_farthestpointsampling")
+    if _pin_reg:
+        nt = lib.rf_farthestpointsampling_temp_floats(b, n)
+        temp = H.empty((nt,), F32, dev) if nt else None
+        check(lib.rf_farthestpointsampling(b, n, npoint, H.ptr(p), H.ptr(temp), H.ptr(out),
+                                           H.stream(dev)), "rf_farthestpointsampling")
+        return st.give(out)
+    ws, wsz = H.workspace(lib.rf_farthestpointsampling_workspace_bytes(b, n, npoint), dev, "fps")
+    check(lib.rf_farthestpointsampling_ws(b, n, npoint, H.ptr(p), H.ptr(ws), wsz, H.ptr(out), H.stream(dev)),
+          "rf_farthestpointsampling_ws")
     return st.give(out)
 
 
@@ -441,6 +447,35 @@ def farthest_point_sample_cluster(npoint, inp, k=4, static_map=False, return_sta
                                                H.ptr(out), H.stream(dev)), "rf_farthestpointsampling_cluster")
     if return_state:
         return st.give(out), state
+    return st.give(out)
+
+
+def farthest_point_sample_reg(npoint, inp):
+    """farthest_point_sample pinned to the register-resident kernel of the unsorted cloud (measurement aid)."""
+    return farthest_point_sample(npoint, inp, _pin_reg=True)
+
+
+@H.on_input_device
+def farthest_point_sample_sorted(npoint, inp, form=0, with_xyz=False):
+    """farthest_point_sample over the spatially sorted cloud (sampling.hip fps_sorted_kernel): the same indices, for clouds of
+    8193..16384 points.  -> idx (b, npoint) [, new_xyz (b, npoint, 3)]"""
+    npoint = int(npoint)
+    if npoint <= 0:
+        raise H.invalid("FarthestPointSample expects positive npoint")
+    st = H.Staged()
+    p = st.take(inp, F32)
+    if not _shape3(p, 3):
+        raise H.invalid("FarthestPointSample expects (batch_size,num_points,3) inp shape")
+    b, n = p.shape[0], p.shape[1]
+    dev = st.device_()
+    p, = st.up(p)
+    out = H.empty((b, npoint), I32, dev)
+    nx = H.empty((b, npoint, 3), F32, dev) if with_xyz else None
+    ws, wsz = H.workspace(lib.rf_farthestpointsampling_sorted_workspace_bytes(b, n), dev, "fps")
+    check(lib.rf_farthestpointsampling_sorted(b, n, npoint, int(form), H.ptr(p), H.ptr(ws), wsz, H.ptr(out), H.ptr(nx),
+                                              H.stream(dev)), "rf_farthestpointsampling_sorted")
+    if with_xyz:
+        return st.give(out), st.give(nx)
     return st.give(out)
 
 

@@ -12,6 +12,11 @@ namespace rfi {
 // n exceeds the register-resident limit (rf_farthestpointsampling_temp_floats), NULL otherwise.
 int fps(int b, int n, int m, const float *inp, float *temp, int *out, float *new_xyz, hipStream_t s);
 
+// The same op over a cloud that is already sorted (fps_sorted_kernel: clouds of 8193..16384 points): the same indices; a new
+// sample only re-scans the regions it can still change.  fps_sorted_pays: from how many samples on the sort is repaid.
+bool fps_sorted_pays(int n, int m);
+int fps_sorted(int b, int n, int m, const float *inp, const rfp::Sorted &sv, int *out, float *new_xyz, hipStream_t s);
+
 // query_ball_point on a sorted dataset (grouping.hip, query_ball_boxes_kernel).  grouped_xyz (b, m, nsample, 3) or NULL:
 // group_point(xyz1, idx) fused; zero_empty: rows of empty balls are written as index 0 instead of being left untouched.
 // The caller has checked the domain (64 <= n <= 65536, nsample <= 64, b <= 65535).

@@ -8,8 +8,8 @@
 //     gather launch;
 //   * the ball query runs over the sorted dataset's boxes and writes the grouped coordinates with the index rows (the row is
 //     in LDS): no group launch for xyz;
-//   * the dataset's sort does not depend on FPS: given a second stream it runs BESIDE FPS (FPS keeps b of the 256 CUs busy
-//     for a millisecond) and costs the chain nothing.
+//   * the dataset's sort serves BOTH ops where FPS runs over the sorted cloud (8193..16384 points, >= 192 samples); elsewhere it
+//     does not depend on FPS: given a second stream it runs BESIDE FPS and costs the chain nothing.
 // So the pass is two launches on the caller's stream and one on the auxiliary stream.  Results are those of the four
 // separate ops, bit for bit (tests/test_gpu_sample_group.py).
 #include "common.hpp"
@@ -47,6 +47,13 @@ int rf_sample_and_group(int b, int n, int npoint, float radius, const float *rad
     const int nn[1] = {n};
     const float *src[1] = {xyz};
     hipEvent_t fork = nullptr, join = nullptr;
+    if (rfi::fps_sorted_pays(n, npoint)) {
+        // FPS itself runs over the sorted cloud (fps_sorted_kernel: a third shorter iterations): one sort serves both ops, on
+        // the caller's stream -- nothing is left to run beside FPS
+        if (int e = rfp::sort_sets(b, 1, nn, src, &so, s, nullptr)) return e;
+        if (int e = rfi::fps_sorted(b, n, npoint, xyz, so, fps_idx, new_xyz, s)) return e;
+        return rfi::ball_boxes(b, n, npoint, radius, radius_dev, nsample, xyz, new_xyz, so, idx, pts_cnt, grouped_xyz, 1, s);
+    }
     if (aux && aux != s) {
         // the sort beside FPS: aux waits for the caller's stream (the inputs are ready there), the caller's stream waits for
         // the sort before the ball query.  The events live for this call only; an event that is still pending when it is

@@ -17,10 +17,12 @@
 // DPP (max d2, then min tie rank) -> the winner's xyz is re-read with a scalar load.
 #include "common.hpp"
 #include "group_internal.hpp"
+#include "nn_pruned.hpp"
 
 namespace {
 
 constexpr int FPS_MAX_REG_POINTS = 16384;
+constexpr int FPS_SORTED_MIN_SAMPLES = 192;  // from here on the sorted form's shorter iterations repay its sort
 
 // tie rank of point k under the reference's 512-thread layout: lower is preferred
 __device__ __forceinline__ unsigned tie_rank(int k) { return ((unsigned)(k & 511) << 22) | (unsigned)(k >> 9); }
@@ -341,6 +343,195 @@ __global__ __launch_bounds__(512) void fps_cluster_kernel(int n, int m, int stat
     }
 }
 
+// ---- FPS over the spatially sorted cloud: the same samples, most of the cloud left alone in most iterations (round 5) ----
+// The cloud arrives in sort-tile-recursive order (rfp::sort_clouds); a lane owns PPT CONSECUTIVE sorted points -- a region with a
+// small box.  A new sample s lowers the running minimum td[p] only if |p - s|^2 < td[p]; with `lmx` the largest td of the lane's
+// region and `lb` the box's lower bound on the distance (the same instruction sequence as d2 on the per-axis gaps: lb <= the d2
+// of every point in the box, by the monotonicity of fp32 rounding), lb >= lmx proves that nothing in the region changes.  A WAVE
+// none of whose 64 regions is touched skips its scan and its reductions: its cached (maximum, tie rank) still stands.
+// The reference's tie order (largest td, then smallest k mod 512, then smallest k: tf_sampling_g.cu:105-170 as fps_reg_kernel
+// restates it) is kept through tie_rank(ORIGINAL index) of every point, minimised among equal maxima at every level.
+// Round 3 built this with 8 waves x 32 points per lane and it lost (1.16 vs 1.12 ms: the one wave that must scan issues alone at
+// half the rate of two interleaved ones).  Here 16 waves x 16 points: a touched wave's scan is half as long, the regions are
+// tighter, and the wave's rank reduction is taken only when two lanes tie for the maximum.
+__device__ __forceinline__ unsigned wave_allmin_u(unsigned v) {
+    v = row_allmin_u(v);
+    const unsigned r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+    const unsigned r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    return min(min(r0, r1), min(r2, r3));
+}
+
+#ifdef RF_FPS_STATS
+__device__ unsigned long long g_fps_touched[4096];  // (experiments) touched waves per iteration, summed over the clouds
+#endif
+template <int NT, int PPT, bool EMIT>
+__global__ __launch_bounds__(NT) void fps_sorted_kernel(int n, int m, int npad, const float *__restrict__ inp,
+                                                        const int *__restrict__ sorig, int *__restrict__ out,
+                                                        float *__restrict__ new_xyz) {
+    constexpr int NW = NT / 64;
+    static_assert(NW <= 16, "slot reduction is one 16-lane DPP row");
+    static_assert(PPT >= 2 && (PPT & (PPT - 1)) == 0, "the slots of a lane are ordered by a bitonic network");
+    // a wave's candidate: its maximum and the tie rank of the point that holds it (double-buffered: ONE barrier per iteration).
+    // (The candidates' coordinates riding along, so that the winner's come back from LDS instead of a scalar re-read of the
+    // cloud, measured SLOWER: 0.963 against 0.844 ms at C3 -- five LDS reads per lane behind the barrier and three more indexed
+    // register reads before it cost more than the ~300 cycles of the scalar loads.)
+    __shared__ float slot_d[2][16];
+    __shared__ unsigned slot_r[2][16];
+    __shared__ unsigned short cpos[NT * PPT];  // the c-th real record's sorted position (the sort pads every segment to 64 records)
+    __shared__ int wcnt[NW + 1];
+    const int bi = blockIdx.x;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const float *__restrict__ P = inp + (size_t)bi * n * 3;
+    const int *__restrict__ SO = sorig + (size_t)bi * npad;
+    int *__restrict__ O = out + (size_t)bi * m;
+    // compaction of the real records (orig >= 0), once
+    {
+        int run = 0;
+        for (int base = 0; base < npad; base += NT) {
+            const int p = base + t;
+            const bool real = p < npad && SO[p] >= 0;
+            const unsigned long long mk = __ballot(real);
+            if (lane == 0) wcnt[wave] = __builtin_popcountll(mk);
+            __syncthreads();
+            int before = run;
+            for (int w = 0; w < wave; w++) before += wcnt[w];
+            int tot = 0;
+            for (int w = 0; w < NW; w++) tot += wcnt[w];
+            if (real) cpos[before + __builtin_popcountll(mk & ((1ull << lane) - 1ull))] = (unsigned short)p;
+            run += tot;
+            __syncthreads();
+        }
+    }
+    float px[PPT], py[PPT], pz[PPT], td[PPT];
+    unsigned rk[PPT];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int s = 0; s < PPT; s++) {
+        const int c = t * PPT + s;
+        if (c < n) {
+            // (the coordinates from the cloud itself, through the original index: the winners' coordinates are re-read from there
+            // every iteration, and this pass is what brings the cloud into this XCD's L2 -- read from the sorted copy, a launch that
+            // follows other work paid a miss to HBM per iteration: 0.96 against 0.84 ms behind a ball query)
+            const int k = SO[cpos[c]];
+            px[s] = P[(size_t)k * 3 + 0];
+            py[s] = P[(size_t)k * 3 + 1];
+            pz[s] = P[(size_t)k * 3 + 2];
+            rk[s] = tie_rank(k);
+            lo[0] = fminf(lo[0], px[s]), hi[0] = fmaxf(hi[0], px[s]);
+            lo[1] = fminf(lo[1], py[s]), hi[1] = fmaxf(hi[1], py[s]);
+            lo[2] = fminf(lo[2], pz[s]), hi[2] = fmaxf(hi[2], pz[s]);
+        } else {
+            px[s] = py[s] = pz[s] = 0.f;
+            rk[s] = 0xFFFFFFFFu;
+        }
+    }
+    // the lane's slots in ascending tie rank (bitonic network, static indices, once): the lowest slot that attains the lane's
+    // maximum is then the one the reference's tie order picks, as in fps_reg_kernel -- two VALU per point instead of three
+#pragma unroll
+    for (int k = 2; k <= PPT; k <<= 1) {
+#pragma unroll
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+#pragma unroll
+            for (int i = 0; i < PPT; i++) {
+                const int l = i ^ jj;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const bool sw = up ? rk[i] > rk[l] : rk[i] < rk[l];
+                    const unsigned ra = rk[i], rb = rk[l];
+                    const float xa = px[i], xb = px[l], ya = py[i], yb = py[l], za = pz[i], zb = pz[l];
+                    rk[i] = sw ? rb : ra, rk[l] = sw ? ra : rb;
+                    px[i] = sw ? xb : xa, px[l] = sw ? xa : xb;
+                    py[i] = sw ? yb : ya, py[l] = sw ? ya : yb;
+                    pz[i] = sw ? zb : za, pz[l] = sw ? za : zb;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < PPT; s++) td[s] = rk[s] == 0xFFFFFFFFu ? -1.0f : 1e38f;  // (padding: below every real distance, like the reference's best = -1)
+    // cached: the largest td of the lane's region; the wave's candidate (value, tie rank, coordinates); -2 never wins
+    float lmx = td[0];
+    float wm = -2.0f;
+    unsigned wr = 0xFFFFFFFFu;
+    if (t < 32) {
+        slot_d[t >> 4][t & 15] = -2.0f;
+        slot_r[t >> 4][t & 15] = 0xFFFFFFFFu;
+    }
+    float *__restrict__ NX = EMIT ? new_xyz + (size_t)bi * m * 3 : nullptr;
+    // the samples collect in LDS (cpos is free again: m <= n <= NT * PPT entries) and leave together behind the loop -- indices
+    // and, EMIT, coordinates as coalesced stores of all threads.  (Stored by thread 0 inside the loop, the coordinates cost
+    // 0.13 ms of a 0.84 ms launch: every barrier waits for the previous iteration's stores.)
+    __syncthreads();
+    if (t == 0) cpos[0] = 0;
+    float ox = P[0], oy = P[1], oz = P[2];  // old = 0
+    for (int j = 1; j < m; j++) {
+        const float gx = fmaxf(fmaxf(lo[0] - ox, ox - hi[0]), 0.f);
+        const float gy = fmaxf(fmaxf(lo[1] - oy, oy - hi[1]), 0.f);
+        const float gz = fmaxf(fmaxf(lo[2] - oz, oz - hi[2]), 0.f);
+        const float lb = rf::d2_fma(gx, gy, gz);
+        if (__builtin_amdgcn_ballot_w64(lb < lmx) != 0ull) {  // (uniform; a NaN sample touches nothing: td stays, as min(NaN, td))
+#ifdef RF_FPS_STATS
+            if (lane == 0 && j < 4096) atomicAdd(&g_fps_touched[j], 1ull);
+#endif
+            float mx = -1.0f;
+#pragma unroll
+            for (int s = 0; s < PPT; s++) {
+                td[s] = vmin(rf::d2_fma(px[s] - ox, py[s] - oy, pz[s] - oz), td[s]);
+                if (s & 1) mx = vmax3(mx, td[s - 1], td[s]);
+            }
+            int sidx = 0;  // the lowest slot attaining the lane's maximum = its lowest tie rank
+#pragma unroll
+            for (int s = PPT - 1; s >= 1; s--) sidx = (td[s] == mx) ? s : sidx;
+            sidx = (td[0] == mx) ? 0 : sidx;
+            lmx = mx;
+            wm = wave_allmax(mx);
+            const unsigned long long hl = __ballot(mx == wm);
+            int wl = hl ? __builtin_ctzll(hl) : 0;
+            if (__builtin_popcountll(hl) > 1) {  // (uniform, rare) several lanes tie for the wave's maximum: the lowest rank among their candidates
+                unsigned lr = 0xFFFFFFFFu;
+#pragma unroll
+                for (int s = 0; s < PPT; s++) lr = min(lr, td[s] == mx ? rk[s] : 0xFFFFFFFFu);
+                const unsigned best = wave_allmin_u(mx == wm ? lr : 0xFFFFFFFFu);
+                const unsigned long long bl = __ballot(mx == wm && lr == best);
+                wl = bl ? __builtin_ctzll(bl) : wl;
+            }
+            const int bs = __builtin_amdgcn_readlane(sidx, wl);
+            // the candidate's rank out of lane wl's slot bs: bs is wave-uniform, so the indexed register read is a single move
+            // under s_set_gpr_idx
+            wr = (unsigned)__builtin_amdgcn_readlane((int)rk[bs], wl);
+            if (wm < 0.f) wr = 0xFFFFFFFFu;  // (a wave of padding only)
+        }
+        const int buf = j & 1;
+        if (lane == 0) {
+            slot_d[buf][wave] = wm;
+            slot_r[buf][wave] = wr;
+        }
+        __syncthreads();
+        const float sd = slot_d[buf][lane & 15];
+        const unsigned sr = slot_r[buf][lane & 15];
+        const float gm = row_allmax(sd);
+        const unsigned rank = sd == gm ? sr : 0xFFFFFFFFu;
+        const unsigned gr = __builtin_amdgcn_readfirstlane(row_allmin_u(rank));
+        const int gk = gr == 0xFFFFFFFFu ? 0 : (int)(((gr & 0x3FFFFFu) << 9) | (gr >> 22));
+        ox = P[gk * 3 + 0];  // uniform address: scalar loads
+        oy = P[gk * 3 + 1];
+        oz = P[gk * 3 + 2];
+        if (t == 0) cpos[j] = (unsigned short)gk;
+    }
+    __syncthreads();
+    for (int j = t; j < m; j += NT) {
+        const int gk = cpos[j];
+        O[j] = gk;
+        if (EMIT) {
+            NX[j * 3 + 0] = P[gk * 3 + 0];
+            NX[j * 3 + 1] = P[gk * 3 + 1];
+            NX[j * 3 + 2] = P[gk * 3 + 2];
+        }
+    }
+}
+
 // Fallback for clouds beyond the register-resident limit: running min-distances in the
 // caller's temp buffer (b*n floats), points re-read from global/L2.  Same selection rule.
 __global__ __launch_bounds__(1024) void fps_mem_kernel(int n, int m, const float *__restrict__ inp,
@@ -608,9 +799,47 @@ int fps(int b, int n, int m, const float *inp, float *temp, int *out, float *new
     }
     return RF_OK;
 }
+// FPS over an already sorted cloud (fps_sorted_kernel).  Pays from about 200 samples on (same device: the sort is 26 us, the
+// kernel's own prologue ~10, an iteration 0.27 us shorter than fps_reg's).
+bool fps_sorted_pays(int n, int m) { return n > 8192 && n <= FPS_MAX_REG_POINTS && m >= FPS_SORTED_MIN_SAMPLES && m <= FPS_MAX_REG_POINTS; }
+int fps_sorted(int b, int n, int m, const float *inp, const rfp::Sorted &sv, int *out, float *new_xyz, hipStream_t s) {
+    if (b <= 0 || m <= 0) return RF_OK;
+    if (n <= 8192 || n > FPS_MAX_REG_POINTS || m > FPS_MAX_REG_POINTS || !inp || !out) return RF_EINVAL;  // (the samples collect in LDS)
+    if (new_xyz) {
+        RF_LAUNCH("fps_sorted", (fps_sorted_kernel<1024, 16, true>), dim3(b), dim3(1024), 0, s, n, m, sv.npad, inp, sv.orig, out,
+                  new_xyz);
+    } else {
+        RF_LAUNCH("fps_sorted", (fps_sorted_kernel<1024, 16, false>), dim3(b), dim3(1024), 0, s, n, m, sv.npad, inp, sv.orig, out,
+                  new_xyz);
+    }
+    return RF_OK;
+}
 }  // namespace rfi
 
 extern "C" {
+
+// The op with caller scratch of a stated size: for clouds of 8193..16384 points and >= 192 samples it sorts the cloud into the
+// workspace and runs fps_sorted_kernel (the same indices), otherwise rf_farthestpointsampling's kernels.
+size_t rf_farthestpointsampling_workspace_bytes(int b, int n, int m) {
+    if (b <= 0 || n <= 0) return 0;
+    if (rfi::fps_sorted_pays(n, m)) return rfp::sort_workspace_bytes(b, n);
+    return sizeof(float) * (n > FPS_MAX_REG_POINTS ? (size_t)b * n : 0);
+}
+
+int rf_farthestpointsampling_ws(int b, int n, int m, const float *inp, void *workspace, size_t workspace_bytes, int *out,
+                                rf_stream_t stream) {
+    if (b < 0 || n < 0 || m < 0) return RF_EINVAL;
+    if (b == 0 || m == 0) return RF_OK;
+    if (workspace_bytes < rf_farthestpointsampling_workspace_bytes(b, n, m)) return RF_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    if (n > 0 && rfi::fps_sorted_pays(n, m)) {
+        if (!inp || !out || !workspace) return RF_EINVAL;
+        rfp::Sorted sv;
+        if (int e = rfp::sort_clouds(b, n, inp, workspace, workspace_bytes, s, &sv)) return e;
+        return rfi::fps_sorted(b, n, m, inp, sv, out, nullptr, s);
+    }
+    return rfi::fps(b, n, m, inp, (float *)workspace, out, nullptr, s);
+}
 
 size_t rf_farthestpointsampling_temp_floats(int b, int n) {
     return n > FPS_MAX_REG_POINTS ? (size_t)b * n : 0;
@@ -620,6 +849,32 @@ int rf_farthestpointsampling(int b, int n, int m, const float *inp, float *temp,
                              rf_stream_t stream) {
     return rfi::fps(b, n, m, inp, temp, out, nullptr, (hipStream_t)stream);
 }
+
+// FPS over the sorted cloud (fps_sorted_kernel): workspace = rfp::sorted_bytes(b, n), for clouds of 8193..16384 points.
+size_t rf_farthestpointsampling_sorted_workspace_bytes(int b, int n) {
+    return (b > 0 && n > 8192 && n <= FPS_MAX_REG_POINTS) ? rfp::sort_workspace_bytes(b, n) : 0;
+}
+
+int rf_farthestpointsampling_sorted(int b, int n, int m, int form, const float *inp, void *workspace, size_t workspace_bytes,
+                                    int *out, float *new_xyz, rf_stream_t stream) {
+    if (b < 0 || n < 0 || m < 0) return RF_EINVAL;
+    if (b == 0 || m == 0) return RF_OK;
+    if (n <= 8192 || n > FPS_MAX_REG_POINTS || !inp || !out || !workspace) return RF_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    rfp::Sorted sv;
+    if (int e = rfp::sort_clouds(b, n, inp, workspace, workspace_bytes, s, &sv)) return e;
+    (void)form;
+    return rfi::fps_sorted(b, n, m, inp, sv, out, new_xyz, s);
+}
+
+#ifdef RF_FPS_STATS
+int rf_fps_stats_read(unsigned long long *host) {
+    RF_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fps_touched), sizeof(unsigned long long) * 4096));
+    unsigned long long z[4096] = {};
+    RF_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_fps_touched), z, sizeof(z)));
+    return RF_OK;
+}
+#endif
 
 size_t rf_fps_cluster_state_bytes(int b) {
     return b > 0 ? 16 + sizeof(unsigned long long) * 2 * FPS_CLUSTER_MAXK * (size_t)b : 0;
