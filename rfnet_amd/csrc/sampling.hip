@@ -361,6 +361,9 @@ __device__ __forceinline__ unsigned wave_allmin_u(unsigned v) {
     return min(min(r0, r1), min(r2, r3));
 }
 
+#ifndef RF_FPSS_ABL
+#define RF_FPSS_ABL 0  // (timing ablations of fps_sorted_kernel, experiments only: 1 no re-read of the winner, 2 no wave ever scans)
+#endif
 #ifdef RF_FPS_STATS
 __device__ unsigned long long g_fps_touched[4096];  // (experiments) touched waves per iteration, summed over the clouds
 #endif
@@ -451,6 +454,17 @@ __global__ __launch_bounds__(NT) void fps_sorted_kernel(int n, int m, int npad, 
     }
 #pragma unroll
     for (int s = 0; s < PPT; s++) td[s] = rk[s] == 0xFFFFFFFFu ? -1.0f : 1e38f;  // (padding: below every real distance, like the reference's best = -1)
+    // the coordinates in PAIRS of points for the scan: v_pk_add / v_pk_mul / v_pk_fma take two points per instruction (the same
+    // IEEE operations in the same order: bit-identical distances).  A touched wave scans alone on its SIMD, one instruction every
+    // four cycles whatever it is -- there the packed forms halve the distance work (in a full SIMD they are no faster per element).
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f PX[PPT / 2], PY[PPT / 2], PZ[PPT / 2];
+#pragma unroll
+    for (int h = 0; h < PPT / 2; h++) {
+        PX[h] = v2f{px[2 * h], px[2 * h + 1]};
+        PY[h] = v2f{py[2 * h], py[2 * h + 1]};
+        PZ[h] = v2f{pz[2 * h], pz[2 * h + 1]};
+    }
     // cached: the largest td of the lane's region; the wave's candidate (value, tie rank, coordinates); -2 never wins
     float lmx = td[0];
     float wm = -2.0f;
@@ -471,15 +485,18 @@ __global__ __launch_bounds__(NT) void fps_sorted_kernel(int n, int m, int npad, 
         const float gy = fmaxf(fmaxf(lo[1] - oy, oy - hi[1]), 0.f);
         const float gz = fmaxf(fmaxf(lo[2] - oz, oz - hi[2]), 0.f);
         const float lb = rf::d2_fma(gx, gy, gz);
-        if (__builtin_amdgcn_ballot_w64(lb < lmx) != 0ull) {  // (uniform; a NaN sample touches nothing: td stays, as min(NaN, td))
+        if (RF_FPSS_ABL != 2 && __builtin_amdgcn_ballot_w64(lb < lmx) != 0ull) {  // (uniform; a NaN sample touches nothing: td stays, as min(NaN, td))
 #ifdef RF_FPS_STATS
             if (lane == 0 && j < 4096) atomicAdd(&g_fps_touched[j], 1ull);
 #endif
             float mx = -1.0f;
 #pragma unroll
-            for (int s = 0; s < PPT; s++) {
-                td[s] = vmin(rf::d2_fma(px[s] - ox, py[s] - oy, pz[s] - oz), td[s]);
-                if (s & 1) mx = vmax3(mx, td[s - 1], td[s]);
+            for (int h = 0; h < PPT / 2; h++) {
+                const v2f dx = PX[h] - ox, dy = PY[h] - oy, dz = PZ[h] - oz;
+                const v2f d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));  // (rf::d2_fma's order)
+                td[2 * h] = vmin(d2.x, td[2 * h]);
+                td[2 * h + 1] = vmin(d2.y, td[2 * h + 1]);
+                mx = vmax3(mx, td[2 * h], td[2 * h + 1]);
             }
             int sidx = 0;  // the lowest slot attaining the lane's maximum = its lowest tie rank
 #pragma unroll
@@ -515,9 +532,13 @@ __global__ __launch_bounds__(NT) void fps_sorted_kernel(int n, int m, int npad, 
         const unsigned rank = sd == gm ? sr : 0xFFFFFFFFu;
         const unsigned gr = __builtin_amdgcn_readfirstlane(row_allmin_u(rank));
         const int gk = gr == 0xFFFFFFFFu ? 0 : (int)(((gr & 0x3FFFFFu) << 9) | (gr >> 22));
+#if RF_FPSS_ABL == 1  /* timing ablation: no re-read of the winner */
+        ox = (float)(gk & 1023) * 0.0009765625f, oy = (float)((gk >> 4) & 1023) * 0.0009765625f, oz = (float)((gk >> 2) & 1023) * 0.0009765625f;
+#else
         ox = P[gk * 3 + 0];  // uniform address: scalar loads
         oy = P[gk * 3 + 1];
         oz = P[gk * 3 + 2];
+#endif
         if (t == 0) cpos[j] = (unsigned short)gk;
     }
     __syncthreads();
