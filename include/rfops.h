@@ -174,8 +174,8 @@ size_t rf_fps_cluster_state_bytes(int b);
 int rf_farthestpointsampling_cluster(int b, int n, int m, int k, int static_map, const float *inp, void *state,
                                      int *out, rf_stream_t stream);
 
-/* The op with caller scratch of a stated size -- the entry point a binding should prefer: for clouds of 8193..16384 points and
- * at least 192 samples it sorts the cloud into the workspace and samples over the sorted cloud (rf_farthestpointsampling_sorted
+/* The op with caller scratch of a stated size -- the entry point a binding should prefer: for clouds of 4097..16384 points from
+ * 256 samples on (2049..4096 points: from 512) it sorts the cloud into the workspace and samples over the sorted cloud (rf_farthestpointsampling_sorted
  * below: the same indices, iterations a quarter shorter), otherwise it is rf_farthestpointsampling with `workspace` as `temp`.
  * workspace: rf_farthestpointsampling_workspace_bytes(b, n, m) bytes, 16-byte aligned (may be NULL when that is 0). */
 size_t rf_farthestpointsampling_workspace_bytes(int b, int n, int m);
@@ -184,7 +184,7 @@ int rf_farthestpointsampling_ws(int b, int n, int m, const float *inp, void *wor
 
 /* The same op (same indices, bit for bit) over the spatially sorted cloud: the call sorts the cloud into `workspace`
  * (rf_farthestpointsampling_sorted_workspace_bytes(b, n) bytes, 16-byte aligned) and a new sample then only re-scans the
- * regions it can still change (sampling.hip fps_sorted_kernel).  8192 < n <= 16384, m <= 16384.  form: reserved (0).
+ * regions it can still change (sampling.hip fps_sorted_kernel).  1024 < n <= 16384, m <= the kernel's capacity (1024 x 2, 4, 8 or 16 points: the power of two that holds n).  form: reserved (0).
  * new_xyz (b, m, 3), may be NULL: the samples' coordinates. */
 size_t rf_farthestpointsampling_sorted_workspace_bytes(int b, int n);
 int rf_farthestpointsampling_sorted(int b, int n, int m, int form, const float *inp, void *workspace,

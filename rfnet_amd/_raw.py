@@ -458,7 +458,7 @@ def farthest_point_sample_reg(npoint, inp):
 @H.on_input_device
 def farthest_point_sample_sorted(npoint, inp, form=0, with_xyz=False):
     """farthest_point_sample over the spatially sorted cloud (sampling.hip fps_sorted_kernel): the same indices, for clouds of
-    8193..16384 points.  -> idx (b, npoint) [, new_xyz (b, npoint, 3)]"""
+    1025..16384 points.  -> idx (b, npoint) [, new_xyz (b, npoint, 3)]"""
     npoint = int(npoint)
     if npoint <= 0:
         raise H.invalid("FarthestPointSample expects positive npoint")

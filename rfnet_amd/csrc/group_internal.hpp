@@ -12,7 +12,7 @@ namespace rfi {
 // n exceeds the register-resident limit (rf_farthestpointsampling_temp_floats), NULL otherwise.
 int fps(int b, int n, int m, const float *inp, float *temp, int *out, float *new_xyz, hipStream_t s);
 
-// The same op over a cloud that is already sorted (fps_sorted_kernel: clouds of 8193..16384 points): the same indices; a new
+// The same op over a cloud that is already sorted (fps_sorted_kernel: clouds of 1025..16384 points): the same indices; a new
 // sample only re-scans the regions it can still change.  fps_sorted_pays: from how many samples on the sort is repaid.
 bool fps_sorted_pays(int n, int m);
 int fps_sorted(int b, int n, int m, const float *inp, const rfp::Sorted &sv, int *out, float *new_xyz, hipStream_t s);

@@ -8,7 +8,7 @@
 //     gather launch;
 //   * the ball query runs over the sorted dataset's boxes and writes the grouped coordinates with the index rows (the row is
 //     in LDS): no group launch for xyz;
-//   * the dataset's sort serves BOTH ops where FPS runs over the sorted cloud (8193..16384 points, >= 192 samples); elsewhere it
+//   * the dataset's sort serves BOTH ops where FPS runs over the sorted cloud (rfi::fps_sorted_pays); elsewhere it
 //     does not depend on FPS: given a second stream it runs BESIDE FPS and costs the chain nothing.
 // So the pass is two launches on the caller's stream and one on the auxiliary stream.  Results are those of the four
 // separate ops, bit for bit (tests/test_gpu_sample_group.py).

@@ -22,7 +22,7 @@
 namespace {
 
 constexpr int FPS_MAX_REG_POINTS = 16384;
-constexpr int FPS_SORTED_MIN_SAMPLES = 192;  // from here on the sorted form's shorter iterations repay its sort
+constexpr int FPS_SORTED_MIN_POINTS = 1024;   // fps_sorted_kernel: 1024 threads x 2, 4, 8 or 16 points per lane
 
 // tie rank of point k under the reference's 512-thread layout: lower is preferred
 __device__ __forceinline__ unsigned tie_rank(int k) { return ((unsigned)(k & 511) << 22) | (unsigned)(k >> 9); }
@@ -820,27 +820,42 @@ int fps(int b, int n, int m, const float *inp, float *temp, int *out, float *new
     }
     return RF_OK;
 }
-// FPS over an already sorted cloud (fps_sorted_kernel).  Pays from about 200 samples on (same device: the sort is 26 us, the
-// kernel's own prologue ~10, an iteration 0.27 us shorter than fps_reg's).
-bool fps_sorted_pays(int n, int m) { return n > 8192 && n <= FPS_MAX_REG_POINTS && m >= FPS_SORTED_MIN_SAMPLES && m <= FPS_MAX_REG_POINTS; }
+// FPS over an already sorted cloud (fps_sorted_kernel).  Pays from a few hundred samples on: the sort is 18-26 us, the kernel's own
+// prologue ~10, an iteration 0.1-0.3 us shorter than fps_reg's.
+// (same device, batch 32, uniform clouds, tools/ab_fps_sizes.py -- fps_reg against sort + fps_sorted, ms: 16384 points 256 samples
+// 0.284 / 0.275, 1024 1.118 / 0.824; 8192: 256 0.212 / 0.210, 1024 0.835 / 0.676; 4096: 256 0.164 / 0.170, 512 0.322 / 0.302, 1024
+// 0.635 / 0.563; 2048: 1024 0.538 / 0.519)
+bool fps_sorted_pays(int n, int m) {
+    if (n > FPS_MAX_REG_POINTS || m > n) return false;
+    return (n > 4096 && m >= 256) || (n > 2048 && m >= 512);
+}
 int fps_sorted(int b, int n, int m, const float *inp, const rfp::Sorted &sv, int *out, float *new_xyz, hipStream_t s) {
     if (b <= 0 || m <= 0) return RF_OK;
-    if (n <= 8192 || n > FPS_MAX_REG_POINTS || m > FPS_MAX_REG_POINTS || !inp || !out) return RF_EINVAL;  // (the samples collect in LDS)
-    if (new_xyz) {
-        RF_LAUNCH("fps_sorted", (fps_sorted_kernel<1024, 16, true>), dim3(b), dim3(1024), 0, s, n, m, sv.npad, inp, sv.orig, out,
-                  new_xyz);
-    } else {
-        RF_LAUNCH("fps_sorted", (fps_sorted_kernel<1024, 16, false>), dim3(b), dim3(1024), 0, s, n, m, sv.npad, inp, sv.orig, out,
-                  new_xyz);
+    if (n <= FPS_SORTED_MIN_POINTS || n > FPS_MAX_REG_POINTS || !inp || !out) return RF_EINVAL;
+    int ppt = 2;
+    while (1024 * ppt < n) ppt *= 2;
+    if (m > 1024 * ppt) return RF_EINVAL;  // (the samples collect in LDS, in the table of the kernel's prologue)
+#define FPSS_CASE(PPT)                                                                                                         \
+    if (ppt == PPT) {                                                                                                          \
+        if (new_xyz) {                                                                                                         \
+            RF_LAUNCH("fps_sorted", (fps_sorted_kernel<1024, PPT, true>), dim3(b), dim3(1024), 0, s, n, m, sv.npad, inp, sv.orig, \
+                      out, new_xyz);                                                                                           \
+        } else {                                                                                                               \
+            RF_LAUNCH("fps_sorted", (fps_sorted_kernel<1024, PPT, false>), dim3(b), dim3(1024), 0, s, n, m, sv.npad, inp, sv.orig, \
+                      out, new_xyz);                                                                                           \
+        }                                                                                                                      \
+        return RF_OK;                                                                                                          \
     }
-    return RF_OK;
+    FPSS_CASE(2) FPSS_CASE(4) FPSS_CASE(8) FPSS_CASE(16)
+#undef FPSS_CASE
+    return RF_EINVAL;
 }
 }  // namespace rfi
 
 extern "C" {
 
-// The op with caller scratch of a stated size: for clouds of 8193..16384 points and >= 192 samples it sorts the cloud into the
-// workspace and runs fps_sorted_kernel (the same indices), otherwise rf_farthestpointsampling's kernels.
+// The op with caller scratch of a stated size: where rfi::fps_sorted_pays (clouds of more than 4096 points from 256 samples, of more
+// than 2048 from 512) it sorts the cloud into the workspace and runs fps_sorted_kernel (the same indices), otherwise rf_farthestpointsampling's kernels.
 size_t rf_farthestpointsampling_workspace_bytes(int b, int n, int m) {
     if (b <= 0 || n <= 0) return 0;
     if (rfi::fps_sorted_pays(n, m)) return rfp::sort_workspace_bytes(b, n);
@@ -873,14 +888,14 @@ int rf_farthestpointsampling(int b, int n, int m, const float *inp, float *temp,
 
 // FPS over the sorted cloud (fps_sorted_kernel): workspace = rfp::sorted_bytes(b, n), for clouds of 8193..16384 points.
 size_t rf_farthestpointsampling_sorted_workspace_bytes(int b, int n) {
-    return (b > 0 && n > 8192 && n <= FPS_MAX_REG_POINTS) ? rfp::sort_workspace_bytes(b, n) : 0;
+    return (b > 0 && n > FPS_SORTED_MIN_POINTS && n <= FPS_MAX_REG_POINTS) ? rfp::sort_workspace_bytes(b, n) : 0;
 }
 
 int rf_farthestpointsampling_sorted(int b, int n, int m, int form, const float *inp, void *workspace, size_t workspace_bytes,
                                     int *out, float *new_xyz, rf_stream_t stream) {
     if (b < 0 || n < 0 || m < 0) return RF_EINVAL;
     if (b == 0 || m == 0) return RF_OK;
-    if (n <= 8192 || n > FPS_MAX_REG_POINTS || !inp || !out || !workspace) return RF_EINVAL;
+    if (n <= FPS_SORTED_MIN_POINTS || n > FPS_MAX_REG_POINTS || !inp || !out || !workspace) return RF_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     rfp::Sorted sv;
     if (int e = rfp::sort_clouds(b, n, inp, workspace, workspace_bytes, s, &sv)) return e;

@@ -308,9 +308,10 @@ def test_fps_cluster_form_is_bit_identical(b, n, m):
                 assert torch.equal(got, want), (kind, k, static_map)
 
 
-@pytest.mark.parametrize("b,n,m", [(4, 16384, 300), (3, 8193, 64), (2, 12001, 1200), (5, 16000, 40), (1, 9000, 9000)])
+@pytest.mark.parametrize("b,n,m", [(4, 16384, 300), (3, 8193, 64), (2, 12001, 1200), (5, 16000, 40), (1, 9000, 9000), (3, 1025, 700),
+                                   (2, 2048, 2048), (3, 3000, 600), (2, 4097, 513), (2, 7000, 33)])
 def test_fps_over_the_sorted_cloud_is_bit_identical(orc, b, n, m):
-    """rf_farthestpointsampling_sorted (sampling.hip fps_sorted_kernel: the cloud in sort-tile-recursive order, a lane's 16 or 32
+    """rf_farthestpointsampling_sorted (sampling.hip fps_sorted_kernel: the cloud in sort-tile-recursive order, a lane's 2 to 16
     consecutive points skipped while the new sample is provably too far to lower any of their running minima): the same indices
     as farthest_point_sample and the samples' coordinates, on uniform clouds, lattices (masses of exact ties: the reference's
     tie order through the ORIGINAL indices), duplicated points, a cloud with an outlier and a cloud with a NaN point; one cloud
@@ -326,10 +327,10 @@ def test_fps_over_the_sorted_cloud_is_bit_identical(orc, b, n, m):
     for kind, a in kinds.items():
         x = cu(a.astype(np.float32))
         want = R.farthest_point_sample(m, x)
-        for form in (0, 1):
-            got, nx = R.farthest_point_sample_sorted(m, x, form=form, with_xyz=True)
-            assert torch.equal(got, want), (kind, form)
-            assert torch.equal(nx.nan_to_num(nan=-7.0), R.gather_point(x, want).nan_to_num(nan=-7.0)), (kind, form)
+        got, nx = R.farthest_point_sample_sorted(m, x, with_xyz=True)
+        assert torch.equal(got, want), kind
+        assert torch.equal(nx.nan_to_num(nan=-7.0), R.gather_point(x, want).nan_to_num(nan=-7.0)), kind
+        assert torch.equal(R.farthest_point_sample_reg(m, x), want), kind  # (whichever form the op itself chose)
     if m <= 300:
         a = kinds["lattice"].astype(np.float32)
         assert np.array_equal(R.farthest_point_sample_sorted(m, cu(a)).cpu().numpy()[:1], orc.farthest_point_sample(m, a[:1]))
