@@ -47,6 +47,10 @@ constexpr float kLog2e = 1.44269502f;  // 0x3FB8AA3B, the constant __expf multip
 #ifndef RFA_MC_NT
 #define RFA_MC_NT 0
 #endif
+#ifndef RFA_PK
+#define RFA_PK 1
+#endif
+typedef float am_v2f __attribute__((ext_vector_type(2)));
 constexpr int TPB = 256;
 constexpr int LVG = 16;             // levels per group in the materialisation kernel
 constexpr int MAX_LEVELS = 64;
@@ -157,14 +161,46 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
     const float *__restrict__ S1 = remainR + (size_t)bi * stride;
     const int c0 = seg * seglen, c1 = c0 + seglen;  // multiples of SUB, inside the padded range
     // one column (its coordinates and scalars wave-uniform) against the lane's RPT rows
+    // (RFA_PK: the lane's two rows as the halves of packed fp32 operations, as in am_rowl_kernel -- bit-identical sums.  Where it
+    // pays: P3 alone 41.6 -> 35.2 us at C4, P1 alone +-0; the FUSED P3 + P1 sweep -- four exponentials per column -- got 6 % slower
+    // and keeps the scalar form unless RFA_PK is 2; with only its distances packed: +-0)
+    constexpr bool PK = RPT == 2 && (RFA_PK == 2 || (RFA_PK != 0 && !(HAS_P3 && P1 != 0)));
+    am_v2f X1 = {x1[0], x1[RPT - 1]}, Y1 = {y1[0], y1[RPT - 1]}, Z1 = {z1[0], z1[RPT - 1]}, RL = {rl[0], rl[RPT - 1]};
+    am_v2f ACC3 = {acc3[0], acc3[RPT - 1]}, ACC1 = {acc1[0], acc1[RPT - 1]};
     auto column = [&](float cx, float cy, float cz, float s3u, float s1u) {
+        if constexpr (PK) {
+            const am_v2f dx = cx - X1, dy = cy - Y1, dz = cz - Z1;
+            const am_v2f d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));  // (rf::d2_fma's order)
+            auto ex2 = [](am_v2f a) { return am_v2f{fast_exp2(a.x), fast_exp2(a.y)}; };
+            if (SKIP == 1) {
+                if (__ballot(d2.x < tskip || d2.y < tskip) == 0ull) return;  // (uniform) every weight of this column is exactly 0 in this wave
+                asm volatile("; column kept");
+            }
+            if (SKIP != 0 && HAS_P3) {  // the two parts under their own tests
+                ACC1 = __builtin_elementwise_fma(ex2(d2 * c_cur), am_v2f{s1u, s1u}, ACC1);
+                if (__ballot(d2.x < tskip_prev || d2.y < tskip_prev) != 0ull) {  // (uniform)
+                    asm volatile("; previous level kept");
+                    ACC3 = __builtin_elementwise_fma(RL * ex2(d2 * c_prev), am_v2f{s3u, s3u}, ACC3);
+                }
+                return;
+            }
+            am_v2f e3 = {0.f, 0.f};
+            if (HAS_P3) {
+                e3 = ex2(d2 * c_prev);
+                ACC3 = __builtin_elementwise_fma(RL * e3, am_v2f{s3u, s3u}, ACC3);
+            }
+            if (HAS_P1) ACC1 = __builtin_elementwise_fma(P1 == 2 ? am_v2f{1.0f, 1.0f} : (P1 == 3 ? e3 : ex2(d2 * c_cur)), am_v2f{s1u, s1u}, ACC1);
+            return;
+        }
         float d2[RPT];
         bool near = false, near_prev = false;
+        {
 #pragma unroll
-        for (int r = 0; r < RPT; r++) {
-            d2[r] = rf::d2_fma(cx - x1[r], cy - y1[r], cz - z1[r]);
-            near = near || d2[r] < tskip;
-            near_prev = near_prev || d2[r] < tskip_prev;
+            for (int r = 0; r < RPT; r++) {
+                d2[r] = rf::d2_fma(cx - x1[r], cy - y1[r], cz - z1[r]);
+                near = near || d2[r] < tskip;
+                near_prev = near_prev || d2[r] < tskip_prev;
+            }
         }
         if (SKIP == 1) {
             if (__ballot(near) == 0ull) return;  // (uniform) every weight of this column is exactly 0 in this wave
@@ -253,6 +289,10 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
             for (int u = 0; u < SUB; u++) column(cb[u * 3], cb[u * 3 + 1], cb[u * 3 + 2], s3[u], s1[u]);
         }
     }
+    if constexpr (PK) {
+        acc3[0] = ACC3.x, acc3[RPT - 1] = ACC3.y;
+        acc1[0] = ACC1.x, acc1[RPT - 1] = ACC1.y;
+    }
 #pragma unroll
     for (int r = 0; r < RPT; r++) {
         part3[seg][r * 64 + lane] = acc3[r];
@@ -310,7 +350,25 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
     const float *__restrict__ C = xyz1p + (size_t)bi * xyz1p_stride;
     const float *__restrict__ S = ratioL + (size_t)bi * stride;
     const int c0 = seg * seglen, c1 = c0 + seglen;
+    // RFA_PK: the lane's two rows as the two halves of packed fp32 operations (v_pk_add / v_pk_mul / v_pk_fma: the same IEEE
+    // operations in the same order -- bit-identical sums): 6 instead of 16 vector instructions per column beside the exponentials
+    am_v2f X2 = {x2[0], x2[RPT - 1]}, Y2 = {y2[0], y2[RPT - 1]}, Z2 = {z2[0], z2[RPT - 1]}, ACC = {0.f, 0.f};
     auto column = [&](float cx, float cy, float cz, float su) {
+        if constexpr (RPT == 2 && RFA_PK) {
+            const am_v2f dx = X2 - cx, dy = Y2 - cy, dz = Z2 - cz;
+            const am_v2f d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));  // (rf::d2_fma's order)
+            if (SKIP) {
+                if (__ballot(d2.x < tskip || d2.y < tskip) == 0ull) return;  // (uniform)
+                asm volatile("; column kept");
+            }
+            am_v2f e = {1.0f, 1.0f};
+            if (!ZERO) {
+                const am_v2f a = d2 * c_cur;
+                e = am_v2f{fast_exp2(a.x), fast_exp2(a.y)};
+            }
+            ACC = __builtin_elementwise_fma(e, am_v2f{su, su}, ACC);
+            return;
+        }
         float d2[RPT];
         bool near = false;
 #pragma unroll
@@ -372,6 +430,10 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
 #pragma unroll
             for (int u = 0; u < SUB; u++) column(cb[u * 3], cb[u * 3 + 1], cb[u * 3 + 2], sc[u]);
         }
+    }
+    if constexpr (RPT == 2 && RFA_PK) {
+        acc[0] = ACC.x;
+        acc[RPT - 1] = ACC.y;
     }
 #pragma unroll
     for (int r = 0; r < RPT; r++) part[seg][r * 64 + lane] = acc[r];
