@@ -50,6 +50,12 @@ constexpr float kLog2e = 1.44269502f;  // 0x3FB8AA3B, the constant __expf multip
 #ifndef RFA_PK
 #define RFA_PK 1
 #endif
+#ifndef RFA_SKIP2
+#define RFA_SKIP2 0
+#endif
+#ifndef RFA_PP_DENSE
+#define RFA_PP_DENSE 1  // the packed sweeps take their column operands through two scalar register sets in turn, as the skipping sweeps
+#endif
 typedef float am_v2f __attribute__((ext_vector_type(2)));
 constexpr int TPB = 256;
 constexpr int LVG = 16;             // levels per group in the materialisation kernel
@@ -164,7 +170,7 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
     // (RFA_PK: the lane's two rows as the halves of packed fp32 operations, as in am_rowl_kernel -- bit-identical sums.  Where it
     // pays: P3 alone 41.6 -> 35.2 us at C4, P1 alone +-0; the FUSED P3 + P1 sweep -- four exponentials per column -- got 6 % slower
     // and keeps the scalar form unless RFA_PK is 2; with only its distances packed: +-0)
-    constexpr bool PK = RPT == 2 && (RFA_PK == 2 || (RFA_PK != 0 && !(HAS_P3 && P1 != 0)));
+    constexpr bool PK = RPT == 2 && RFA_PK != 0 && (SKIP == 0 || RFA_PK == 2);
     am_v2f X1 = {x1[0], x1[RPT - 1]}, Y1 = {y1[0], y1[RPT - 1]}, Z1 = {z1[0], z1[RPT - 1]}, RL = {rl[0], rl[RPT - 1]};
     am_v2f ACC3 = {acc3[0], acc3[RPT - 1]}, ACC1 = {acc1[0], acc1[RPT - 1]};
     auto column = [&](float cx, float cy, float cz, float s3u, float s1u) {
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
             if (HAS_P1) acc1[r] = fmaf(P1 == 2 ? 1.0f : (P1 == 3 ? e3 : fast_exp2(d2[r] * c_cur)), s1u, acc1[r]);
         }
     };
-    if constexpr (SKIP != 0) {
+    if constexpr (SKIP != 0 || (RFA_PP_DENSE && PK)) {
         // The skipping sweeps issue 14 VALU per column and lane pair against ~10 scalar instructions -- and a CU has ONE scalar
         // unit for its 16 waves: they are bound by IT (an x-only pre-test that removed 4 VALU from 50 % of the columns changed
         // nothing).  So here the column operands go through TWO scalar register sets used in turn instead of load-then-copy (5
@@ -352,9 +358,10 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
     const int c0 = seg * seglen, c1 = c0 + seglen;
     // RFA_PK: the lane's two rows as the two halves of packed fp32 operations (v_pk_add / v_pk_mul / v_pk_fma: the same IEEE
     // operations in the same order -- bit-identical sums): 6 instead of 16 vector instructions per column beside the exponentials
+    constexpr bool PKL = RPT == 2 && RFA_PK != 0 && (!SKIP || RFA_PK == 2);
     am_v2f X2 = {x2[0], x2[RPT - 1]}, Y2 = {y2[0], y2[RPT - 1]}, Z2 = {z2[0], z2[RPT - 1]}, ACC = {0.f, 0.f};
     auto column = [&](float cx, float cy, float cz, float su) {
-        if constexpr (RPT == 2 && RFA_PK) {
+        if constexpr (PKL) {
             const am_v2f dx = X2 - cx, dy = Y2 - cy, dz = Z2 - cz;
             const am_v2f d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));  // (rf::d2_fma's order)
             if (SKIP) {
@@ -383,7 +390,7 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
 #pragma unroll
         for (int r = 0; r < RPT; r++) acc[r] = fmaf(ZERO ? 1.0f : fast_exp2(d2[r] * c_cur), su, acc[r]);
     };
-    if constexpr (SKIP) {  // two scalar register sets in turn: the skipping sweeps are bound by the CU's scalar unit (am_rowk_kernel)
+    if constexpr (SKIP || (RFA_PP_DENSE && PKL)) {  // two scalar register sets in turn (am_rowk_kernel)
         const cfloat *Cc = (const cfloat *)C, *Sc = (const cfloat *)S;
         float xa[3 * SUB], sa[SUB], xb[3 * SUB], sb[SUB];
 #define RFA_FETCH_L(xs, ts, c)                                                               \
@@ -431,7 +438,7 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
             for (int u = 0; u < SUB; u++) column(cb[u * 3], cb[u * 3 + 1], cb[u * 3 + 2], sc[u]);
         }
     }
-    if constexpr (RPT == 2 && RFA_PK) {
+    if constexpr (PKL) {
         acc[0] = ACC.x;
         acc[RPT - 1] = ACC.y;
     }
@@ -1669,8 +1676,9 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
             const float *pL = ratios + (size_t)(v - 1) * L.V, *pR = pL + L.npad;
             RF_LAUNCH("am_p3p1", (am_rowk_kernel<true, 1, RPT, 1>), gks, dim3(64 * segk), 0, s,
                       AM_ROWK_ARGS(pR, pL, lc.c[v - 1]));
-        } else if (permA && v > 0 && !zero && lc.c[v] < 0.f && lc.c[v - 1] < lc.c[v] && skip_t(v - 1) <= kCullMaxT) {
-            // this level is too broad to drop columns, the fused P3's level is not
+        } else if (RFA_SKIP2 && permA && v > 0 && !zero && lc.c[v] < 0.f && lc.c[v - 1] < lc.c[v] && skip_t(v - 1) <= kCullMaxT) {
+            // this level is too broad to drop columns, the fused P3's level is not.  (Off since the dense sweep runs packed:
+            // 54.7 us for level 3 at C4 this way against 47 for the dense form.)
             const float *pL = ratios + (size_t)(v - 1) * L.V, *pR = pL + L.npad;
             RF_LAUNCH("am_p3p1", (am_rowk_kernel<true, 1, RPT, 2>), gks, dim3(64 * segk), 0, s,
                       AM_ROWK_ARGS(pR, pL, lc.c[v - 1]));
