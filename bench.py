@@ -68,7 +68,7 @@ if ROOT not in sys.path:
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector peak
 # VALU instructions per (row, column) pair of every launch of approx_match's reference schedule (10 levels, the last with
 # multiplier 0), counted in rfnet_amd/csrc/approxmatch.hip and confirmed by SQ_INSTS_VALU (profiles/r04_rocprofv3_summary.txt):
-# (launches, plain VALU, v_exp_f32) -- d2 is 6, an exponential term is mul + exp (+ mul by the row ratio) + fma
+# (launches, plain VALU, v_exp_f32[, packed VALU]) per pair -- d2 is 6, an exponential term is mul + exp (+ mul by the row ratio) + fma
 EMD_LAUNCH_MIX = {
     # round 5: the sweeps of the three sharp levels take their rows in spatial order and drop, after the distance (6) and the
     # test (~1), the columns whose weights are exactly 0 for the whole wave; a wave keeps 0.088 / 0.185 / 0.418 of its columns at
@@ -78,14 +78,16 @@ EMD_LAUNCH_MIX = {
     "am_p2, level 0 (skipping)": (1, 7 + 0.088 * 2, 0.088),
     "am_p2, level 1 (skipping)": (1, 7 + 0.185 * 2, 0.185),
     "am_p2, level 2 (skipping)": (1, 7 + 0.418 * 2, 0.418),
-    "am_p2, levels 3-6": (4, 8, 1),
+    # round 5, late: the DENSE sweeps run their lane's two rows as the halves of packed fp32 operations (v_pk_add / v_pk_mul /
+    # v_pk_fma: 4th field = packed instructions per pair, two pairs per instruction): P2 8 packed per two pairs, the fused
+    # P3 + P1 11, P3 alone 9; level 3's fused sweep is dense again (packed, it beats the form with the conditional P3)
+    "am_p2, levels 3-6 (packed)": (4, 0, 1, 4.0),
     "am_p3p1, levels 0+1 (skipping, P3 under its own test)": (1, 7 + 0.185 * 2 + 0.088 * 3, 0.185 + 0.088),
     "am_p3p1, levels 1+2 (skipping)": (1, 7 + 0.418 * 2 + 0.185 * 3, 0.418 + 0.185),
-    "am_p3p1, levels 2+3 (only the P3 part conditional)": (1, 6.5 + 2 + 0.418 * 3, 1 + 0.418),
-    "am_p3p1, level pairs 3+4, 4+5, 5+6": (3, 11, 2),
+    "am_p3p1, level pairs 2+3, 3+4, 4+5, 5+6 (packed)": (4, 0, 2, 5.5),
     # round 5, late: levels 7, 8 and 9 (-1, -0.25, 0) are not swept any more -- their row sums come from a truncated Taylor expansion
     # about the clouds' centre (emd_fgt.hip: 7 small fp64 launches, `emd.roofline.expanded_levels`), so the P3 of level 6 runs alone
-    "am_p3 (level 6 alone)": (1, 9, 1),
+    "am_p3 (level 6 alone, packed)": (1, 0, 1, 4.5),
     # round 5: levels 1, 3, 5, 7 take their weight from the next level's by two squarings (2 mul instead of mul + exp)
     # ... and the sharpest level is evaluated only where some column of the wave is within its cut-off of the row (14 % of the
     # (wave, row) pairs at C4: 1 - (1 - 0.0023)^64)
@@ -101,14 +103,16 @@ def emd_issue_floor_ms(eb, n, m):
         with open(os.path.join(ROOT, "profiles", "issue_costs.json")) as f:
             ic = json.load(f)
         c = ic["cycles_per_wave_instruction_per_simd"]
-        cyc = sum(k * (p * c["vop2_f32"] + e * c["v_exp_f32"]) for k, p, e in EMD_LAUNCH_MIX.values())
+        mix = [(v + (0.0,))[:4] for v in EMD_LAUNCH_MIX.values()]
+        cyc = sum(k * (p * c["vop2_f32"] + e * c["v_exp_f32"] + q * c["v_pk_f32"]) for k, p, e, q in mix)
         nonadd = 9.0 * c["emd_column_mix_9_instr"] / (8.0 * c["vop2_f32"] + c["v_exp_f32"])
         add_ms = cyc * (eb * n * m / 64.0) / 1024.0 / (ic["clock_ghz"] * 1e9) * 1e3
     except (OSError, ValueError, KeyError, TypeError, ZeroDivisionError):  # a missing or reshaped constants file costs the roof, not the bench
         return None
     return {"additive_ms": add_ms, "mix_ms": add_ms * nonadd, "non_additivity": nonadd,
-            "valu_per_pair": sum(k * (p + e) for k, p, e in EMD_LAUNCH_MIX.values()),
-            "exp_per_pair": sum(k * e for k, p, e in EMD_LAUNCH_MIX.values()),
+            "valu_per_pair": sum(k * (p + e + q) for k, p, e, q in mix),
+            "exp_per_pair": sum(k * e for k, p, e, q in mix),
+            "packed_per_pair": sum(k * q for k, p, e, q in mix),
             "constants": "profiles/issue_costs.json (tools/ubench/valu_rate.hip, profiles/r04_valu_rate.txt): not measured in this run"}
 
 HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: HBM3E spec peak
@@ -827,6 +831,7 @@ def main():
             "roofline": {
                 "bound": "valu+trans", "kernel": "am_p1 + am_p2 + am_p3p1 + am_p3 + am_match (approx_match: 15 swept launches; + 8 launches of the expanded levels, the row sort)",
                 "lane_ops_per_pair": efl["valu_per_pair"] if efl else None, "exp_per_pair": efl["exp_per_pair"] if efl else None,
+                "packed_instructions_per_pair": efl["packed_per_pair"] if efl else None,
                 "achieved": lane_ops / (am_kernel_ms * 1e-3) / 1e12, "unit": "T lane-ops/s",
                 "issue_floor_ms": efl["mix_ms"] if efl else None,
                 "issue_floor_additive_ms": efl["additive_ms"] if efl else None,
@@ -847,7 +852,8 @@ def main():
                                      "what": "the schedule with every pair of every level evaluated (round 5 before the skipping sweeps "
                                              "and the expanded levels); the skipped terms are exact zeros"},
                 "note": "frac = issue floor derived from EXECUTED instructions (counted, with the model's keep fractions for the "
-                        "skipping sweeps) x measured issue costs / measured kernel time; "
+                        "skipping sweeps; a packed instruction = two fp32 operations per lane, counted once and priced at its own measured "
+                        "issue cost; the 1.155 non-additivity factor was measured on the scalar column mix) x measured issue costs / measured kernel time; "
                         "frac_of_fp32_peak counts 2 flop per lane-op against the 157.3 TFLOP/s vector peak"},
             "metric": "EMD iters/sec (approx_match + match_cost batch calls)",
             "value": world * emd_steps / dt_emd, "unit": "calls/s", "ms_per_call": dt_emd / emd_steps * 1e3,
