@@ -77,14 +77,13 @@ EMD_LAUNCH_MIX = {
     "am_p1 (level 0, skipping)": (1, 7 + 0.088 * 2, 0.088),
     "am_p2, level 0 (skipping)": (1, 7 + 0.088 * 2, 0.088),
     "am_p2, level 1 (skipping)": (1, 7 + 0.185 * 2, 0.185),
-    "am_p2, level 2 (skipping)": (1, 7 + 0.418 * 2, 0.418),
     # round 5, late: the DENSE sweeps run their lane's two rows as the halves of packed fp32 operations (v_pk_add / v_pk_mul /
     # v_pk_fma: 4th field = packed instructions per pair, two pairs per instruction): P2 8 packed per two pairs, the fused
-    # P3 + P1 11, P3 alone 9; level 3's fused sweep is dense again (packed, it beats the form with the conditional P3)
-    "am_p2, levels 3-6 (packed)": (4, 0, 1, 4.0),
+    # P3 + P1 11, P3 alone 9; from level 2 (-4^5: a wave keeps 42 % of its columns) on the sweeps are dense -- packed, they beat
+    # the skipping form there and the form with only its P3 part conditional
+    "am_p2, levels 2-6 (packed)": (5, 0, 1, 4.0),
     "am_p3p1, levels 0+1 (skipping, P3 under its own test)": (1, 7 + 0.185 * 2 + 0.088 * 3, 0.185 + 0.088),
-    "am_p3p1, levels 1+2 (skipping)": (1, 7 + 0.418 * 2 + 0.185 * 3, 0.418 + 0.185),
-    "am_p3p1, level pairs 2+3, 3+4, 4+5, 5+6 (packed)": (4, 0, 2, 5.5),
+    "am_p3p1, level pairs 1+2, 2+3, 3+4, 4+5, 5+6 (packed)": (5, 0, 2, 5.5),
     # round 5, late: levels 7, 8 and 9 (-1, -0.25, 0) are not swept any more -- their row sums come from a truncated Taylor expansion
     # about the clouds' centre (emd_fgt.hip: 7 small fp64 launches, `emd.roofline.expanded_levels`), so the P3 of level 6 runs alone
     "am_p3 (level 6 alone, packed)": (1, 0, 1, 4.5),

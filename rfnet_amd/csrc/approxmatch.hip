@@ -1285,6 +1285,12 @@ __global__ __launch_bounds__(TPB) void emd_fused_kernel(int n, int m, int mpad, 
 // of the schedule, so the dense kernels never have to write a twin.  Sums run over columns in sorted order: the same
 // terms in another order, like the dense kernels' column segments -- inside the stated tolerance, not bit-identical.
 constexpr float kCullArg = 160.f;    // exp2(x) == +0 for x <= -160
+#ifndef RFA_SKIP_MAXT
+#define RFA_SKIP_MAXT 0.05f
+#endif
+// the DENSE-order skipping sweeps (am_rowk / am_rowl SKIP) pay while a wave keeps few of its columns: cut-offs up to d = 0.22
+// (levels -4^7 and -4^6: 9 / 19 % kept at C4); at -4^5 (42 % kept) the packed dense sweep is faster (P2 33 us against 39)
+constexpr float kSkipMaxT = RFA_SKIP_MAXT;
 constexpr float kCullMaxT = 0.2f;    // a sweep is culled when its threshold on d2 is at most this (d >= 0.45: pays
                                      // for clouds of about unit extent, the reference's normalised shapes; always exact)
 #ifndef RFA_CULL_MIN_PTS
@@ -1609,7 +1615,7 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
     // (am_rowk_kernel SKIP; bit-identical sums).  Level v qualifies when its weight is exactly 0 from a d2 of at most kCullMaxT on.
     auto skip_t = [&](int v) { return (v >= 0 && v < nlevels && lc.c[v] < 0.f) ? kSkipArg / -lc.c[v] : INFINITY; };
     const int *permA = nullptr, *permB = nullptr;
-    if (ncull == 0 && L.rowsort_ok && skip_t(0) <= kCullMaxT) {
+    if (ncull == 0 && L.rowsort_ok && skip_t(0) <= kSkipMaxT) {
         const rfp::Sorted so[2] = {rfp::sorted_view(b, n, w + L.off_sa), rfp::sorted_view(b, m, w + L.off_sb)};
         const int nn[2] = {n, m};
         const float *src[2] = {xyz1, xyz2};
@@ -1645,7 +1651,7 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
             continue;
         }
         const float tsk = skip_t(v);        // (a fused P3 of level v-1 is sharper or equal wherever this one is skippable)
-        const bool skip = permA && tsk <= kCullMaxT && (v == 0 || (lc.c[v - 1] < 0.f && lc.c[v - 1] <= lc.c[v]));
+        const bool skip = permA && tsk <= kSkipMaxT && (v == 0 || (lc.c[v - 1] < 0.f && lc.c[v - 1] <= lc.c[v]));
         if (v < ncull) {
             float *ratL_s = tw + (size_t)(1 + v) * L.Vs, *ratR_s = ratL_s + L.nsa;
             const float Tcur = kCullArg / -lc.c[v];
@@ -1708,7 +1714,7 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
             RF_LAUNCH("am_p2", (am_rowl_kernel<RPT, true>), gl, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
                       (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR,
                       L.bstride, lc.c[v], permB, L.nsb, tsk, gptr, 1);
-        } else if (permB && tsk <= kCullMaxT) {
+        } else if (permB && tsk <= kSkipMaxT) {
             RF_LAUNCH("am_p2", (am_rowl_kernel<RPT, false, true>), gls, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
                       (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR,
                       L.bstride, lc.c[v], permB, L.nsb, tsk, gptr, 1);
