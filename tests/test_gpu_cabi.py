@@ -41,6 +41,21 @@ def test_status_codes_and_workspace_contract(orc):
     assert lib.rf_queryballpoint(b, n, m, C.c_float(0.1), 0, p(a), p(c), p(i1), p(i1), None) == -1
     assert lib.rf_farthestpointsampling(b, 0, 4, p(a), None, p(i1), None) == -1
     assert lib.rf_farthestpointsampling(b, n, 0, p(a), None, p(i1), None) == 0
+    # the sampling entry point with caller scratch of a stated size: 0 bytes where the unsorted kernels run, the sorted set where
+    # the sorted-cloud kernel does (6000 points, 300 samples); too little is RF_EWORKSPACE; results equal the plain entry's
+    assert lib.rf_farthestpointsampling_workspace_bytes(b, n, 40) == 0
+    big = torch.from_numpy(rng.rand(2, 6000, 3).astype(np.float32)).to(dev)
+    fneed = lib.rf_farthestpointsampling_workspace_bytes(2, 6000, 300)
+    assert fneed > 0 and lib.rf_farthestpointsampling_workspace_bytes(2, 6000, 100) == 0
+    fws = torch.empty(fneed, dtype=torch.uint8, device=dev)
+    o1 = torch.empty(2, 300, dtype=torch.int32, device=dev); o2 = torch.empty_like(o1)
+    assert lib.rf_farthestpointsampling_ws(2, 6000, 300, p(big), p(fws), fneed - 1, p(o1), None) == -2
+    assert lib.rf_farthestpointsampling_ws(2, 6000, 300, p(big), p(fws), fneed, p(o1), None) == 0
+    assert lib.rf_farthestpointsampling(2, 6000, 300, p(big), None, p(o2), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2)
+    # (6000 points run 8 per lane: the kernel holds 8192 samples; asked for more it refuses before it writes anything)
+    assert lib.rf_farthestpointsampling_sorted(2, 6000, 9000, 0, p(big), p(fws), fneed, p(o1), None, None) == -1
     lv = (C.c_float * 65)()
     assert lib.rf_approxmatch_levels(b, n, m, p(a), p(c), p(d1), lv, 65, p(ws), need, None) == -1
     assert lib.rf_status_string(-1) == b"invalid argument"

@@ -388,3 +388,25 @@ def test_match_cost_grad_whole_row_form_shapes(orc, b, n, m):
     assert view.data_ptr() % 16 != 0
     h1, h2 = R.match_cost_grad(cu(a), cu(c), view)
     assert torch.allclose(h1, g1, rtol=1e-4, atol=2e-6) and torch.allclose(h2, g2, rtol=1e-4, atol=2e-6)
+
+
+def test_broad_levels_by_expansion_ragged_sizes(orc):
+    """The expanded broad levels with clouds of different sizes (multiL / multiR != 1, the two sides' moment chains of different
+    lengths, a last 256-row workgroup that is mostly padding): 24 x 2400 x 1500 = 8.6e7 pairs, first and last sample against the
+    oracle's chain; the fused earth_mover cost on the same route."""
+    from pc_distance.tf_approxmatch import approx_match, match_cost
+    from rfnet_amd import _raw as R
+    rng = np.random.RandomState(47)
+    B, N, M = 24, 2400, 1500
+    a = (rng.random_sample((B, N, 3)) - 0.5).astype(np.float32)
+    c = (rng.random_sample((B, M, 3)) - 0.5).astype(np.float32)
+    pick = [0, B - 1]
+    om = orc.approx_match(a[pick], c[pick])
+    got_all = approx_match(cu(a), cu(c))
+    got = got_all[pick].cpu().numpy()
+    strict_bar_report("2400 x 1500 (expanded)", got, om)
+    bad = np.abs(got - om) > 1e-6 + 1e-4 * np.abs(om)
+    assert int(bad.sum()) <= 32 and np.abs(got - om).max() < 2e-4, int(bad.sum())
+    oc = orc.match_cost(a[pick], c[pick], om)
+    assert_rel(match_cost(cu(a), cu(c), got_all).cpu().numpy()[pick], oc, 1e-5, what="cost")
+    assert_rel(R.earth_mover(cu(a), cu(c)).cpu().numpy()[pick], oc, 1e-5, what="fused cost")
