@@ -377,7 +377,9 @@ __global__ __launch_bounds__(NT) void fps_sorted_kernel(int n, int m, int npad, 
     // a wave's candidate: its maximum and the tie rank of the point that holds it (double-buffered: ONE barrier per iteration).
     // (The candidates' coordinates riding along, so that the winner's come back from LDS instead of a scalar re-read of the
     // cloud, measured SLOWER: 0.963 against 0.844 ms at C3 -- five LDS reads per lane behind the barrier and three more indexed
-    // register reads before it cost more than the ~300 cycles of the scalar loads.)
+    // register reads before it cost more than the ~300 cycles of the scalar loads.  A second form -- the winning lane writes its
+    // candidate's coordinates to the wave's slot, untouched waves copy theirs over, ONE broadcast read of the winner's slot behind
+    // the reduction -- was slower still: 1.015 ms.)
     __shared__ float slot_d[2][16];
     __shared__ unsigned slot_r[2][16];
     __shared__ unsigned short cpos[NT * PPT];  // the c-th real record's sorted position (the sort pads every segment to 64 records)
