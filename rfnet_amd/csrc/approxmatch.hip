@@ -50,6 +50,9 @@ constexpr float kLog2e = 1.44269502f;  // 0x3FB8AA3B, the constant __expf multip
 #ifndef RFA_PK
 #define RFA_PK 1
 #endif
+#ifndef RFA_PK_FUSED
+#define RFA_PK_FUSED 1  // emd_fused_kernel (cost only): two columns per step, packed
+#endif
 #ifndef RFA_SKIP2
 #define RFA_SKIP2 0
 #endif
@@ -489,6 +492,22 @@ __device__ __forceinline__ void level_weights(float d2, const float (&cl)[NLV > 
             e[v] = q * q;
         } else {
             e[v] = fast_exp2(d2 * cl[v]);
+        }
+    }
+}
+// the same for two pairs at once (the halves of packed fp32 operations: the same IEEE operations per half)
+template <int NLV, bool LASTZERO, bool SQ, int V0 = 0>
+__device__ __forceinline__ void level_weights2(am_v2f d2, const float (&cl)[NLV > 0 ? NLV : 1], am_v2f (&e)[NLV > 0 ? NLV : 1]) {
+#pragma unroll
+    for (int v = NLV - 1; v >= V0; v--) {
+        if (LASTZERO && v == NLV - 1) {
+            e[v] = am_v2f{1.0f, 1.0f};
+        } else if (SQ && (v & 1) && v + 1 < NLV - (LASTZERO ? 1 : 0)) {
+            const am_v2f q = e[v + 1] * e[v + 1];
+            e[v] = q * q;
+        } else {
+            const am_v2f a = d2 * cl[v];
+            e[v] = am_v2f{fast_exp2(a.x), fast_exp2(a.y)};
         }
     }
 }
@@ -1137,7 +1156,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RFA_MR_WAVE
 constexpr int EF_REC = 16;  // floats per column record: x y z 0 | ratioR[0..NLV) | 0 ..
 __global__ void emd_pack_cols_kernel(int m, int mpad, int nlv, const float *__restrict__ xyz2,
                                      const float *__restrict__ ratios, size_t lv_stride,
-                                     size_t b_stride, int roff, float *__restrict__ rec) {
+                                     size_t b_stride, int roff, float *__restrict__ rec, int pairs) {
     const int bi = blockIdx.y;
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= mpad) return;
@@ -1148,6 +1167,12 @@ __global__ void emd_pack_cols_kernel(int m, int mpad, int nlv, const float *__re
         const float *p = xyz2 + ((size_t)bi * m + l) * 3;
         r[0] = p[0]; r[1] = p[1]; r[2] = p[2];
         for (int v = 0; v < nlv; v++) r[4 + v] = ratios[(size_t)bi * b_stride + (size_t)v * lv_stride + roff + l];
+    }
+    if (pairs) {  // two columns' records interleaved field by field: (x_l, x_l+1), (y_l, y_l+1), ... -- scalar register PAIRS for packed operations
+        float *q = rec + ((size_t)bi * mpad + (l & ~1)) * EF_REC + (l & 1);
+#pragma unroll
+        for (int i = 0; i < EF_REC; i++) q[2 * i] = r[i];
+        return;
     }
     float4 *q = (float4 *)(rec + ((size_t)bi * mpad + l) * EF_REC);
 #pragma unroll
@@ -1189,6 +1214,36 @@ __global__ __launch_bounds__(TPB) void emd_fused_kernel(int n, int m, int mpad, 
     const int lend = min(mpad, lbeg + lspan);  // multiples of MG_TL; records beyond m are zero
     const int bl = t & (MG_TL - 1);
     const int br = t / MG_TL;
+    if constexpr (!GRAD && RFA_PK_FUSED != 0) {
+        // cost only: two columns per step as the halves of packed fp32 operations, their operands in scalar register pairs (the
+        // pair layout of emd_pack_cols_kernel); per entry the same operations in the same order, the cost summed column by column
+        for (int l0 = lbeg; l0 < lend; l0 += MG_TL) {
+#pragma unroll 2
+            for (int l = 0; l < MG_TL; l += 2) {
+                const am_v2f *__restrict__ c = (const am_v2f *)(R + (size_t)(l0 + l) * EF_REC);  // uniform: 32 dwords by scalar loads
+                const am_v2f dx = c[0] - x1, dy = c[1] - y1, dz = c[2] - z1;
+                const am_v2f d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));  // (rf::d2_fma's order)
+                am_v2f e[NLV];
+                am_v2f acc = {0.f, 0.f};
+                if (SQ) {
+                    level_weights2<NLV, LASTZERO, SQ, 1>(d2, cl, e);
+                    if (__ballot(d2.x < t0 || d2.y < t0) != 0ull) {
+                        asm volatile("; level 0 kept");
+                        const am_v2f a0 = d2 * cl[0];
+                        acc = __builtin_elementwise_fma(rl[0] * am_v2f{fast_exp2(a0.x), fast_exp2(a0.y)}, c[4], acc);
+                    }
+#pragma unroll
+                    for (int v = 1; v < NLV; v++) acc = __builtin_elementwise_fma(rl[v] * e[v], c[4 + v], acc);
+                } else {
+                    level_weights2<NLV, LASTZERO, SQ>(d2, cl, e);
+#pragma unroll
+                    for (int v = 0; v < NLV; v++) acc = __builtin_elementwise_fma(rl[v] * e[v], c[4 + v], acc);
+                }
+                csum = fmaf(sqrtf(d2.x), acc.x, csum);
+                csum = fmaf(sqrtf(d2.y), acc.y, csum);
+            }
+        }
+    } else
     for (int l0 = lbeg; l0 < lend; l0 += MG_TL) {
 #pragma unroll 4
         for (int l = 0; l < MG_TL; l++) {
@@ -1963,7 +2018,7 @@ int rf_earth_mover(int b, int n, int m, const float *xyz1, const float *xyz2, fl
     const float *ratios = w + L.V;
     float *rec = w + E.off_rec, *partial = w + E.off_partial;
     RF_LAUNCH("emd_pack_cols", emd_pack_cols_kernel, dim3(rf::ceil_div(L.mpad, 256), b), dim3(256), 0, s, m,
-              L.mpad, nl, xyz2, ratios, L.V, L.bstride, L.npad, rec);
+              L.mpad, nl, xyz2, ratios, L.V, L.bstride, L.npad, rec, (RFA_PK_FUSED && !want_grad) ? 1 : 0);
     const dim3 g(rf::ceil_div(n, TPB), E.lsplit, b);
     const bool sq = quarter_chain(lc.c, 10, true);
     if (want_grad && sq) {
