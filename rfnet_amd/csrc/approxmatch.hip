@@ -40,12 +40,15 @@ constexpr float kSkipArg = 161.f;  // d2 * |c| >= 161 => fl(d2 * c) <= -160 => v
 constexpr float kLog2e = 1.44269502f;  // 0x3FB8AA3B, the constant __expf multiplies by
 // am_match's stores of `match` are non-temporal: the tensor (512 MiB at C4) is twice the memory-side cache and is read next by
 // another launch; written through the caches it leaves that launch competing with the write-back of its own input
-// (approx_match + match_cost 0.987 -> 0.956 ms same-device, am_match itself 139 -> 135.5 us; non-temporal LOADS in match_cost: no gain)
+// (approx_match + match_cost 0.987 -> 0.956 ms same-device, am_match itself 139 -> 135.5 us)
 #ifndef RFA_MATCH_NT
 #define RFA_MATCH_NT 1
 #endif
+// match_cost reads `match` with non-temporal loads too: 88.4 -> 78.6 us alone, 87.7 -> 79.7 inside the sequence (a pure read of
+// 512 MiB: 83 us plain, 76 non-temporal -- tools/ubench/stream_rate.hip); the gradient pass behind it then finds less of the tensor's
+// head in the memory-side cache (85.8 -> 91.2 us): -3 us for the three ops together, -8 for approx_match + match_cost
 #ifndef RFA_MC_NT
-#define RFA_MC_NT 0
+#define RFA_MC_NT 1
 #endif
 #ifndef RFA_PK
 #define RFA_PK 1
