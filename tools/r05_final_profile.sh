@@ -14,11 +14,13 @@ bash tools/profile_py.sh r05h/ball tools/run_ball_once.py 0.1
 timeout 200 python3 tools/ab_ball.py > "$O/ab_ball.txt" 2>&1; cat "$O/ab_ball.txt"
 timeout 200 python3 tools/ab_c3.py > "$O/ab_c3.txt" 2>&1; cat "$O/ab_c3.txt"
 # same-device A/Bs against builds with this round's EMD changes switched off (python tools/build_variant.py, see profiles/README.md):
-#   r4emd  = -DRFA_FGT_MIN_PAIRS=1e30 -DRFA_ROWSORT_MIN_PAIRS=1e30 -DRFA_MATCH_NT=0 -DRFA_MCG_ROWS=0 -DRFA_MG_NT=0 -DRFA_PK=0 -DRFA_PP_DENSE=0
-#   nofgt = -DRFA_FGT_MIN_PAIRS=1e30   nopk = -DRFA_PK=0 -DRFA_PP_DENSE=0 -DRFA_SKIP2=1   mcgold = -DRFA_MCG_ROWS=0 -DRFA_MG_NT=0
+#   r4emd  = -DRFA_FGT_MIN_PAIRS=1e30 -DRFA_ROWSORT_MIN_PAIRS=1e30 -DRFA_MATCH_NT=0 -DRFA_MC_NT=0 -DRFA_MCG_ROWS=0 -DRFA_MG_NT=0 -DRFA_PK=0
+#            -DRFA_PP_DENSE=0 -DRFA_PK_FUSED=0 -DRFA_SKIP_MAXT=0.2f -DRFA_SKIP2=1
+#   nofgt = -DRFA_FGT_MIN_PAIRS=1e30   nopk = -DRFA_PK=0 -DRFA_PP_DENSE=0 -DRFA_SKIP2=1 -DRFA_SKIP_MAXT=0.2f -DRFA_PK_FUSED=0   mcgold = -DRFA_MCG_ROWS=0 -DRFA_MG_NT=0
 timeout 300 python3 tools/ab_emd_kernels.py r4emd nofgt nopk base > "$O/ab_emd.txt" 2>&1; cut -c1-200 "$O/ab_emd.txt"
 timeout 300 python3 tools/ab_emd_sizes.py nofgt base > "$O/ab_emd_sizes.txt" 2>&1; cut -c1-300 "$O/ab_emd_sizes.txt"
 AB_MCG_SHAPES=1 timeout 300 python3 tools/ab_mcg.py mcgold base > "$O/ab_mcg.txt" 2>&1; cut -c1-300 "$O/ab_mcg.txt"
 bash tools/experiments/trace_emd.sh > "$O/emd_launches.txt" 2>&1
 timeout 300 python3 tools/ab_fps_sorted.py base > "$O/ab_fps_sorted.txt" 2>&1; cut -c1-300 "$O/ab_fps_sorted.txt"
 timeout 400 python3 tools/ab_fps_sizes.py > "$O/ab_fps_sizes.txt" 2>&1; tail -9 "$O/ab_fps_sizes.txt"
+./tools/ubench/stream_rate > "$O/stream_rate.txt" 2>&1; cat "$O/stream_rate.txt"
