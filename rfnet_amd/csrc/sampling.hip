@@ -361,12 +361,6 @@ __device__ __forceinline__ unsigned wave_allmin_u(unsigned v) {
     return min(min(r0, r1), min(r2, r3));
 }
 
-#ifndef RF_FPSS_ABL
-#define RF_FPSS_ABL 0  // (timing ablations of fps_sorted_kernel, experiments only: 1 no re-read of the winner, 2 no wave ever scans)
-#endif
-#ifdef RF_FPS_STATS
-__device__ unsigned long long g_fps_touched[4096];  // (experiments) touched waves per iteration, summed over the clouds
-#endif
 template <int NT, int PPT, bool EMIT>
 __global__ __launch_bounds__(NT) void fps_sorted_kernel(int n, int m, int npad, const float *__restrict__ inp,
                                                         const int *__restrict__ sorig, int *__restrict__ out,
@@ -487,10 +481,7 @@ __global__ __launch_bounds__(NT) void fps_sorted_kernel(int n, int m, int npad, 
         const float gy = fmaxf(fmaxf(lo[1] - oy, oy - hi[1]), 0.f);
         const float gz = fmaxf(fmaxf(lo[2] - oz, oz - hi[2]), 0.f);
         const float lb = rf::d2_fma(gx, gy, gz);
-        if (RF_FPSS_ABL != 2 && __builtin_amdgcn_ballot_w64(lb < lmx) != 0ull) {  // (uniform; a NaN sample touches nothing: td stays, as min(NaN, td))
-#ifdef RF_FPS_STATS
-            if (lane == 0 && j < 4096) atomicAdd(&g_fps_touched[j], 1ull);
-#endif
+        if (__builtin_amdgcn_ballot_w64(lb < lmx) != 0ull) {  // (uniform; a NaN sample touches nothing: td stays, as min(NaN, td))
             float mx = -1.0f;
 #pragma unroll
             for (int h = 0; h < PPT / 2; h++) {
@@ -534,13 +525,9 @@ __global__ __launch_bounds__(NT) void fps_sorted_kernel(int n, int m, int npad, 
         const unsigned rank = sd == gm ? sr : 0xFFFFFFFFu;
         const unsigned gr = __builtin_amdgcn_readfirstlane(row_allmin_u(rank));
         const int gk = gr == 0xFFFFFFFFu ? 0 : (int)(((gr & 0x3FFFFFu) << 9) | (gr >> 22));
-#if RF_FPSS_ABL == 1  /* timing ablation: no re-read of the winner */
-        ox = (float)(gk & 1023) * 0.0009765625f, oy = (float)((gk >> 4) & 1023) * 0.0009765625f, oz = (float)((gk >> 2) & 1023) * 0.0009765625f;
-#else
         ox = P[gk * 3 + 0];  // uniform address: scalar loads
         oy = P[gk * 3 + 1];
         oz = P[gk * 3 + 2];
-#endif
         if (t == 0) cpos[j] = (unsigned short)gk;
     }
     __syncthreads();
@@ -904,15 +891,6 @@ int rf_farthestpointsampling_sorted(int b, int n, int m, int form, const float *
     (void)form;
     return rfi::fps_sorted(b, n, m, inp, sv, out, new_xyz, s);
 }
-
-#ifdef RF_FPS_STATS
-int rf_fps_stats_read(unsigned long long *host) {
-    RF_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fps_touched), sizeof(unsigned long long) * 4096));
-    unsigned long long z[4096] = {};
-    RF_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_fps_touched), z, sizeof(z)));
-    return RF_OK;
-}
-#endif
 
 size_t rf_fps_cluster_state_bytes(int b) {
     return b > 0 ? 16 + sizeof(unsigned long long) * 2 * FPS_CLUSTER_MAXK * (size_t)b : 0;

@@ -1,4 +1,4 @@
-"""Touched waves per iteration of fps_sorted_kernel at C3 (a build with -DRF_FPS_STATS: python tools/build_variant.py fpsstats -DRF_FPS_STATS;
+"""Touched waves per iteration of fps_sorted_kernel at C3 (a build of sampling.hip with tools/experiments/fps_sorted_instrumented_builds.patch.txt applied and -DRF_FPS_STATS: python tools/build_variant.py fpsstats -DRF_FPS_STATS;
 run with RFOPS_LIB=rfnet_amd/variants/librfops_fpsstats.so)."""
 import ctypes, os, sys
 import numpy as np, torch
