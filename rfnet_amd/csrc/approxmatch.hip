@@ -56,9 +56,6 @@ constexpr float kLog2e = 1.44269502f;  // 0x3FB8AA3B, the constant __expf multip
 #ifndef RFA_PK_FUSED
 #define RFA_PK_FUSED 1  // emd_fused_kernel (cost only): two columns per step, packed
 #endif
-#ifndef RFA_SKIP2
-#define RFA_SKIP2 0
-#endif
 #ifndef RFA_PP_DENSE
 #define RFA_PP_DENSE 1  // the packed sweeps take their column operands through two scalar register sets in turn, as the skipping sweeps
 #endif
@@ -173,10 +170,11 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
     const float *__restrict__ S1 = remainR + (size_t)bi * stride;
     const int c0 = seg * seglen, c1 = c0 + seglen;  // multiples of SUB, inside the padded range
     // one column (its coordinates and scalars wave-uniform) against the lane's RPT rows
-    // (RFA_PK: the lane's two rows as the halves of packed fp32 operations, as in am_rowl_kernel -- bit-identical sums.  Where it
-    // pays: P3 alone 41.6 -> 35.2 us at C4, P1 alone +-0; the FUSED P3 + P1 sweep -- four exponentials per column -- got 6 % slower
-    // and keeps the scalar form unless RFA_PK is 2; with only its distances packed: +-0)
-    constexpr bool PK = RPT == 2 && RFA_PK != 0 && (SKIP == 0 || RFA_PK == 2);
+    // (RFA_PK: the lane's two rows as the halves of packed fp32 operations, as in am_rowl_kernel -- bit-identical sums -- together
+    // with the column operands through two scalar register sets in turn: the dense fused P3 + P1 sweep 61.8 -> 47.5 us at C4, P3
+    // alone 41.6 -> 33; packed alone the fused sweep got 6 % SLOWER, the two register sets alone 3 %.  The skipping sweeps keep
+    // the scalar form: most of their columns end after the distance and its test, packed 41.6 / 53.4 for 35.9 / 47.1 us.)
+    constexpr bool PK = RPT == 2 && RFA_PK != 0 && SKIP == 0;
     am_v2f X1 = {x1[0], x1[RPT - 1]}, Y1 = {y1[0], y1[RPT - 1]}, Z1 = {z1[0], z1[RPT - 1]}, RL = {rl[0], rl[RPT - 1]};
     am_v2f ACC3 = {acc3[0], acc3[RPT - 1]}, ACC1 = {acc1[0], acc1[RPT - 1]};
     auto column = [&](float cx, float cy, float cz, float s3u, float s1u) {
@@ -364,7 +362,7 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
     const int c0 = seg * seglen, c1 = c0 + seglen;
     // RFA_PK: the lane's two rows as the two halves of packed fp32 operations (v_pk_add / v_pk_mul / v_pk_fma: the same IEEE
     // operations in the same order -- bit-identical sums): 6 instead of 16 vector instructions per column beside the exponentials
-    constexpr bool PKL = RPT == 2 && RFA_PK != 0 && (!SKIP || RFA_PK == 2);
+    constexpr bool PKL = RPT == 2 && RFA_PK != 0 && !SKIP;
     am_v2f X2 = {x2[0], x2[RPT - 1]}, Y2 = {y2[0], y2[RPT - 1]}, Z2 = {z2[0], z2[RPT - 1]}, ACC = {0.f, 0.f};
     auto column = [&](float cx, float cy, float cz, float su) {
         if constexpr (PKL) {
@@ -926,19 +924,13 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // v_permlane16_swap + add (12 -> 6), then four DPP row rotations per value leave every lane of a 16-lane row with the row's total of
 // its six values; lane j < 6 of each row picks value j: 24 lanes hold the 24 sums and add them to grad2 with one atomic each.
 // 65 VALU per 8 rows x 4 k instead of a 6-VALU-per-entry column phase behind an LDS transpose: 18 VALU per match entry (13 for
-// q and grad1, 3 for the row sums, 2 for the reduction) against mcg_kernel's 25.  The rows a lane will need are in flight 16 deep
+// q and grad1, 3 for the row sums, 2 for the reduction) against mcg_kernel's 25.  The rows a lane will need are in flight 8 deep
 // (rolling: a row's register is reloaded when its group is done); the rows' x2 are wave-uniform scalar loads.
 // Needs n % 4 == 0 and 16-byte aligned xyz1 / match (else mcg_kernel).
 constexpr int MR_KPL = 4;     // k per lane
-#ifndef RFA_MR_G
-#define RFA_MR_G 4
-#endif
-#ifndef RFA_MR_DEPTH
-#define RFA_MR_DEPTH 8
-#endif
-constexpr int MR_LSPAN_MAX = 1024;      // rows per workgroup at most (its grad2 sums live in LDS)
-constexpr int MR_G = RFA_MR_G;          // rows per reduce-scatter group (4 or 8)
-constexpr int MR_DEPTH = RFA_MR_DEPTH;  // rows in flight per lane (a multiple of MR_G)
+constexpr int MR_LSPAN_MAX = 1024;  // rows per workgroup at most (its grad2 sums live in LDS)
+constexpr int MR_G = 4;      // rows per reduce-scatter group (8: +-2 %)
+constexpr int MR_DEPTH = 8;  // rows in flight per lane, 2 or 4 groups (16: +-2 %, and 128 registers)
 // one group: MR_G rows x 4 k.  xs: the rows' x2 records (wave-uniform).  TAIL: rows at or beyond `lend` are masked by a
 // multiplication (their registers hold the range's last row).
 // `match` is read once, front to back: non-temporal loads (C4 same-device: mcg_rows 104.5 -> 94.3 us, 5.1 -> 5.7 TB/s; inside
@@ -1022,11 +1014,8 @@ __device__ __forceinline__ void mr_reduce_emit(const float (&S)[3 * MR_G], int l
     if (j < NQ && lg + vi / 3 < lend) __hip_atomic_fetch_add(&g2s[(lg - lbeg) * 3 + vi], -out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-#ifndef RFA_MR_WAVES
-#define RFA_MR_WAVES 4
-#endif
 template <bool FULL>
-__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RFA_MR_WAVES, RFA_MR_WAVES))) void mcg_rows_kernel(int n, int m, int lspan,
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void mcg_rows_kernel(int n, int m, int lspan,
                                                   const float *__restrict__ xyz1,
                                                   const float *__restrict__ xyz2,
                                                   const float *__restrict__ match,
@@ -1740,12 +1729,6 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
             const float *pL = ratios + (size_t)(v - 1) * L.V, *pR = pL + L.npad;
             RF_LAUNCH("am_p3p1", (am_rowk_kernel<true, 1, RPT, 1>), gks, dim3(64 * segk), 0, s,
                       AM_ROWK_ARGS(pR, pL, lc.c[v - 1]));
-        } else if (RFA_SKIP2 && permA && v > 0 && !zero && lc.c[v] < 0.f && lc.c[v - 1] < lc.c[v] && skip_t(v - 1) <= kCullMaxT) {
-            // this level is too broad to drop columns, the fused P3's level is not.  (Off since the dense sweep runs packed:
-            // 54.7 us for level 3 at C4 this way against 47 for the dense form.)
-            const float *pL = ratios + (size_t)(v - 1) * L.V, *pR = pL + L.npad;
-            RF_LAUNCH("am_p3p1", (am_rowk_kernel<true, 1, RPT, 2>), gks, dim3(64 * segk), 0, s,
-                      AM_ROWK_ARGS(pR, pL, lc.c[v - 1]));
         } else if (v == 0) {
             if (zero) {
                 RF_LAUNCH("am_p1", (am_rowk_kernel<false, 2, RPT>), gk, dim3(64 * segk), 0, s,
@@ -1887,9 +1870,7 @@ int rf_matchcost(int b, int n, int m, const float *xyz1, const float *xyz2, cons
 #ifndef RFA_MCG_ROWS
 #define RFA_MCG_ROWS 1
 #endif
-#ifndef RFA_MCG_ROWS_WG
-#define RFA_MCG_ROWS_WG 1024  // workgroups the l-ranges are cut for (four per CU)
-#endif
+constexpr int MCG_ROWS_WG = 1024;  // workgroups the l-ranges are cut for: four per CU (1536 / 2048 at 6 waves per SIMD: +3 .. +6 %)
 static int mcg_launch(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match, float *grad1,
                        float *grad2, hipStream_t s) {
     const int kspan = TPB * MR_KPL;
@@ -1897,7 +1878,7 @@ static int mcg_launch(int b, int n, int m, const float *xyz1, const float *xyz2,
     if (RFA_MCG_ROWS && n % MR_KPL == 0 && 4 * (long)n >= 3L * rf::ceil_div(n, kspan) * kspan && m >= 2 * MR_DEPTH &&
         (((uintptr_t)xyz1 | (uintptr_t)match) & 15) == 0) {
         const int kb = rf::ceil_div(n, kspan);
-        int lsplit = rf::ceil_div(RFA_MCG_ROWS_WG, b * kb);
+        int lsplit = rf::ceil_div(MCG_ROWS_WG, b * kb);
         lsplit = max(1, min(lsplit, m / MR_DEPTH));
         lsplit = max(lsplit, rf::ceil_div(m, MR_LSPAN_MAX - MR_DEPTH));
         const int lspan = rf::ceil_div(rf::ceil_div(m, lsplit), MR_DEPTH) * MR_DEPTH;

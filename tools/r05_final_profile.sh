@@ -15,8 +15,8 @@ timeout 200 python3 tools/ab_ball.py > "$O/ab_ball.txt" 2>&1; cat "$O/ab_ball.tx
 timeout 200 python3 tools/ab_c3.py > "$O/ab_c3.txt" 2>&1; cat "$O/ab_c3.txt"
 # same-device A/Bs against builds with this round's EMD changes switched off (python tools/build_variant.py, see profiles/README.md):
 #   r4emd  = -DRFA_FGT_MIN_PAIRS=1e30 -DRFA_ROWSORT_MIN_PAIRS=1e30 -DRFA_MATCH_NT=0 -DRFA_MC_NT=0 -DRFA_MCG_ROWS=0 -DRFA_MG_NT=0 -DRFA_PK=0
-#            -DRFA_PP_DENSE=0 -DRFA_PK_FUSED=0 -DRFA_SKIP_MAXT=0.2f -DRFA_SKIP2=1
-#   nofgt = -DRFA_FGT_MIN_PAIRS=1e30   nopk = -DRFA_PK=0 -DRFA_PP_DENSE=0 -DRFA_SKIP2=1 -DRFA_SKIP_MAXT=0.2f -DRFA_PK_FUSED=0   mcgold = -DRFA_MCG_ROWS=0 -DRFA_MG_NT=0
+#            -DRFA_PP_DENSE=0 -DRFA_PK_FUSED=0 -DRFA_SKIP_MAXT=0.2f
+#   nofgt = -DRFA_FGT_MIN_PAIRS=1e30   nopk = -DRFA_PK=0 -DRFA_PP_DENSE=0 -DRFA_SKIP_MAXT=0.2f -DRFA_PK_FUSED=0   mcgold = -DRFA_MCG_ROWS=0 -DRFA_MG_NT=0
 timeout 300 python3 tools/ab_emd_kernels.py r4emd nofgt nopk base > "$O/ab_emd.txt" 2>&1; cut -c1-200 "$O/ab_emd.txt"
 timeout 300 python3 tools/ab_emd_sizes.py nofgt base > "$O/ab_emd_sizes.txt" 2>&1; cut -c1-300 "$O/ab_emd_sizes.txt"
 AB_MCG_SHAPES=1 timeout 300 python3 tools/ab_mcg.py mcgold base > "$O/ab_mcg.txt" 2>&1; cut -c1-300 "$O/ab_mcg.txt"
