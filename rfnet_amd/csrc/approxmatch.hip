@@ -56,6 +56,9 @@ constexpr float kLog2e = 1.44269502f;  // 0x3FB8AA3B, the constant __expf multip
 #ifndef RFA_PK_FUSED
 #define RFA_PK_FUSED 1  // emd_fused_kernel (cost only): two columns per step, packed
 #endif
+#ifndef RFA_SKIP_MASK
+#define RFA_SKIP_MASK 1  // level 0's skipping sweeps list the columns level 1's will need; level 1's visit only those (am_rowk_kernel MASK)
+#endif
 #ifndef RFA_PP_DENSE
 #define RFA_PP_DENSE 1  // the packed sweeps take their column operands through two scalar register sets in turn, as the skipping sweeps
 #endif
@@ -134,13 +137,21 @@ __global__ __launch_bounds__(AI_TPB) void am_init_kernel(AmInit a) {
 //           sharper level is evaluated only for columns within its own cut-off `tskip_prev` (<= tskip) of some row;
 // SKIP = 2: this level is too broad to drop columns (every weight is evaluated) but the fused P3's level is not: only its part
 //           is conditional.  Both tests are wave-uniform branches on a ballot.
-template <bool HAS_P3, int P1, int RPT, int SKIP = 0>
+// MASK (with SKIP = 1): 1 = this launch also LISTS, per wave, the columns that are within `tmask` -- the NEXT level's cut-off -- of
+//           some row of the wave (their indices in column order, and the count); 2 = this launch visits only the columns an earlier
+//           launch of the same grid listed (the geometry does not change between the phases of a call): at level -4^6 a wave keeps a
+//           fifth of its columns, and computing and testing the distances of all of them again was what its skipping sweep still
+//           cost.  The listed columns' operands are gathered by the lanes (one column per lane, one memory round trip for 64
+//           columns), parked in LDS and read back as broadcasts: same operations per kept column, same order -- same bits.
+template <bool HAS_P3, int P1, int RPT, int SKIP = 0, int MASK = 0>
 __global__ __launch_bounds__(1024) void am_rowk_kernel(
     int n, int seglen, const float *__restrict__ xyz1, const float *__restrict__ xyz2p,
     size_t xyz2p_stride, const float *__restrict__ ratioR_prev, const float *__restrict__ remainR,
     const float *__restrict__ ratioL_prev, float *__restrict__ remainL,
     float *__restrict__ ratioL_out, size_t stride, float c_prev, float c_cur, const int *__restrict__ perm,
-    int perm_stride, float tskip, float tskip_prev, const int *__restrict__ guard, int guard_want) {
+    int perm_stride, float tskip, float tskip_prev, const int *__restrict__ guard, int guard_want,
+    unsigned short *__restrict__ mask = nullptr, float tmask = 0.f) {
+    static_assert(MASK == 0 || SKIP == 1, "column lists belong to the skipping sweeps");
     __shared__ float part3[16][64 * RPT], part1[16][64 * RPT];
     // (the broad levels: this sweep runs only when the expansion of emd_fgt.hip was refused for the call's clouds, or -- the
     // P3-only form before the first expanded level -- only when it was accepted; guard = NULL: always)
@@ -177,7 +188,9 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
     constexpr bool PK = RPT == 2 && RFA_PK != 0 && SKIP == 0;
     am_v2f X1 = {x1[0], x1[RPT - 1]}, Y1 = {y1[0], y1[RPT - 1]}, Z1 = {z1[0], z1[RPT - 1]}, RL = {rl[0], rl[RPT - 1]};
     am_v2f ACC3 = {acc3[0], acc3[RPT - 1]}, ACC1 = {acc1[0], acc1[RPT - 1]};
-    auto column = [&](float cx, float cy, float cz, float s3u, float s1u) {
+    int nlisted = 0;                       // (MASK == 1, uniform) columns listed so far
+    unsigned short *__restrict__ lst = nullptr;  // (MASK != 0) this wave's list: [0] = count, then the columns
+    auto column = [&](float cx, float cy, float cz, float s3u, float s1u, int cidx = 0) {
         if constexpr (PK) {
             const am_v2f dx = cx - X1, dy = cy - Y1, dz = cz - Z1;
             const am_v2f d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));  // (rf::d2_fma's order)
@@ -211,6 +224,16 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
                 near = near || d2[r] < tskip;
                 near_prev = near_prev || d2[r] < tskip_prev;
             }
+        }
+        if (MASK == 1) {
+            // the broader test first: a column beyond the NEXT level's cut-off of every row is beyond this level's too
+            bool near_mask = false;
+#pragma unroll
+            for (int r = 0; r < RPT; r++) near_mask = near_mask || d2[r] < tmask;
+            if (__ballot(near_mask) == 0ull) return;  // (uniform)
+            asm volatile("; column listed");
+            if (lane == 0) lst[1 + nlisted] = (unsigned short)cidx;
+            nlisted++;
         }
         if (SKIP == 1) {
             if (__ballot(near) == 0ull) return;  // (uniform) every weight of this column is exactly 0 in this wave
@@ -253,6 +276,37 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
             t1[i] = HAS_P1 ? S1c[(c) + i] : 0.f;                                             \
         }                                                                                    \
     } while (0)
+        // the wave's list: ((batch element, row group), column segment) -> 1 + seglen entries
+        if (MASK != 0) lst = mask + (((size_t)bi * gridDim.x + blockIdx.x) * nseg + seg) * (size_t)(seglen + 1);
+        if constexpr (MASK == 2) {
+            __shared__ float colbuf[16][64][8];  // per wave: 64 listed columns' operands (x y z s3 s1)
+            float(*cb)[8] = colbuf[seg];
+            const int cnt = ((const __attribute__((address_space(4))) unsigned short *)lst)[0];
+            for (int base = 0; base < cnt; base += 64) {
+                const int j = base + lane;
+                if (j < cnt) {
+                    const int c = c0 + lst[1 + j];
+                    cb[lane][0] = C[(size_t)c * 3], cb[lane][1] = C[(size_t)c * 3 + 1], cb[lane][2] = C[(size_t)c * 3 + 2];
+                    cb[lane][3] = HAS_P3 ? S3[c] : 0.f;
+                    cb[lane][4] = HAS_P1 ? S1[c] : 0.f;
+                }
+                // (a wave's own LDS writes are visible to it without a barrier: in-order LDS queue)
+                const int nb = min(64, cnt - base);
+                int u = 0;
+                for (; u + 4 <= nb; u += 4) {  // four records in flight: one LDS round trip per four columns
+                    float4 v[4];
+                    float w[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) v[q] = *(const float4 *)cb[u + q], w[q] = cb[u + q][4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) column(v[q].x, v[q].y, v[q].z, v[q].w, w[q]);
+                }
+                for (; u < nb; u++) {
+                    const float4 v = *(const float4 *)cb[u];
+                    column(v.x, v.y, v.z, v.w, cb[u][4]);
+                }
+            }
+        } else {
         RFA_FETCH_K(xa, a3, a1, c0);
         for (int c = c0; c < c1; c += 2 * SUB) {
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): set a has arrived
@@ -260,14 +314,16 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
             RFA_FETCH_K(xb, b3, b1, c + SUB);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < SUB; u++) column(xa[u * 3], xa[u * 3 + 1], xa[u * 3 + 2], a3[u], a1[u]);
+            for (int u = 0; u < SUB; u++) column(xa[u * 3], xa[u * 3 + 1], xa[u * 3 + 2], a3[u], a1[u], c - c0 + u);
             if (c + SUB >= c1) break;
             __builtin_amdgcn_s_waitcnt(0xC07F);  // set b has arrived
             __builtin_amdgcn_sched_barrier(0);
             RFA_FETCH_K(xa, a3, a1, c + 2 * SUB);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < SUB; u++) column(xb[u * 3], xb[u * 3 + 1], xb[u * 3 + 2], b3[u], b1[u]);
+            for (int u = 0; u < SUB; u++) column(xb[u * 3], xb[u * 3 + 1], xb[u * 3 + 2], b3[u], b1[u], c + SUB - c0 + u);
+        }
+        if (MASK == 1 && lane == 0) lst[0] = (unsigned short)nlisted;
         }
 #undef RFA_FETCH_K
     } else {
@@ -333,12 +389,14 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
 //   sumr = sum_k fma(e, ratioL[k], .);  t = sumr*remainR[l];  cons = min(remainR[l]/(t+1e-9), 1)
 //   ratioR[l] = remainR[l]*cons;  remainR[l] = max(0, remainR[l]-t)
 // ZERO: the level's multiplier is 0 -> e = 1.0 exactly, no distance and no exponential (see am_rowk).
-template <int RPT, bool ZERO, bool SKIP = false>
+template <int RPT, bool ZERO, bool SKIP = false, int MASK = 0>
 __global__ __launch_bounds__(1024) void am_rowl_kernel(
     int m, int seglen, const float *__restrict__ xyz2, const float *__restrict__ xyz1p,
     size_t xyz1p_stride, const float *__restrict__ ratioL, float *__restrict__ remainR,
     float *__restrict__ ratioR_out, size_t stride, float c_cur, const int *__restrict__ perm, int perm_stride,
-    float tskip, const int *__restrict__ guard, int guard_want) {
+    float tskip, const int *__restrict__ guard, int guard_want, unsigned short *__restrict__ mask = nullptr,
+    float tmask = 0.f) {
+    static_assert(MASK == 0 || SKIP, "column lists belong to the skipping sweeps (am_rowk_kernel MASK)");
     if (guard && (*guard != 0) != (guard_want != 0)) return;  // (see am_rowk_kernel)
     __shared__ float part[16][64 * RPT];
     const int bi = blockIdx.y;
@@ -364,7 +422,9 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
     // operations in the same order -- bit-identical sums): 6 instead of 16 vector instructions per column beside the exponentials
     constexpr bool PKL = RPT == 2 && RFA_PK != 0 && !SKIP;
     am_v2f X2 = {x2[0], x2[RPT - 1]}, Y2 = {y2[0], y2[RPT - 1]}, Z2 = {z2[0], z2[RPT - 1]}, ACC = {0.f, 0.f};
-    auto column = [&](float cx, float cy, float cz, float su) {
+    int nlisted = 0;                            // (MASK == 1, uniform)
+    unsigned short *__restrict__ lst = nullptr;  // (MASK != 0) this wave's list: [0] = count, then the columns
+    auto column = [&](float cx, float cy, float cz, float su, int cidx = 0) {
         if constexpr (PKL) {
             const am_v2f dx = X2 - cx, dy = Y2 - cy, dz = Z2 - cz;
             const am_v2f d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));  // (rf::d2_fma's order)
@@ -387,6 +447,15 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
             d2[r] = rf::d2_fma(x2[r] - cx, y2[r] - cy, z2[r] - cz);
             near = near || d2[r] < tskip;
         }
+        if (MASK == 1) {  // (the broader test first: am_rowk_kernel)
+            bool near_mask = false;
+#pragma unroll
+            for (int r = 0; r < RPT; r++) near_mask = near_mask || d2[r] < tmask;
+            if (__ballot(near_mask) == 0ull) return;  // (uniform)
+            asm volatile("; column listed");
+            if (lane == 0) lst[1 + nlisted] = (unsigned short)cidx;
+            nlisted++;
+        }
         if (SKIP) {
             if (__ballot(near) == 0ull) return;  // (uniform)
             asm volatile("; column kept");
@@ -402,6 +471,32 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
         _Pragma("unroll") for (int i = 0; i < 3 * SUB; i++) xs[i] = Cc[(size_t)(c) * 3 + i]; \
         _Pragma("unroll") for (int i = 0; i < SUB; i++) ts[i] = Sc[(c) + i];                 \
     } while (0)
+        if (MASK != 0) lst = mask + (((size_t)bi * gridDim.x + blockIdx.x) * nseg + seg) * (size_t)(seglen + 1);
+        if constexpr (MASK == 2) {  // only the listed columns, gathered 64 at a time through LDS (am_rowk_kernel)
+            __shared__ float colbuf[16][64][4];
+            float(*cb)[4] = colbuf[seg];
+            const int cnt = ((const __attribute__((address_space(4))) unsigned short *)lst)[0];
+            for (int base = 0; base < cnt; base += 64) {
+                const int j = base + lane;
+                if (j < cnt) {
+                    const int c = c0 + lst[1 + j];
+                    *(float4 *)cb[lane] = make_float4(C[(size_t)c * 3], C[(size_t)c * 3 + 1], C[(size_t)c * 3 + 2], S[c]);
+                }
+                const int nb = min(64, cnt - base);
+                int u = 0;
+                for (; u + 4 <= nb; u += 4) {
+                    float4 v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) v[q] = *(const float4 *)cb[u + q];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) column(v[q].x, v[q].y, v[q].z, v[q].w);
+                }
+                for (; u < nb; u++) {
+                    const float4 v = *(const float4 *)cb[u];
+                    column(v.x, v.y, v.z, v.w);
+                }
+            }
+        } else {
         RFA_FETCH_L(xa, sa, c0);
         for (int c = c0; c < c1; c += 2 * SUB) {
             __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -409,14 +504,16 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
             RFA_FETCH_L(xb, sb, c + SUB);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < SUB; u++) column(xa[u * 3], xa[u * 3 + 1], xa[u * 3 + 2], sa[u]);
+            for (int u = 0; u < SUB; u++) column(xa[u * 3], xa[u * 3 + 1], xa[u * 3 + 2], sa[u], c - c0 + u);
             if (c + SUB >= c1) break;
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_sched_barrier(0);
             RFA_FETCH_L(xa, sa, c + 2 * SUB);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < SUB; u++) column(xb[u * 3], xb[u * 3 + 1], xb[u * 3 + 2], sb[u]);
+            for (int u = 0; u < SUB; u++) column(xb[u * 3], xb[u * 3 + 1], xb[u * 3 + 2], sb[u], c + SUB - c0 + u);
+        }
+        if (MASK == 1 && lane == 0) lst[0] = (unsigned short)nlisted;
         }
 #undef RFA_FETCH_L
     } else {
@@ -1514,6 +1611,7 @@ struct AmLayout {
     bool rowsort_ok;       // the dense sweeps of the sharp levels take their rows in the clouds' spatial order (am_rowk_kernel SKIP)
     bool fgt_ok;           // the broad levels by expansion (emd_fgt.hip): scratch reserved
     size_t off_fgt;
+    size_t off_maskk, off_maskl;  // (rowsort_ok) the skipping sweeps' column lists, rows of set 1 / rows of set 2 (am_rowk_kernel MASK)
     int nsa, nsb;          // padded sizes of the two sorted sets
     size_t Vs;             // floats per sorted twin pair [L: nsa | R: nsb]
     size_t tw_stride;      // floats per batch element of the twin region: (1 + CULL_MAXLV) * Vs
@@ -1572,6 +1670,17 @@ AmLayout am_layout(int b, int n, int m, int nlevels, bool allow_cull) {
         off = (off + 63) / 64 * 64;
         L.off_fgt = off;
         off += (rfe::fgt_workspace_bytes(b, n > m ? n : m) + 3) / 4 + 64;
+    }
+    L.off_maskk = L.off_maskl = 0;
+    if (L.rowsort_ok) {
+        // per (wave of 64 or 128 sorted rows, column segment) a count and up to seglen 16-bit column numbers
+        const size_t wk = (size_t)b * rf::ceil_div(L.nsa, 64) * ((size_t)L.mpad + 16);
+        const size_t wl = (size_t)b * rf::ceil_div(L.nsb, 64) * ((size_t)L.npad + 16);
+        off = (off + 63) / 64 * 64;
+        L.off_maskk = off;
+        off += wk / 2 + 64;
+        L.off_maskl = off;
+        off += wl / 2 + 64;
     }
     L.total = off;
     return L;
@@ -1677,6 +1786,11 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
     const int segk = pick_nseg(b, n, L.mpad, RPT), segl = pick_nseg(b, m, L.npad, RPT);
     const dim3 gk(rf::ceil_div(n, 64 * RPT), b), gl(rf::ceil_div(m, 64 * RPT), b);
     const dim3 gks(rf::ceil_div(L.nsa, 64 * RPT), b), gls(rf::ceil_div(L.nsb, 64 * RPT), b);  // SKIP: over the sorted positions
+    // levels 0 and 1 both on the skipping sweeps (sharper cut-off first): level 0's launches list, per wave, the columns within level
+    // 1's cut-off; level 1's launches visit only those (RFA_SKIP_MASK)
+    const bool masked = RFA_SKIP_MASK && permA && permB && nlevels > 2 && lc.c[0] < lc.c[1] && lc.c[1] < 0.f && skip_t(1) <= kSkipMaxT &&
+                        n < 65536 && m < 65536;  // (16-bit column numbers)
+    unsigned short *maskk = (unsigned short *)(w + L.off_maskk), *maskl = (unsigned short *)(w + L.off_maskl);
     for (int v = 0; v < nlevels; v++) {
         float *ratioL = ratios + (size_t)v * L.V, *ratioR = ratioL + L.npad;
         const bool zero = lc.c[v] == 0.0f;  // e = exp2(d2 * 0) = 1 exactly: no exponential needed
@@ -1722,9 +1836,16 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
 #define AM_ROWK_ARGS(pR_, pL_, cprev)                                                                 \
     n, L.mpad / segk, xyz1, (const float *)x2p, (size_t)L.mpad * 3, pR_, (const float *)remainR, pL_,  \
         remainL, ratioL, L.bstride, cprev, lc.c[v], permA, L.nsa, tsk, skip_t(v - 1), gptr, 1
-        if (skip && v == 0) {
+        if (skip && v == 0 && masked) {  // ... and lists, per wave, the columns the next level's sweep will have to visit
+            RF_LAUNCH("am_p1", (am_rowk_kernel<false, 1, RPT, 1, 1>), gks, dim3(64 * segk), 0, s,
+                      AM_ROWK_ARGS((const float *)remainR, (const float *)remainL, 0.f), maskk, skip_t(1));
+        } else if (skip && v == 0) {
             RF_LAUNCH("am_p1", (am_rowk_kernel<false, 1, RPT, 1>), gks, dim3(64 * segk), 0, s,
                       AM_ROWK_ARGS((const float *)remainR, (const float *)remainL, 0.f));
+        } else if (skip && v == 1 && masked) {  // only the columns level 0's sweep listed
+            const float *pL = ratios + (size_t)(v - 1) * L.V, *pR = pL + L.npad;
+            RF_LAUNCH("am_p3p1", (am_rowk_kernel<true, 1, RPT, 1, 2>), gks, dim3(64 * segk), 0, s,
+                      AM_ROWK_ARGS(pR, pL, lc.c[v - 1]), maskk, 0.f);
         } else if (skip && lc.c[v - 1] != lc.c[v]) {
             const float *pL = ratios + (size_t)(v - 1) * L.V, *pR = pL + L.npad;
             RF_LAUNCH("am_p3p1", (am_rowk_kernel<true, 1, RPT, 1>), gks, dim3(64 * segk), 0, s,
@@ -1755,6 +1876,16 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
             RF_LAUNCH("am_p2", (am_rowl_kernel<RPT, true>), gl, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
                       (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR,
                       L.bstride, lc.c[v], permB, L.nsb, tsk, gptr, 1);
+        } else if (permB && tsk <= kSkipMaxT && masked && v <= 1) {
+            if (v == 0) {
+                RF_LAUNCH("am_p2", (am_rowl_kernel<RPT, false, true, 1>), gls, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
+                          (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR,
+                          L.bstride, lc.c[v], permB, L.nsb, tsk, gptr, 1, maskl, skip_t(1));
+            } else {
+                RF_LAUNCH("am_p2", (am_rowl_kernel<RPT, false, true, 2>), gls, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
+                          (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR,
+                          L.bstride, lc.c[v], permB, L.nsb, tsk, gptr, 1, maskl, 0.f);
+            }
         } else if (permB && tsk <= kSkipMaxT) {
             RF_LAUNCH("am_p2", (am_rowl_kernel<RPT, false, true>), gls, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
                       (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR,

@@ -328,6 +328,13 @@ def test_sharp_level_sweeps_with_sorted_rows_keep_every_bit():
         assert torch.equal(cm, c1.expand(reps)), (n, m)
         # (the gradients are atomic sums over workgroups: equal to fp32 summation noise, not bit for bit)
         assert torch.allclose(gm[0], g1[0], rtol=1e-5, atol=1e-6) and torch.allclose(hm[-1], h1[0], rtol=1e-5, atol=1e-6)
+        # DIFFERENT clouds per sample (level 0's sweeps list, per wave and sample, the columns level 1's will visit -- am_rowk_kernel
+        # MASK: a list read for the wrong sample would go unnoticed in a batch of copies), clustered so that the lists differ a lot
+        A = (rng.random_sample((reps, n, 3)) - 0.5).astype(np.float32) * np.linspace(0.2, 1.0, reps, dtype=np.float32)[:, None, None]
+        C = (rng.random_sample((reps, m, 3)) - 0.5).astype(np.float32) * np.linspace(1.0, 0.3, reps, dtype=np.float32)[:, None, None]
+        many = R.approx_match(cu(A), cu(C))
+        for i in range(reps):
+            assert torch.equal(many[i], R.approx_match(cu(A[i:i + 1]), cu(C[i:i + 1]))[0]), (n, m, i)
 
 
 @pytest.mark.parametrize("scale,what", [(1.0, "expanded"), (4.0, "refused: direct sums"), (float("nan"), "refused: a NaN coordinate")])
