@@ -259,6 +259,17 @@ int rf_grouppoint_grad(int b, int n, int c, int m, int nsample, const float *gra
  * grad_points (b,m,c) zero-filled here. */
 int rf_threenn(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist, int *idx,
                rf_stream_t stream);
+/* The same op over spatially sorted copies of the two sets (the Chamfer sweep's sort, rf_nn_sort): a wave of 64
+ * neighbouring unknown points visits only the candidate blocks whose box can still hold one of its three nearest.
+ * dist / idx bit-identical to rf_threenn (ties included: the three smallest by (distance, index), which is what
+ * the scan's strict '<' insertion in index order yields, tf_interpolate.cpp:78-93).  1 <= n, m <= 65536,
+ * b <= 65535 (else RF_EINVAL: use rf_threenn).  sorted1 / sorted2: rf_nn_sort handles of xyz1 / xyz2 or NULL
+ * (sorted here, into the workspace).  workspace: rf_threenn_boxes_workspace_bytes(b, n, m) bytes, 16-byte
+ * aligned (0 = outside the domain).  Pays from about 1e8 pairs per call on (the sort is ~25 us). */
+size_t rf_threenn_boxes_workspace_bytes(int b, int n, int m);
+int rf_threenn_boxes(int b, int n, int m, const float *xyz1, const float *xyz2, const void *sorted1,
+                     const void *sorted2, float *dist, int *idx, void *workspace, size_t workspace_bytes,
+                     rf_stream_t stream);
 int rf_threeinterpolate(int b, int m, int c, int n, const float *points, const int *idx,
                         const float *weight, float *out, rf_stream_t stream);
 int rf_threeinterpolate_grad(int b, int n, int c, int m, const float *grad_out, const int *idx,

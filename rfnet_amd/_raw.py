@@ -652,9 +652,16 @@ def group_point_grad(points, idx, grad_out):
 
 
 # ------------------------------------------------------------------ interpolation ----------
+TN_BOXES_MIN_PAIRS = 100_000_000  # three_nn: pairs per call from which sorting both sets is repaid
+
+
 @H.on_input_device
-def three_nn(xyz1, xyz2):
-    """ThreeNNOp, tf_ops/interpolation/tf_interpolate.cpp:157-187 -> dist (b,n,3), idx (b,n,3)."""
+def three_nn(xyz1, xyz2, form="auto", sorted1=None, sorted2=None):
+    """ThreeNNOp, tf_ops/interpolation/tf_interpolate.cpp:157-187 -> dist (b,n,3), idx (b,n,3).
+
+    form: "auto" (the boxed kernel over sorted copies of the two sets from TN_BOXES_MIN_PAIRS pairs per call on, the scan
+    below that), "boxes", "scan" -- same results, ties included; sorted1 / sorted2: rf_nn_sort handles of xyz1 / xyz2
+    (nn_sort), which skip the boxed form's own sort of that set."""
     st = H.Staged()
     u, k = st.take(xyz1, F32), st.take(xyz2, F32)
     if not _shape3(u, 3):
@@ -665,8 +672,18 @@ def three_nn(xyz1, xyz2):
     dev = st.device_()
     u, k = st.up(u, k)
     dist, idx = H.empty((b, n, 3), F32, dev), H.empty((b, n, 3), I32, dev)
-    check(lib.rf_threenn(b, n, m, H.ptr(u), H.ptr(k), H.ptr(dist), H.ptr(idx), H.stream(dev)),
-          "rf_threenn")
+    wsz = lib.rf_threenn_boxes_workspace_bytes(b, n, m) if b * n * m > 0 else 0
+    boxes = form == "boxes" or (form == "auto" and b * n * m >= TN_BOXES_MIN_PAIRS and n >= 1024 and m >= 256)
+    if form == "boxes" and not wsz:
+        raise H.invalid("ThreeNN: the boxed form takes sets of 1..65536 points")
+    if boxes and wsz:
+        ws = H.empty((wsz // 4,), F32, dev)
+        check(lib.rf_threenn_boxes(b, n, m, H.ptr(u), H.ptr(k), H.ptr(sorted1) if sorted1 is not None else None,
+                                   H.ptr(sorted2) if sorted2 is not None else None, H.ptr(dist), H.ptr(idx), H.ptr(ws), wsz,
+                                   H.stream(dev)), "rf_threenn_boxes")
+    else:
+        check(lib.rf_threenn(b, n, m, H.ptr(u), H.ptr(k), H.ptr(dist), H.ptr(idx), H.stream(dev)),
+              "rf_threenn")
     return st.give(dist), st.give(idx)
 
 

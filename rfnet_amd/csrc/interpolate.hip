@@ -13,7 +13,16 @@
 // lane's sorted triple only if d < b3; that test is one compare, and the insertion chain sits
 // behind a wave-uniform branch (taken for ~half of the candidates at m = 1024, ever more rarely as
 // m grows), instead of being predicated over every pair.
+//
+// three_nn over SORTED clouds (three_nn_boxes_kernel, rf_threenn_boxes): both sets in the spatial order of the Chamfer sweep's
+// sort (nn_pruned.hip: 64-record superblocks and 16-record blocks with their boxes).  A wave takes 64 consecutive sorted
+// unknown points -- a compact cell -- and visits only the candidate blocks whose box can still hold a point at or inside some
+// lane's third-best distance.  The bound is the SAME unfused fp32 expression evaluated on the per-axis gaps to the box: rounding
+// is monotone, so bound <= distance holds in fp32 exactly and nothing that the full scan would insert is skipped.  The scan
+// visits candidates in index order and inserts on strict '<': its result is the three smallest by (distance, index); the boxed
+// form visits them in any order and inserts by that pair -- the same triple, ties included.
 #include "common.hpp"
+#include "nn_pruned.hpp"
 
 namespace {
 
@@ -92,6 +101,221 @@ __global__ __launch_bounds__(TN_TPB) void three_nn_kernel(int n, int m,
     }
 }
 
+
+// ---- three_nn over sorted clouds ----------------------------------------------------------------------------------------
+#ifndef RFI_TB_WAVES
+#define RFI_TB_WAVES 4
+#endif
+constexpr int TB_WAVES = RFI_TB_WAVES;  // waves per workgroup, each on its own (no barrier)
+
+#define TB_ROW(OP, N) asm volatile("s_nop 1\n\t" OP " %0, %0, %0 row_ror:" #N " row_mask:0xf bank_mask:0xf" : "+v"(v))
+__device__ __forceinline__ float tb_wave_max(float v) {  // uniform result; inputs not NaN
+    TB_ROW("v_max_f32_dpp", 8);
+    TB_ROW("v_max_f32_dpp", 4);
+    TB_ROW("v_max_f32_dpp", 2);
+    TB_ROW("v_max_f32_dpp", 1);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+__device__ __forceinline__ float tb_wave_min(float v) {
+    TB_ROW("v_min_f32_dpp", 8);
+    TB_ROW("v_min_f32_dpp", 4);
+    TB_ROW("v_min_f32_dpp", 2);
+    TB_ROW("v_min_f32_dpp", 1);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fminf(fminf(r0, r1), fminf(r2, r3));
+}
+#undef TB_ROW
+
+// squared distance from a point (or, with plo != phi, a box) to a box, per axis the gap max(lo - phi, plo - hi, 0): the
+// unfused expression of the op itself, so that bound <= d in fp32 (header).  An empty box (lo = +inf, hi = -inf) is at +inf.
+__device__ __forceinline__ float tb_gap(float a, float b) { return fmaxf(fmaxf(a, b), 0.f); }
+__device__ __forceinline__ float tb_bound(float lx, float ly, float lz, float hx, float hy, float hz, float pxl, float pyl,
+                                          float pzl, float pxh, float pyh, float pzh) {
+    const float gx = tb_gap(lx - pxh, pxl - hx), gy = tb_gap(ly - pyh, pyl - hy), gz = tb_gap(lz - pzh, pzl - hz);
+    return (gx * gx + gy * gy) + gz * gz;
+}
+
+__global__ __launch_bounds__(64 * TB_WAVES) void three_nn_boxes_kernel(
+    int n, int npq, int npc, const float *__restrict__ qxyz, const int *__restrict__ qorig, const float *__restrict__ qb64,
+    const float *__restrict__ cxyz, const int *__restrict__ corig, const float *__restrict__ cb16,
+    const float *__restrict__ cb64, float *__restrict__ dist, int *__restrict__ idx) {
+    const int lane = threadIdx.x & 63;
+    const int group = blockIdx.x * TB_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bi = blockIdx.y;
+    if (group * 64 >= npq) return;  // (uniform)
+    const int p = group * 64 + lane;
+    const float *__restrict__ Q = qxyz + ((size_t)bi * npq + p) * 3;
+    const float x1 = Q[0], y1 = Q[1], z1 = Q[2];
+    const int oq = qorig[(size_t)bi * npq + p];
+    // a point with a NaN or infinite coordinate is at a NaN or infinite distance from everything: nothing is ever inserted
+    // (tf_interpolate.cpp:78-93: every comparison fails) and it takes no part in the search
+    const bool search = oq >= 0 && isfinite(x1) && isfinite(y1) && isfinite(z1);
+    // the lane's three best as 64-bit keys (distance bits, index): a squared distance is never negative, so its bit pattern orders
+    // as the float does, a NaN above +inf; "smaller key" is then the scan's strict '<' in index order, ties included, in ONE
+    // comparison.  Unfilled slots are (+inf, 0) as the op leaves them; a lane that does not search holds zeros -- nothing is
+    // below them -- until the end.
+    typedef unsigned long long u64;
+    const u64 kInf = (u64)0x7f800000u << 32;
+    u64 k1 = search ? kInf : 0ull, k2 = k1, k3 = k1;
+    const float *__restrict__ CX = cxyz + (size_t)bi * npc * 3;
+    const int *__restrict__ CO = corig + (size_t)bi * npc;
+    const int nsb = npc >> 6;
+    const float *__restrict__ B16 = cb16 + (size_t)bi * nsb * 24;
+    const float *__restrict__ B64 = cb64 + (size_t)bi * nsb * 8;
+#define TB_B3 __uint_as_float((unsigned)(k3 >> 32))
+
+    // One candidate (uniform coordinates and original index, through scalar registers).  A padding record (index -1 = the largest
+    // unsigned, coordinates +inf) never enters: its key is not below (+inf, 0).
+#define TB_CONSIDER(cx, cy, cz, oi)                                                                         \
+    {                                                                                                       \
+        const float dx_ = (cx) - x1, dy_ = (cy) - y1, dz_ = (cz) - z1;                                       \
+        const float xx_ = dx_ * dx_, yy_ = dy_ * dy_, zz_ = dz_ * dz_;                                       \
+        const float d_ = (xx_ + yy_) + zz_;                                                                  \
+        if (__ballot(d_ <= TB_B3) != 0ull) { /* wave-uniform */                                              \
+            asm volatile("; some lane may insert");                                                          \
+            const u64 key_ = ((u64)__float_as_uint(d_) << 32) | (u64)(unsigned)(oi);                         \
+            const bool c3_ = key_ < k3, c2_ = key_ < k2, c1_ = key_ < k1;                                    \
+            k3 = c3_ ? (c2_ ? k2 : key_) : k3;                                                               \
+            k2 = c2_ ? (c1_ ? k1 : key_) : k2;                                                               \
+            k1 = c1_ ? key_ : k1;                                                                            \
+        }                                                                                                   \
+    }
+#ifdef TB_STATS
+    int nblk = 0, nsbv = 0;  // (uniform) block scans, superblock visits
+#endif
+    // one superblock: per 16-record block the lanes' bounds against their third-best (TEST), then the records of the blocks
+    // some lane needs, eight at a time through two scalar register sets in turn (the next eight are on their way while
+    // these are compared)
+    auto visit = [&](int sb, bool test) {
+#ifdef TB_STATS
+        nsbv++;
+#endif
+        unsigned hm = 0xFFu;  // the half-blocks to scan
+        if (test) {
+            const float *bx = B16 + (size_t)sb * 24;  // (uniform -> scalar loads)
+            float bb[24];
+#pragma unroll
+            for (int i = 0; i < 24; i++) bb[i] = bx[i];
+            hm = 0u;
+#pragma unroll
+            for (int blk = 0; blk < 4; blk++) {
+                const float lb = tb_bound(bb[blk * 6], bb[blk * 6 + 1], bb[blk * 6 + 2], bb[blk * 6 + 3], bb[blk * 6 + 4],
+                                          bb[blk * 6 + 5], x1, y1, z1, x1, y1, z1);
+                if (__ballot(lb <= TB_B3) != 0ull) hm |= 3u << (2 * blk);  // (uniform)
+            }
+            if (hm == 0u) return;
+        }
+#ifdef TB_STATS
+        nblk += __builtin_popcount(hm) >> 1;
+#endif
+        const float *cb = CX + (size_t)sb * 192;
+        const int *ob = CO + sb * 64;
+        float ca[24], cc[24];
+        int oa[8], oc[8];
+#define TB_FETCH(C, O, H)                                           \
+    {                                                               \
+        const float *cp_ = cb + (H) * 24;                           \
+        const int *op_ = ob + (H) * 8;                              \
+        _Pragma("unroll") for (int i = 0; i < 24; i++) C[i] = cp_[i]; \
+        _Pragma("unroll") for (int i = 0; i < 8; i++) O[i] = op_[i];  \
+    }
+#define TB_SCAN8(C, O) _Pragma("unroll") for (int u = 0; u < 8; u++) TB_CONSIDER(C[u * 3], C[u * 3 + 1], C[u * 3 + 2], O[u])
+        int h = __builtin_ctz(hm);
+        hm &= hm - 1u;
+        TB_FETCH(ca, oa, h);
+        for (;;) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): set a has arrived
+            __builtin_amdgcn_sched_barrier(0);
+            const bool more_b = hm != 0u;
+            if (more_b) {
+                h = __builtin_ctz(hm);
+                hm &= hm - 1u;
+                TB_FETCH(cc, oc, h);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            TB_SCAN8(ca, oa);
+            if (!more_b) break;
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // set c has arrived
+            __builtin_amdgcn_sched_barrier(0);
+            const bool more_a = hm != 0u;
+            if (more_a) {
+                h = __builtin_ctz(hm);
+                hm &= hm - 1u;
+                TB_FETCH(ca, oa, h);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            TB_SCAN8(cc, oc);
+            if (!more_a) break;
+        }
+#undef TB_SCAN8
+#undef TB_FETCH
+    };
+
+    // the wave's own box (its 64 unknown points are one superblock of their sorted set); without a point to search for, no search
+    const float *qb = qb64 + ((size_t)bi * (npq >> 6) + group) * 8;
+    const float qlx = qb[0], qly = qb[1], qlz = qb[2], qhx = qb[4], qhy = qb[5], qhz = qb[6];
+    if (__ballot(search) != 0ull) {
+        // 1. lanes <-> candidate superblocks: the one nearest to the wave's box goes first and sets the third-bests
+        float best = INFINITY;
+        int arg = 0;
+        for (int r0 = 0; r0 < nsb; r0 += 64) {
+            const int g = r0 + lane;
+            float lb = INFINITY;
+            if (g < nsb) {
+                const float4 lo = *(const float4 *)(B64 + (size_t)g * 8), hi = *(const float4 *)(B64 + (size_t)g * 8 + 4);
+                lb = tb_bound(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, qlx, qly, qlz, qhx, qhy, qhz);
+            }
+            if (lb < best) best = lb, arg = g;
+        }
+        const float wmin = tb_wave_min(best);
+        const unsigned long long at = __ballot(best == wmin);
+        const int seed = at != 0ull ? __builtin_amdgcn_readlane(arg, __builtin_ctzll(at)) : 0;
+        visit(seed, false);
+        // 2. every other superblock whose box is not beyond the wave's largest third-best (which shrinks as the visits go)
+        float w3 = tb_wave_max(TB_B3);  // (a lane that does not search holds 0)
+        for (int r0 = 0; r0 < nsb; r0 += 64) {
+            const int g = r0 + lane;
+            float lb = INFINITY;
+            if (g < nsb && g != seed) {
+                const float4 lo = *(const float4 *)(B64 + (size_t)g * 8), hi = *(const float4 *)(B64 + (size_t)g * 8 + 4);
+                lb = tb_bound(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, qlx, qly, qlz, qhx, qhy, qhz);
+            }
+            unsigned long long todo = __ballot(lb <= w3 && lb != INFINITY);
+            while (todo != 0ull) {  // (uniform)
+                const int j = __builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                const float lbj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lb), j));
+                if (!(lbj <= w3)) continue;  // (the bound has moved since the ballot)
+                visit(r0 + j, true);
+                w3 = tb_wave_max(TB_B3);
+            }
+        }
+    }
+#undef TB_CONSIDER
+#undef TB_B3
+    if (oq >= 0) {
+        if (!search) k1 = k2 = k3 = kInf;
+        const size_t o = ((size_t)bi * n + oq) * 3;
+        dist[o] = __uint_as_float((unsigned)(k1 >> 32));
+        dist[o + 1] = __uint_as_float((unsigned)(k2 >> 32));
+        dist[o + 2] = __uint_as_float((unsigned)(k3 >> 32));
+        idx[o] = (int)(unsigned)k1;
+#ifdef TB_STATS
+        idx[o + 1] = nsbv, idx[o + 2] = nblk;
+#else
+        idx[o + 1] = (int)(unsigned)k2;
+        idx[o + 2] = (int)(unsigned)k3;
+#endif
+    }
+}
+
 __global__ void three_interpolate_kernel(int m, int c, int n, long total,
                                          const float *__restrict__ points,
                                          const int *__restrict__ idx,
@@ -135,6 +359,40 @@ int rf_threenn(int b, int n, int m, const float *xyz1, const float *xyz2, float 
     if (!xyz1 || !dist || !idx || (m > 0 && !xyz2)) return RF_EINVAL;
     RF_LAUNCH("three_nn", three_nn_kernel, dim3(rf::ceil_div(n, TN_TPB), b), dim3(TN_TPB), 0,
               (hipStream_t)stream, n, m, xyz1, xyz2, dist, idx);
+    return RF_OK;
+}
+
+// ---- the boxed form: needs scratch (the sorted copies of the two sets unless the caller hands rf_nn_sort handles over)
+size_t rf_threenn_boxes_workspace_bytes(int b, int n, int m) {
+    if (b <= 0 || b > 65535 || !rfp::pruned_supported(b, n, m)) return 0;
+    return rfp::sorted_bytes(b, n) + rfp::sorted_bytes(b, m);
+}
+
+int rf_threenn_boxes(int b, int n, int m, const float *xyz1, const float *xyz2, const void *sorted1, const void *sorted2,
+                     float *dist, int *idx, void *workspace, size_t workspace_bytes, rf_stream_t stream) {
+    if (b < 0 || n < 0 || m < 0) return RF_EINVAL;
+    if (b == 0 || n == 0) return RF_OK;
+    if (b > 65535 || !rfp::pruned_supported(b, n, m)) return RF_EINVAL;  // (m = 0 and huge clouds: rf_threenn)
+    if (!xyz1 || !xyz2 || !dist || !idx || !workspace || !rf::aligned16(workspace)) return RF_EINVAL;
+    if ((sorted1 && !rf::aligned16(sorted1)) || (sorted2 && !rf::aligned16(sorted2))) return RF_EINVAL;
+    if (workspace_bytes < rf_threenn_boxes_workspace_bytes(b, n, m)) return RF_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    rfp::Sorted sv[2];
+    sv[0] = rfp::sorted_view(b, n, sorted1 ? sorted1 : workspace);
+    sv[1] = rfp::sorted_view(b, m, sorted2 ? sorted2 : (const char *)workspace + rfp::sorted_bytes(b, n));
+    {  // the sets that came without a handle, in one launch
+        int nn[2];
+        const float *src[2];
+        rfp::Sorted out[2];
+        int k = 0;
+        if (!sorted1) nn[k] = n, src[k] = xyz1, out[k] = sv[0], k++;
+        if (!sorted2) nn[k] = m, src[k] = xyz2, out[k] = sv[1], k++;
+        if (k > 0)
+            if (int e = rfp::sort_sets(b, k, nn, src, out, s, nullptr)) return e;
+    }
+    RF_LAUNCH("three_nn_boxes", three_nn_boxes_kernel, dim3(rf::ceil_div(sv[0].npad / 64, TB_WAVES), b), dim3(64 * TB_WAVES), 0, s,
+              n, sv[0].npad, sv[1].npad, sv[0].xyz, sv[0].orig, sv[0].box64, sv[1].xyz, sv[1].orig, sv[1].box16, sv[1].box64,
+              dist, idx);
     return RF_OK;
 }
 
