@@ -309,7 +309,7 @@ def run_c3(rank, dev, fence, reps):
     query_ball_point(0.1, 32, xyz, new_xyz); group_point(xyz, idx).  Which roof binds each op: SURVEY.md 8(d)
     (FPS: serial-reduction latency, reported as us per iteration and distance updates/s; ball query: VALU scan
     with early exit, reported as pair tests/s against the scan's upper bound; gather / group: HBM)."""
-    from rfnet_amd._raw import farthest_point_sample, gather_point, group_point, nn_sort, query_ball_point, sample_and_group
+    from rfnet_amd._raw import farthest_point_sample, gather_point, group_point, nn_sort, query_ball_point, sample_and_group, three_nn
     B, n, m, ns, r = 32, 16384, 1024, 32, 0.1
     rng = np.random.RandomState(100 + rank)
     xyz = torch.from_numpy(rng.random_sample((B, n, 3)).astype(np.float32)).to(dev)
@@ -337,6 +337,14 @@ def run_c3(rank, dev, fence, reps):
     fps_same = bool(torch.equal(farthest_point_sample_reg(m, xyz), idx))
     box_kms = qb_k.get("query_ball_boxes", qb_ms)
     updates = float(B) * n * (m - 1)
+    # the way back (feature propagation): the three nearest SAMPLED points of every point of the cloud
+    tn_d, tn_i = three_nn(xyz, new_xyz)                                  # auto: over sorted copies of both sets at this size
+    tn_ds, tn_is = three_nn(xyz, new_xyz, form="scan")
+    tn_ms, tn_k = timed(lambda: three_nn(xyz, new_xyz), reps, fence)
+    h_new = nn_sort(new_xyz)
+    tnh_ms, tnh_k = timed(lambda: three_nn(xyz, new_xyz, sorted1=handle.buf, sorted2=h_new.buf), reps, fence)
+    tns_ms, tns_k = timed(lambda: three_nn(xyz, new_xyz, form="scan"), reps, fence)
+    tn_kms = tn_k.get("three_nn_boxes", tn_ms)
     return {
         "workload": f"B={B} per GPU, farthest_point_sample {n} -> {m} + gather_point + query_ball_point(r={r}, nsample={ns}) "
                     "+ group_point(c=3), U[0,1)^3 seed 100 (BASELINE.json configs[2])",
@@ -386,6 +394,20 @@ def run_c3(rank, dev, fence, reps):
                          "achieved": 8.0 * B * n * m / (box_kms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": 8.0 * B * n * m / (box_kms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
                          "scan_kernel_frac": 8.0 * B * n * m / (qs_k.get("query_ball_point", qs_ms) * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}},
+        "three_nn": {
+            "what": f"three_nn(xyz, new_xyz): the {m} sampled points as the known set of all {n} points (a10; not part of ms_per_pass)",
+            "ms": tn_ms, "kernels_ms": tn_k, "ms_on_sorted_handles": tnh_ms, "ms_scan_kernel": tns_ms,
+            "form": "boxed: both sets in sort-tile-recursive order (one nnp_sort launch), a wave = 64 consecutive sorted unknown points, "
+                    "candidate superblocks nearest box first, per 16-record block the lanes' box bounds against their third-best, records "
+                    "through scalar registers, the triple as 64-bit (distance, index) keys (interpolate.hip three_nn_boxes_kernel)",
+            "identical_to_scan_kernel": bool(torch.equal(tn_d, tn_ds)) and bool(torch.equal(tn_i, tn_is)),
+            "roofline": {"bound": "valu-issue",
+                         "what": "the boxed kernel evaluates ~15 % of the B*n*m pairs (the union of 64 lanes' neighbourhoods: ~10 of 64 "
+                                 "blocks per wave); `achieved` prices the B*n*m pair tests of the SCAN it replaces (8 flop each) against "
+                                 "the fp32 vector peak -- an effective figure, like the culled Chamfer's",
+                         "achieved": 8.0 * B * n * m / (tn_kms * 1e-3) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": 8.0 * B * n * m / (tn_kms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                         "scan_kernel_frac": 8.0 * B * n * m / (tns_k.get("three_nn", tns_ms) * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}},
         "group_point": {"ms": gp_ms, "roofline": hbm_roof(4.0 * B * m * ns * (1 + 2 * 3), gp_k.get("group_point", gp_ms), "group_point",
                                                           "4*B*m*nsample*(1+2c) bytes (SURVEY 8(d)): 29 MB; inside rf_sample_and_group "
                                                           "the ball query writes grouped_xyz itself")},

@@ -652,7 +652,11 @@ def group_point_grad(points, idx, grad_out):
 
 
 # ------------------------------------------------------------------ interpolation ----------
-TN_BOXES_MIN_PAIRS = 100_000_000  # three_nn: pairs per call from which sorting both sets is repaid
+# three_nn: pairs per call from which sorting both sets is repaid (tools/ab_three_nn.py: the sort is ~25 us for sets of up to
+# 16384 points -- one workgroup per cloud with the points in registers -- and ~270 us beyond)
+TN_BOXES_MIN_PAIRS = 100_000_000
+TN_BOXES_MIN_PAIRS_LARGE = 4_000_000_000
+TN_BOXES_MIN_KNOWN = 512  # fewer known points: a handful of blocks, nothing to skip
 
 
 @H.on_input_device
@@ -673,7 +677,8 @@ def three_nn(xyz1, xyz2, form="auto", sorted1=None, sorted2=None):
     u, k = st.up(u, k)
     dist, idx = H.empty((b, n, 3), F32, dev), H.empty((b, n, 3), I32, dev)
     wsz = lib.rf_threenn_boxes_workspace_bytes(b, n, m) if b * n * m > 0 else 0
-    boxes = form == "boxes" or (form == "auto" and b * n * m >= TN_BOXES_MIN_PAIRS and n >= 1024 and m >= 256)
+    need = TN_BOXES_MIN_PAIRS if max(n if sorted1 is None else 0, m if sorted2 is None else 0) <= 16384 else TN_BOXES_MIN_PAIRS_LARGE
+    boxes = form == "boxes" or (form == "auto" and b * n * m >= need and n >= 1024 and m >= TN_BOXES_MIN_KNOWN)
     if form == "boxes" and not wsz:
         raise H.invalid("ThreeNN: the boxed form takes sets of 1..65536 points")
     if boxes and wsz:

@@ -278,7 +278,8 @@ __global__ __launch_bounds__(64 * TB_WAVES) void three_nn_boxes_kernel(
         const unsigned long long at = __ballot(best == wmin);
         const int seed = at != 0ull ? __builtin_amdgcn_readlane(arg, __builtin_ctzll(at)) : 0;
         visit(seed, false);
-        // 2. every other superblock whose box is not beyond the wave's largest third-best (which shrinks as the visits go)
+        // 2. every other superblock whose box is not beyond the wave's largest third-best (which shrinks as the visits go),
+        //    64 superblocks at a time
         float w3 = tb_wave_max(TB_B3);  // (a lane that does not search holds 0)
         for (int r0 = 0; r0 < nsb; r0 += 64) {
             const int g = r0 + lane;
@@ -287,12 +288,13 @@ __global__ __launch_bounds__(64 * TB_WAVES) void three_nn_boxes_kernel(
                 const float4 lo = *(const float4 *)(B64 + (size_t)g * 8), hi = *(const float4 *)(B64 + (size_t)g * 8 + 4);
                 lb = tb_bound(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, qlx, qly, qlz, qhx, qhy, qhz);
             }
-            unsigned long long todo = __ballot(lb <= w3 && lb != INFINITY);
-            while (todo != 0ull) {  // (uniform)
-                const int j = __builtin_ctzll(todo);
-                todo &= todo - 1ull;
-                const float lbj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lb), j));
-                if (!(lbj <= w3)) continue;  // (the bound has moved since the ballot)
+            // nearest box first: the third-bests shrink fastest that way, and the first box beyond the wave's largest ends the round
+            bool pend = lb <= w3 && lb != INFINITY;
+            while (__ballot(pend) != 0ull) {  // (uniform)
+                const float wmin = tb_wave_min(pend ? lb : INFINITY);
+                if (!(wmin <= w3)) break;
+                const int j = __builtin_ctzll(__ballot(pend && lb == wmin));
+                pend = pend && lane != j;
                 visit(r0 + j, true);
                 w3 = tb_wave_max(TB_B3);
             }

@@ -146,6 +146,8 @@ def test_fuzz_three_nn_interpolate(orc, seed):
     od, oi = orc.three_nn(a, c)
     assert np.array_equal(i.cpu().numpy(), oi), f"seed {seed} b={b} n={n} m={m}"
     assert np.array_equal(d.cpu().numpy(), od)
+    db, ib = _raw.three_nn(cu(a), cu(c), form="boxes")  # over sorted copies of the two sets: the same bits
+    assert torch.equal(ib, i) and torch.equal(db.view(torch.int32), d.view(torch.int32)), f"boxes: seed {seed} b={b} n={n} m={m}"
     if m >= 3:
         ch = rng.randint(1, 20)
         pts = rng.randn(b, m, ch).astype(np.float32)

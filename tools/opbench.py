@@ -109,6 +109,7 @@ def main():
         p3 = torch.from_numpy(rng.random_sample((32, 3000, 3)).astype(np.float32)).to(dev)
         timeit("FPS 32x3000->32 (model)", lambda: R.farthest_point_sample(32, p3), a.iters)
         timeit("three_nn 32x16384 vs 1024", lambda: R.three_nn(p, q), a.iters)
+        timeit("three_nn 32x16384 vs 1024, scan kernel", lambda: R.three_nn(p, q, form="scan"), a.iters)
     if w == "c4":
         # BASELINE configs[3] alone (one launch shape per kernel name: what the PMC passes of tools/profile_op.sh need)
         u = torch.from_numpy((rng.random_sample((32, 2048, 3)) - 0.5).astype(np.float32)).to(dev)
