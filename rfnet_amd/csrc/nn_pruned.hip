@@ -2029,6 +2029,12 @@ __global__ __launch_bounds__(64 * NSH) __attribute__((amdgpu_waves_per_eu(RFP_WP
 #ifndef RFP_GS_TPB
 #define RFP_GS_TPB 256
 #endif
+#ifndef RFP_GS_F64
+#define RFP_GS_F64 1  // the tile's sums in DOUBLE: ds_add_f64 runs at 18 lane-operations per ns and CU, ds_add_f32 at 0.8 (tools/ubench/lds_atomic_rate.hip)
+#endif
+#ifndef RFP_GS_SEG
+#define RFP_GS_SEG 0  // the pre-reduction of the fp32 days (grad_tile)
+#endif
 #ifndef RFP_GS_KB
 #define RFP_GS_KB 4
 #endif
@@ -2052,7 +2058,12 @@ struct GradSArgs {
 // One destination tile (256 threads): `tile` in [0, tiles[0] + tiles[1]) of cloud bi.  acc: gt * 3 floats of LDS; list:
 // GS_MAXG entries; nlist_p: one LDS word.  (A device function since round 4's fused-step experiment ran the same tile
 // inside the sweep's launch: tools/experiments/fused_step.patch.txt)
-__device__ __forceinline__ void grad_tile(const GradSArgs &a, const int bi, int tile, float *__restrict__ acc,
+#if RFP_GS_F64
+typedef double gs_acc_t;
+#else
+typedef float gs_acc_t;
+#endif
+__device__ __forceinline__ void grad_tile(const GradSArgs &a, const int bi, int tile, gs_acc_t *__restrict__ acc,
                                           unsigned short *__restrict__ list, int *nlist_p) {
     int &nlist = *nlist_p;
     const int D = tile >= a.tiles[0];
@@ -2093,7 +2104,7 @@ __device__ __forceinline__ void grad_tile(const GradSArgs &a, const int bi, int 
             own[u][2] = __int_as_float(rc.w);
         }
     }
-    for (int i = tid; i < jn * 3; i += GS_TPB) acc[i] = 0.f;
+    for (int i = tid; i < jn * 3; i += GS_TPB) acc[i] = (gs_acc_t)0;
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < RG; u++)
@@ -2118,16 +2129,18 @@ __device__ __forceinline__ void grad_tile(const GradSArgs &a, const int bi, int 
         }
 #pragma unroll
         for (int i = 0; i < GS_KB; i++) {
-            // ds_add_f32 costs per ACTIVE LANE on the CU's one LDS pipe (measured: an eighth of the lanes, an
-            // eighth of the time), and consecutive sorted sources mostly share their winner: runs of equal
-            // destination inside a 16-lane row are summed in registers first (segmented scan by DPP row
-            // shifts) and only the last lane of a run touches LDS.
+            // The sums are DOUBLES: a CU's LDS adds 18 lanes per ns with ds_add_f64 and 0.8 with ds_add_f32 (80 ns for a wave's
+            // instruction whatever the addresses: tools/ubench/lds_atomic_rate.hip), which is what this kernel was bound by
+            // (16.3 -> 12.8 us, step 84 -> 80.5 us).  RFP_GS_SEG: the pre-reduction that made the fp32 atomics bearable -- runs of
+            // equal destination inside a 16-lane row summed in registers (segmented scan by DPP row shifts), only the last lane
+            // of a run touching LDS; it changes nothing any more and is off.
             const int j = w[i] - j0;
             const int key = (unsigned)j < (unsigned)jn ? j : -1;
+            float sx = -v[i][0], sy = -v[i][1], sz = -v[i][2];
+#if RFP_GS_SEG
             const int kprev = __builtin_amdgcn_update_dpp(-2, key, 0x111, 0xf, 0xf, false);  // row_shr:1
             const int knext = __builtin_amdgcn_update_dpp(-2, key, 0x101, 0xf, 0xf, false);  // row_shl:1
             int f = key != kprev;  // head of a run (or of the row)
-            float sx = -v[i][0], sy = -v[i][1], sz = -v[i][2];
 #define RFP_SEG(CTRL)                                                                                   \
     {                                                                                                   \
         const int fp = __builtin_amdgcn_update_dpp(1, f, CTRL, 0xf, 0xf, false);                        \
@@ -2141,10 +2154,14 @@ __device__ __forceinline__ void grad_tile(const GradSArgs &a, const int bi, int 
     }
             RFP_SEG(0x111) RFP_SEG(0x112) RFP_SEG(0x114) RFP_SEG(0x118)
 #undef RFP_SEG
-            if (key >= 0 && key != knext) {
-                atomicAdd(&acc[key * 3 + 0], sx);
-                atomicAdd(&acc[key * 3 + 1], sy);
-                atomicAdd(&acc[key * 3 + 2], sz);
+            const bool last = key != knext;
+#else
+            const bool last = true;
+#endif
+            if (key >= 0 && last) {
+                atomicAdd(&acc[key * 3 + 0], (gs_acc_t)sx);
+                atomicAdd(&acc[key * 3 + 1], (gs_acc_t)sy);
+                atomicAdd(&acc[key * 3 + 2], (gs_acc_t)sz);
             }
         }
     }
@@ -2159,13 +2176,13 @@ __device__ __forceinline__ void grad_tile(const GradSArgs &a, const int bi, int 
             struct P3 {
                 float x, y, z;
             };
-            *(P3 *)(out + (size_t)oo[u] * 3) = P3{own[u][0] + acc[j * 3 + 0], own[u][1] + acc[j * 3 + 1], own[u][2] + acc[j * 3 + 2]};
+            *(P3 *)(out + (size_t)oo[u] * 3) = P3{own[u][0] + (float)acc[j * 3 + 0], own[u][1] + (float)acc[j * 3 + 1], own[u][2] + (float)acc[j * 3 + 2]};
         }
     }
 }
 
 __global__ __launch_bounds__(GS_TPB) void nnp_grad_sorted_kernel(GradSArgs a) {
-    extern __shared__ float acc_dyn[];  // [gt * 3], gt = the larger of the two sets' tile sizes
+    extern __shared__ __attribute__((aligned(8))) unsigned char acc_dyn[];  // gs_acc_t [gt * 3], gt = the larger of the two sets' tile sizes
     __shared__ unsigned short list[GS_MAXG];
     __shared__ int nlist;
     // cloud-major logical order, each XCD a contiguous eighth (as sort and sweep): the re-reads of a cloud's
@@ -2174,7 +2191,7 @@ __global__ __launch_bounds__(GS_TPB) void nnp_grad_sorted_kernel(GradSArgs a) {
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (int)(blockIdx.x >> 3);
     const int wpc = a.tiles[0] + a.tiles[1];
     const int bi = logical / wpc;
-    grad_tile(a, bi, logical - bi * wpc, acc_dyn, list, &nlist);
+    grad_tile(a, bi, logical - bi * wpc, (gs_acc_t *)acc_dyn, list, &nlist);
 }
 
 int round_up(long v, int q) { return (int)((v + q - 1) / q * q); }
@@ -2370,7 +2387,7 @@ int pruned_step(int b, int n, int m, const float *xyz1, const float *xyz2, const
     if (int e = sweep_sorted_impl(b, n, m, so[0], so[1], dist1, idx1, dist2, idx2, 3, s, nullptr, &ge)) return e;
     const int gtmax = ga.gt[0] > ga.gt[1] ? ga.gt[0] : ga.gt[1];
     RF_LAUNCH("nnp_grad_sorted", nnp_grad_sorted_kernel, dim3(b * (ga.tiles[0] + ga.tiles[1])), dim3(GS_TPB),
-              (size_t)gtmax * 3 * sizeof(float), s, ga);
+              (size_t)gtmax * 3 * sizeof(gs_acc_t), s, ga);
     return RF_OK;
 }
 
