@@ -318,6 +318,174 @@ __global__ __launch_bounds__(64 * TB_WAVES) void three_nn_boxes_kernel(
     }
 }
 
+// ---- three_interpolate / its gradient, row-shaped --------------------------------------------------------------------------
+// One element per thread (the kernels below) pays a 64-bit division per output element and six index / weight loads for four
+// bytes of output: 1.7 TB/s forward, 0.5 TB/s backward at 32 x 16384 x 1024, c = 128.  Here a thread row owns an unknown point:
+// its three indices and weights are loaded once, the channels go by as VEC-wide vectors over the row's lanes (32-bit
+// arithmetic, no division).  Same expression per element: (p1*w1 + p2*w2) + p3*w3, every product rounded (-ffp-contract=off).
+constexpr int TI_TPB = 256;
+constexpr int TI_PP = 4;  // points per thread row and block
+
+typedef float ti_v4f __attribute__((ext_vector_type(4)));
+template <int VEC>
+struct TiVec;
+template <>
+struct TiVec<4> {
+    typedef ti_v4f T;
+    static __device__ __forceinline__ T mul(T a, float w) { return a * w; }  // (per component, every product rounded)
+    static __device__ __forceinline__ T add(T a, T b) { return a + b; }
+    static __device__ __forceinline__ float at(T a, int v) { return a[v]; }
+};
+template <>
+struct TiVec<1> {
+    typedef float T;
+    static __device__ __forceinline__ T mul(T a, float w) { return a * w; }
+    static __device__ __forceinline__ T add(T a, T b) { return a + b; }
+    static __device__ __forceinline__ float at(T a, int) { return a; }
+};
+
+template <int VEC>
+__global__ __launch_bounds__(TI_TPB) void three_interpolate_rows_kernel(int m, int c, int n, int tx_log2,
+                                                                        const float *__restrict__ points,
+                                                                        const int *__restrict__ idx,
+                                                                        const float *__restrict__ weight,
+                                                                        float *__restrict__ out) {
+    typedef typename TiVec<VEC>::T V;
+    const int bi = blockIdx.y;
+    const int TX = 1 << tx_log2, TY = TI_TPB >> tx_log2;
+    const int lx = threadIdx.x & (TX - 1), ly = threadIdx.x >> tx_log2;
+    const int cv = c / VEC;
+    const V *__restrict__ P = (const V *)(points + (size_t)bi * m * c);
+    V *__restrict__ O = (V *)(out + (size_t)bi * n * c);
+    const int *__restrict__ I = idx + (size_t)bi * n * 3;
+    const float *__restrict__ W = weight + (size_t)bi * n * 3;
+    int r[TI_PP][3];
+    float w[TI_PP][3];
+    int jj[TI_PP];
+#pragma unroll
+    for (int u = 0; u < TI_PP; u++) {
+        jj[u] = (blockIdx.x * TI_PP + u) * TY + ly;
+        const int j = min(jj[u], n - 1);
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            r[u][t] = I[j * 3 + t] * cv;
+            w[u][t] = W[j * 3 + t];
+        }
+    }
+    for (int l = lx; l < cv; l += TX) {
+        V a[TI_PP], b2[TI_PP], d[TI_PP];
+#pragma unroll
+        for (int u = 0; u < TI_PP; u++) a[u] = P[r[u][0] + l], b2[u] = P[r[u][1] + l], d[u] = P[r[u][2] + l];
+#pragma unroll
+        for (int u = 0; u < TI_PP; u++) {
+            if (jj[u] < n)  // (written once, read by another kernel: past the caches)
+                __builtin_nontemporal_store(TiVec<VEC>::add(TiVec<VEC>::add(TiVec<VEC>::mul(a[u], w[u][0]), TiVec<VEC>::mul(b2[u], w[u][1])),
+                                                            TiVec<VEC>::mul(d[u], w[u][2])), &O[(size_t)jj[u] * cv + l]);
+        }
+    }
+}
+
+// The gradient: a workgroup owns a SLICE of cs channels of one sample's (m, c) gradient as an LDS tile of doubles -- ds_add_f64
+// runs at 18 lane-operations per ns and CU against 0.8 for ds_add_f32 (tools/ubench/lds_atomic_rate.hip), and L2 atomics from
+// every element (the kernel below) reach 0.3 per ns and CU -- and walks a part of the unknown points: grad_out is read once,
+// cs * 4 bytes per point and workgroup; the tile leaves as plain stores (one part) or atomic adds (several).
+constexpr int TG_TPB = 1024;  // (128 KiB of LDS: one workgroup per CU -- its 16 waves are all the loads in flight there are)
+constexpr int TG_U = 4;  // points per thread row in flight
+
+template <int VEC>
+__global__ __launch_bounds__(TG_TPB) void three_interpolate_grad_tile_kernel(int m, int c, int n, int cs_log2, int tx_log2,
+                                                                             int nslices, int parts,
+                                                                             const float *__restrict__ grad_out,
+                                                                             const int *__restrict__ idx,
+                                                                             const float *__restrict__ weight,
+                                                                             float *__restrict__ grad_points) {
+    typedef typename TiVec<VEC>::T V;
+    extern __shared__ __attribute__((aligned(16))) double ti_tile[];  // [m << cs_log2]
+    const int bi = blockIdx.y;
+    const int slice = blockIdx.x % nslices, part = blockIdx.x / nslices;
+    const int cs = 1 << cs_log2;
+    const int TX = 1 << tx_log2, TY = TG_TPB >> tx_log2;
+    const int lx = threadIdx.x & (TX - 1), ly = threadIdx.x >> tx_log2;
+    for (int e = threadIdx.x; e < (m << cs_log2); e += TG_TPB) ti_tile[e] = 0.0;
+    const int per = (n + parts - 1) / parts;
+    const int jbeg = part * per, jend = min(n, jbeg + per);
+    const float *__restrict__ G = grad_out + (size_t)bi * n * c + slice * cs + lx * VEC;
+    const int *__restrict__ I = idx + (size_t)bi * n * 3;
+    const float *__restrict__ W = weight + (size_t)bi * n * 3;
+    __syncthreads();
+    // a point's cs sums sit v-major in the tile (channel lx * VEC + v at v * TX + lx): the lanes of a row then add to consecutive
+    // doubles in every instruction; the next batch of points is loaded before this one is added (two waves per SIMD at 128 KiB
+    // of LDS: nothing else hides the loads)
+    const int rot = VEC == 4 ? (ly & 3) : 0;  // this row's first channel of four
+    int voff[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; k++) voff[k] = ((k + rot) & (VEC - 1)) << tx_log2;
+    V g[TG_U], gn[TG_U];
+    int r[TG_U][3], rn[TG_U][3];
+    float w[TG_U][3], wn[TG_U][3];
+#define TG_LOAD(GG, RR, WW, J0)                                                   \
+    _Pragma("unroll") for (int u = 0; u < TG_U; u++) {                            \
+        const int j = min((J0) + u * TY, jend - 1);                               \
+        GG[u] = *(const V *)(G + (size_t)j * c);                                  \
+        _Pragma("unroll") for (int t = 0; t < 3; t++) {                           \
+            RR[u][t] = (I[j * 3 + t] << cs_log2) + lx;                            \
+            WW[u][t] = W[j * 3 + t];                                              \
+        }                                                                         \
+    }
+    if (jbeg + ly < jend) {
+        TG_LOAD(g, r, w, jbeg + ly)
+    }
+    for (int j0 = jbeg + ly; j0 < jend; j0 += TY * TG_U) {
+        const bool more = j0 + TY * TG_U < jend;
+        if (more) {
+            TG_LOAD(gn, rn, wn, j0 + TY * TG_U)
+        }
+        // (neighbouring rows start at different channels: in one instruction the rows of a wave would otherwise all add to the
+        // same 8 banks of their points' 32)
+        float gr[TG_U][VEC];
+#pragma unroll
+        for (int u = 0; u < TG_U; u++)
+#pragma unroll
+            for (int k = 0; k < VEC; k++) {
+                float x = TiVec<VEC>::at(g[u], k);
+                if (VEC == 4) {
+                    const float y = TiVec<VEC>::at(g[u], (k + 1) & 3), z = TiVec<VEC>::at(g[u], (k + 2) & 3), q = TiVec<VEC>::at(g[u], (k + 3) & 3);
+                    x = rot == 0 ? x : (rot == 1 ? y : (rot == 2 ? z : q));
+                }
+                gr[u][k] = x;
+            }
+#pragma unroll
+        for (int u = 0; u < TG_U; u++) {
+            if (j0 + u * TY < jend) {
+#pragma unroll
+                for (int t = 0; t < 3; t++)
+#pragma unroll
+                    for (int k = 0; k < VEC; k++) atomicAdd(&ti_tile[r[u][t] + voff[k]], (double)(gr[u][k] * w[u][t]));
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < TG_U; u++) {
+                g[u] = gn[u];
+#pragma unroll
+                for (int t = 0; t < 3; t++) r[u][t] = rn[u][t], w[u][t] = wn[u][t];
+            }
+        }
+    }
+#undef TG_LOAD
+    __syncthreads();
+    float *__restrict__ GP = grad_points + (size_t)bi * m * c + slice * cs;
+    for (int e = threadIdx.x; e < (m << cs_log2); e += TG_TPB) {
+        const int i = e >> cs_log2, ch = e & (cs - 1);
+        const float v = (float)ti_tile[(i << cs_log2) + (ch % VEC << tx_log2) + ch / VEC];
+        if (parts == 1) {
+            GP[(size_t)i * c + ch] = v;
+        } else {
+            atomicAdd(&GP[(size_t)i * c + ch], v);
+        }
+    }
+}
+
 __global__ void three_interpolate_kernel(int m, int c, int n, long total,
                                          const float *__restrict__ points,
                                          const int *__restrict__ idx,
@@ -404,6 +572,24 @@ int rf_threeinterpolate(int b, int m, int c, int n, const float *points, const i
     long total = (long)b * n * c;
     if (total == 0) return RF_OK;
     if (!points || !idx || !weight || !out) return RF_EINVAL;
+    if (b <= 65535 && (long)n * c < (1L << 31) && (long)m * c < (1L << 31) && (long)n * 3 < (1L << 31)) {
+        const bool vec = c % 4 == 0 && rf::aligned16(points) && rf::aligned16(out);
+        const int cv = vec ? c / 4 : c;
+        int tx_log2 = 0;
+        while ((1 << tx_log2) < cv && tx_log2 < 6) tx_log2++;
+        const int ppb = (TI_TPB >> tx_log2) * TI_PP;  // points per block
+        if (rf::ceil_div(n, ppb) <= 0x7FFFFFFF) {
+            const dim3 grid(rf::ceil_div(n, ppb), b);
+            if (vec) {
+                RF_LAUNCH("three_interpolate", three_interpolate_rows_kernel<4>, grid, dim3(TI_TPB), 0, (hipStream_t)stream, m, c, n,
+                          tx_log2, points, idx, weight, out);
+            } else {
+                RF_LAUNCH("three_interpolate", three_interpolate_rows_kernel<1>, grid, dim3(TI_TPB), 0, (hipStream_t)stream, m, c, n,
+                          tx_log2, points, idx, weight, out);
+            }
+            return RF_OK;
+        }
+    }
     RF_LAUNCH("three_interpolate", three_interpolate_kernel, dim3(rf::ceil_div(total, 256)), dim3(256), 0,
               (hipStream_t)stream, m, c, n, total, points, idx, weight, out);
     return RF_OK;
@@ -413,13 +599,47 @@ int rf_threeinterpolate_grad(int b, int n, int c, int m, const float *grad_out, 
                              const float *weight, float *grad_points, rf_stream_t stream) {
     if (b < 0 || n < 0 || m < 0 || c < 0) return RF_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if ((size_t)b * m * c) {
-        if (!grad_points) return RF_EINVAL;
-        RF_ZERO(grad_points, sizeof(float) * (size_t)b * m * c, s);
-    }
+    if ((size_t)b * m * c && !grad_points) return RF_EINVAL;
     long total = (long)b * n * c;
+    if (total != 0 && m != 0 && (!grad_out || !idx || !weight)) return RF_EINVAL;
+    // the LDS-tile form: slices of cs channels (a power of two dividing c, 8..64) with m * cs doubles in 128 KiB
+    int cs_log2 = -1;
+    if (total != 0 && m != 0 && b <= 65535 && (long)n * c < (1L << 31) && (long)m * c < (1L << 31) && (long)n * 3 < (1L << 31)) {
+        for (int k = 6; k >= 3; k--)
+            if (c % (1 << k) == 0 && ((long)m << k) <= 16384) {
+                cs_log2 = k;
+                break;
+            }
+    }
+    if (cs_log2 >= 0) {
+#ifndef RFI_TG_VEC
+#define RFI_TG_VEC 1
+#endif
+#ifndef RFI_TG_WGS
+#define RFI_TG_WGS 256
+#endif
+        const bool vec = RFI_TG_VEC && rf::aligned16(grad_out);  // (cs is a multiple of 8: rows of a slice start 16-byte aligned when the tensor does)
+        const int nslices = c >> cs_log2;
+        const int tx_log2 = cs_log2 - (vec ? 2 : 0);
+        // parts of the unknown points: a workgroup per CU (the tile leaves room for one), every part still thousands of points
+        int parts = 1;
+        while ((long)b * nslices * parts < RFI_TG_WGS && n / (parts * 2) >= 2048) parts *= 2;
+        if (parts > 1) RF_ZERO(grad_points, sizeof(float) * (size_t)b * m * c, s);
+        const size_t lds = sizeof(double) * ((size_t)m << cs_log2);
+        const dim3 grid(nslices * parts, b);
+        if (vec) {
+            RF_HIP(hipFuncSetAttribute((const void *)three_interpolate_grad_tile_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+            RF_LAUNCH("three_interpolate_grad", three_interpolate_grad_tile_kernel<4>, grid, dim3(TG_TPB), lds, s, m, c, n, cs_log2,
+                      tx_log2, nslices, parts, grad_out, idx, weight, grad_points);
+        } else {
+            RF_HIP(hipFuncSetAttribute((const void *)three_interpolate_grad_tile_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+            RF_LAUNCH("three_interpolate_grad", three_interpolate_grad_tile_kernel<1>, grid, dim3(TG_TPB), lds, s, m, c, n, cs_log2,
+                      tx_log2, nslices, parts, grad_out, idx, weight, grad_points);
+        }
+        return RF_OK;
+    }
+    if ((size_t)b * m * c) RF_ZERO(grad_points, sizeof(float) * (size_t)b * m * c, s);
     if (total == 0 || m == 0) return RF_OK;
-    if (!grad_out || !idx || !weight) return RF_EINVAL;
     RF_LAUNCH("three_interpolate_grad", three_interpolate_grad_kernel, dim3(rf::ceil_div(total, 256)),
               dim3(256), 0, s, m, c, n, total, grad_out, idx, weight, grad_points);
     return RF_OK;

@@ -211,6 +211,40 @@ def test_interpolate_random(orc, b, n, m, c):
     assert_rel(tp.grad.cpu().numpy(), orc.three_interpolate_grad(pts, oi, w, go), 1e-5, 1e-5)
 
 
+@pytest.mark.parametrize("b,n,m,c", [(2, 5000, 300, 64), (2, 3000, 1024, 16), (1, 70000, 128, 8), (3, 2500, 2048, 8), (2, 4100, 256, 40),
+                                     (2, 2000, 513, 128), (1, 9000, 4096, 32), (2, 777, 50, 6), (2, 1000, 90, 12)])
+def test_interpolate_row_and_tile_forms(orc, b, n, m, c):
+    """three_interpolate as rows (a thread row per unknown point, channels as 4-wide vectors where c % 4 == 0 and the tensors are
+    16-byte aligned) and its gradient as LDS tiles of doubles (slices of 8..64 channels with m * cs <= 16384, the unknown points
+    in parts; the element-per-thread kernels outside that): out bit-exact, grad_points within fp32 summation noise of the
+    reference's sequential sums (tf_interpolate.cpp:107-153) -- also through views that are NOT 16-byte aligned, and with every
+    unknown point on the same three known points (one address for all the adds)."""
+    from rfnet_amd import _raw as R
+    rng = np.random.RandomState(n + m + c)
+    u = rng.rand(b, n, 3).astype(np.float32)
+    k = rng.rand(b, m, 3).astype(np.float32)
+    _, oi = orc.three_nn(u, k)
+    pts = rng.randn(b, m, c).astype(np.float32)
+    w = rng.rand(b, n, 3).astype(np.float32)
+    go = rng.randn(b, n, c).astype(np.float32)
+    for idx in (oi, np.broadcast_to(np.array([m - 1, 0, m // 2], np.int32), (b, n, 3)).copy()):
+        want_out = orc.three_interpolate(pts, idx, w)
+        want_g = orc.three_interpolate_grad(pts, idx, w, go)
+        out = R.three_interpolate(cu(pts), cu(idx), cu(w))
+        assert np.array_equal(out.cpu().numpy(), want_out)
+        g = R.three_interpolate_grad(cu(pts), cu(idx), cu(w), cu(go))
+        assert_rel(g.cpu().numpy(), want_g, 1e-5, 1e-5 * max(1.0, float(np.abs(want_g).max())))
+        # the same through tensors that start 4 bytes into their allocation
+        def off(a):
+            flat = torch.empty(a.size + 1, dtype=torch.from_numpy(a).dtype, device="cuda")
+            flat[1:] = cu(a).reshape(-1)
+            return flat[1:].view(a.shape)
+        out = R.three_interpolate(off(pts), cu(idx), cu(w))
+        assert np.array_equal(out.cpu().numpy(), want_out)
+        g = R.three_interpolate_grad(cu(pts), cu(idx), cu(w), off(go))
+        assert_rel(g.cpu().numpy(), want_g, 1e-5, 1e-5 * max(1.0, float(np.abs(want_g).max())))
+
+
 def test_numpy_and_cpu_tensor_inputs_round_trip(orc):
     from tf_ops.sampling.tf_sampling import farthest_point_sample, gather_point
     p = np.random.RandomState(1).rand(2, 700, 3).astype(np.float32)
