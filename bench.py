@@ -1016,8 +1016,10 @@ def main():
                 44.0 * B * (N + M), (prof.get("nnp_grad_sorted", prof.get("nn_grad", (0.0, 1)))[0] /
                                      max(prof.get("nnp_grad_sorted", prof.get("nn_grad", (0.0, 1)))[1], 1)) or 1e-9,
                 "nnp_grad_sorted" if "nnp_grad_sorted" in prof else "nn_grad",
-                "44*B*(N+M) algorithmic bytes incl. zero fill (SURVEY 8(d)); the sorted-space backward is bound by LDS "
-                "atomic lanes and kernel-boundary latency, not by HBM (profiles/r03_ab_grad_sorted.txt)"),
+                "44*B*(N+M) algorithmic bytes incl. zero fill (SURVEY 8(d)); the sorted-space backward is bound by its fixed chain "
+                "(launch, masks, list, barriers, scattered stores: ~9 us without a single visit, profiles/r03_ab_grad_sorted.txt), not by "
+                "HBM; its scatter terms meet in LDS as DOUBLES since ds_add_f64 runs 23x the rate of ds_add_f32 on this chip "
+                "(profiles/r05_lds_atomic_rate.txt: 16.3 -> 12.5 us)"),
             "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items())},
             "kernel_sum_ms_per_step": kernel_sum_ms,
             # (kernel_sum comes from the SECOND, hipEvent-instrumented pass over the same K steps, whose event records sit between the

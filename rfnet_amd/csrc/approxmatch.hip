@@ -1080,7 +1080,15 @@ __device__ __forceinline__ void mr_group(const float4 (&mv)[MR_DEPTH], const flo
 }
 
 // the group's 3 * MR_G per-lane sums reduced over the wave's 64 lanes and added to the workgroup's grad2 sums (the rows from lg on, below lend)
-__device__ __forceinline__ void mr_reduce_emit(const float (&S)[3 * MR_G], int lane, int lg, int lend, int lbeg, float *g2s) {
+#ifndef RFA_MR_F64
+#define RFA_MR_F64 1  // the workgroup's row sums in double: ds_add_f64 is 23x the rate of ds_add_f32 here (tools/ubench/lds_atomic_rate.hip)
+#endif
+#if RFA_MR_F64
+typedef double mr_sum_t;
+#else
+typedef float mr_sum_t;
+#endif
+__device__ __forceinline__ void mr_reduce_emit(const float (&S)[3 * MR_G], int lane, int lg, int lend, int lbeg, mr_sum_t *g2s) {
     // reduce-scatter: 3G -> 3G/2 (lanes >= 32 keep the upper half) -> 3G/4 (odd 16-lane rows keep the upper half)
     constexpr int NH = 3 * MR_G / 2, NQ = 3 * MR_G / 4;
     float W[NH], U[NQ];
@@ -1108,7 +1116,7 @@ __device__ __forceinline__ void mr_reduce_emit(const float (&S)[3 * MR_G], int l
     // lane -> index into the group's 3G sums (row * 3 + component)
     const int vi = j + ((lane & 16) ? NQ : 0) + ((lane & 32) ? NH : 0);
     // (into the workgroup's own sums in LDS: its four waves hold different k of the same rows; one global atomic per sum at the end)
-    if (j < NQ && lg + vi / 3 < lend) __hip_atomic_fetch_add(&g2s[(lg - lbeg) * 3 + vi], -out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (j < NQ && lg + vi / 3 < lend) __hip_atomic_fetch_add(&g2s[(lg - lbeg) * 3 + vi], (mr_sum_t)-out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 template <bool FULL>
@@ -1141,8 +1149,8 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     float ax[MR_KPL], ay[MR_KPL], az[MR_KPL];
 #pragma unroll
     for (int e = 0; e < MR_KPL; e++) ax[e] = ay[e] = az[e] = 0.f;
-    __shared__ float g2s[MR_LSPAN_MAX * 3];  // grad2 of the workgroup's rows, summed over its four waves
-    for (int i = t; i < (lend - lbeg) * 3; i += TPB) g2s[i] = 0.f;
+    __shared__ mr_sum_t g2s[MR_LSPAN_MAX * 3];  // grad2 of the workgroup's rows, summed over its four waves
+    for (int i = t; i < (lend - lbeg) * 3; i += TPB) g2s[i] = (mr_sum_t)0;
     __syncthreads();
     // the x2 records of a group of rows: 3 * MR_G consecutive dwords by scalar loads (the base row clamped into the cloud: a
     // prefetch behind the range loads records nobody reads)
@@ -1220,7 +1228,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         gs[(t * MR_KPL + e) * 3 + 2] = az[e];
     }
     __syncthreads();
-    for (int i = t; i < (lend - lbeg) * 3; i += TPB) atomicAdd(&g2[(size_t)lbeg * 3 + i], g2s[i]);
+    for (int i = t; i < (lend - lbeg) * 3; i += TPB) atomicAdd(&g2[(size_t)lbeg * 3 + i], (float)g2s[i]);
     {
         const int k0 = blockIdx.x * TPB * MR_KPL;
         const int cnt = min(TPB * MR_KPL, n - k0) * 3;  // (>= 0: the grid covers n)

@@ -477,7 +477,15 @@ struct GradArgs {
 template <bool LOSS>
 __global__ __launch_bounds__(GTPB) void nn_grad_kernel(GradArgs a) {
     // the tile's sums in DOUBLE: ds_add_f64 runs at 18 lane-operations per ns and CU, ds_add_f32 at 0.8 (tools/ubench/lds_atomic_rate.hip)
-    __shared__ double acc[GT * 3];
+#ifndef RFN_GRAD_F64
+#define RFN_GRAD_F64 1
+#endif
+#if RFN_GRAD_F64
+    typedef double acc_t;
+#else
+    typedef float acc_t;
+#endif
+    __shared__ acc_t acc[GT * 3];
     int bid = blockIdx.x;
     const int which = bid >= a.nblk0;
     if (which) bid -= a.nblk0;
@@ -489,7 +497,7 @@ __global__ __launch_bounds__(GTPB) void nn_grad_kernel(GradArgs a) {
     const int jn = min(D.gt, D.nd - j0);
     const float *__restrict__ dxyz = D.dst_xyz + (size_t)bi * D.nd * 3;
     const float *__restrict__ sxyz = D.src_xyz + (size_t)bi * D.ns * 3;
-    for (int i = threadIdx.x; i < jn * 3; i += GTPB) acc[i] = 0.0;
+    for (int i = threadIdx.x; i < jn * 3; i += GTPB) acc[i] = (acc_t)0;
     // own term first: its idx -> gather chain is independent of the scatter scan below, so the two
     // dependent-load chains overlap instead of running back to back (the kernel is latency-bound)
     constexpr int OWN = GT * 3 / GTPB;
@@ -557,7 +565,7 @@ __global__ __launch_bounds__(GTPB) void nn_grad_kernel(GradArgs a) {
                 const float gd = LOSS ? scs * 0.5f / sqrtf(hg[u]) : hg[u];
                 const float g = gd + gd;
 #pragma unroll
-                for (int c = 0; c < 3; c++) atomicAdd(&acc[j * 3 + c], (double)-((hs[u][c] - hd[u][c]) * g));
+                for (int c = 0; c < 3; c++) atomicAdd(&acc[j * 3 + c], (acc_t)-((hs[u][c] - hd[u][c]) * g));
             }
         }
 #pragma unroll

@@ -2033,7 +2033,7 @@ __global__ __launch_bounds__(64 * NSH) __attribute__((amdgpu_waves_per_eu(RFP_WP
 #define RFP_GS_F64 1  // the tile's sums in DOUBLE: ds_add_f64 runs at 18 lane-operations per ns and CU, ds_add_f32 at 0.8 (tools/ubench/lds_atomic_rate.hip)
 #endif
 #ifndef RFP_GS_SEG
-#define RFP_GS_SEG 0  // the pre-reduction of the fp32 days (grad_tile)
+#define RFP_GS_SEG 1  // runs of equal destination inside a 16-lane row summed in registers before they touch LDS (grad_tile)
 #endif
 #ifndef RFP_GS_KB
 #define RFP_GS_KB 2  // (4 while the fp32 atomics were the bound: 12.6 vs 12.3 us now)

@@ -17,10 +17,15 @@ timeout 200 python3 tools/ab_c3.py > "$O/ab_c3.txt" 2>&1; cat "$O/ab_c3.txt"
 #   r4emd  = -DRFA_FGT_MIN_PAIRS=1e30 -DRFA_ROWSORT_MIN_PAIRS=1e30 -DRFA_MATCH_NT=0 -DRFA_MC_NT=0 -DRFA_MCG_ROWS=0 -DRFA_MG_NT=0 -DRFA_PK=0
 #            -DRFA_PP_DENSE=0 -DRFA_PK_FUSED=0 -DRFA_SKIP_MAXT=0.2f
 #   nofgt = -DRFA_FGT_MIN_PAIRS=1e30   nopk = -DRFA_PK=0 -DRFA_PP_DENSE=0 -DRFA_SKIP_MAXT=0.2f -DRFA_PK_FUSED=0   mcgold = -DRFA_MCG_ROWS=0 -DRFA_MG_NT=0
-timeout 300 python3 tools/ab_emd_kernels.py r4emd nofgt nopk base > "$O/ab_emd.txt" 2>&1; cut -c1-200 "$O/ab_emd.txt"
+#   nolist = -DRFA_SKIP_MASK=0 (level 0's sweeps do not list the columns for level 1's)   gsf32 = -DRFP_GS_F64=0 -DRFP_GS_SEG=1 (the backward's fp32 LDS sums)
+timeout 400 python3 tools/ab_emd_kernels.py r4emd nofgt nopk nolist base > "$O/ab_emd.txt" 2>&1; cut -c1-200 "$O/ab_emd.txt"
 timeout 300 python3 tools/ab_emd_sizes.py nofgt base > "$O/ab_emd_sizes.txt" 2>&1; cut -c1-300 "$O/ab_emd_sizes.txt"
 AB_MCG_SHAPES=1 timeout 300 python3 tools/ab_mcg.py mcgold base > "$O/ab_mcg.txt" 2>&1; cut -c1-300 "$O/ab_mcg.txt"
 bash tools/experiments/trace_emd.sh > "$O/emd_launches.txt" 2>&1
 timeout 300 python3 tools/ab_fps_sorted.py base > "$O/ab_fps_sorted.txt" 2>&1; cut -c1-300 "$O/ab_fps_sorted.txt"
 timeout 400 python3 tools/ab_fps_sizes.py > "$O/ab_fps_sizes.txt" 2>&1; tail -9 "$O/ab_fps_sizes.txt"
 ./tools/ubench/stream_rate > "$O/stream_rate.txt" 2>&1; cat "$O/stream_rate.txt"
+./tools/ubench/lds_atomic_rate > "$O/lds_atomic_rate.txt" 2>&1; cat "$O/lds_atomic_rate.txt"
+timeout 600 python3 tools/ab_step.py gsf32 base > "$O/ab_step_f64.txt" 2>&1; cut -c1-400 "$O/ab_step_f64.txt"
+timeout 300 python3 tools/ab_three_nn.py > "$O/ab_three_nn.txt" 2>&1; cat "$O/ab_three_nn.txt"
+timeout 300 python3 tools/experiments/three_interpolate_rate.py > "$O/three_interpolate_rate.txt" 2>&1; cat "$O/three_interpolate_rate.txt"
