@@ -23,6 +23,8 @@
 //   end, so no slot is written twice.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 #include "nn_pruned.hpp"
 #include "group_internal.hpp"
@@ -503,6 +505,78 @@ __global__ void group_point3_kernel(int n, int per_batch, const float *__restric
     *(P3 *)(out + js * 3) = *(const P3 *)(points + (bi * n + ii) * 3);
 }
 
+// Any c: a thread row per (query, sample) slot -- its index loaded once -- and the channels as VEC-wide vectors over the row's
+// lanes, 32-bit arithmetic, the batch element from the grid (the element-per-thread kernels below pay two 64-bit divisions per
+// ELEMENT; they remain for what does not fit 32 bits).  GRAD: the same walk, adding grad_out into grad_points.
+constexpr int GPR_TPB = 256;
+constexpr int GPR_PP = 4;  // slots per thread row and block
+typedef float gpr_v4f __attribute__((ext_vector_type(4)));
+template <int VEC, bool GRAD>
+__global__ __launch_bounds__(GPR_TPB) void group_point_rows_kernel(int n, int c, int per_batch, int tx_log2,
+                                                                   const float *__restrict__ src /* points | grad_out */,
+                                                                   const int *__restrict__ idx,
+                                                                   float *__restrict__ dst /* out | grad_points */) {
+    typedef typename std::conditional<VEC == 4, gpr_v4f, float>::type V;
+    const size_t bi = blockIdx.y;
+    const int TX = 1 << tx_log2, TY = GPR_TPB >> tx_log2;
+    const int lx = threadIdx.x & (TX - 1), ly = threadIdx.x >> tx_log2;
+    const int cv = c / VEC;
+    const int *__restrict__ I = idx + bi * per_batch;
+    const float *__restrict__ P = GRAD ? src + bi * per_batch * c : src + bi * n * c;  // rows of slots | rows of points
+    float *__restrict__ O = GRAD ? dst + bi * n * c : dst + bi * per_batch * c;
+    int js[GPR_PP], row[GPR_PP];
+#pragma unroll
+    for (int u = 0; u < GPR_PP; u++) {
+        js[u] = (blockIdx.x * GPR_PP + u) * TY + ly;
+        row[u] = I[min(js[u], per_batch - 1)];
+    }
+    for (int l = lx; l < cv; l += TX) {
+        V v[GPR_PP];
+#pragma unroll
+        for (int u = 0; u < GPR_PP; u++) v[u] = ((const V *)P)[(size_t)(GRAD ? min(js[u], per_batch - 1) : row[u]) * cv + l];
+#pragma unroll
+        for (int u = 0; u < GPR_PP; u++) {
+            if (js[u] >= per_batch) continue;
+            if (!GRAD) {
+                __builtin_nontemporal_store(v[u], &((V *)O)[(size_t)js[u] * cv + l]);
+            } else {
+                float *g = O + ((size_t)row[u] * cv + l) * VEC;
+                if constexpr (VEC == 4) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) atomicAdd(g + k, v[u][k]);
+                } else {
+                    atomicAdd(g, v[u]);
+                }
+            }
+        }
+    }
+}
+
+template <bool GRAD>
+static int group_rows_launch(int b, int n, int c, long per_batch, const float *src, const int *idx, float *dst, const char *name,
+                             hipStream_t s) {
+    // (the gradient one channel per lane: a wave's atomic instruction then covers whole cache lines -- four adds per lane at a stride
+    // of 16 bytes across the lanes measured 0.91 ms against 0.24 for 32 x 1024 x 32 slots of 64 channels)
+    const bool vec = !GRAD && c % 4 == 0 && rf::aligned16(src) && rf::aligned16(dst);
+    const int cv = vec ? c / 4 : c;
+    int tx_log2 = 0;
+    while ((1 << tx_log2) < cv && tx_log2 < 6) tx_log2++;
+    const int spb = (GPR_TPB >> tx_log2) * GPR_PP;  // slots per block
+    const dim3 grid((unsigned)((per_batch + spb - 1) / spb), b);
+    if (vec) {
+        RF_LAUNCH(name, (group_point_rows_kernel<4, GRAD>), grid, dim3(GPR_TPB), 0, s, n, c, (int)per_batch, tx_log2, src, idx, dst);
+    } else {
+        RF_LAUNCH(name, (group_point_rows_kernel<1, GRAD>), grid, dim3(GPR_TPB), 0, s, n, c, (int)per_batch, tx_log2, src, idx, dst);
+    }
+    return RF_OK;
+}
+#ifndef RFG_ROWS
+#define RFG_ROWS 1
+#endif
+static bool group_rows_ok(int b, int n, int c, long per_batch) {
+    return RFG_ROWS && b <= 65535 && per_batch * c < (1L << 31) && (long)n * c < (1L << 31) && per_batch < (1L << 30);
+}
+
 __global__ void group_point_grad_kernel(int n, int c, long per_batch, long total,
                                         const float *__restrict__ grad_out,
                                         const int *__restrict__ idx, float *__restrict__ grad_points) {
@@ -649,6 +723,7 @@ int rf_grouppoint(int b, int n, int c, int m, int nsample, const float *points, 
                   (hipStream_t)stream, n, (int)per_batch, points, idx, out);
         return RF_OK;
     }
+    if (group_rows_ok(b, n, c, per_batch)) return group_rows_launch<false>(b, n, c, per_batch, points, idx, out, "group_point", (hipStream_t)stream);
     RF_LAUNCH("group_point", group_point_kernel, dim3(rf::ceil_div(total, 256)), dim3(256), 0,
               (hipStream_t)stream, n, c, per_batch, total, points, idx, out);
     return RF_OK;
@@ -666,6 +741,7 @@ int rf_grouppoint_grad(int b, int n, int c, int m, int nsample, const float *gra
     long total = (long)b * per_batch * c;
     if (total == 0 || n == 0) return RF_OK;
     if (!grad_out || !idx) return RF_EINVAL;
+    if (group_rows_ok(b, n, c, per_batch)) return group_rows_launch<true>(b, n, c, per_batch, grad_out, idx, grad_points, "group_point_grad", s);
     RF_LAUNCH("group_point_grad", group_point_grad_kernel, dim3(rf::ceil_div(total, 256)), dim3(256), 0,
               s, n, c, per_batch, total, grad_out, idx, grad_points);
     return RF_OK;
