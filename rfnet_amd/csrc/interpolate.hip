@@ -389,27 +389,34 @@ __global__ __launch_bounds__(TI_TPB) void three_interpolate_rows_kernel(int m, i
 // runs at 18 lane-operations per ns and CU against 0.8 for ds_add_f32 (tools/ubench/lds_atomic_rate.hip), and L2 atomics from
 // every element (the kernel below) reach 0.3 per ns and CU -- and walks a part of the unknown points: grad_out is read once,
 // cs * 4 bytes per point and workgroup; the tile leaves as plain stores (one part) or atomic adds (several).
+#ifndef RFI_TG_VEC
+#define RFI_TG_VEC 1
+#endif
+#ifndef RFI_TG_WGS
+#define RFI_TG_WGS 256
+#endif
 constexpr int TG_TPB = 1024;  // (128 KiB of LDS: one workgroup per CU -- its 16 waves are all the loads in flight there are)
 constexpr int TG_U = 4;  // points per thread row in flight
 
-template <int VEC>
-__global__ __launch_bounds__(TG_TPB) void three_interpolate_grad_tile_kernel(int m, int c, int n, int cs_log2, int tx_log2,
+template <int VEC, bool POW2>  // POW2: cs is a power of two (shifts instead of multiplications and a division)
+__global__ __launch_bounds__(TG_TPB) void three_interpolate_grad_tile_kernel(int m, int c, int n, int cs, int tx_log2,
                                                                              int nslices, int parts,
                                                                              const float *__restrict__ grad_out,
                                                                              const int *__restrict__ idx,
                                                                              const float *__restrict__ weight,
                                                                              float *__restrict__ grad_points) {
     typedef typename TiVec<VEC>::T V;
-    extern __shared__ __attribute__((aligned(16))) double ti_tile[];  // [m << cs_log2]
+    extern __shared__ __attribute__((aligned(16))) double ti_tile[];  // [m * cs]; cs = VEC << tx_log2, or (VEC == 1) any cs <= 1 << tx_log2
     const int bi = blockIdx.y;
     const int slice = blockIdx.x % nslices, part = blockIdx.x / nslices;
-    const int cs = 1 << cs_log2;
     const int TX = 1 << tx_log2, TY = TG_TPB >> tx_log2;
     const int lx = threadIdx.x & (TX - 1), ly = threadIdx.x >> tx_log2;
-    for (int e = threadIdx.x; e < (m << cs_log2); e += TG_TPB) ti_tile[e] = 0.0;
+    const bool lane_on = POW2 || lx * VEC < cs;  // (a slice of 3 or 13 channels leaves the last lanes of its rows idle)
+    const int csl = POW2 ? 31 - __clz(cs) : 0;
+    for (int e = threadIdx.x; e < m * cs; e += TG_TPB) ti_tile[e] = 0.0;
     const int per = (n + parts - 1) / parts;
     const int jbeg = part * per, jend = min(n, jbeg + per);
-    const float *__restrict__ G = grad_out + (size_t)bi * n * c + slice * cs + lx * VEC;
+    const float *__restrict__ G = grad_out + (size_t)bi * n * c + slice * cs + (lane_on ? lx * VEC : 0);
     const int *__restrict__ I = idx + (size_t)bi * n * 3;
     const float *__restrict__ W = weight + (size_t)bi * n * 3;
     __syncthreads();
@@ -428,7 +435,7 @@ __global__ __launch_bounds__(TG_TPB) void three_interpolate_grad_tile_kernel(int
         const int j = min((J0) + u * TY, jend - 1);                               \
         GG[u] = *(const V *)(G + (size_t)j * c);                                  \
         _Pragma("unroll") for (int t = 0; t < 3; t++) {                           \
-            RR[u][t] = (I[j * 3 + t] << cs_log2) + lx;                            \
+            RR[u][t] = (POW2 ? I[j * 3 + t] << csl : I[j * 3 + t] * cs) + lx;     \
             WW[u][t] = W[j * 3 + t];                                              \
         }                                                                         \
     }
@@ -456,7 +463,7 @@ __global__ __launch_bounds__(TG_TPB) void three_interpolate_grad_tile_kernel(int
             }
 #pragma unroll
         for (int u = 0; u < TG_U; u++) {
-            if (j0 + u * TY < jend) {
+            if (j0 + u * TY < jend && lane_on) {
 #pragma unroll
                 for (int t = 0; t < 3; t++)
 #pragma unroll
@@ -475,9 +482,9 @@ __global__ __launch_bounds__(TG_TPB) void three_interpolate_grad_tile_kernel(int
 #undef TG_LOAD
     __syncthreads();
     float *__restrict__ GP = grad_points + (size_t)bi * m * c + slice * cs;
-    for (int e = threadIdx.x; e < (m << cs_log2); e += TG_TPB) {
-        const int i = e >> cs_log2, ch = e & (cs - 1);
-        const float v = (float)ti_tile[(i << cs_log2) + (ch % VEC << tx_log2) + ch / VEC];
+    for (int e = threadIdx.x; e < m * cs; e += TG_TPB) {
+        const int i = POW2 ? e >> csl : e / cs, ch = e - i * cs;
+        const float v = (float)ti_tile[i * cs + (ch % VEC << tx_log2) + ch / VEC];
         if (parts == 1) {
             GP[(size_t)i * c + ch] = v;
         } else {
@@ -602,40 +609,41 @@ int rf_threeinterpolate_grad(int b, int n, int c, int m, const float *grad_out, 
     if ((size_t)b * m * c && !grad_points) return RF_EINVAL;
     long total = (long)b * n * c;
     if (total != 0 && m != 0 && (!grad_out || !idx || !weight)) return RF_EINVAL;
-    // the LDS-tile form: slices of cs channels (a power of two dividing c, 8..64) with m * cs doubles in 128 KiB
-    int cs_log2 = -1;
+    // the LDS-tile form: slices of cs channels with m * cs doubles in 128 KiB -- cs a power of two dividing c (8..64), or, for c
+    // that has none (3, 6, 13 ...), all c <= 64 channels in one slice
+    int cs = 0;
     if (total != 0 && m != 0 && b <= 65535 && (long)n * c < (1L << 31) && (long)m * c < (1L << 31) && (long)n * 3 < (1L << 31)) {
         for (int k = 6; k >= 3; k--)
             if (c % (1 << k) == 0 && ((long)m << k) <= 16384) {
-                cs_log2 = k;
+                cs = 1 << k;
                 break;
             }
+        if (cs == 0 && c <= 64 && (long)m * c <= 16384) cs = c;
     }
-    if (cs_log2 >= 0) {
-#ifndef RFI_TG_VEC
-#define RFI_TG_VEC 1
-#endif
-#ifndef RFI_TG_WGS
-#define RFI_TG_WGS 256
-#endif
-        const bool vec = RFI_TG_VEC && rf::aligned16(grad_out);  // (cs is a multiple of 8: rows of a slice start 16-byte aligned when the tensor does)
-        const int nslices = c >> cs_log2;
-        const int tx_log2 = cs_log2 - (vec ? 2 : 0);
+    if (cs > 0) {
+        const bool pow2 = (cs & (cs - 1)) == 0 && cs >= 8;
+        const bool vec = RFI_TG_VEC && pow2 && rf::aligned16(grad_out);  // (rows of a slice start 16-byte aligned when the tensor does)
+        const int nslices = c / cs;
+        int tx_log2 = 0;
+        while ((1 << tx_log2) < (vec ? cs / 4 : cs)) tx_log2++;
         // parts of the unknown points: a workgroup per CU (the tile leaves room for one), every part still thousands of points
         int parts = 1;
         while ((long)b * nslices * parts < RFI_TG_WGS && n / (parts * 2) >= 2048) parts *= 2;
         if (parts > 1) RF_ZERO(grad_points, sizeof(float) * (size_t)b * m * c, s);
-        const size_t lds = sizeof(double) * ((size_t)m << cs_log2);
+        const size_t lds = sizeof(double) * (size_t)m * cs;
         const dim3 grid(nslices * parts, b);
+#define TG_GO(KERNEL)                                                                                                      \
+    RF_HIP(hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));                 \
+    RF_LAUNCH("three_interpolate_grad", KERNEL, grid, dim3(TG_TPB), lds, s, m, c, n, cs, tx_log2, nslices, parts, grad_out, idx, \
+              weight, grad_points)
         if (vec) {
-            RF_HIP(hipFuncSetAttribute((const void *)three_interpolate_grad_tile_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-            RF_LAUNCH("three_interpolate_grad", three_interpolate_grad_tile_kernel<4>, grid, dim3(TG_TPB), lds, s, m, c, n, cs_log2,
-                      tx_log2, nslices, parts, grad_out, idx, weight, grad_points);
+            TG_GO((three_interpolate_grad_tile_kernel<4, true>));
+        } else if (pow2) {
+            TG_GO((three_interpolate_grad_tile_kernel<1, true>));
         } else {
-            RF_HIP(hipFuncSetAttribute((const void *)three_interpolate_grad_tile_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-            RF_LAUNCH("three_interpolate_grad", three_interpolate_grad_tile_kernel<1>, grid, dim3(TG_TPB), lds, s, m, c, n, cs_log2,
-                      tx_log2, nslices, parts, grad_out, idx, weight, grad_points);
+            TG_GO((three_interpolate_grad_tile_kernel<1, false>));
         }
+#undef TG_GO
         return RF_OK;
     }
     if ((size_t)b * m * c) RF_ZERO(grad_points, sizeof(float) * (size_t)b * m * c, s);

@@ -215,8 +215,8 @@ def test_interpolate_random(orc, b, n, m, c):
                                      (2, 2000, 513, 128), (1, 9000, 4096, 32), (2, 777, 50, 6), (2, 1000, 90, 12)])
 def test_interpolate_row_and_tile_forms(orc, b, n, m, c):
     """three_interpolate as rows (a thread row per unknown point, channels as 4-wide vectors where c % 4 == 0 and the tensors are
-    16-byte aligned) and its gradient as LDS tiles of doubles (slices of 8..64 channels with m * cs <= 16384, the unknown points
-    in parts; the element-per-thread kernels outside that): out bit-exact, grad_points within fp32 summation noise of the
+    16-byte aligned) and its gradient as LDS tiles of doubles (slices of 8..64 channels -- or all of a c like 6 or 12 in one slice --
+    with m * cs <= 16384, the unknown points in parts; the element-per-thread kernel outside that: 4096 known points here): out bit-exact, grad_points within fp32 summation noise of the
     reference's sequential sums (tf_interpolate.cpp:107-153) -- also through views that are NOT 16-byte aligned, and with every
     unknown point on the same three known points (one address for all the adds)."""
     from rfnet_amd import _raw as R
