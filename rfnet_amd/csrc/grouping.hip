@@ -508,16 +508,23 @@ __global__ void group_point3_kernel(int n, int per_batch, const float *__restric
 // Any c: a thread row per (query, sample) slot -- its index loaded once -- and the channels as VEC-wide vectors over the row's
 // lanes, 32-bit arithmetic, the batch element from the grid (the element-per-thread kernels below pay two 64-bit divisions per
 // ELEMENT; they remain for what does not fit 32 bits).  GRAD: the same walk, adding grad_out into grad_points.
+#ifndef RFG_XCD
+#define RFG_XCD 1  // a sample's workgroups on one XCD (rf::xcd_contiguous)
+#endif
 constexpr int GPR_TPB = 256;
 constexpr int GPR_PP = 4;  // slots per thread row and block
 typedef float gpr_v4f __attribute__((ext_vector_type(4)));
 template <int VEC, bool GRAD>
-__global__ __launch_bounds__(GPR_TPB) void group_point_rows_kernel(int n, int c, int per_batch, int tx_log2,
+__global__ __launch_bounds__(GPR_TPB) void group_point_rows_kernel(int n, int c, int per_batch, int tx_log2, int bpb /* blocks per sample */,
+                                                                   int xcd_contiguous,
                                                                    const float *__restrict__ src /* points | grad_out */,
                                                                    const int *__restrict__ idx,
                                                                    float *__restrict__ dst /* out | grad_points */) {
     typedef typename std::conditional<VEC == 4, gpr_v4f, float>::type V;
-    const size_t bi = blockIdx.y;
+    // (a sample's blocks on ONE XCD: the rows it gathers cross the fabric once instead of eight times)
+    const unsigned logical = xcd_contiguous ? rf::xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+    const size_t bi = logical / bpb;
+    const int bx = logical - (unsigned)bi * bpb;
     const int TX = 1 << tx_log2, TY = GPR_TPB >> tx_log2;
     const int lx = threadIdx.x & (TX - 1), ly = threadIdx.x >> tx_log2;
     const int cv = c / VEC;
@@ -527,7 +534,7 @@ __global__ __launch_bounds__(GPR_TPB) void group_point_rows_kernel(int n, int c,
     int js[GPR_PP], row[GPR_PP];
 #pragma unroll
     for (int u = 0; u < GPR_PP; u++) {
-        js[u] = (blockIdx.x * GPR_PP + u) * TY + ly;
+        js[u] = (bx * GPR_PP + u) * TY + ly;
         row[u] = I[min(js[u], per_batch - 1)];
     }
     for (int l = lx; l < cv; l += TX) {
@@ -562,11 +569,12 @@ static int group_rows_launch(int b, int n, int c, long per_batch, const float *s
     int tx_log2 = 0;
     while ((1 << tx_log2) < cv && tx_log2 < 6) tx_log2++;
     const int spb = (GPR_TPB >> tx_log2) * GPR_PP;  // slots per block
-    const dim3 grid((unsigned)((per_batch + spb - 1) / spb), b);
+    const long bpb = (per_batch + spb - 1) / spb;
+    const dim3 grid((unsigned)(bpb * b));
     if (vec) {
-        RF_LAUNCH(name, (group_point_rows_kernel<4, GRAD>), grid, dim3(GPR_TPB), 0, s, n, c, (int)per_batch, tx_log2, src, idx, dst);
+        RF_LAUNCH(name, (group_point_rows_kernel<4, GRAD>), grid, dim3(GPR_TPB), 0, s, n, c, (int)per_batch, tx_log2, (int)bpb, RFG_XCD, src, idx, dst);
     } else {
-        RF_LAUNCH(name, (group_point_rows_kernel<1, GRAD>), grid, dim3(GPR_TPB), 0, s, n, c, (int)per_batch, tx_log2, src, idx, dst);
+        RF_LAUNCH(name, (group_point_rows_kernel<1, GRAD>), grid, dim3(GPR_TPB), 0, s, n, c, (int)per_batch, tx_log2, (int)bpb, RFG_XCD, src, idx, dst);
     }
     return RF_OK;
 }
@@ -574,7 +582,7 @@ static int group_rows_launch(int b, int n, int c, long per_batch, const float *s
 #define RFG_ROWS 1
 #endif
 static bool group_rows_ok(int b, int n, int c, long per_batch) {
-    return RFG_ROWS && b <= 65535 && per_batch * c < (1L << 31) && (long)n * c < (1L << 31) && per_batch < (1L << 30);
+    return RFG_ROWS && b <= 65535 && per_batch * b < (1L << 31) && per_batch * c < (1L << 31) && (long)n * c < (1L << 31) && per_batch < (1L << 30);
 }
 
 __global__ void group_point_grad_kernel(int n, int c, long per_batch, long total,

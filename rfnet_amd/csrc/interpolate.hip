@@ -345,13 +345,16 @@ struct TiVec<1> {
 };
 
 template <int VEC>
-__global__ __launch_bounds__(TI_TPB) void three_interpolate_rows_kernel(int m, int c, int n, int tx_log2,
+__global__ __launch_bounds__(TI_TPB) void three_interpolate_rows_kernel(int m, int c, int n, int tx_log2, int bpb /* blocks per sample */,
+                                                                        int xcd_contiguous,
                                                                         const float *__restrict__ points,
                                                                         const int *__restrict__ idx,
                                                                         const float *__restrict__ weight,
                                                                         float *__restrict__ out) {
     typedef typename TiVec<VEC>::T V;
-    const int bi = blockIdx.y;
+    // (a sample's blocks on ONE XCD: its rows of `points` then cross the fabric once instead of eight times -- FETCH_SIZE 71 -> MB)
+    const unsigned logical = xcd_contiguous ? rf::xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int bi = logical / bpb, bx = logical - bi * bpb;
     const int TX = 1 << tx_log2, TY = TI_TPB >> tx_log2;
     const int lx = threadIdx.x & (TX - 1), ly = threadIdx.x >> tx_log2;
     const int cv = c / VEC;
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(TI_TPB) void three_interpolate_rows_kernel(int m, i
     int jj[TI_PP];
 #pragma unroll
     for (int u = 0; u < TI_PP; u++) {
-        jj[u] = (blockIdx.x * TI_PP + u) * TY + ly;
+        jj[u] = (bx * TI_PP + u) * TY + ly;
         const int j = min(jj[u], n - 1);
 #pragma unroll
         for (int t = 0; t < 3; t++) {
@@ -389,6 +392,9 @@ __global__ __launch_bounds__(TI_TPB) void three_interpolate_rows_kernel(int m, i
 // runs at 18 lane-operations per ns and CU against 0.8 for ds_add_f32 (tools/ubench/lds_atomic_rate.hip), and L2 atomics from
 // every element (the kernel below) reach 0.3 per ns and CU -- and walks a part of the unknown points: grad_out is read once,
 // cs * 4 bytes per point and workgroup; the tile leaves as plain stores (one part) or atomic adds (several).
+#ifndef RFI_XCD
+#define RFI_XCD 1  // a sample's workgroups on one XCD (rf::xcd_contiguous)
+#endif
 #ifndef RFI_TG_VEC
 #define RFI_TG_VEC 1
 #endif
@@ -400,15 +406,18 @@ constexpr int TG_U = 4;  // points per thread row in flight
 
 template <int VEC, bool POW2>  // POW2: cs is a power of two (shifts instead of multiplications and a division)
 __global__ __launch_bounds__(TG_TPB) void three_interpolate_grad_tile_kernel(int m, int c, int n, int cs, int tx_log2,
-                                                                             int nslices, int parts,
+                                                                             int nslices, int parts, int xcd_contiguous,
                                                                              const float *__restrict__ grad_out,
                                                                              const int *__restrict__ idx,
                                                                              const float *__restrict__ weight,
                                                                              float *__restrict__ grad_points) {
     typedef typename TiVec<VEC>::T V;
     extern __shared__ __attribute__((aligned(16))) double ti_tile[];  // [m * cs]; cs = VEC << tx_log2, or (VEC == 1) any cs <= 1 << tx_log2
-    const int bi = blockIdx.y;
-    const int slice = blockIdx.x % nslices, part = blockIdx.x / nslices;
+    // (a sample's slices and parts on ONE XCD: neighbouring slices share the cache lines of grad_out's rows)
+    const unsigned logical = xcd_contiguous ? rf::xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int wps = nslices * parts;  // workgroups per sample
+    const int bi = logical / wps, bx = logical - bi * wps;
+    const int slice = bx % nslices, part = bx / nslices;
     const int TX = 1 << tx_log2, TY = TG_TPB >> tx_log2;
     const int lx = threadIdx.x & (TX - 1), ly = threadIdx.x >> tx_log2;
     const bool lane_on = POW2 || lx * VEC < cs;  // (a slice of 3 or 13 channels leaves the last lanes of its rows idle)
@@ -585,14 +594,15 @@ int rf_threeinterpolate(int b, int m, int c, int n, const float *points, const i
         int tx_log2 = 0;
         while ((1 << tx_log2) < cv && tx_log2 < 6) tx_log2++;
         const int ppb = (TI_TPB >> tx_log2) * TI_PP;  // points per block
-        if (rf::ceil_div(n, ppb) <= 0x7FFFFFFF) {
-            const dim3 grid(rf::ceil_div(n, ppb), b);
+        const long bpb = rf::ceil_div(n, ppb);
+        if (bpb * b <= 0x7FFFFFFF) {
+            const dim3 grid((unsigned)(bpb * b));
             if (vec) {
                 RF_LAUNCH("three_interpolate", three_interpolate_rows_kernel<4>, grid, dim3(TI_TPB), 0, (hipStream_t)stream, m, c, n,
-                          tx_log2, points, idx, weight, out);
+                          tx_log2, (int)bpb, RFI_XCD, points, idx, weight, out);
             } else {
                 RF_LAUNCH("three_interpolate", three_interpolate_rows_kernel<1>, grid, dim3(TI_TPB), 0, (hipStream_t)stream, m, c, n,
-                          tx_log2, points, idx, weight, out);
+                          tx_log2, (int)bpb, RFI_XCD, points, idx, weight, out);
             }
             return RF_OK;
         }
@@ -631,10 +641,10 @@ int rf_threeinterpolate_grad(int b, int n, int c, int m, const float *grad_out, 
         while ((long)b * nslices * parts < RFI_TG_WGS && n / (parts * 2) >= 2048) parts *= 2;
         if (parts > 1) RF_ZERO(grad_points, sizeof(float) * (size_t)b * m * c, s);
         const size_t lds = sizeof(double) * (size_t)m * cs;
-        const dim3 grid(nslices * parts, b);
+        const dim3 grid((unsigned)(nslices * parts * b));
 #define TG_GO(KERNEL)                                                                                                      \
     RF_HIP(hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));                 \
-    RF_LAUNCH("three_interpolate_grad", KERNEL, grid, dim3(TG_TPB), lds, s, m, c, n, cs, tx_log2, nslices, parts, grad_out, idx, \
+    RF_LAUNCH("three_interpolate_grad", KERNEL, grid, dim3(TG_TPB), lds, s, m, c, n, cs, tx_log2, nslices, parts, RFI_XCD, grad_out, idx, \
               weight, grad_points)
         if (vec) {
             TG_GO((three_interpolate_grad_tile_kernel<4, true>));
