@@ -297,6 +297,10 @@ __global__ __launch_bounds__(64 * QS) void query_ball_lanes_kernel(int n, int m,
 // whatever the radius: results are bit-identical to the scan kernels' (tests/test_gpu_sampling_grouping.py).
 constexpr int QX_LIST = 128;  // surviving superblocks a boxed query may hold: max(16, G / 8) <= 128 for G <= 1024
 constexpr int QX_STAGE = 64;  // nsample <= 64
+#ifndef RFG_QX_XCD
+#define RFG_QX_XCD 1
+#endif
+constexpr int QX_XCD = RFG_QX_XCD;
 #ifndef RFG_QX_BATCH
 #define RFG_QX_BATCH 4
 #endif
@@ -343,8 +347,12 @@ __global__ __launch_bounds__(1024) void query_ball_boxes_kernel(
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wpb = blockDim.x >> 6;
-    const int bi = blockIdx.y;
-    const int q = blockIdx.x * wpb + wib;
+    // a sample's workgroups on ONE XCD (rf::xcd_contiguous): its sorted records and boxes (270 KB at 16384 points) then stay in
+    // that XCD's L2 -- spread over all eight, 32 samples are 8.6 MB per 4 MB L2
+    const unsigned logical = QX_XCD ? rf::xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int bpb = (m + wpb - 1) / wpb;  // workgroups per sample
+    const int bi = logical / bpb;
+    const int q = (logical - bi * bpb) * wpb + wib;
     const int G = npad >> 6;
     const int gpad = (G + 63) & ~63;
     float *__restrict__ bx = (float *)qx_lds;
@@ -629,7 +637,7 @@ int ball_boxes(int b, int n, int m, float radius, const float *radius_dev, int n
     // (C3, same device: 4 / 8 / 16 queries per workgroup 33.1 / 31.9 / 34.0 us)
     const int wpb = n <= 32768 ? 8 : 4;
     const size_t shmem = sizeof(unsigned) * ((size_t)6 * gpad + (size_t)wpb * (words + QX_LIST + QX_STAGE));
-    RF_LAUNCH("query_ball_boxes", query_ball_boxes_kernel, dim3(rf::ceil_div(m, wpb), b), dim3(64 * wpb), shmem, s, n, m,
+    RF_LAUNCH("query_ball_boxes", query_ball_boxes_kernel, dim3(rf::ceil_div(m, wpb) * b), dim3(64 * wpb), shmem, s, n, m,
               so.npad, words, thresh, radius_dev, nsample, xyz1, xyz2, so.xyz, so.orig, so.box64, so.pos0 + 2 * b, idx, pts_cnt,
               grouped_xyz, zero_empty);
     return RF_OK;

@@ -106,6 +106,9 @@ __global__ __launch_bounds__(TN_TPB) void three_nn_kernel(int n, int m,
 #ifndef RFI_TB_WAVES
 #define RFI_TB_WAVES 4
 #endif
+#ifndef RFI_TB_XCD
+#define RFI_TB_XCD 1
+#endif
 constexpr int TB_WAVES = RFI_TB_WAVES;  // waves per workgroup, each on its own (no barrier)
 
 #define TB_ROW(OP, N) asm volatile("s_nop 1\n\t" OP " %0, %0, %0 row_ror:" #N " row_mask:0xf bank_mask:0xf" : "+v"(v))
@@ -147,8 +150,11 @@ __global__ __launch_bounds__(64 * TB_WAVES) void three_nn_boxes_kernel(
     const float *__restrict__ cxyz, const int *__restrict__ corig, const float *__restrict__ cb16,
     const float *__restrict__ cb64, float *__restrict__ dist, int *__restrict__ idx) {
     const int lane = threadIdx.x & 63;
-    const int group = blockIdx.x * TB_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int bi = blockIdx.y;
+    // a sample's workgroups on the XCD that sorted it (rf::xcd_contiguous, as nnp_sort): its records are still in that L2
+    const int bpb = ((npq >> 6) + TB_WAVES - 1) / TB_WAVES;  // workgroups per sample
+    const unsigned logical = RFI_TB_XCD ? rf::xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int bi = logical / bpb;
+    const int group = (logical - bi * bpb) * TB_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (group * 64 >= npq) return;  // (uniform)
     const int p = group * 64 + lane;
     const float *__restrict__ Q = qxyz + ((size_t)bi * npq + p) * 3;
@@ -576,7 +582,7 @@ int rf_threenn_boxes(int b, int n, int m, const float *xyz1, const float *xyz2, 
         if (k > 0)
             if (int e = rfp::sort_sets(b, k, nn, src, out, s, nullptr)) return e;
     }
-    RF_LAUNCH("three_nn_boxes", three_nn_boxes_kernel, dim3(rf::ceil_div(sv[0].npad / 64, TB_WAVES), b), dim3(64 * TB_WAVES), 0, s,
+    RF_LAUNCH("three_nn_boxes", three_nn_boxes_kernel, dim3(rf::ceil_div(sv[0].npad / 64, TB_WAVES) * b), dim3(64 * TB_WAVES), 0, s,
               n, sv[0].npad, sv[1].npad, sv[0].xyz, sv[0].orig, sv[0].box64, sv[1].xyz, sv[1].orig, sv[1].box16, sv[1].box64,
               dist, idx);
     return RF_OK;

@@ -11,6 +11,7 @@ python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$O/smo
 bash tools/profile_bench.sh r05h/prof
 bash tools/profile_op.sh c4 r05h/c4
 bash tools/profile_py.sh r05h/ball tools/run_ball_once.py 0.1
+bash tools/profile_py.sh r05h/interp tools/run_interp_once.py
 timeout 200 python3 tools/ab_ball.py > "$O/ab_ball.txt" 2>&1; cat "$O/ab_ball.txt"
 timeout 200 python3 tools/ab_c3.py > "$O/ab_c3.txt" 2>&1; cat "$O/ab_c3.txt"
 # same-device A/Bs against builds with this round's EMD changes switched off (python tools/build_variant.py, see profiles/README.md):
@@ -29,3 +30,4 @@ timeout 400 python3 tools/ab_fps_sizes.py > "$O/ab_fps_sizes.txt" 2>&1; tail -9 
 timeout 600 python3 tools/ab_step.py gsf32 base > "$O/ab_step_f64.txt" 2>&1; cut -c1-400 "$O/ab_step_f64.txt"
 timeout 300 python3 tools/ab_three_nn.py > "$O/ab_three_nn.txt" 2>&1; cat "$O/ab_three_nn.txt"
 timeout 300 python3 tools/experiments/three_interpolate_rate.py > "$O/three_interpolate_rate.txt" 2>&1; cat "$O/three_interpolate_rate.txt"
+timeout 300 python3 tools/experiments/group_point_rate.py > "$O/group_point_rate.txt" 2>&1; cat "$O/group_point_rate.txt"
