@@ -358,7 +358,7 @@ __global__ __launch_bounds__(TI_TPB) void three_interpolate_rows_kernel(int m, i
                                                                         const float *__restrict__ weight,
                                                                         float *__restrict__ out) {
     typedef typename TiVec<VEC>::T V;
-    // (a sample's blocks on ONE XCD: its rows of `points` then cross the fabric once instead of eight times -- FETCH_SIZE 71 -> MB)
+    // (a sample's blocks on ONE XCD: its rows of `points` then cross the fabric once instead of eight times -- FETCH_SIZE 71 -> 14 MB, 68 -> 57 us)
     const unsigned logical = xcd_contiguous ? rf::xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
     const int bi = logical / bpb, bx = logical - bi * bpb;
     const int TX = 1 << tx_log2, TY = TI_TPB >> tx_log2;
