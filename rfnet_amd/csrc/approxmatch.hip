@@ -56,6 +56,9 @@ constexpr float kLog2e = 1.44269502f;  // 0x3FB8AA3B, the constant __expf multip
 #ifndef RFA_PK_FUSED
 #define RFA_PK_FUSED 1  // emd_fused_kernel (cost only): two columns per step, packed
 #endif
+#ifndef RFA_XCD
+#define RFA_XCD 1
+#endif
 #ifndef RFA_SKIP_MASK
 #define RFA_SKIP_MASK 1  // level 0's skipping sweeps list the columns level 1's will need; level 1's visit only those (am_rowk_kernel MASK)
 #endif
@@ -157,7 +160,9 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
     // P3-only form before the first expanded level -- only when it was accepted; guard = NULL: always)
     if (guard && (*guard != 0) != (guard_want != 0)) return;
     static_assert(SKIP == 0 || P1 == 1, "the skipping sweeps evaluate this level's own exponential");
-    const int bi = blockIdx.y;
+    // (a sample's workgroups on ONE XCD, rf::xcd_contiguous: its columns are then read from HBM by one L2 instead of eight)
+    const unsigned lgc = RFA_XCD ? rf::xcd_contiguous(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y) : blockIdx.y * gridDim.x + blockIdx.x;
+    const int bi = lgc / gridDim.x, bx = lgc - bi * gridDim.x;
     const int lane = threadIdx.x & 63;
     const int seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr bool HAS_P1 = P1 != 0;
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
     int krow[RPT];  // the lane's rows (original indices; < 0: none)
 #pragma unroll
     for (int r = 0; r < RPT; r++) {
-        const int pos = (int)blockIdx.x * 64 * RPT + r * 64 + lane;
+        const int pos = bx * 64 * RPT + r * 64 + lane;
         krow[r] = SKIP != 0 ? (pos < perm_stride ? perm[(size_t)bi * perm_stride + pos] : -1) : (pos < n ? pos : -1);
         const int kk = krow[r] >= 0 ? krow[r] : n - 1;
         x1[r] = A[kk * 3]; y1[r] = A[kk * 3 + 1]; z1[r] = A[kk * 3 + 2];
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
         }                                                                                    \
     } while (0)
         // the wave's list: ((batch element, row group), column segment) -> 1 + seglen entries
-        if (MASK != 0) lst = mask + (((size_t)bi * gridDim.x + blockIdx.x) * nseg + seg) * (size_t)(seglen + 1);
+        if (MASK != 0) lst = mask + (((size_t)bi * gridDim.x + bx) * nseg + seg) * (size_t)(seglen + 1);
         if constexpr (MASK == 2) {
             __shared__ float colbuf[16][64][8];  // per wave: 64 listed columns' operands (x y z s3 s1)
             float(*cb)[8] = colbuf[seg];
@@ -399,7 +404,9 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
     static_assert(MASK == 0 || SKIP, "column lists belong to the skipping sweeps (am_rowk_kernel MASK)");
     if (guard && (*guard != 0) != (guard_want != 0)) return;  // (see am_rowk_kernel)
     __shared__ float part[16][64 * RPT];
-    const int bi = blockIdx.y;
+    // (a sample's workgroups on ONE XCD, rf::xcd_contiguous: its columns are then read from HBM by one L2 instead of eight)
+    const unsigned lgc = RFA_XCD ? rf::xcd_contiguous(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y) : blockIdx.y * gridDim.x + blockIdx.x;
+    const int bi = lgc / gridDim.x, bx = lgc - bi * gridDim.x;
     const int lane = threadIdx.x & 63;
     const int seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nseg = blockDim.x >> 6;
@@ -408,7 +415,7 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
     int lrow[RPT];  // the lane's rows (original indices; < 0: none); SKIP: in the cloud's spatial order (see am_rowk_kernel)
 #pragma unroll
     for (int r = 0; r < RPT; r++) {
-        const int pos = (int)blockIdx.x * 64 * RPT + r * 64 + lane;
+        const int pos = bx * 64 * RPT + r * 64 + lane;
         lrow[r] = SKIP ? (pos < perm_stride ? perm[(size_t)bi * perm_stride + pos] : -1) : (pos < m ? pos : -1);
         const int ll = lrow[r] >= 0 ? lrow[r] : m - 1;
         x2[r] = B[ll * 3]; y2[r] = B[ll * 3 + 1]; z2[r] = B[ll * 3 + 2];
@@ -471,7 +478,7 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
         _Pragma("unroll") for (int i = 0; i < 3 * SUB; i++) xs[i] = Cc[(size_t)(c) * 3 + i]; \
         _Pragma("unroll") for (int i = 0; i < SUB; i++) ts[i] = Sc[(c) + i];                 \
     } while (0)
-        if (MASK != 0) lst = mask + (((size_t)bi * gridDim.x + blockIdx.x) * nseg + seg) * (size_t)(seglen + 1);
+        if (MASK != 0) lst = mask + (((size_t)bi * gridDim.x + bx) * nseg + seg) * (size_t)(seglen + 1);
         if constexpr (MASK == 2) {  // only the listed columns, gathered 64 at a time through LDS (am_rowk_kernel)
             __shared__ float colbuf[16][64][4];
             float(*cb)[4] = colbuf[seg];
@@ -625,9 +632,15 @@ __global__ __launch_bounds__(TPB) void am_match_kernel(int n, int m, const float
     // ratios: [b][level][ (ratioL: npad) (ratioR: mpad) ]; roff = npad
     __shared__ float cxyz[LSEG][4];
     __shared__ float crr[LSEG][LVG];
-    const int bi = blockIdx.z;
-    const int k = blockIdx.x * TPB + threadIdx.x;
-    const int l0 = blockIdx.y * LSEG;
+    // (a sample's workgroups on ONE XCD, rf::xcd_contiguous: the sweeps' order)
+    const unsigned per = gridDim.x * gridDim.y;
+    const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const unsigned lgc = RFA_XCD ? rf::xcd_contiguous(lin, per * gridDim.z) : lin;
+    const int bi = lgc / per;
+    const unsigned rem = lgc - bi * per;
+    const int by = rem / gridDim.x, bx = rem - by * gridDim.x;
+    const int k = bx * TPB + threadIdx.x;
+    const int l0 = by * LSEG;
     const int lcnt = min(LSEG, m - l0);
     xyz1 += (size_t)bi * n * 3;
     xyz2 += (size_t)bi * m * 3;
@@ -1290,9 +1303,14 @@ __global__ __launch_bounds__(TPB) void emd_fused_kernel(int n, int m, int mpad, 
     __shared__ float4 sx1[GRAD ? TPB : 1];
     __shared__ float ps[GRAD ? TPB / MG_TL : 1][MG_TL][3];
     __shared__ float wsum[TPB / 64];
-    const int bi = blockIdx.z;
+    // (a sample's workgroups on ONE XCD, rf::xcd_contiguous: the sweeps' order)
+    const unsigned per_ = gridDim.x * gridDim.y;
+    const unsigned lin_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const unsigned lgc_ = RFA_XCD ? rf::xcd_contiguous(lin_, per_ * gridDim.z) : lin_;
+    const int bi = lgc_ / per_;
+    const int by = (lgc_ - bi * per_) / gridDim.x, bx = (lgc_ - bi * per_) - by * gridDim.x;
     const int t = threadIdx.x;
-    const int k = blockIdx.x * TPB + t;
+    const int k = bx * TPB + t;
     const bool live = k < n;
     const int kk = live ? k : n - 1;
     const float *__restrict__ A = xyz1 + (size_t)bi * n * 3;
@@ -1307,7 +1325,7 @@ __global__ __launch_bounds__(TPB) void emd_fused_kernel(int n, int m, int mpad, 
     const float t0 = cl[0] < 0.f ? kSkipArg / -cl[0] : INFINITY;  // (uniform)
     if (GRAD) sx1[t] = make_float4(x1, y1, z1, 0.f);
     float ax = 0.f, ay = 0.f, az = 0.f, csum = 0.f;
-    const int lbeg = blockIdx.y * lspan;
+    const int lbeg = by * lspan;
     const int lend = min(mpad, lbeg + lspan);  // multiples of MG_TL; records beyond m are zero
     const int bl = t & (MG_TL - 1);
     const int br = t / MG_TL;
@@ -1409,7 +1427,7 @@ __global__ __launch_bounds__(TPB) void emd_fused_kernel(int n, int m, int mpad, 
     if ((t & 63) == 0) wsum[t >> 6] = csum;
     __syncthreads();
     if (t == 0)
-        partial[((size_t)bi * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] =
+        partial[((size_t)bi * gridDim.y + by) * gridDim.x + bx] =
             (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
     if (GRAD && live) {
         float *g = grad1 + ((size_t)bi * n + k) * 3;
