@@ -88,6 +88,9 @@ def test_workspace_queries_are_pure_host_functions():
     assert 0 < one < lib.rf_chamfer_loss_workspace_bytes(32, 16384, 16384, 1, 1, 0, 0)
     assert lib.rf_merge_layer_workspace_bytes(32, 3000, 16384, 1) >= 32 * 16384 * 4
     assert lib.rf_auctionmatch_workspace_bytes(32, 4096) == 0  # no (n, n) cost matrix any more
+    # the boxed three_nn sorts both sets into its scratch: two sorted sets; nothing outside 1..65536 points
+    assert lib.rf_threenn_boxes_workspace_bytes(32, 16384, 1024) == lib.rf_nn_sort_bytes(32, 16384) + lib.rf_nn_sort_bytes(32, 1024)
+    assert lib.rf_threenn_boxes_workspace_bytes(2, 100, 0) == 0 and lib.rf_threenn_boxes_workspace_bytes(2, 65537, 10) == 0
     assert lib.rf_point_affine_supported(128, 3) == 1 and lib.rf_point_affine_supported(126, 3) == 0
     assert lib.rf_device_check() in (0, -3)  # RF_OK on the MI355X box, RF_ENODEVICE here
 
@@ -105,6 +108,8 @@ def test_misaligned_workspace_is_an_argument_error():
     assert lib.rf_nn_sort(1, 4096, p, ws + 4, big, None) == -1
     assert lib.rf_nn_distance_sorted(1, 4096, 4096, ws + 4, ws, p, p, p, p, None) == -1
     assert lib.rf_approxmatch(1, 300, 300, p, p, p, ws + 12, big, None) == -1
+    assert lib.rf_threenn_boxes(2, 500, 300, p, p, None, None, p, p, ws + 4, big, None) == -1
+    assert lib.rf_threenn_boxes(2, 500, 300, p, p, ws + 8, None, p, p, ws, big, None) == -1
     assert lib.rf_earth_mover(1, 300, 300, p, p, p, None, None, ws + 4, big, None) == -1
 
 
