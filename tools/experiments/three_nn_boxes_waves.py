@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""three_nn_boxes_kernel on handles at four shapes, for builds with 1 / 2 / 4 / 8 waves per workgroup
+(python tools/build_variant.py tbwN -DRFI_TB_WAVES=N; RFOPS_LIB selects the build).  Measured: within 4 % of each other; 4 kept."""
 import os, sys, numpy as np, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..")))
 from rfnet_amd import _raw as R
 def timed(fn, it=30):
     for _ in range(3): fn()
