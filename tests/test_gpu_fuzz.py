@@ -7,6 +7,8 @@ in-workgroup merge, tile sizes and source slices of the backward, LDS-staged and
 query, register-resident FPS variants) is hit by some case.  Bars as in the per-op files:
 bit-exact for indices and Chamfer distances, fp32 tolerance for accumulated gradients.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -14,6 +16,9 @@ import torch
 from conftest import assert_rel, strict_bar_report
 
 pytestmark = pytest.mark.gpu
+
+# RF_FUZZ_SCALE=10 runs ten times the seeds of every test below (an extended parity run; the default suite is what it was)
+FUZZ_SCALE = max(1, int(os.environ.get("RF_FUZZ_SCALE", "1")))
 
 
 def cu(x):
@@ -35,7 +40,7 @@ def _cloud(rng, b, n, kind):
     return x
 
 
-@pytest.mark.parametrize("seed", range(80))
+@pytest.mark.parametrize("seed", range(80 * FUZZ_SCALE))
 def test_fuzz_nn_distance_and_grad(orc, seed):
     from rfnet_amd import _raw
     rng = np.random.RandomState(1000 + seed)
@@ -57,7 +62,7 @@ def test_fuzz_nn_distance_and_grad(orc, seed):
     assert_rel(g2.cpu().numpy(), o2, 1e-5, scale, what=f"seed {seed} grad2")
 
 
-@pytest.mark.parametrize("seed", range(32))
+@pytest.mark.parametrize("seed", range(32 * FUZZ_SCALE))
 def test_fuzz_fps_gather(orc, seed):
     from rfnet_amd import _raw
     rng = np.random.RandomState(2000 + seed)
@@ -72,7 +77,7 @@ def test_fuzz_fps_gather(orc, seed):
     assert np.array_equal(out.cpu().numpy(), orc.gather_point(x, oi))
 
 
-@pytest.mark.parametrize("seed", range(32))
+@pytest.mark.parametrize("seed", range(32 * FUZZ_SCALE))
 def test_fuzz_query_ball_group(orc, seed):
     from rfnet_amd import _raw
     rng = np.random.RandomState(3000 + seed)
@@ -93,7 +98,7 @@ def test_fuzz_query_ball_group(orc, seed):
     assert np.array_equal(grp.cpu().numpy(), orc.group_point(pts, oi))
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(40 * FUZZ_SCALE))
 def test_fuzz_query_ball_boxes_and_one_call(orc, seed):
     """The boxed ball query (every dataset size from 64 up, whatever the auto rule would pick) and the one-call
     sample-and-group on random shapes, cloud kinds (uniform / lattice ties / duplicated halves / one tight cluster) and radii
@@ -135,7 +140,7 @@ def test_fuzz_query_ball_boxes_and_one_call(orc, seed):
         assert torch.equal(w, g), f"seed {seed} {name} b={b} n={n} npoint={npoint} ns={ns} r={r} kind={kind}"
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 * FUZZ_SCALE))
 def test_fuzz_three_nn_interpolate(orc, seed):
     from rfnet_amd import _raw
     rng = np.random.RandomState(4000 + seed)
@@ -163,7 +168,10 @@ def _match_close(got, exp, what):
     the fp32 ORACLE itself is up to 1.9e-4 away from a float64 evaluation of the same schedule in
     1-6 entries per sample, the GPU up to 3.6e-4 in 1-4 entries, oracle vs GPU 5.1e-4 in 8 of 75 076
     entries -- while every row/column sum agrees to 1e-6.  So: >= 99.9 % of the entries inside
-    abs 1e-6 + rel 1e-4, every entry inside 2e-3 of a unit mass, and all marginals inside 1e-5."""
+    abs 1e-6 + rel 1e-4, every entry inside 2e-3 of a unit mass, and all marginals inside 1e-5.
+    (With RF_FUZZ_SCALE=60, 11 of 960 seeds of the EMD chain test leave the marginal bar by up to 2e-4 -- clamp flips that move
+    mass between columns -- identically on the round-4 kernels; their cost stays within 3.5e-7 of the oracle's:
+    profiles/r05_soak.txt.)"""
     got, exp = np.asarray(got, np.float64), np.asarray(exp, np.float64)
     strict_bar_report(what, got, exp)  # the un-relaxed bar, always reported
     err = np.abs(got - exp)
@@ -174,7 +182,7 @@ def _match_close(got, exp, what):
     assert_rel(got.sum(2), exp.sum(2), 1e-5, 1e-5, what=what + " row sums")
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(16 * FUZZ_SCALE))
 def test_fuzz_emd_chain_and_fused(orc, seed):
     from rfnet_amd import _raw
     rng = np.random.RandomState(5000 + seed)
@@ -200,7 +208,7 @@ def test_fuzz_emd_chain_and_fused(orc, seed):
     assert_rel(g2.cpu().numpy(), o2, 1e-4, 1e-5 * max(1, n // m), what="fused grad2")
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 * FUZZ_SCALE))
 def test_fuzz_match_cost_grad_both_forms(orc, seed):
     """match_cost_grad over random shapes on both sides of its dispatch rule (approxmatch.hip mcg_launch: whole rows per workgroup
     when n % 4 == 0 and the 1024-k blocks are at least 3/4 alive, the LDS-tile form otherwise), arbitrary non-negative `match`,
