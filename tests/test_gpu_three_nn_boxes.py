@@ -108,6 +108,35 @@ def test_boxes_non_finite_coordinates(orc):
     assert np.array_equal(si, oi) and _same(sd, od)
 
 
+@pytest.mark.parametrize("which", ["known all NaN", "known all +inf", "unknown all NaN", "known: one finite point"])
+def test_boxes_sets_without_a_usable_point(orc, which):
+    """Every box of the set empty (no finite point to bound): nothing is ever inserted -- (+inf, 0) three times, as the scan and
+    the reference leave it; with ONE finite known point that one is everybody's first neighbour and the other two slots stay unfilled."""
+    from rfnet_amd import _raw as R
+    rng = np.random.RandomState(17)
+    b, n, m = 2, 1500, 700
+    u = rng.rand(b, n, 3).astype(np.float32)
+    k = rng.rand(b, m, 3).astype(np.float32)
+    if which == "known all NaN":
+        k[:] = np.nan
+    elif which == "known all +inf":
+        k[:] = np.inf
+    elif which == "unknown all NaN":
+        u[:] = np.nan
+    else:
+        keep = k[:, 333].copy()
+        k[:] = np.nan
+        k[:, 333] = keep
+    bd, bi, sd, si = _both(R, u, k)
+    od, oi = orc.three_nn(u, k)
+    assert np.array_equal(bi, oi) and _same(bd, od), which
+    assert np.array_equal(si, oi) and _same(sd, od), which
+    if which == "known: one finite point":
+        assert np.all(bi[..., 0] == 333) and np.all(np.isinf(bd[..., 1:])) and np.all(bi[..., 1:] == 0)
+    else:
+        assert np.all(np.isinf(bd)) and np.all(bi == 0)
+
+
 def test_boxes_on_caller_handles_and_the_auto_rule(orc):
     from rfnet_amd import _raw as R
     rng = np.random.RandomState(9)
