@@ -402,7 +402,7 @@ def run_c3(rank, dev, fence, reps):
                          "scalar re-read of the winner.  `distance_updates_per_s` counts the reference's (npoint-1)*n updates (an effective "
                          "figure: most are proven unnecessary and not executed).  Spreading a cloud over 2/4/8 workgroups "
                          "was built and is 1.27-1.43x SLOWER: one all-to-all exchange of the winners costs 0.5-0.9 us against the ~1 us "
-                         "of a whole iteration (profiles/r05_fps_cluster.txt)",
+                         "of a whole iteration (profiles/r05_fps_cluster.txt; the build: tools/experiments/fps_cluster.patch.txt)",
                          "cus_busy": B, "valu_flops_per_s": 8.0 * updates / (fps_kms * 1e-3),
                          "frac_of_fp32_peak_on_busy_cus": 8.0 * updates / (fps_kms * 1e-3) / 1e12 / (FP32_PEAK_TFLOPS * B / 256.0)}},
         "gather_point": {"ms": ga_ms, "roofline": hbm_roof(28.0 * B * m, ga_k.get("gather_point", ga_ms), "gather_point",
@@ -943,8 +943,10 @@ def main():
                 "frac": (efl["mix_ms"] / am_swept_ms) if efl else None,
                 "swept_kernel_sum_ms": am_swept_ms,
                 "expanded_levels": {"what": "levels -1, -0.25 and 0 of the schedule: row sums from one truncated Taylor expansion about the "
-                                            "clouds' centre (emd_fgt.hip, fp64, degree 10 / 6 / 0, <= 3e-9 of the direct sum inside a unit "
-                                            "cube; refused per call on the device for larger or non-finite clouds, which take direct sums)",
+                                            "clouds' centre (emd_fgt.hip, fp64, degree 10 / 8 / 0).  Every row's sum carries a certificate: an error bound from one "
+                                            "extra moment; a row whose bound exceeds 4e-6 of its sum is summed directly (C4: bound <= 2.5e-6, true error "
+                                            "<= 3.4e-7, no row fails; two clusters in opposite corners: every row fails and is summed directly); clouds "
+                                            "beyond a unit cube or with non-finite coordinates are refused per batch element on the device",
                                     "kernels_ms": {k: v for k, v in am_k.items() if k.startswith("am_fgt")}},
                 "frac_of_fp32_peak": 2.0 * lane_ops / (am_kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
                 # against the CHIP, not the model above: the reference schedule's 30*B*n*m exponentials per call over the whole

@@ -145,6 +145,24 @@ int rf_approxmatch_levels(int b, int n, int m, const float *xyz1, const float *x
                           const float *levels_host, int nlevels, void *workspace,
                           size_t workspace_bytes, rf_stream_t stream);
 
+/* The same op with its route pinned.  The reference's kernel loops over the samples of a batch independently
+ * (tf_approxmatch.cu:13), so a sample's match does not depend on the batch it is called in.  RF_EMD_AUTO (what rf_approxmatch /
+ * rf_approxmatch_levels / rf_earth_mover pass) picks launch shapes and routes by the size of the WHOLE batch: from 6e7 pairs on
+ * the sweeps take their rows in spatial order, from 8e7 pairs on the three broad levels come from an expansion, and the column
+ * segments of a sweep follow b -- every route within the op's tolerances, but the bits of sample i differ between a call on the
+ * batch and a call on that sample alone.  RF_EMD_SWEPT pins the route: every level a dense sweep over the clouds in the caller's
+ * order, launch shapes those of a batch of one -- sample i's match (and rf_earth_mover_mode's cost) is bit-identical whatever the
+ * batch around it or the shard it lands in (what a loss compared across differently sharded runs wants; C4 costs ~1.2x the
+ * time).  RF_EMD_EXPANDED takes the sorted-row sweeps and the expansion wherever the SHAPES allow them (n, m >= 512), whatever the
+ * batch: for tests of that route on small batches.  levels_host == NULL with nlevels == 0: the reference schedule. */
+#define RF_EMD_AUTO 0
+#define RF_EMD_SWEPT 1
+#define RF_EMD_EXPANDED 2
+size_t rf_approxmatch_mode_workspace_bytes(int b, int n, int m, int nlevels /* 0 = reference's 10 */, int mode);
+int rf_approxmatch_mode(int b, int n, int m, const float *xyz1, const float *xyz2, float *match,
+                        const float *levels_host, int nlevels, void *workspace, size_t workspace_bytes,
+                        rf_stream_t stream, int mode);
+
 /* Replaces matchcostLauncher (tf_approxmatch.cpp:142, tf_approxmatch.cu:226-228): cost (b). */
 size_t rf_matchcost_workspace_bytes(int b, int n, int m);
 int rf_matchcost(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match,
@@ -163,16 +181,6 @@ int rf_matchcost_grad(int b, int n, int m, const float *xyz1, const float *xyz2,
 size_t rf_farthestpointsampling_temp_floats(int b, int n);
 int rf_farthestpointsampling(int b, int n, int m, const float *inp, float *temp, int *out,
                              rf_stream_t stream);
-
-/* The same op (same indices, bit for bit) with every cloud spread over a cluster of k = 2, 4 or 8 workgroups that
- * exchange their per-iteration winners through `state` (rf_fps_cluster_state_bytes(b) bytes of caller scratch,
- * 16-byte aligned, zeroed by the call).  n <= 16384.  static_map != 0 keys membership on the block index instead
- * of the arrival order (measurement aid: needs b % 8 == 0 and the whole grid of b*k workgroups resident).  After the
- * stream has drained, word 1 of `state` is non-zero if a member gave up waiting (the output is then invalid).
- * Measured against the one-workgroup form in DESIGN.md 5.3b; rf_farthestpointsampling does not use it. */
-size_t rf_fps_cluster_state_bytes(int b);
-int rf_farthestpointsampling_cluster(int b, int n, int m, int k, int static_map, const float *inp, void *state,
-                                     int *out, rf_stream_t stream);
 
 /* The op with caller scratch of a stated size -- the entry point a binding should prefer: for clouds of 4097..16384 points from
  * 256 samples on (2049..4096 points: from 512) it sorts the cloud into the workspace and samples over the sorted cloud (rf_farthestpointsampling_sorted
@@ -311,6 +319,11 @@ size_t rf_earth_mover_workspace_bytes(int b, int n, int m);
 int rf_earth_mover(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost,
                    float *grad1, float *grad2, void *workspace, size_t workspace_bytes,
                    rf_stream_t stream);
+/* ... with the route pinned as rf_approxmatch_mode pins it (RF_EMD_SWEPT: cost[i] bit-identical whatever the batch). */
+size_t rf_earth_mover_mode_workspace_bytes(int b, int n, int m, int mode);
+int rf_earth_mover_mode(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost,
+                        float *grad1, float *grad2, void *workspace, size_t workspace_bytes,
+                        rf_stream_t stream, int mode);
 
 /* `chamfer_big` / `fidelity_loss` (vv_recon.py:381-390) are reduce_mean(sqrt(dist)) over the
  * nn_distance outputs.  rf_chamfer_loss returns the per-sample means loss (b, 2):

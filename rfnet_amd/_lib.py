@@ -55,6 +55,8 @@ SIGNATURES = {
     "rf_approxmatch_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "rf_approxmatch": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rf_approxmatch_levels": (_i, [_i, _i, _i, _vp, _vp, _vp, C.POINTER(_f), _i, _vp, _sz, _vp]),
+    "rf_approxmatch_mode_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "rf_approxmatch_mode": (_i, [_i, _i, _i, _vp, _vp, _vp, C.POINTER(_f), _i, _vp, _sz, _vp, _i]),
     "rf_matchcost_workspace_bytes": (_sz, [_i, _i, _i]),
     "rf_matchcost": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rf_matchcost_grad": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -64,8 +66,6 @@ SIGNATURES = {
     "rf_farthestpointsampling_ws": (_i, [_i, _i, _i, _vp, _vp, _sz, _vp, _vp]),
     "rf_farthestpointsampling_sorted_workspace_bytes": (_sz, [_i, _i]),
     "rf_farthestpointsampling_sorted": (_i, [_i, _i, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
-    "rf_fps_cluster_state_bytes": (_sz, [_i]),
-    "rf_farthestpointsampling_cluster": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "rf_gatherpoint": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "rf_scatteraddpoint": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "rf_queryballpoint": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -88,6 +88,8 @@ SIGNATURES = {
     "rf_probsample": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "rf_earth_mover_workspace_bytes": (_sz, [_i, _i, _i]),
     "rf_earth_mover": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "rf_earth_mover_mode_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "rf_earth_mover_mode": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _i]),
     "rf_maxpool_points_workspace_bytes": (_sz, [_i, _i, _i]),
     "rf_maxpool_points": (_i, [_i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "rf_maxpool_points_idx_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -315,12 +315,19 @@ def _emd_inputs(st, xyz1, xyz2, opname):
     return a, b_
 
 
+# rf_approxmatch_mode / rf_earth_mover_mode (include/rfops.h): "swept" pins the route -- a sample's bits do not depend on the batch
+EMD_MODES = {"auto": 0, "swept": 1, "expanded": 2}
+
+
 @H.on_input_device
-def approx_match(xyz1, xyz2, levels=None):
+def approx_match(xyz1, xyz2, levels=None, mode="auto"):
     """ApproxMatchGpuOp::Compute, pc_distance/tf_approxmatch.cpp:148-172 -> match (b,m,n).
 
     `levels` (optional, extension): explicit annealing schedule; default = the reference's 10.
+    `mode` (extension): "auto" | "swept" (batch-invariant bits per sample, as the reference's per-sample loop) | "expanded".
     """
+    if mode not in EMD_MODES:
+        raise H.invalid(f"ApproxMatch: mode must be one of {sorted(EMD_MODES)}")
     st = H.Staged()
     a, b_ = _emd_inputs(st, xyz1, xyz2, "ApproxMatch")
     b, n, m = a.shape[0], a.shape[1], b_.shape[1]
@@ -328,6 +335,12 @@ def approx_match(xyz1, xyz2, levels=None):
     a, b_ = st.up(a, b_)
     match = H.empty((b, m, n), F32, dev)
     nlv = 0 if levels is None else len(levels)
+    if mode != "auto":
+        ws, wsz = H.workspace(lib.rf_approxmatch_mode_workspace_bytes(b, n, m, nlv, EMD_MODES[mode]), dev, "am")
+        lv = None if levels is None else (C.c_float * nlv)(*[float(v) for v in levels])
+        check(lib.rf_approxmatch_mode(b, n, m, H.ptr(a), H.ptr(b_), H.ptr(match), lv, nlv, H.ptr(ws), wsz, H.stream(dev),
+                                      EMD_MODES[mode]), "rf_approxmatch_mode")
+        return st.give(match)
     ws, wsz = H.workspace(lib.rf_approxmatch_workspace_bytes(b, n, m, nlv), dev, "am")
     if levels is None:
         check(lib.rf_approxmatch(b, n, m, H.ptr(a), H.ptr(b_), H.ptr(match), H.ptr(ws), wsz,
@@ -378,10 +391,13 @@ def match_cost_grad(xyz1, xyz2, match):
 
 
 @H.on_input_device
-def earth_mover(xyz1, xyz2, with_grad=False):
+def earth_mover(xyz1, xyz2, with_grad=False, mode="auto"):
     """Row f1: the fused form of `earth_mover`'s op chain (vv_recon.py:392-399):
     approx_match -> match_cost [-> MatchCostGrad], without materialising match.
-    -> cost (b)  or  (cost, grad1 (b,n,3), grad2 (b,m,3)) with `with_grad`."""
+    -> cost (b)  or  (cost, grad1 (b,n,3), grad2 (b,m,3)) with `with_grad`.
+    mode="swept": cost[i] bit-identical whatever the batch around sample i (rf_earth_mover_mode)."""
+    if mode not in EMD_MODES:
+        raise H.invalid(f"ApproxMatch: mode must be one of {sorted(EMD_MODES)}")
     st = H.Staged()
     a, b_ = _emd_inputs(st, xyz1, xyz2, "ApproxMatch")
     b, n, m = a.shape[0], a.shape[1], b_.shape[1]
@@ -390,10 +406,10 @@ def earth_mover(xyz1, xyz2, with_grad=False):
     cost = H.empty((b,), F32, dev)
     g1 = H.empty((b, n, 3), F32, dev) if with_grad else None
     g2 = H.empty((b, m, 3), F32, dev) if with_grad else None
-    ws, wsz = H.workspace(lib.rf_earth_mover_workspace_bytes(b, n, m), dev, "emd")
-    check(lib.rf_earth_mover(b, n, m, H.ptr(a), H.ptr(b_), H.ptr(cost),
-                             H.ptr(g1) if with_grad else None, H.ptr(g2) if with_grad else None,
-                             H.ptr(ws), wsz, H.stream(dev)), "rf_earth_mover")
+    ws, wsz = H.workspace(lib.rf_earth_mover_mode_workspace_bytes(b, n, m, EMD_MODES[mode]), dev, "emd")
+    check(lib.rf_earth_mover_mode(b, n, m, H.ptr(a), H.ptr(b_), H.ptr(cost),
+                                  H.ptr(g1) if with_grad else None, H.ptr(g2) if with_grad else None,
+                                  H.ptr(ws), wsz, H.stream(dev), EMD_MODES[mode]), "rf_earth_mover_mode")
     if with_grad:
         return st.give(cost), st.give(g1), st.give(g2)
     return st.give(cost)
@@ -424,29 +440,6 @@ def farthest_point_sample(npoint, inp, _pin_reg=False):
     ws, wsz = H.workspace(lib.rf_farthestpointsampling_workspace_bytes(b, n, npoint), dev, "fps")
     check(lib.rf_farthestpointsampling_ws(b, n, npoint, H.ptr(p), H.ptr(ws), wsz, H.ptr(out), H.stream(dev)),
           "rf_farthestpointsampling_ws")
-    return st.give(out)
-
-
-@H.on_input_device
-def farthest_point_sample_cluster(npoint, inp, k=4, static_map=False, return_state=False):
-    """farthest_point_sample with each cloud spread over k workgroups (sampling.hip fps_cluster_kernel): the same
-    indices; kept for measurement."""
-    npoint = int(npoint)
-    if npoint <= 0:
-        raise H.invalid("FarthestPointSample expects positive npoint")
-    st = H.Staged()
-    p = st.take(inp, F32)
-    if not _shape3(p, 3):
-        raise H.invalid("FarthestPointSample expects (batch_size,num_points,3) inp shape")
-    b, n = p.shape[0], p.shape[1]
-    dev = st.device_()
-    p, = st.up(p)
-    out = H.empty((b, npoint), I32, dev)
-    state = H.empty(((lib.rf_fps_cluster_state_bytes(b) + 3) // 4,), I32, dev)
-    check(lib.rf_farthestpointsampling_cluster(b, n, npoint, int(k), int(bool(static_map)), H.ptr(p), H.ptr(state),
-                                               H.ptr(out), H.stream(dev)), "rf_farthestpointsampling_cluster")
-    if return_state:
-        return st.give(out), state
     return st.give(out)
 
 

@@ -1657,7 +1657,11 @@ int round_up_i(int v, int q) { return (v + q - 1) / q * q; }
 
 // allow_cull: only the cost-only rf_earth_mover ever runs culled levels; rf_approxmatch(_levels) and the gradient form
 // must not carry the sorted sets and twin slots (about 50 MB at 32 x 16384^2) for nothing
-AmLayout am_layout(int b, int n, int m, int nlevels, bool allow_cull) {
+// mode (include/rfops.h): RF_EMD_AUTO -- the routes by the size of the whole batch (below); RF_EMD_SWEPT -- every level as a
+// dense sweep over the clouds in the caller's order and every launch shape taken as for b = 1: a sample's bits do not depend on
+// the batch it is called in (the reference is batch-independent per sample, tf_approxmatch.cu:13); RF_EMD_EXPANDED -- sorted rows,
+// skipping sweeps and the expanded broad levels wherever the SHAPES allow them, whatever the batch (small-batch tests of that route).
+AmLayout am_layout(int b, int n, int m, int nlevels, bool allow_cull, int mode = RF_EMD_AUTO) {
     AmLayout L;
     L.npad = round_up_i(n, CPAD);
     L.mpad = round_up_i(m, CPAD);
@@ -1668,9 +1672,10 @@ AmLayout am_layout(int b, int n, int m, int nlevels, bool allow_cull) {
     off += (size_t)b * L.npad * 3 + 64;
     L.off_x2 = off;
     off += (size_t)b * L.mpad * 3 + 64;
-    L.cull_ok = allow_cull && n >= CULL_MIN_PTS && m >= CULL_MIN_PTS && rfp::pruned_supported(b, n, m);
+    const bool swept = mode == RF_EMD_SWEPT, forced = mode == RF_EMD_EXPANDED;
+    L.cull_ok = !swept && allow_cull && n >= CULL_MIN_PTS && m >= CULL_MIN_PTS && rfp::pruned_supported(b, n, m);
     // (sizes alone decide; same device: 32 x 1024^2 = 3.4e7 pairs 0.324 ms with the sort against 0.316 without, 32 x 2048^2 = 1.3e8 pairs 1.026 against 1.057)
-    L.rowsort_ok = n >= 512 && m >= 512 && (double)b * n * m >= ROWSORT_MIN_PAIRS && rfp::pruned_supported(b, n, m);
+    L.rowsort_ok = !swept && n >= 512 && m >= 512 && (forced || (double)b * n * m >= ROWSORT_MIN_PAIRS) && rfp::pruned_supported(b, n, m);
     L.nsa = L.nsb = 0;
     L.Vs = L.tw_stride = L.off_sa = L.off_sb = L.off_tw = 0;
     if (L.cull_ok || L.rowsort_ok) {
@@ -1690,7 +1695,7 @@ AmLayout am_layout(int b, int n, int m, int nlevels, bool allow_cull) {
         off += (size_t)b * L.tw_stride + 64;
     }
     // (from about 4e6 pairs per sweep on: below, five tiny dense sweeps are cheaper than the expansion's seven launches)
-    L.fgt_ok = n >= 512 && m >= 512 && (double)b * n * m >= FGT_MIN_PAIRS;
+    L.fgt_ok = !swept && n >= 512 && m >= 512 && (forced || (double)b * n * m >= FGT_MIN_PAIRS);
     L.off_fgt = 0;
     if (L.fgt_ok) {
         off = (off + 63) / 64 * 64;
@@ -1745,8 +1750,8 @@ void am_multipliers(int n, int m, float &multiL, float &multiR) {
 // tools/experiments/emd_cull_vs_dense_error.py -- so only the cost-only rf_earth_mover, which never materialises match, asks for it).
 int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int nlevels,
                   const LevelConsts &lc, float multiL, float multiR, void *workspace, hipStream_t s,
-                  bool allow_cull) {
-    AmLayout L = am_layout(b, n, m, nlevels, allow_cull);
+                  bool allow_cull, int mode = RF_EMD_AUTO) {
+    AmLayout L = am_layout(b, n, m, nlevels, allow_cull, mode);
     float *w = (float *)workspace;
     float *remainL = w, *remainR = w + L.npad;          // slot 0 of the vector region
     float *ratios = w + L.V;                            // slot 1+v: [ratioL npad | ratioR mpad]
@@ -1809,13 +1814,16 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
     // 2 rows per lane (measured best of 1 / 2 / 4: longer compute per scalar prefetch covers the L2
     // latency of the s_loads without dropping below 4 waves per SIMD)
     constexpr int RPT = 2;
-    const int segk = pick_nseg(b, n, L.mpad, RPT), segl = pick_nseg(b, m, L.npad, RPT);
+    // (the column segments fix the order of a row's sum: under RF_EMD_SWEPT they are those of a batch of one)
+    const int bseg = mode == RF_EMD_SWEPT ? 1 : b;
+    const int segk = pick_nseg(bseg, n, L.mpad, RPT), segl = pick_nseg(bseg, m, L.npad, RPT);
     const dim3 gk(rf::ceil_div(n, 64 * RPT), b), gl(rf::ceil_div(m, 64 * RPT), b);
     const dim3 gks(rf::ceil_div(L.nsa, 64 * RPT), b), gls(rf::ceil_div(L.nsb, 64 * RPT), b);  // SKIP: over the sorted positions
     // levels 0 and 1 both on the skipping sweeps (sharper cut-off first): level 0's launches list, per wave, the columns within level
     // 1's cut-off; level 1's launches visit only those (RFA_SKIP_MASK)
     const bool masked = RFA_SKIP_MASK && permA && permB && nlevels > 2 && lc.c[0] < lc.c[1] && lc.c[1] < 0.f && skip_t(1) <= kSkipMaxT &&
-                        n < 65536 && m < 65536;  // (16-bit column numbers)
+                        n < 65536 && m < 65536 &&  // (16-bit column numbers ...
+                        L.mpad / segk <= 65535 && L.npad / segl <= 65535;  // ... and 16-bit per-wave counts: a segment of 65536 columns, all listed, would wrap to 0)
     unsigned short *maskk = (unsigned short *)(w + L.off_maskk), *maskl = (unsigned short *)(w + L.off_maskl);
     for (int v = 0; v < nlevels; v++) {
         float *ratioL = ratios + (size_t)v * L.V, *ratioR = ratioL + L.npad;
@@ -1937,20 +1945,37 @@ int rf_probe_exp2(const float *x, float *y, int count, rf_stream_t stream) {
     return RF_OK;
 }
 
+static bool emd_mode_ok(int mode) { return mode == RF_EMD_AUTO || mode == RF_EMD_SWEPT || mode == RF_EMD_EXPANDED; }
+
 size_t rf_approxmatch_workspace_bytes(int b, int n, int m, int nlevels) {
-    if (b <= 0 || n <= 0 || m <= 0) return 0;
+    return rf_approxmatch_mode_workspace_bytes(b, n, m, nlevels, RF_EMD_AUTO);
+}
+
+size_t rf_approxmatch_mode_workspace_bytes(int b, int n, int m, int nlevels, int mode) {
+    if (b <= 0 || n <= 0 || m <= 0 || !emd_mode_ok(mode)) return 0;
     if (nlevels <= 0) nlevels = 10;
-    return am_layout(b, n, m, nlevels, false).total * sizeof(float);
+    return am_layout(b, n, m, nlevels, false, mode).total * sizeof(float);
 }
 
 int rf_approxmatch_levels(int b, int n, int m, const float *xyz1, const float *xyz2, float *match,
                           const float *levels_host, int nlevels, void *workspace,
                           size_t workspace_bytes, rf_stream_t stream) {
-    if (b < 0 || b > MAX_BATCH || n < 0 || m < 0 || nlevels <= 0 || nlevels > MAX_LEVELS || !levels_host)
+    return rf_approxmatch_mode(b, n, m, xyz1, xyz2, match, levels_host, nlevels, workspace, workspace_bytes, stream, RF_EMD_AUTO);
+}
+
+int rf_approxmatch_mode(int b, int n, int m, const float *xyz1, const float *xyz2, float *match,
+                        const float *levels_host, int nlevels, void *workspace,
+                        size_t workspace_bytes, rf_stream_t stream, int mode) {
+    float lv_default[16];
+    if (!levels_host && nlevels == 0) {  // the reference schedule
+        nlevels = default_levels(lv_default);
+        levels_host = lv_default;
+    }
+    if (b < 0 || b > MAX_BATCH || n < 0 || m < 0 || nlevels <= 0 || nlevels > MAX_LEVELS || !levels_host || !emd_mode_ok(mode))
         return RF_EINVAL;
     if (b == 0 || n == 0 || m == 0) return RF_OK;
     if (!xyz1 || !xyz2 || !match || !workspace || !rf::aligned16(workspace)) return RF_EINVAL;
-    if (workspace_bytes < rf_approxmatch_workspace_bytes(b, n, m, nlevels)) return RF_EWORKSPACE;
+    if (workspace_bytes < rf_approxmatch_mode_workspace_bytes(b, n, m, nlevels, mode)) return RF_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     float multiL, multiR;
     am_multipliers(n, m, multiL, multiR);
@@ -1965,10 +1990,10 @@ int rf_approxmatch_levels(int b, int n, int m, const float *xyz1, const float *x
     LevelConsts lc;
     for (int v = 0; v < MAX_LEVELS; v++) lc.c[v] = v < nlevels ? levels_host[v] * kLog2e : 0.f;
     {
-        const int st = am_run_levels(b, n, m, xyz1, xyz2, nlevels, lc, multiL, multiR, workspace, s, false);
+        const int st = am_run_levels(b, n, m, xyz1, xyz2, nlevels, lc, multiL, multiR, workspace, s, false, mode);
         if (st != RF_OK) return st;
     }
-    const AmLayout L = am_layout(b, n, m, nlevels, false);
+    const AmLayout L = am_layout(b, n, m, nlevels, false, mode);
     const float *ratios = (const float *)workspace + L.V;
     // P3 of the last level only updates remainL, which nothing reads afterwards: not launched.
     const dim3 gm(rf::ceil_div(n, TPB), rf::ceil_div(m, LSEG), b);
@@ -2072,7 +2097,7 @@ struct EmdLayout {
     size_t off_rec, off_partial, off_match, off_mc, total;  // floats
     int lsplit, lspan;
 };
-EmdLayout emd_layout(int b, int n, int m) {
+EmdLayout emd_layout(int b, int n, int m, int mode = RF_EMD_AUTO) {
     EmdLayout E;
     E.small = n <= AM_SMALL && m <= AM_SMALL;
     E.lsplit = 1; E.lspan = 0;
@@ -2083,9 +2108,10 @@ EmdLayout emd_layout(int b, int n, int m) {
         E.off_rec = E.off_partial = 0;
         return E;
     }
-    const AmLayout L = am_layout(b, n, m, 10, true);  // (one size for both forms of rf_earth_mover: the cost-only one culls)
+    const AmLayout L = am_layout(b, n, m, 10, true, mode);  // (one size for both forms of rf_earth_mover: the cost-only one culls)
     // enough workgroups to fill the chip: >= 4096 of 4 waves, l-spans of whole 32-column tiles
-    const long base = (long)b * rf::ceil_div(n, TPB);
+    // (the l-spans fix the order of the cost's partial sums: under RF_EMD_SWEPT they are those of a batch of one)
+    const long base = (long)(mode == RF_EMD_SWEPT ? 1 : b) * rf::ceil_div(n, TPB);
     int lsplit = 1;
     while (lsplit < 64 && base * lsplit < 4096 && L.mpad / (lsplit * 2) >= 2 * MG_TL) lsplit *= 2;
     E.lspan = round_up_i(rf::ceil_div(L.mpad, lsplit), MG_TL);
@@ -2098,15 +2124,23 @@ EmdLayout emd_layout(int b, int n, int m) {
 }
 }  // namespace
 
-size_t rf_earth_mover_workspace_bytes(int b, int n, int m) {
-    if (b <= 0 || n <= 0 || m <= 0) return 0;
-    return emd_layout(b, n, m).total * sizeof(float);
+size_t rf_earth_mover_workspace_bytes(int b, int n, int m) { return rf_earth_mover_mode_workspace_bytes(b, n, m, RF_EMD_AUTO); }
+
+size_t rf_earth_mover_mode_workspace_bytes(int b, int n, int m, int mode) {
+    if (b <= 0 || n <= 0 || m <= 0 || !emd_mode_ok(mode)) return 0;
+    return emd_layout(b, n, m, mode).total * sizeof(float);
 }
 
 int rf_earth_mover(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost,
                    float *grad1, float *grad2, void *workspace, size_t workspace_bytes,
                    rf_stream_t stream) {
-    if (b < 0 || b > MAX_BATCH || n < 0 || m < 0) return RF_EINVAL;
+    return rf_earth_mover_mode(b, n, m, xyz1, xyz2, cost, grad1, grad2, workspace, workspace_bytes, stream, RF_EMD_AUTO);
+}
+
+int rf_earth_mover_mode(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost,
+                        float *grad1, float *grad2, void *workspace, size_t workspace_bytes,
+                        rf_stream_t stream, int mode) {
+    if (b < 0 || b > MAX_BATCH || n < 0 || m < 0 || !emd_mode_ok(mode)) return RF_EINVAL;
     if ((grad1 == nullptr) != (grad2 == nullptr)) return RF_EINVAL;
     if (b == 0) return RF_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -2121,8 +2155,8 @@ int rf_earth_mover(int b, int n, int m, const float *xyz1, const float *xyz2, fl
         return RF_OK;
     }
     if (!xyz1 || !xyz2 || !workspace || !rf::aligned16(workspace)) return RF_EINVAL;
-    if (workspace_bytes < rf_earth_mover_workspace_bytes(b, n, m)) return RF_EWORKSPACE;
-    const EmdLayout E = emd_layout(b, n, m);
+    if (workspace_bytes < rf_earth_mover_mode_workspace_bytes(b, n, m, mode)) return RF_EWORKSPACE;
+    const EmdLayout E = emd_layout(b, n, m, mode);
     float *w = (float *)workspace;
     float lv[16];
     const int nl = default_levels(lv);
@@ -2152,10 +2186,10 @@ int rf_earth_mover(int b, int n, int m, const float *xyz1, const float *xyz2, fl
     {
         // (cost only: with gradients asked for, the dense sweeps -- gradients are sums of match entries and follow
         // them: 7 of 12288 components of a 4096^2 case left rel 1e-4 + abs 1e-4 with the culled levels, by up to 5e-4)
-        const int st = am_run_levels(b, n, m, xyz1, xyz2, nl, lc, multiL, multiR, workspace, s, !want_grad);
+        const int st = am_run_levels(b, n, m, xyz1, xyz2, nl, lc, multiL, multiR, workspace, s, !want_grad, mode);
         if (st != RF_OK) return st;
     }
-    const AmLayout L = am_layout(b, n, m, nl, !want_grad);
+    const AmLayout L = am_layout(b, n, m, nl, !want_grad, mode);
     const float *ratios = w + L.V;
     float *rec = w + E.off_rec, *partial = w + E.off_partial;
     RF_LAUNCH("emd_pack_cols", emd_pack_cols_kernel, dim3(rf::ceil_div(L.mpad, 256), b), dim3(256), 0, s, m,

@@ -7,14 +7,24 @@
 //     exp(-a |x - y|^2) = exp(-a |x|^2) exp(-a |y|^2) exp(2a x.y),      x, y relative to O
 //     exp(g x.y) = sum over multi-indices (i,j,k) of  g^(i+j+k) / (i! j! k!) * x^(ijk) * y^(ijk),   g = 2a
 // so   S[row] = exp(-a |row|^2) * sum_(ijk) coef(ijk) * row^(ijk) * M(ijk),      M(ijk) = sum_col w[col] exp(-a |col|^2) col^(ijk):
-// 286 moments (total degree <= 10; 84 at level -0.25, one at level 0) per batch element replace the 2048 x 2048 exponentials of a
-// sweep.  Truncation error at g * R_rows * R_cols = 1.32 (C4's clouds at level -1): 7e-10 relative, measured against the direct fp64 sum
-// (tools/experiments/fgt_proto.py); everything here is fp64, the state vectors stay fp32 with the dense sweeps' own update
-// formulas.  Against the reference the result moves by LESS than the dense sweeps' segment-order sums do (which sit ~1e-7 from
+// 286 moments (total degree <= 10; 165 -- degree 8 -- at level -0.25, one at level 0) per batch element replace the 2048 x 2048
+// exponentials of a sweep.  Everything here is fp64, the state vectors stay fp32 with the dense sweeps' own update formulas.
+//
+// ACCURACY IS CERTIFIED PER ROW, not assumed.  The degree-P series of exp(t), t = g x.y, misses by at most
+// |t|^(P+1) / (P+1)! * max(1, e^t); with |t| <= g |x| |y| and |y| <= R_cols the error of a row's sum is at most
+//     E(x) = exp(-a |x|^2) * (g |x|)^(P+1) / (P+1)! * exp(g |x| R_cols) * Q,      Q = sum_col w[col] exp(-a |col|^2) |col|^(P+1)
+// -- ONE more scalar moment per set (slot FG_NM of every moment row).  A row whose E(x) exceeds kRowEps (4e-6) of its sum is
+// NOT taken from the series: the workgroup forms the sums of its failed rows directly (row_fixup: the dense sweeps' fp32 terms).
+// On clouds that fill their box (C4: uniform in a unit cube, g R R = 1.39 at level -1) few pairs are extreme: with the weights
+// the schedule really meets there (the mass the sharp levels leave over lives in the corners) the true error peaks at 3.4e-7
+// and the bound at 2.5e-6 over C4's 32 samples -- no row fails.  Two clusters in opposite corners put EVERY pair at t ~ -1.5,
+// where the degree-10 series is 4e-6 off (bound 1.8e-5): every row fails its certificate and is summed directly
+// (tests/test_gpu_emd.py::test_expansion_on_opposite_corner_clusters; numbers: tools/experiments/fgt_row_bound.py
+// with flat weights, fgt_row_bound_chain.py with the chain's own).  Against the reference the result moves by LESS than the dense sweeps' segment-order sums do (which sit ~1e-7 from
 // the reference's sequential fp32 sums): replacing the sums of levels 6-8 by exact ones leaves the set of `match` entries outside
 // the strict bar unchanged, entry for entry (tools/experiments/fgt_parity.py).
 //
-// Validity is checked on the device, per batch element: fgt_prep measures R_rows * R_cols and raises the element's `bad` flag when
+// A coarse pre-filter runs per batch element: fgt_prep measures R_rows * R_cols and raises the element's `bad` flag when
 // g_max * R_rows * R_cols > kBound (clouds much larger than the unit cube) or a coordinate is not finite: the kernels here then
 // form that element's row sums directly (direct_sum: the dense sweeps' arithmetic, inside the same launches) -- no host
 // synchronisation either way, and nothing to clear before a call.
@@ -30,9 +40,11 @@
 namespace {
 using rfe::Geom;
 using rfe::kBound;
+using rfe::kRowEps;
 
 constexpr int FG_P = 10;                                            // largest total degree of an expansion
 constexpr int FG_NM = (FG_P + 1) * (FG_P + 2) * (FG_P + 3) / 6;     // 286 monomials
+constexpr int FG_NMX = FG_NM + 2;                                   // a moment row: the monomials, then Q (see above), then padding
 constexpr int FG_ROWS = 256;                                        // rows (and new columns) per workgroup
 constexpr int FG_TPB = 2 * FG_ROWS;                                 // threads per workgroup: two per row (see fgt_step_kernel)
 constexpr int FG_PWS = FG_ROWS + 1;                                 // row stride of the power tables in LDS (doubles)
@@ -98,7 +110,7 @@ int chunks_of(int npts) { return (npts + FG_ROWS - 1) / FG_ROWS; }  // one parti
 
 struct FgtWs {
     Geom *geom;
-    double *mom[2];  // [side][(set * b + bi) * chunks + chunk][FG_NM]: side 0 = moments over xyz1 (columns of P2), 1 = over xyz2
+    double *mom[2];  // [side][(set * b + bi) * chunks + chunk][FG_NMX]: side 0 = moments over xyz1 (columns of P2), 1 = over xyz2
     int chmax;
 };
 FgtWs view(const void *ws, int b, int nmax) {
@@ -107,7 +119,7 @@ FgtWs view(const void *ws, int b, int nmax) {
     v.geom = (Geom *)p;
     p += align256(sizeof(Geom) * (size_t)b);
     v.chmax = chunks_of(nmax);
-    const size_t per = align256(sizeof(double) * 2 * (size_t)b * v.chmax * FG_NM);
+    const size_t per = align256(sizeof(double) * 2 * (size_t)b * v.chmax * FG_NMX);
     v.mom[0] = (double *)p;
     v.mom[1] = (double *)(p + per);
     return v;
@@ -118,7 +130,7 @@ struct Step {
     const float *rows;   // (b, nrows, 3)
     int nrows;
     // moments of the other cloud, to evaluate with: up to two sets
-    const double *min;   // [(set * b + bi) * chin + chunk][FG_NM]
+    const double *min;   // [(set * b + bi) * chin + chunk][FG_NMX]
     int chin;            // chunks per batch element in `min`
     int nin;             // 1 or 2 sets
     double a_in[2];      // sharpness of each input set
@@ -126,9 +138,10 @@ struct Step {
     // the columns behind those moments, for the direct sums of a refused call (`bad`): points and the sets' fp32 weights
     const float *cols;   // (b, ncols, 3)
     int ncols;
+    int cols_are_set2;   // the columns are xyz2 (their radius about the centre: Geom::r2), else xyz1 (Geom::r1)
     const float *wcol[2];
     // moments this launch leaves for the next phase (NULL: none)
-    double *mout;        // [(set * b + bi) * chout + chunk][FG_NM]
+    double *mout;        // [(set * b + bi) * chout + chunk][FG_NMX]
     int chout;
     int nout;            // 0, 1 or 2 sets
     double a_out[2];
@@ -246,6 +259,76 @@ __device__ __forceinline__ void direct_sum(const float *C_, const float *w0_, co
     for (; l < hi; l++) term(C[(size_t)l * 3], C[(size_t)l * 3 + 1], C[(size_t)l * 3 + 2], w0[l], TWO ? w1[l] : 0.f);
 }
 
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// The rows of this workgroup that failed their certificate, FX_G at a time by the WHOLE workgroup: every thread loads its share of
+// the columns once per group and forms its terms for all the group's rows (the dense sweeps' fp32 terms -- d2 by the fma chain,
+// v_exp_f32 -- products and sums in double); one block reduction per group.  (One wave per failed row was tried first: a lone
+// failed row then cost its workgroup -- and so the launch -- a chain of eight dependent load round trips, ~10 us.)
+// All FG_TPB threads must call.  red: 8 x 2 FX_G doubles of LDS.
+constexpr int FX_G = 8;
+__device__ __forceinline__ void row_fixup(const Step &p, int bi, int nf, const int *__restrict__ flist, double *__restrict__ fix,
+                                          double *__restrict__ red) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float c0 = (float)(-p.a_in[0] / 0.69314718055994530942), c1 = (float)(-p.a_in[1] / 0.69314718055994530942);
+    const float *C = p.cols + (size_t)bi * p.ncols * 3;
+    const float *w0 = p.wcol[0] + (size_t)bi * p.stride;
+    const float *w1 = p.nin == 2 ? p.wcol[1] + (size_t)bi * p.stride : w0;
+    const float *Rb = p.rows + ((size_t)bi * p.nrows + (size_t)blockIdx.x * FG_ROWS) * 3;
+    for (int e0 = 0; e0 < nf; e0 += FX_G) {
+        const int cnt = min(FX_G, nf - e0);
+        float rx[FX_G], ry[FX_G], rz[FX_G];
+        double a0[FX_G], a1[FX_G];
+#pragma unroll
+        for (int u = 0; u < FX_G; u++) {
+            const float *R = Rb + (size_t)flist[min(e0 + u, nf - 1)] * 3;
+            rx[u] = R[0], ry[u] = R[1], rz[u] = R[2];
+            a0[u] = a1[u] = 0.0;
+        }
+        for (int l0 = tid; l0 < p.ncols; l0 += 4 * FG_TPB) {  // four columns per thread in flight
+            float cx[4], cy[4], cz[4], u0[4], u1[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int l = min(l0 + FG_TPB * q, p.ncols - 1);
+                const bool in = l0 + FG_TPB * q < p.ncols;
+                cx[q] = C[(size_t)l * 3], cy[q] = C[(size_t)l * 3 + 1], cz[q] = C[(size_t)l * 3 + 2];
+                u0[q] = in ? w0[l] : 0.f;
+                u1[q] = in ? w1[l] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+#pragma unroll
+                for (int u = 0; u < FX_G; u++) {
+                    const float d2 = rf::d2_fma(cx[q] - rx[u], cy[q] - ry[u], cz[q] - rz[u]);
+                    a0[u] += (double)(c0 == 0.f ? 1.0f : __builtin_amdgcn_exp2f(d2 * c0)) * (double)u0[q];
+                    if (p.nin == 2) a1[u] += (double)__builtin_amdgcn_exp2f(d2 * c1) * (double)u1[q];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < FX_G; u++) {
+            a0[u] = wave_sum_f64(a0[u]);
+            a1[u] = wave_sum_f64(a1[u]);
+            if (lane == 0) {
+                red[wv * 2 * FX_G + u] = a0[u];
+                red[wv * 2 * FX_G + FX_G + u] = a1[u];
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * FX_G && (tid & (FX_G - 1)) < cnt) {
+            double sum = 0.0;
+#pragma unroll
+            for (int w = 0; w < FG_TPB / 64; w++) sum += red[w * 2 * FX_G + tid];
+            fix[(tid / FX_G) * FG_ROWS + flist[e0 + (tid & (FX_G - 1))]] = sum;
+        }
+        __syncthreads();
+    }
+}
+
 // 512 threads for 256 rows: the chip has only b * rows / 64 = 1024 waves of rows at C4, ONE per SIMD, and both halves of this
 // kernel are latency-bound at that (fp64 fma chains in the evaluation, LDS reads in the moments: 21-39 us per launch with 256
 // threads).  So thread t and t + 256 share row t: they evaluate one input set each, and in the moment accumulation each takes
@@ -262,6 +345,9 @@ __global__ __launch_bounds__(FG_TPB) void fgt_step_kernel(Step p) {
     double *s1x = fg_lds + 2 * FG_NR * FG_RL;
     double *xc = s1x + FG_ROWS;
     double *pw = xc + FG_ROWS;
+    __shared__ int nfail;          // rows of this workgroup whose certificate failed
+    __shared__ double qin[2];      // the input sets' Q (slot FG_NM of their moment rows, chunk partials summed)
+    __shared__ double qred[2][4];  // the four row-waves' partial Q of the moments this launch leaves
     const int bi = blockIdx.y, tid = threadIdx.x;
     const int rt = tid & (FG_ROWS - 1), half = tid >> 8;  // FG_ROWS == 256
     const int row = blockIdx.x * FG_ROWS + rt;
@@ -280,18 +366,25 @@ __global__ __launch_bounds__(FG_TPB) void fgt_step_kernel(Step p) {
             // ---- stage the input moments: chunk partials summed in a fixed order (eight loads in flight), times
             //      coef(ijk) = g^(i+j+k) / (i! j! k!); entries beyond a set's degree stay zero
             for (int t = tid; t < 2 * FG_NR * FG_RL; t += FG_TPB) (&Ms[0][0])[t] = 0.0;
+            if (tid == FG_TPB - 1) nfail = 0;
+            if (tid < p.nin) {  // (fixed order: deterministic)
+                const double *src = p.min + ((size_t)(tid * p.b + bi) * p.chin) * FG_NMX + FG_NM;
+                double q = 0.0;
+                for (int c0 = 0; c0 < p.chin; c0++) q += src[(size_t)c0 * FG_NMX];
+                qin[tid] = q;
+            }
             __syncthreads();
             for (int s = 0; s < p.nin; s++) {
                 const double gam = 2.0 * p.a_in[s];
                 for (int t = tid; t < FG_NM; t += FG_TPB) {
                     const Ijk e = kMono.t[t];
                     if (e.n > p.deg_in[s]) continue;
-                    const double *src = p.min + ((size_t)(s * p.b + bi) * p.chin) * FG_NM + t;
+                    const double *src = p.min + ((size_t)(s * p.b + bi) * p.chin) * FG_NMX + t;
                     double sum = 0.0;
                     for (int c0 = 0; c0 < p.chin; c0 += 8) {
                         double v[8];
 #pragma unroll
-                        for (int u = 0; u < 8; u++) v[u] = c0 + u < p.chin ? src[(size_t)(c0 + u) * FG_NM] : 0.0;
+                        for (int u = 0; u < 8; u++) v[u] = c0 + u < p.chin ? src[(size_t)(c0 + u) * FG_NMX] : 0.0;
 #pragma unroll
                         for (int u = 0; u < 8; u++) sum += v[u];
                     }
@@ -313,6 +406,31 @@ __global__ __launch_bounds__(FG_TPB) void fgt_step_kernel(Step p) {
                 if (half == 1) s1x[rt] = part * x;
                 __syncthreads();
                 S0 = exp(-p.a_in[0] * r2) * (part + s1x[rt]);
+            }
+            // ---- the certificate (header): a row whose error bound exceeds kRowEps of its sum does not take it from the series
+            double *fix = pw;                        // [2][FG_ROWS] (the power tables are not in use yet)
+            int *flist = (int *)(pw + 2 * FG_ROWS);  // the workgroup's failed rows
+            bool fail = false;
+            if (half == 0 && live) {
+                const double r = sqrt(r2), rc = p.cols_are_set2 ? g.r2 : g.r1;
+                for (int s = 0; s < p.nin; s++) {
+                    const double gr = 2.0 * p.a_in[s] * r;
+                    double pwr = gr;
+                    for (int q = 0; q < p.deg_in[s]; q++) pwr *= gr;  // (g |x|)^(P + 1)
+                    const double bound = exp(gr * rc - p.a_in[s] * r2) * pwr * kInvFact[p.deg_in[s] + 1] * qin[s];
+                    fail = fail || !(bound <= kRowEps * (s == 0 ? S0 : S1));
+                }
+            }
+            if (fail) flist[atomicAdd(&nfail, 1)] = rt;
+            __syncthreads();
+            const int nf = nfail;
+            if (nf > 0) {  // (uniform)
+                row_fixup(p, bi, nf, flist, fix, pw + 2 * FG_ROWS + FG_ROWS / 2);
+                __syncthreads();
+                if (fail) {
+                    S0 = fix[rt];
+                    S1 = fix[FG_ROWS + rt];
+                }
             }
         } else {
             // refused: direct sums, half of the columns for each of a row's two threads
@@ -370,6 +488,19 @@ __global__ __launch_bounds__(FG_TPB) void fgt_step_kernel(Step p) {
     if (half == 0 && live) {
         wt0 = (double)wnew[0] * exp(-p.a_out[0] * r2);
         if (p.nout == 2) wt1 = (double)wnew[1] * exp(-p.a_out[1] * r2);
+    }
+    {  // Q of the sets these rows leave: sum of W |col|^(P + 1) (one partial per row-wave here, one per workgroup below)
+        const double r = sqrt(r2);
+        double q0 = wt0 * r, q1 = wt1 * r;
+        for (int q = 0; q < p.deg_out[0]; q++) q0 *= r;
+        if (p.nout == 2)
+            for (int q = 0; q < p.deg_out[1]; q++) q1 *= r;
+        q0 = wave_sum_f64(q0);
+        q1 = wave_sum_f64(q1);
+        if (half == 0 && (tid & 63) == 0) {
+            qred[0][tid >> 6] = q0;
+            qred[1][tid >> 6] = q1;
+        }
     }
     const int dmax = p.nout == 2 ? max(p.deg_out[0], p.deg_out[1]) : p.deg_out[0];
     const int item = rt;  // (161 of the 256 are items)
@@ -431,14 +562,18 @@ __global__ __launch_bounds__(FG_TPB) void fgt_step_kernel(Step p) {
         a01 += xch[1 * FG_ROWS + rt];
         a10 += xch[2 * FG_ROWS + rt];
         a11 += xch[3 * FG_ROWS + rt];
-        double *out0 = p.mout + ((size_t)(0 * p.b + bi) * p.chout + blockIdx.x) * FG_NM;
+        double *out0 = p.mout + ((size_t)(0 * p.b + bi) * p.chout + blockIdx.x) * FG_NMX;
         out0[it.t0] = a00;
         if (it.cnt == 2) out0[it.t1] = a10;
         if (p.nout == 2) {
-            double *out1 = p.mout + ((size_t)(1 * p.b + bi) * p.chout + blockIdx.x) * FG_NM;
+            double *out1 = p.mout + ((size_t)(1 * p.b + bi) * p.chout + blockIdx.x) * FG_NMX;
             out1[it.t0] = a01;
             if (it.cnt == 2) out1[it.t1] = a11;
         }
+    }
+    if (half == 0 && rt == FG_NI) {  // (an idle lane of the item pass)
+        for (int s = 0; s < p.nout; s++)
+            p.mout[((size_t)(s * p.b + bi) * p.chout + blockIdx.x) * FG_NMX + FG_NM] = (qred[s][0] + qred[s][1]) + (qred[s][2] + qred[s][3]);
     }
 }
 
@@ -455,13 +590,14 @@ namespace rfe {
 
 size_t fgt_workspace_bytes(int b, int nmax) {
     if (b <= 0 || nmax <= 0) return 0;
-    return align256(sizeof(Geom) * (size_t)b) + 2 * align256(sizeof(double) * 2 * (size_t)b * chunks_of(nmax) * FG_NM);
+    return align256(sizeof(Geom) * (size_t)b) + 2 * align256(sizeof(double) * 2 * (size_t)b * chunks_of(nmax) * FG_NMX);
 }
 
 void *fgt_geom(void *ws, int b, int nmax) { return (void *)view(ws, b, nmax).geom; }
 
-// total degree for sharpness a (relative truncation error <= ~1e-11 up to the validity bound: tools/experiments/fgt_proto.py)
-static int degree_for(double a) { return a <= 1e-12 ? 0 : (a <= 0.3 ? 6 : FG_P); }
+// total degree for sharpness a.  (Level -0.25: degree 6 met the certificate's 1e-7 only on box-filling clouds -- 1.3e-7 true error on
+// corner clusters -- degree 8 holds 3e-10 there: tools/experiments/fgt_row_bound.py.)
+static int degree_for(double a) { return a <= 1e-12 ? 0 : (a <= 0.3 ? 8 : FG_P); }
 
 // moments over xyz2 with w = remainR at a: what the first fgt_p3p1 (without a fused P3) evaluates
 static int moments_only(int b, int npts, const float *pts, const float *w, size_t stride, double a, double *mout, int chout,
@@ -504,6 +640,7 @@ int fgt_p3p1(int b, int n, int m, const float *xyz1, const float *xyz2, bool has
     p.deg_in[1] = degree_for(a_prev);
     p.cols = xyz2;
     p.ncols = m;
+    p.cols_are_set2 = 1;
     p.wcol[0] = remainR;
     p.wcol[1] = ratioR_prev;
     p.mout = v.mom[0];
@@ -534,6 +671,7 @@ int fgt_p2(int b, int n, int m, const float *xyz1, const float *xyz2, double a_c
     p.deg_in[0] = degree_for(a_cur);
     p.cols = xyz1;
     p.ncols = n;
+    p.cols_are_set2 = 0;
     p.wcol[0] = ratioL;
     p.mout = v.mom[1];
     p.chout = chunks_of(m);

@@ -6,11 +6,25 @@
 
 namespace rfe {
 
-constexpr double kBound = 1.5;  // g * R_rows * R_cols up to which degree 10 holds 3e-9 (any two clouds inside a unit cube: <= 1.5 at level -1)
+// A PRE-FILTER, not the accuracy bound: g * R_rows * R_cols beyond which the expansion is not even attempted (every row of such
+// an element would fail its certificate).  Any two clouds inside a unit cube stay below it at level -1.  What the expansion
+// delivers is certified ROW BY ROW in emd_fgt.hip (kRowEps): the degree-P series of exp(t) misses by |t|^(P+1)/(P+1)! max(1, e^t),
+// i.e. 8.6e-6 of the term at t = -1.5 with P = 10 -- little for clouds that fill their box (few pairs sit there: 8e-8 of a row
+// sum on C4 with the weights the schedule really meets, whose leftover mass lives in the corners; 4e-10 with flat weights), NOT
+// for two clusters in opposite corners, where every pair of a row sits there (4e-6).
+constexpr double kBound = 1.5;
+// certified relative error of an expanded row sum.  The dense sweeps these levels replace carry ~1e-7 per term (v_exp_f32) and a
+// few 1e-7 of fp32 summation; level -1 moves 0.14 % of C4's mass (14 % for corner clusters), so 4e-6 of its row sums is 6e-9
+// (6e-7) of the cost, and 4e-6 of an entry's share from these levels against the entries' rel 1e-4 bar.  Over C4's 32 samples
+// the bound peaks at 2.5e-6 (true error 3.4e-7): no row fails.  At 1e-6, 43 of 196 608 rows would -- and one failed row costs
+// its launch ~4 us (the workgroup's direct sums sit on the launch's critical path): am_fgt 148 us per call against 121 without
+// the certificate; at 1e-7, 3 % of the rows fail (212 us).  tools/experiments/fgt_row_bound_chain.py.
+constexpr double kRowEps = 4.0e-6;
 
 struct Geom {  // per batch element
     double ox, oy, oz, rarb;
-    int bad, pad;  // bad != 0: this element's extent breaks the series' bound, or a coordinate is not finite -- direct sums
+    double r1, r2;  // the largest distances of xyz1's / xyz2's points from the centre
+    int bad, pad;   // bad != 0: this element's extent is beyond the pre-filter, or a coordinate is not finite -- direct sums
 };
 
 __device__ __forceinline__ float prep_wave_min(float v) {
@@ -96,7 +110,8 @@ __device__ __forceinline__ void fgt_prep_block(int bi, int n, int m, const float
             c = fmaxf(c, red[w][1]);
         }
         const double rarb = sqrt((double)a) * sqrt((double)c);
-        geom[bi] = Geom{(double)ox, (double)oy, (double)oz, rarb, (nonfin != 0 || !(2.0 * a_max * rarb <= kBound)) ? 1 : 0, 0};
+        geom[bi] = Geom{(double)ox, (double)oy, (double)oz, rarb, sqrt((double)a), sqrt((double)c),
+                        (nonfin != 0 || !(2.0 * a_max * rarb <= kBound)) ? 1 : 0, 0};
     }
 }
 

@@ -46,7 +46,6 @@ int rf_sample_and_group(int b, int n, int npoint, float radius, const float *rad
     const rfp::Sorted so = rfp::sorted_view(b, n, w);
     const int nn[1] = {n};
     const float *src[1] = {xyz};
-    hipEvent_t fork = nullptr, join = nullptr;
     if (rfi::fps_sorted_pays(n, npoint)) {
         // FPS itself runs over the sorted cloud (fps_sorted_kernel: a third shorter iterations): one sort serves both ops, on
         // the caller's stream -- nothing is left to run beside FPS
@@ -54,25 +53,45 @@ int rf_sample_and_group(int b, int n, int npoint, float radius, const float *rad
         if (int e = rfi::fps_sorted(b, n, npoint, xyz, so, fps_idx, new_xyz, s)) return e;
         return rfi::ball_boxes(b, n, npoint, radius, radius_dev, nsample, xyz, new_xyz, so, idx, pts_cnt, grouped_xyz, 1, s);
     }
+    // The sort beside FPS on the auxiliary stream: aux waits for the caller's stream (the inputs are ready there), the caller's
+    // stream waits for the sort before the ball query.  The events live for this call only and are destroyed on EVERY exit (an
+    // event still pending when it is destroyed is released by the runtime once it has completed); once the sort has been
+    // queued on aux, the caller's stream joins it on every exit too -- an error return never leaves aux running ahead unjoined.
+    struct Fork {
+        hipEvent_t fork = nullptr, join = nullptr;
+        hipStream_t s = nullptr, aux = nullptr;
+        bool queued = false;  // work sits on aux that s has not joined yet
+        int join_now() {
+            if (!queued) return RF_OK;
+            queued = false;
+            RF_HIP(hipEventRecord(join, aux));
+            RF_HIP(hipStreamWaitEvent(s, join, 0));
+            return RF_OK;
+        }
+        ~Fork() {
+            (void)join_now();
+            if (fork) (void)hipEventDestroy(fork);
+            if (join) (void)hipEventDestroy(join);
+        }
+    } fk;
     if (aux && aux != s) {
-        // the sort beside FPS: aux waits for the caller's stream (the inputs are ready there), the caller's stream waits for
-        // the sort before the ball query.  The events live for this call only; an event that is still pending when it is
-        // destroyed is released by the runtime once it has completed.
-        RF_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-        RF_HIP(hipEventCreateWithFlags(&join, hipEventDisableTiming));
-        RF_HIP(hipEventRecord(fork, s));
-        RF_HIP(hipStreamWaitEvent(aux, fork, 0));
+        fk.s = s, fk.aux = aux;
+        RF_HIP(hipEventCreateWithFlags(&fk.fork, hipEventDisableTiming));
+        RF_HIP(hipEventCreateWithFlags(&fk.join, hipEventDisableTiming));
+        RF_HIP(hipEventRecord(fk.fork, s));
+        RF_HIP(hipStreamWaitEvent(aux, fk.fork, 0));
+        fk.queued = true;
         if (int e = rfp::sort_sets(b, 1, nn, src, &so, aux, nullptr)) return e;
-        RF_HIP(hipEventRecord(join, aux));
+        RF_HIP(hipEventRecord(fk.join, aux));  // (recorded NOW, behind the sort: FPS below does not wait for it)
     } else {
         if (int e = rfp::sort_sets(b, 1, nn, src, &so, s, nullptr)) return e;
     }
     if (int e = rfi::fps(b, n, npoint, xyz, temp, fps_idx, new_xyz, s)) return e;
-    if (join) RF_HIP(hipStreamWaitEvent(s, join, 0));
-    const int st = rfi::ball_boxes(b, n, npoint, radius, radius_dev, nsample, xyz, new_xyz, so, idx, pts_cnt, grouped_xyz, 1, s);
-    if (fork) (void)hipEventDestroy(fork);
-    if (join) (void)hipEventDestroy(join);
-    return st;
+    if (fk.queued) {
+        fk.queued = false;
+        RF_HIP(hipStreamWaitEvent(s, fk.join, 0));
+    }
+    return rfi::ball_boxes(b, n, npoint, radius, radius_dev, nsample, xyz, new_xyz, so, idx, pts_cnt, grouped_xyz, 1, s);
 }
 
 }  // extern "C"

@@ -203,146 +203,6 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(int n, int m, const float *
     }
 }
 
-// ---- FPS with one cloud spread over a CLUSTER of K workgroups (round 5; measured in DESIGN.md 5.3b) ----
-// Each member holds n/K points in registers (PPT = n / (512 K) per lane) and runs fps_reg's iteration on them; the
-// cluster then needs every member's (d2, k) winner at every member before the next scan can start: member r stores ONE
-// 8-byte granule {d2 bits | iteration tag (18 bits) | k (14 bits)} into its slot of the cloud's double-buffered slot row
-// (an agent-scope store: write-through, no fence) and wave 0 of every member re-reads the K slots with agent-scope
-// loads until all K carry the iteration's tag (MI355X_MICROARCH.md, "Valid forms": the data IS the flag; a slot is
-// written by one store of one lane, its reader takes it whole).  No member leads and nothing is reset: a slot of parity
-// j&1 can only hold iteration j-2 or j when iteration j is polled, because its writer cannot reach j+2 before every
-// member has published j+1, which comes after that member has read j.
-// Correctness does not depend on where the dispatcher puts the workgroups:
-//   * membership is by ARRIVAL (one returning atomic per workgroup): the workgroups that are resident fill the
-//     clusters in order, so a cluster only ever waits for workgroups that are running or still to be dispatched, and a
-//     complete cluster needs nobody else to finish -- two such launches on two streams cannot starve each other the
-//     way a blockIdx-keyed cluster can (each would hold CUs while waiting for members the other keeps out);
-//   * every shared word is written and read at agent scope; nothing is read through the scalar cache or L1.
-// `static_map` (experiments only): membership from blockIdx so that the K members are 8 apart -- one XCD under the
-// observed round-robin placement -- to price the same-XCD exchange; it relies on the whole grid being resident.
-// State (zeroed by the launcher before EVERY launch): [0] ticket, [1] error word, then slots (b, 2, 8) u64.
-constexpr int FPS_CLUSTER_MAXK = 8;
-constexpr unsigned FPS_SPIN_LIMIT = 1u << 24;  // ~seconds: a lost member must not hang the device
-
-template <int K, int PPT>
-__global__ __launch_bounds__(512) void fps_cluster_kernel(int n, int m, int static_map, const float *__restrict__ inp,
-                                                          int *__restrict__ out, unsigned *__restrict__ state,
-                                                          unsigned long long *__restrict__ slots) {
-    static_assert(K >= 2 && K <= FPS_CLUSTER_MAXK && (K & (K - 1)) == 0, "cluster of 2, 4 or 8 workgroups");
-    __shared__ float slot_d[2][16];
-    __shared__ int slot_k[2][16];
-    __shared__ unsigned tk;
-    __shared__ int gwin[2];
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    if (t == 0) tk = __hip_atomic_fetch_add(state, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t < 32) {
-        slot_d[t >> 4][t & 15] = -2.0f;
-        slot_k[t >> 4][t & 15] = 0;
-    }
-    __syncthreads();
-    int bi, r;
-    if (static_map) {
-        const int g = blockIdx.x / (8 * K), w = blockIdx.x % (8 * K);
-        bi = g * 8 + (w & 7);
-        r = w >> 3;
-    } else {
-        const unsigned tick = tk;
-        bi = tick / K;
-        r = tick % K;
-    }
-    bi = __builtin_amdgcn_readfirstlane(bi);
-    r = __builtin_amdgcn_readfirstlane(r);
-    const float *__restrict__ P = inp + (size_t)bi * n * 3;
-    int *__restrict__ O = out + (size_t)bi * m;
-    unsigned long long *__restrict__ S = slots + (size_t)bi * 2 * FPS_CLUSTER_MAXK;
-
-    float px[PPT], py[PPT], pz[PPT], td[PPT];
-#pragma unroll
-    for (int s = 0; s < PPT; s++) {
-        const int k = t + 512 * (s * K + r);  // (k mod 512) = t for every point of the thread, k ascends with s
-        if (k < n) {
-            px[s] = P[k * 3 + 0];
-            py[s] = P[k * 3 + 1];
-            pz[s] = P[k * 3 + 2];
-            td[s] = 1e38f;
-        } else {
-            px[s] = py[s] = pz[s] = 0.f;
-            td[s] = -1.0f;
-        }
-    }
-    if (t == 0 && r == 0) O[0] = 0;
-    float ox = P[0], oy = P[1], oz = P[2];
-    for (int j = 1; j < m; j++) {
-        float mx = -1.0f;
-#pragma unroll
-        for (int s = 0; s < PPT; s++) {
-            td[s] = vmin(rf::d2_fma(px[s] - ox, py[s] - oy, pz[s] - oz), td[s]);
-            if (PPT == 1) {
-                mx = td[0];
-            } else if (s & 1) {
-                mx = vmax3(mx, td[s - 1], td[s]);
-            }
-        }
-        int sidx = 0;
-#pragma unroll
-        for (int s = PPT - 1; s >= 1; s--) sidx = (td[s] == mx) ? s : sidx;
-        if (PPT > 1) sidx = (td[0] == mx) ? 0 : sidx;
-        const float wm = wave_allmax(mx);
-        const unsigned long long hl = __ballot(mx == wm);
-        const int wl = hl ? __builtin_ctzll(hl) : 0;
-        const int bs = __builtin_amdgcn_readlane(sidx, wl);
-        const int wk = (wave * 64 + wl) + 512 * (bs * K + r);
-        const int buf = j & 1;
-        if (lane == 0) {
-            slot_d[buf][wave] = wm;
-            slot_k[buf][wave] = wm >= 0.f ? wk : 0;
-        }
-        __syncthreads();
-        if (wave == 0) {
-            // the member's own winner (8 wave slots, one 16-lane row) ...
-            const float sd = slot_d[buf][lane & 15];
-            const int sk = slot_k[buf][lane & 15];
-            const float lm = row_allmax(sd);
-            const unsigned lrank = sd == lm ? tie_rank(sk) : 0xFFFFFFFFu;
-            const unsigned lr = __builtin_amdgcn_readfirstlane(row_allmin_u(lrank));
-            const unsigned lk = ((lr & 0x3FFFFFu) << 9) | (lr >> 22);
-            const float lmu = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(lm)));
-            // ... published, then the cluster's K granules polled until they all carry iteration j
-            unsigned long long *__restrict__ Sj = S + buf * FPS_CLUSTER_MAXK;
-            if (lane == 0)
-                __hip_atomic_store(Sj + r, ((unsigned long long)__float_as_uint(lmu) << 32) | ((unsigned long long)j << 14) | lk,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned long long v;
-            unsigned spins = 0;
-            bool lost = false;
-            for (;;) {
-                v = __hip_atomic_load(Sj + (lane & (K - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__all((int)(((unsigned)v >> 14) == (unsigned)j))) break;
-                if (++spins > FPS_SPIN_LIMIT) {  // (uniform) a member never arrived: say so and stop, do not hang
-                    if (lane == 0) __hip_atomic_store(state + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    lost = true;
-                    break;
-                }
-            }
-            const float cd = __uint_as_float((unsigned)(v >> 32));
-            const int ck = (int)((unsigned)v & 0x3FFFu);
-            const float gm = row_allmax(cd);
-            const unsigned rank = cd == gm ? tie_rank(ck) : 0xFFFFFFFFu;
-            const unsigned gr = __builtin_amdgcn_readfirstlane(row_allmin_u(rank));
-            if (lane == 0) gwin[buf] = lost ? -1 : (int)(((gr & 0x3FFFFFu) << 9) | (gr >> 22));
-        }
-        __syncthreads();
-        const int gk = __builtin_amdgcn_readfirstlane(gwin[buf]);
-        if (gk < 0) return;  // (uniform) the error word is set; the other members run into their own limit and leave too
-        ox = P[gk * 3 + 0];
-        oy = P[gk * 3 + 1];
-        oz = P[gk * 3 + 2];
-        if (t == 0 && r == 0) O[j] = gk;
-    }
-}
-
 // ---- FPS over the spatially sorted cloud: the same samples, most of the cloud left alone in most iterations (round 5) ----
 // The cloud arrives in sort-tile-recursive order (rfp::sort_clouds); a lane owns PPT CONSECUTIVE sorted points -- a region with a
 // small box.  A new sample s lowers the running minimum td[p] only if |p - s|^2 < td[p]; with `lmx` the largest td of the lane's
@@ -890,37 +750,6 @@ int rf_farthestpointsampling_sorted(int b, int n, int m, int form, const float *
     if (int e = rfp::sort_clouds(b, n, inp, workspace, workspace_bytes, s, &sv)) return e;
     (void)form;
     return rfi::fps_sorted(b, n, m, inp, sv, out, new_xyz, s);
-}
-
-size_t rf_fps_cluster_state_bytes(int b) {
-    return b > 0 ? 16 + sizeof(unsigned long long) * 2 * FPS_CLUSTER_MAXK * (size_t)b : 0;
-}
-
-int rf_farthestpointsampling_cluster(int b, int n, int m, int k, int static_map, const float *inp, void *state,
-                                     int *out, rf_stream_t stream) {
-    if (b < 0 || n < 0 || m < 0) return RF_EINVAL;
-    if (b == 0 || m == 0) return RF_OK;
-    if (n == 0 || n > FPS_MAX_REG_POINTS || m >= (1 << 18)) return RF_EINVAL;
-    if (k != 2 && k != 4 && k != 8) return RF_EINVAL;
-    if (static_map && b % 8 != 0) return RF_EINVAL;
-    if (!inp || !out || !state || !rf::aligned16(state)) return RF_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
-    RF_ZERO(state, rf_fps_cluster_state_bytes(b), s);
-    unsigned *st = (unsigned *)state;
-    unsigned long long *slots = (unsigned long long *)((char *)state + 16);
-    int ppt = 1;
-    while (512 * k * ppt < n) ppt *= 2;
-#define FPSC_CASE(K, PPT)                                                                                              \
-    if (k == K && ppt == PPT) {                                                                                        \
-        RF_LAUNCH("fps_cluster", (fps_cluster_kernel<K, PPT>), dim3(b * K), dim3(512), 0, s, n, m, static_map, inp, out, st, \
-                  slots);                                                                                              \
-        return RF_OK;                                                                                                  \
-    }
-    FPSC_CASE(2, 1) FPSC_CASE(2, 2) FPSC_CASE(2, 4) FPSC_CASE(2, 8) FPSC_CASE(2, 16)
-    FPSC_CASE(4, 1) FPSC_CASE(4, 2) FPSC_CASE(4, 4) FPSC_CASE(4, 8)
-    FPSC_CASE(8, 1) FPSC_CASE(8, 2) FPSC_CASE(8, 4)
-#undef FPSC_CASE
-    return RF_EINVAL;
 }
 
 int rf_gatherpoint(int b, int n, int m, const float *inp, const int *idx, float *out,

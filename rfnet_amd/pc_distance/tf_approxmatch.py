@@ -60,9 +60,9 @@ def match_cost_grad(xyz1, xyz2, match):
 
 class _EarthMoverCost(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xyz1, xyz2):
+    def forward(ctx, xyz1, xyz2, mode):
         # one launch sequence yields the cost and MatchCostGrad's outputs; the backward only scales
-        cost, g1, g2 = _raw.earth_mover(xyz1, xyz2, with_grad=True)
+        cost, g1, g2 = _raw.earth_mover(xyz1, xyz2, with_grad=True, mode=mode)
         ctx.save_for_backward(g1, g2)
         return cost
 
@@ -70,15 +70,16 @@ class _EarthMoverCost(torch.autograd.Function):
     def backward(ctx, grad_cost):
         g1, g2 = ctx.saved_tensors
         s = grad_cost.reshape(-1, 1, 1)
-        return g1 * s, g2 * s
+        return g1 * s, g2 * s, None
 
 
-def earth_mover_cost(xyz1, xyz2):
+def earth_mover_cost(xyz1, xyz2, mode="auto"):
     """match_cost(xyz1, xyz2, approx_match(xyz1, xyz2)) as ONE fused op: cost (batch_size), with the
     reference's gradient (MatchCostGrad scaled by grad_cost, match held constant) -- but the
     (batch, #query, #dataset) match tensor is never written.  Extension for the loss glue
-    (`earth_mover`, vv_recon.py:392-399); the two-op chain above stays available unchanged."""
+    (`earth_mover`, vv_recon.py:392-399); the two-op chain above stays available unchanged.
+    mode="swept" pins the route so that cost[i] does not depend on the batch around sample i (include/rfops.h, RF_EMD_SWEPT)."""
     if all(isinstance(t, torch.Tensor) for t in (xyz1, xyz2)) and (
             xyz1.requires_grad or xyz2.requires_grad):
-        return _EarthMoverCost.apply(xyz1, xyz2)
-    return _raw.earth_mover(xyz1, xyz2)
+        return _EarthMoverCost.apply(xyz1, xyz2, mode)
+    return _raw.earth_mover(xyz1, xyz2, mode=mode)

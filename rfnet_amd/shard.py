@@ -196,6 +196,9 @@ def chamfer_per_sample(xyz1, xyz2):
 
 
 def emd_per_sample(xyz1, xyz2):
-    """Per-sample EMD as `earth_mover` (vv_recon.py:392-399): match_cost / num_points."""
+    """Per-sample EMD as `earth_mover` (vv_recon.py:392-399): match_cost / num_points.  On the PINNED route
+    (rf_earth_mover_mode, RF_EMD_SWEPT): sample i's value is bit-identical whatever the shard it lands in, as the
+    reference's per-sample kernel loop makes it (tf_approxmatch.cu:13) -- so the gathered loss vector does not depend on
+    how the batch was cut over the ranks (SURVEY 8(d) C5 "cross-GPU loss equality")."""
     from .pc_distance.tf_approxmatch import earth_mover_cost
-    return earth_mover_cost(xyz1, xyz2) / float(xyz1.shape[1])
+    return earth_mover_cost(xyz1, xyz2, mode="swept") / float(xyz1.shape[1])

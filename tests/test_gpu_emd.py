@@ -340,7 +340,7 @@ def test_sharp_level_sweeps_with_sorted_rows_keep_every_bit():
 @pytest.mark.parametrize("scale,what", [(1.0, "expanded"), (4.0, "refused: direct sums"), (float("nan"), "refused: a NaN coordinate")])
 def test_broad_levels_by_expansion_and_its_refusal(orc, scale, what):
     """From 8e7 pairs per call on the three broadest levels of the schedule (-1, -0.25, 0) are not swept: their row sums come from
-    one truncated Taylor expansion about the clouds' centre (emd_fgt.hip, fp64, 1e-11 of the direct sum).  The device refuses the
+    one truncated Taylor expansion about the clouds' centre (emd_fgt.hip, fp64, every row sum certified to 4e-6 or summed directly).  The device refuses the
     expansion per call when the clouds' extent breaks its error bound -- here clouds four times the unit cube -- or a coordinate
     is not finite, and forms the sums directly instead.  Both routes against the oracle's chain on the first and last sample of
     a 21 x 2000 x 2000 call.  The count of `match` entries outside abs 1e-6 + rel 1e-4 is that of the all-swept build on the same
@@ -417,3 +417,102 @@ def test_broad_levels_by_expansion_ragged_sizes(orc):
     oc = orc.match_cost(a[pick], c[pick], om)
     assert_rel(match_cost(cu(a), cu(c), got_all).cpu().numpy()[pick], oc, 1e-5, what="cost")
     assert_rel(R.earth_mover(cu(a), cu(c)).cpu().numpy()[pick], oc, 1e-5, what="fused cost")
+
+
+# ----------------------------------------------------------------------------- the pinned route (rf_approxmatch_mode / rf_earth_mover_mode)
+@pytest.mark.parametrize("B,N", [(21, 2000), (32, 2048)])
+def test_swept_route_is_batch_invariant(B, N):
+    """The reference's kernel loops over the samples independently (tf_approxmatch.cu:13): sample i's match does not depend on the
+    batch it is called in.  RF_EMD_AUTO picks routes and launch shapes by the size of the whole batch (both sizes here are past the
+    sorted-row and expansion thresholds, a batch of one is not); RF_EMD_SWEPT pins them:
+        approx_match(a, c)[i] == approx_match(a[i:i+1], c[i:i+1])   bit for bit
+    for every i, and for slices of other lengths (the shards of an R-way split)."""
+    from rfnet_amd import _raw as R
+    rng = np.random.RandomState(B + N)
+    a = (rng.random_sample((B, N, 3)) - 0.5).astype(np.float32)
+    c = (rng.random_sample((B, N, 3)) - 0.5).astype(np.float32)
+    ta, tc = cu(a), cu(c)
+    full = R.approx_match(ta, tc, mode="swept")
+    for i in range(B):
+        one = R.approx_match(ta[i:i + 1], tc[i:i + 1], mode="swept")
+        assert torch.equal(one[0], full[i]), f"sample {i} alone differs from the batch"
+        del one
+    for lo, hi in ((0, B // 2), (B // 2, B), (3, 8)):
+        part = R.approx_match(ta[lo:hi], tc[lo:hi], mode="swept")
+        assert torch.equal(part, full[lo:hi]), (lo, hi)
+        del part
+    # ... and the pinned route is the op: same bars as the default route against it (both sit within tolerance of the oracle)
+    auto = R.approx_match(ta, tc)
+    d = (auto - full).abs()
+    assert float(d.max()) < 2e-4 and int((d > 1e-6 + 1e-4 * full.abs()).sum()) <= 64 * B
+    assert_rel(R.match_cost(ta, tc, auto).cpu().numpy(), R.match_cost(ta, tc, full).cpu().numpy(), 1e-5, what="cost: auto vs swept")
+
+
+def test_swept_earth_mover_is_identical_over_shard_splits():
+    """SURVEY 8(d) C5 "cross-GPU loss equality": the per-sample EMD of B = 32 samples computed as R in {1, 2, 4, 8} contiguous shards (run
+    one after the other on this GPU, as R ranks would each run theirs) -- identical vectors, bit for bit, on the pinned route;
+    rfnet_amd.shard.emd_per_sample is that route."""
+    from rfnet_amd import _raw as R
+    from rfnet_amd import shard
+    rng = np.random.RandomState(5)
+    for n, m in ((2048, 2048), (1024, 1024), (700, 1100)):
+        B = 32
+        a = cu((rng.random_sample((B, n, 3)) - 0.5).astype(np.float32))
+        c = cu((rng.random_sample((B, m, 3)) - 0.5).astype(np.float32))
+        whole = R.earth_mover(a, c, mode="swept")
+        for parts in (2, 4, 8):
+            pieces = []
+            for r in range(parts):
+                lo, hi = shard.shard_bounds(B, r, parts)
+                pieces.append(R.earth_mover(a[lo:hi], c[lo:hi], mode="swept"))
+            assert torch.equal(torch.cat(pieces), whole), (n, m, parts)
+        assert torch.equal(shard.emd_per_sample(a, c), whole / float(n))
+        halves = torch.cat([shard.emd_per_sample(a[:16], c[:16]), shard.emd_per_sample(a[16:], c[16:])])
+        assert torch.equal(halves, whole / float(n))
+        assert_rel(R.earth_mover(a, c).cpu().numpy(), whole.cpu().numpy(), 1e-5, what="auto vs swept cost")
+
+
+def test_emd_mode_abi_errors():
+    from rfnet_amd import _raw as R
+    from rfnet_amd._lib import lib
+    a = cu(np.zeros((1, 8, 3), np.float32))
+    with pytest.raises(ValueError):
+        R.approx_match(a, a, mode="nope")
+    assert lib.rf_approxmatch_mode_workspace_bytes(1, 600, 600, 0, 7) == 0
+    m = torch.empty(1, 8, 8, device="cuda")
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+    assert lib.rf_approxmatch_mode(1, 8, 8, a.data_ptr(), a.data_ptr(), m.data_ptr(), None, 0, ws.data_ptr(), ws.numel(), None, 7) != 0
+    assert lib.rf_earth_mover_mode(1, 8, 8, a.data_ptr(), a.data_ptr(), m.data_ptr(), None, None, ws.data_ptr(), ws.numel(), None, -1) != 0
+
+
+@pytest.mark.parametrize("kind", ["opposite_corners", "corner_vs_filled", "filled_vs_corner", "filled"])
+def test_expansion_on_opposite_corner_clusters(orc, kind):
+    """The expansion's accuracy is certified row by row (emd_fgt.hip): the degree-10 series of exp(g x.y) is 2e-6 off at g x.y =
+    -1.5, which is where EVERY pair sits when the two clouds are clusters in opposite corners of the unit cube (a partial shape
+    against a complete one comes close) -- on clouds that fill their box those pairs carry no weight (4e-10 of a row sum).  Rows
+    whose bound exceeds 1e-7 of their sum are summed directly.  Forced onto the expansion route (RF_EMD_EXPANDED) at a size the
+    oracle runs in seconds: match against the oracle at the C4 bars, cost rel 1e-5, and against the pinned swept route."""
+    from rfnet_amd import _raw as R
+    rng = np.random.RandomState(11)
+    B, N = 2, 1536
+    filled = lambda: (rng.random_sample((B, N, 3)) - 0.5).astype(np.float32)
+    corner = lambda s: np.clip(s * 0.45 + 0.03 * rng.randn(B, N, 3), -0.5, 0.5).astype(np.float32)
+    a, c = {"opposite_corners": (corner(1.0), corner(-1.0)), "corner_vs_filled": (corner(1.0), filled()),
+            "filled_vs_corner": (filled(), corner(-1.0)), "filled": (filled(), filled())}[kind]
+    om = orc.approx_match(a, c)
+    oc = orc.match_cost(a, c, om)
+    got = R.approx_match(cu(a), cu(c), mode="expanded")
+    gm = got.cpu().numpy()
+    strict_bar_report(f"expanded route, {kind}", gm, om)
+    bad = np.abs(gm - om) > 1e-6 + 1e-4 * np.abs(om)
+    assert int(bad.sum()) <= 32 and np.abs(gm - om).max() < 2e-4, f"{kind}: {int(bad.sum())} strays, max {np.abs(gm - om).max():.2e}"
+    # marginals: all but a few within 1e-5, none beyond the 2e-4 a clamp flip moves (tests/test_oracle_golden.py::test_match_bar_is_ill_conditioned)
+    for ax in (1, 2):
+        dm = np.abs(gm.sum(ax) - om.sum(ax))
+        assert int((dm > 1e-5 + 1e-5 * np.abs(om.sum(ax))).sum()) <= 8 and dm.max() < 2e-4, (kind, ax, float(dm.max()))
+    assert_rel(R.match_cost(cu(a), cu(c), got).cpu().numpy(), oc, 1e-5, what=f"{kind}: cost on the expansion route")
+    assert_rel(R.earth_mover(cu(a), cu(c), mode="expanded").cpu().numpy(), oc, 1e-5, what=f"{kind}: fused cost on the expansion route")
+    swept = R.approx_match(cu(a), cu(c), mode="swept").cpu().numpy()
+    sb = np.abs(swept - om) > 1e-6 + 1e-4 * np.abs(om)
+    # the expansion must not be the less faithful of the two routes by more than a handful of clamp flips
+    assert int(bad.sum()) <= int(sb.sum()) + 16, (int(bad.sum()), int(sb.sum()))

@@ -322,26 +322,6 @@ def test_reference_three_interpolate_gradient_test():
     assert np.abs(numeric - analytic).max() < 1e-4 * max(1.0, np.abs(analytic).max())
 
 
-@pytest.mark.parametrize("b,n,m", [(8, 16384, 96), (8, 3000, 32), (16, 8192, 200), (3, 1500, 1500)])
-def test_fps_cluster_form_is_bit_identical(b, n, m):
-    """rf_farthestpointsampling_cluster (one cloud over k = 2, 4, 8 workgroups exchanging their per-iteration winners
-    through agent-scope granules; measured slower than one workgroup per cloud, profiles/r05_fps_cluster.txt, and kept
-    callable): the same indices as farthest_point_sample, ties included, with membership by arrival and -- where the
-    batch allows it -- keyed on the block index; the error word (a member gave up waiting) stays 0."""
-    from rfnet_amd import _raw as R
-    rng = np.random.RandomState(b + n + m)
-    for kind in ("uniform", "lattice"):
-        a = rng.random_sample((b, n, 3)) if kind == "uniform" else rng.randint(0, 10, size=(b, n, 3)) / 9.0
-        x = cu(a.astype(np.float32))
-        want = R.farthest_point_sample(m, x)
-        for k in (2, 4, 8):
-            for static_map in ((False, True) if b % 8 == 0 else (False,)):
-                got, st = R.farthest_point_sample_cluster(m, x, k=k, static_map=static_map, return_state=True)
-                torch.cuda.synchronize()
-                assert int(st[1].item()) == 0, (kind, k, static_map)
-                assert torch.equal(got, want), (kind, k, static_map)
-
-
 @pytest.mark.parametrize("b,n,m", [(4, 16384, 300), (3, 8193, 64), (2, 12001, 1200), (5, 16000, 40), (1, 9000, 9000), (3, 1025, 700),
                                    (2, 2048, 2048), (3, 3000, 600), (2, 4097, 513), (2, 7000, 33)])
 def test_fps_over_the_sorted_cloud_is_bit_identical(orc, b, n, m):
