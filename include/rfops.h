@@ -259,6 +259,15 @@ int rf_grouppoint(int b, int n, int c, int m, int nsample, const float *points, 
                   float *out, rf_stream_t stream);
 int rf_grouppoint_grad(int b, int n, int c, int m, int nsample, const float *grad_out,
                        const int *idx, float *grad_points, rf_stream_t stream);
+/* The gradient with caller scratch -- the entry point a binding should prefer.  The reference's form (one atomicAdd per element
+ * into the zeroed tensor, tf_grouping_g.cu:61-78) is bound by the L2's float-atomic rate on this chip; given
+ * rf_grouppoint_grad_workspace_bytes(b, n, c, m, nsample) bytes of 16-byte aligned scratch (0: the shape stays on the atomics, pass
+ * NULL) the slots are counting-sorted by destination row and every row of grad_points is written once, from sums in double:
+ * no zero fill, no atomics on memory, the same values to fp32 rounding whatever the order (scatter_rows.hip).  Slots whose index
+ * is outside [0, n) add to no row.  With workspace == NULL or too small: rf_grouppoint_grad. */
+size_t rf_grouppoint_grad_workspace_bytes(int b, int n, int c, int m, int nsample);
+int rf_grouppoint_grad_ws(int b, int n, int c, int m, int nsample, const float *grad_out, const int *idx,
+                          float *grad_points, void *workspace, size_t workspace_bytes, rf_stream_t stream);
 
 /* -------------------------------------------------- interpolation (tf_ops/interpolation) - */
 /* Replace threenn_cpu / threeinterpolate_cpu / threeinterpolate_grad_cpu
@@ -282,6 +291,13 @@ int rf_threeinterpolate(int b, int m, int c, int n, const float *points, const i
                         const float *weight, float *out, rf_stream_t stream);
 int rf_threeinterpolate_grad(int b, int n, int c, int m, const float *grad_out, const int *idx,
                              const float *weight, float *grad_points, rf_stream_t stream);
+/* ... with caller scratch: where a sample's known points do not fit the LDS tile of the in-kernel form (more than 2048 at 8
+ * channels per slice) the 3 n slots are counting-sorted by known point and every row of grad_points is written once
+ * (scatter_rows.hip, as rf_grouppoint_grad_ws).  rf_threeinterpolate_grad_workspace_bytes = 0: no scratch needed, pass NULL. */
+size_t rf_threeinterpolate_grad_workspace_bytes(int b, int n, int c, int m);
+int rf_threeinterpolate_grad_ws(int b, int n, int c, int m, const float *grad_out, const int *idx,
+                                const float *weight, float *grad_points, void *workspace, size_t workspace_bytes,
+                                rf_stream_t stream);
 
 /* ------------------------------------------- rest of the import surface ("next" row f3) --- */
 /* Replaces AuctionMatchLauncher(b,n,xyz1,xyz2,matchl,matchr,cost) (tf_ops/emd/tf_auctionmatch.cpp:25,

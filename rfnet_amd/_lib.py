@@ -76,11 +76,15 @@ SIGNATURES = {
     "rf_sample_and_group": (_i, [_i, _i, _i, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "rf_grouppoint": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "rf_grouppoint_grad": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "rf_grouppoint_grad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "rf_grouppoint_grad_ws": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rf_threenn": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "rf_threenn_boxes_workspace_bytes": (_sz, [_i, _i, _i]),
     "rf_threenn_boxes": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rf_threeinterpolate": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "rf_threeinterpolate_grad": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rf_threeinterpolate_grad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "rf_threeinterpolate_grad_ws": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rf_auctionmatch_supported": (_i, [_i]),
     "rf_auctionmatch_workspace_bytes": (_sz, [_i, _i]),
     "rf_auctionmatch": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

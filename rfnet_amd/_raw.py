@@ -624,8 +624,9 @@ def group_point(points, idx):
 
 
 @H.on_input_device
-def group_point_grad(points, idx, grad_out):
-    """GroupPointGradGpuOp, tf_grouping.cpp:178-212 -> (b,n,c)."""
+def group_point_grad(points, idx, grad_out, form="auto"):
+    """GroupPointGradGpuOp, tf_grouping.cpp:178-212 -> (b,n,c).
+    form: "auto" (rf_grouppoint_grad_ws: sorted slots where they pay) | "atomic" (the reference's form, rf_grouppoint_grad)."""
     st = H.Staged()
     p, ix, go = st.take(points, F32), st.take(idx, I32), st.take(grad_out, F32)
     if p.dim() != 3:
@@ -639,8 +640,13 @@ def group_point_grad(points, idx, grad_out):
     dev = st.device_()
     p, ix, go = st.up(p, ix, go)
     g = H.empty((b, n, c), F32, dev)
-    check(lib.rf_grouppoint_grad(b, n, c, m, ns, H.ptr(go), H.ptr(ix), H.ptr(g), H.stream(dev)),
-          "rf_grouppoint_grad")
+    if form == "atomic":
+        check(lib.rf_grouppoint_grad(b, n, c, m, ns, H.ptr(go), H.ptr(ix), H.ptr(g), H.stream(dev)),
+              "rf_grouppoint_grad")
+        return st.give(g)
+    ws, wsz = H.workspace(lib.rf_grouppoint_grad_workspace_bytes(b, n, c, m, ns), dev, "gpg")
+    check(lib.rf_grouppoint_grad_ws(b, n, c, m, ns, H.ptr(go), H.ptr(ix), H.ptr(g), H.ptr(ws), wsz, H.stream(dev)),
+          "rf_grouppoint_grad_ws")
     return st.give(g)
 
 
@@ -714,8 +720,9 @@ def three_interpolate(points, idx, weight):
 
 
 @H.on_input_device
-def three_interpolate_grad(points, idx, weight, grad_out):
-    """ThreeInterpolateGradOp, tf_interpolate.cpp:225-262 -> (b,m,c)."""
+def three_interpolate_grad(points, idx, weight, grad_out, form="auto"):
+    """ThreeInterpolateGradOp, tf_interpolate.cpp:225-262 -> (b,m,c).
+    form: "auto" (rf_threeinterpolate_grad_ws) | "inline" (rf_threeinterpolate_grad: the LDS tile, or atomics beyond it)."""
     st = H.Staged()
     p, ix, w, go = (st.take(points, F32), st.take(idx, I32), st.take(weight, F32),
                     st.take(grad_out, F32))
@@ -732,8 +739,13 @@ def three_interpolate_grad(points, idx, weight, grad_out):
     dev = st.device_()
     p, ix, w, go = st.up(p, ix, w, go)
     g = H.empty((b, m, c), F32, dev)
-    check(lib.rf_threeinterpolate_grad(b, n, c, m, H.ptr(go), H.ptr(ix), H.ptr(w), H.ptr(g),
-                                       H.stream(dev)), "rf_threeinterpolate_grad")
+    if form == "inline":
+        check(lib.rf_threeinterpolate_grad(b, n, c, m, H.ptr(go), H.ptr(ix), H.ptr(w), H.ptr(g),
+                                           H.stream(dev)), "rf_threeinterpolate_grad")
+        return st.give(g)
+    ws, wsz = H.workspace(lib.rf_threeinterpolate_grad_workspace_bytes(b, n, c, m), dev, "tig")
+    check(lib.rf_threeinterpolate_grad_ws(b, n, c, m, H.ptr(go), H.ptr(ix), H.ptr(w), H.ptr(g), H.ptr(ws), wsz,
+                                          H.stream(dev)), "rf_threeinterpolate_grad_ws")
     return st.give(g)
 
 

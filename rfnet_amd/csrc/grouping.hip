@@ -28,6 +28,7 @@
 #include "common.hpp"
 #include "nn_pruned.hpp"
 #include "group_internal.hpp"
+#include "scatter_rows.hpp"
 
 namespace {
 
@@ -745,22 +746,45 @@ int rf_grouppoint(int b, int n, int c, int m, int nsample, const float *points, 
     return RF_OK;
 }
 
-int rf_grouppoint_grad(int b, int n, int c, int m, int nsample, const float *grad_out,
-                       const int *idx, float *grad_points, rf_stream_t stream) {
+// From this many gradient elements on the sorted-slots form (scatter_rows.hip) beats the atomics (same device, tools/ab_group_grad.py);
+// below, its two launches cost more than the atomics' contention
+// (4.2 M elements: 28 against 27 us; 16.8 M: 34 against 63).  Narrow rows pay earlier -- the atomics' cost is their count and
+// their crowding on a line, not the bytes: 32 x 32768 slots of 3 channels, 3.1 M elements, 26 against 63 us -- hence the slot rule.
+constexpr long GPG_CSR_MIN_ELEMS = 1L << 22, GPG_CSR_MIN_SLOTS = 1L << 19;
+static bool gpg_csr(int b, int n, int c, long per_batch) {
+    return ((long)b * per_batch * c >= GPG_CSR_MIN_ELEMS || (long)b * per_batch >= GPG_CSR_MIN_SLOTS) &&
+           rfs::rows_csr_supported(b, n, c, per_batch, 1);
+}
+
+size_t rf_grouppoint_grad_workspace_bytes(int b, int n, int c, int m, int nsample) {
+    if (b <= 0 || n <= 0 || c <= 0 || m <= 0 || nsample <= 0) return 0;
+    const long per_batch = (long)m * nsample;
+    return gpg_csr(b, n, c, per_batch) ? rfs::rows_csr_workspace_bytes(b, n, per_batch) : 0;
+}
+
+int rf_grouppoint_grad_ws(int b, int n, int c, int m, int nsample, const float *grad_out, const int *idx, float *grad_points,
+                          void *workspace, size_t workspace_bytes, rf_stream_t stream) {
     if (b < 0 || n < 0 || c < 0 || m < 0 || nsample < 0) return RF_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if ((size_t)b * n * c) {
-        if (!grad_points) return RF_EINVAL;
-        RF_ZERO(grad_points, sizeof(float) * (size_t)b * n * c, s);
-    }
-    long per_batch = (long)m * nsample;
-    long total = (long)b * per_batch * c;
+    const long per_batch = (long)m * nsample;
+    const long total = (long)b * per_batch * c;
+    if ((size_t)b * n * c && !grad_points) return RF_EINVAL;
+    if (total != 0 && n != 0 && (!grad_out || !idx)) return RF_EINVAL;
+    const size_t need = total != 0 && n != 0 ? rf_grouppoint_grad_workspace_bytes(b, n, c, m, nsample) : 0;
+    if (need && workspace && workspace_bytes >= need && rf::aligned16(workspace))
+        return rfs::rows_csr_scatter(b, n, c, per_batch, 1, grad_out, idx, nullptr, grad_points, workspace, "group_point_grad_sort",
+                                     "group_point_grad", s);
+    if ((size_t)b * n * c) RF_ZERO(grad_points, sizeof(float) * (size_t)b * n * c, s);
     if (total == 0 || n == 0) return RF_OK;
-    if (!grad_out || !idx) return RF_EINVAL;
     if (group_rows_ok(b, n, c, per_batch)) return group_rows_launch<true>(b, n, c, per_batch, grad_out, idx, grad_points, "group_point_grad", s);
     RF_LAUNCH("group_point_grad", group_point_grad_kernel, dim3(rf::ceil_div(total, 256)), dim3(256), 0,
               s, n, c, per_batch, total, grad_out, idx, grad_points);
     return RF_OK;
+}
+
+int rf_grouppoint_grad(int b, int n, int c, int m, int nsample, const float *grad_out,
+                       const int *idx, float *grad_points, rf_stream_t stream) {
+    return rf_grouppoint_grad_ws(b, n, c, m, nsample, grad_out, idx, grad_points, nullptr, 0, stream);
 }
 
 }  // extern "C"

@@ -22,6 +22,7 @@
 // visits candidates in index order and inserts on strict '<': its result is the three smallest by (distance, index); the boxed
 // form visits them in any order and inserts by that pair -- the same triple, ties included.
 #include "common.hpp"
+#include "scatter_rows.hpp"
 #include "nn_pruned.hpp"
 
 namespace {
@@ -618,24 +619,46 @@ int rf_threeinterpolate(int b, int m, int c, int n, const float *points, const i
     return RF_OK;
 }
 
+// The LDS-tile form's slice: cs channels with m * cs doubles in 128 KiB -- cs a power of two dividing c (8..64), or, for c that has
+// none (3, 6, 13 ...), all c <= 64 channels in one slice; 0: the sample's known points do not fit a tile
+static int tig_tile_cs(int b, int n, int c, int m) {
+    if (!(b <= 65535 && (long)n * c < (1L << 31) && (long)m * c < (1L << 31) && (long)n * 3 < (1L << 31))) return 0;
+    for (int k = 6; k >= 3; k--)
+        if (c % (1 << k) == 0 && ((long)m << k) <= 16384) return 1 << k;
+    if (c <= 64 && (long)m * c <= 16384) return c;
+    return 0;
+}
+// beyond the tile (more than 2048 known points at 8 channels per slice): the sorted-slots form of scatter_rows.hip, from this
+// many gradient elements on (below: the atomics)
+constexpr long TIG_CSR_MIN_ELEMS = 1L << 22;
+static bool tig_csr(int b, int n, int c, int m) {
+    return tig_tile_cs(b, n, c, m) == 0 && (long)b * n * 3 * c >= TIG_CSR_MIN_ELEMS && rfs::rows_csr_supported(b, m, c, (long)n * 3, 3);
+}
+
+size_t rf_threeinterpolate_grad_workspace_bytes(int b, int n, int c, int m) {
+    if (b <= 0 || n <= 0 || c <= 0 || m <= 0) return 0;
+    return tig_csr(b, n, c, m) ? rfs::rows_csr_workspace_bytes(b, m, (long)n * 3) : 0;
+}
+
 int rf_threeinterpolate_grad(int b, int n, int c, int m, const float *grad_out, const int *idx,
                              const float *weight, float *grad_points, rf_stream_t stream) {
+    return rf_threeinterpolate_grad_ws(b, n, c, m, grad_out, idx, weight, grad_points, nullptr, 0, stream);
+}
+
+int rf_threeinterpolate_grad_ws(int b, int n, int c, int m, const float *grad_out, const int *idx,
+                                const float *weight, float *grad_points, void *workspace, size_t workspace_bytes,
+                                rf_stream_t stream) {
+
     if (b < 0 || n < 0 || m < 0 || c < 0) return RF_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if ((size_t)b * m * c && !grad_points) return RF_EINVAL;
     long total = (long)b * n * c;
     if (total != 0 && m != 0 && (!grad_out || !idx || !weight)) return RF_EINVAL;
-    // the LDS-tile form: slices of cs channels with m * cs doubles in 128 KiB -- cs a power of two dividing c (8..64), or, for c
-    // that has none (3, 6, 13 ...), all c <= 64 channels in one slice
-    int cs = 0;
-    if (total != 0 && m != 0 && b <= 65535 && (long)n * c < (1L << 31) && (long)m * c < (1L << 31) && (long)n * 3 < (1L << 31)) {
-        for (int k = 6; k >= 3; k--)
-            if (c % (1 << k) == 0 && ((long)m << k) <= 16384) {
-                cs = 1 << k;
-                break;
-            }
-        if (cs == 0 && c <= 64 && (long)m * c <= 16384) cs = c;
-    }
+    const int cs = (total != 0 && m != 0) ? tig_tile_cs(b, n, c, m) : 0;
+    if (cs == 0 && total != 0 && m != 0 && tig_csr(b, n, c, m) && workspace && rf::aligned16(workspace) &&
+        workspace_bytes >= rf_threeinterpolate_grad_workspace_bytes(b, n, c, m))
+        return rfs::rows_csr_scatter(b, m, c, (long)n * 3, 3, grad_out, idx, weight, grad_points, workspace, "three_interpolate_grad_sort",
+                                     "three_interpolate_grad", s);
     if (cs > 0) {
         const bool pow2 = (cs & (cs - 1)) == 0 && cs >= 8;
         const bool vec = RFI_TG_VEC && pow2 && rf::aligned16(grad_out);  // (rows of a slice start 16-byte aligned when the tensor does)
