@@ -146,15 +146,21 @@ __global__ __launch_bounds__(AI_TPB) void am_init_kernel(AmInit a) {
 //           fifth of its columns, and computing and testing the distances of all of them again was what its skipping sweep still
 //           cost.  The listed columns' operands are gathered by the lanes (one column per lane, one memory round trip for 64
 //           columns), parked in LDS and read back as broadcasts: same operations per kept column, same order -- same bits.
-template <bool HAS_P3, int P1, int RPT, int SKIP = 0, int MASK = 0>
+// CMP (round 6): the columns are the sample's LIVE ones only -- am_compact_kernel's packed copy of the columns whose scalars are
+// not both exactly 0 (xyz2p / ratioR_prev / remainR then point at that copy, `cstride` floats per sample; counts[bi * 4] = how
+// many, a multiple of 16 with zero-scalar padding).  A column whose scalars are +0 adds fma(e, 0, acc) = acc: leaving it out
+// changes no sum.  The live columns are cut into the workgroup's segments evenly (a device-side count: no host round trip).
+template <bool HAS_P3, int P1, int RPT, int SKIP = 0, int MASK = 0, int CMP = 0>
 __global__ __launch_bounds__(1024) void am_rowk_kernel(
     int n, int seglen, const float *__restrict__ xyz1, const float *__restrict__ xyz2p,
     size_t xyz2p_stride, const float *__restrict__ ratioR_prev, const float *__restrict__ remainR,
     const float *__restrict__ ratioL_prev, float *__restrict__ remainL,
     float *__restrict__ ratioL_out, size_t stride, float c_prev, float c_cur, const int *__restrict__ perm,
     int perm_stride, float tskip, float tskip_prev, const int *__restrict__ guard, int guard_want,
-    unsigned short *__restrict__ mask = nullptr, float tmask = 0.f) {
+    unsigned short *__restrict__ mask = nullptr, float tmask = 0.f, const int *__restrict__ counts = nullptr,
+    size_t cstride = 0) {
     static_assert(MASK == 0 || SKIP == 1, "column lists belong to the skipping sweeps");
+    static_assert(CMP == 0 || (SKIP == 0 && MASK == 0), "the live-column form is a dense sweep over a shorter column set");
     __shared__ float part3[16][64 * RPT], part1[16][64 * RPT];
     // (the broad levels: this sweep runs only when the expansion of emd_fgt.hip was refused for the call's clouds, or -- the
     // P3-only form before the first expanded level -- only when it was accepted; guard = NULL: always)
@@ -182,9 +188,15 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
         acc1[r] = (seg == 0) ? 1e-9f : 0.f;
     }
     const float *__restrict__ C = xyz2p + (size_t)bi * xyz2p_stride;
-    const float *__restrict__ S3 = ratioR_prev + (size_t)bi * stride;
-    const float *__restrict__ S1 = remainR + (size_t)bi * stride;
-    const int c0 = seg * seglen, c1 = c0 + seglen;  // multiples of SUB, inside the padded range
+    const float *__restrict__ S3 = ratioR_prev + (size_t)bi * (CMP ? cstride : stride);
+    const float *__restrict__ S1 = remainR + (size_t)bi * (CMP ? cstride : stride);
+    int c0 = seg * seglen, c1 = c0 + seglen;  // multiples of SUB, inside the padded range
+    if (CMP) {  // (uniform) this wave's share of the live columns
+        const int cnt = ((const __attribute__((address_space(4))) int *)counts)[bi * 4];  // a multiple of 2 * SUB
+        const int slen = ((cnt + nseg - 1) / nseg + 2 * SUB - 1) / (2 * SUB) * (2 * SUB);
+        c0 = min(seg * slen, cnt);
+        c1 = min(c0 + slen, cnt);
+    }
     // one column (its coordinates and scalars wave-uniform) against the lane's RPT rows
     // (RFA_PK: the lane's two rows as the halves of packed fp32 operations, as in am_rowl_kernel -- bit-identical sums -- together
     // with the column operands through two scalar register sets in turn: the dense fused P3 + P1 sweep 61.8 -> 47.5 us at C4, P3
@@ -394,14 +406,19 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
 //   sumr = sum_k fma(e, ratioL[k], .);  t = sumr*remainR[l];  cons = min(remainR[l]/(t+1e-9), 1)
 //   ratioR[l] = remainR[l]*cons;  remainR[l] = max(0, remainR[l]-t)
 // ZERO: the level's multiplier is 0 -> e = 1.0 exactly, no distance and no exponential (see am_rowk).
-template <int RPT, bool ZERO, bool SKIP = false, int MASK = 0>
+// LIST (round 6): the rows are the sample's LIVE ones only -- `perm` is am_compact_kernel's list of the rows whose remainR is not
+// exactly 0 (in index order, -1 behind the last; counts[bi * 4 + 1] of them).  A row with remainR = +0 has t = sumr * 0 = 0,
+// cons = min(0 / 1e-9, 1) = 0, ratioR = 0 and stays at 0 whatever its sum: the compaction writes those zeros, this launch skips
+// the rows.  Workgroups beyond the list leave at once.
+template <int RPT, bool ZERO, bool SKIP = false, int MASK = 0, bool LIST = false>
 __global__ __launch_bounds__(1024) void am_rowl_kernel(
     int m, int seglen, const float *__restrict__ xyz2, const float *__restrict__ xyz1p,
     size_t xyz1p_stride, const float *__restrict__ ratioL, float *__restrict__ remainR,
     float *__restrict__ ratioR_out, size_t stride, float c_cur, const int *__restrict__ perm, int perm_stride,
     float tskip, const int *__restrict__ guard, int guard_want, unsigned short *__restrict__ mask = nullptr,
-    float tmask = 0.f) {
+    float tmask = 0.f, const int *__restrict__ counts = nullptr) {
     static_assert(MASK == 0 || SKIP, "column lists belong to the skipping sweeps (am_rowk_kernel MASK)");
+    static_assert(!LIST || (!SKIP && MASK == 0), "the live-row form is a dense sweep over fewer rows");
     if (guard && (*guard != 0) != (guard_want != 0)) return;  // (see am_rowk_kernel)
     __shared__ float part[16][64 * RPT];
     // (a sample's workgroups on ONE XCD, rf::xcd_contiguous: its columns are then read from HBM by one L2 instead of eight)
@@ -410,13 +427,14 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
     const int lane = threadIdx.x & 63;
     const int seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nseg = blockDim.x >> 6;
+    if (LIST && bx * 64 * RPT >= ((const __attribute__((address_space(4))) int *)counts)[bi * 4 + 1]) return;  // (uniform)
     const float *__restrict__ B = xyz2 + (size_t)bi * m * 3;
     float x2[RPT], y2[RPT], z2[RPT], acc[RPT];
     int lrow[RPT];  // the lane's rows (original indices; < 0: none); SKIP: in the cloud's spatial order (see am_rowk_kernel)
 #pragma unroll
     for (int r = 0; r < RPT; r++) {
         const int pos = bx * 64 * RPT + r * 64 + lane;
-        lrow[r] = SKIP ? (pos < perm_stride ? perm[(size_t)bi * perm_stride + pos] : -1) : (pos < m ? pos : -1);
+        lrow[r] = (SKIP || LIST) ? (pos < perm_stride ? perm[(size_t)bi * perm_stride + pos] : -1) : (pos < m ? pos : -1);
         const int ll = lrow[r] >= 0 ? lrow[r] : m - 1;
         x2[r] = B[ll * 3]; y2[r] = B[ll * 3 + 1]; z2[r] = B[ll * 3 + 2];
         if (SKIP && lrow[r] < 0) x2[r] = INFINITY;
@@ -566,6 +584,128 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
             ratioR_out[(size_t)bi * stride + l] = rem * cons;
             remainR[(size_t)bi * stride + l] = fmaxf(0.0f, rem - t);
         }
+    }
+}
+
+// The LIVE columns and rows of set 2 after P2 of a level (round 6).  P2 sets remainR[l] = max(0, remainR[l] - t): a column whose
+// demand reached its supply is EXACTLY +0 from then on -- 44 % of C4's columns after two levels, 68 / 80 / 87 / 92 / 97 % after
+// three .. seven -- and, with it, ratioR of every later level.  What the schedule still computes for such a column is
+// fma(e, +0, acc) = acc in P1 / P3 and a row of zeros in P2.  This kernel packs, per sample and in index order,
+//   * the columns with ratioR_v != 0 (a superset of remainR != 0) -- coordinates, ratioR_v, remainR -- for the fused P3(v) + P1(v+1)
+//     sweep (am_rowk_kernel CMP), padded with zero-scalar columns to a multiple of 16 plus one sub-chunk of prefetch slack;
+//   * the rows with remainR != 0 for P2(v+1) (am_rowl_kernel LIST), padded with -1 to a whole workgroup's 128;
+// and writes ratioR_{v+1} = 0 for the rows P2(v+1) will skip.  One workgroup per sample; a thread owns `per` consecutive entries.
+constexpr int CK_TPB = 1024;
+__global__ __launch_bounds__(CK_TPB) void am_compact_kernel(int m, int mpad, const float *__restrict__ xyz2p, size_t xyz2p_stride,
+                                                            const float *__restrict__ ratioR, const float *__restrict__ remainR,
+                                                            float *__restrict__ ratioR_next, size_t stride, float *__restrict__ cc,
+                                                            float *__restrict__ s3c, float *__restrict__ s1c, int *__restrict__ rows,
+                                                            int *__restrict__ counts, size_t cstride) {
+    __shared__ unsigned wsc[CK_TPB / 64], wsr[CK_TPB / 64];
+    const int bi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *__restrict__ C = xyz2p + (size_t)bi * xyz2p_stride;
+    const float *__restrict__ RR = ratioR + (size_t)bi * stride;
+    const float *__restrict__ RM = remainR + (size_t)bi * stride;
+    float *__restrict__ CC = cc + (size_t)bi * cstride * 3;
+    float *__restrict__ S3 = s3c + (size_t)bi * cstride;
+    float *__restrict__ S1 = s1c + (size_t)bi * cstride;
+    int *__restrict__ RW = rows + (size_t)bi * mpad;
+    const int per = (m + CK_TPB - 1) / CK_TPB;
+    const int l0 = tid * per;
+    unsigned ncol = 0, nrow = 0;
+    // (a thread's entries and their coordinates in ONE round trip when it owns at most CK_REG of them -- clouds of up to 4096 points)
+    constexpr int CK_REG = 4;
+    float vr[CK_REG], vm[CK_REG], vx[CK_REG], vy[CK_REG], vz[CK_REG];
+    const bool reg = per <= CK_REG;
+    if (reg) {
+#pragma unroll
+        for (int q = 0; q < CK_REG; q++) {
+            const int l = min(l0 + q, m - 1);
+            const bool in = q < per && l0 + q < m;
+            vr[q] = in ? RR[l] : 0.f;
+            vm[q] = in ? RM[l] : 0.f;
+            vx[q] = C[(size_t)l * 3], vy[q] = C[(size_t)l * 3 + 1], vz[q] = C[(size_t)l * 3 + 2];
+        }
+#pragma unroll
+        for (int q = 0; q < CK_REG; q++) {
+            ncol += vr[q] != 0.f ? 1u : 0u;
+            nrow += vm[q] != 0.f ? 1u : 0u;
+        }
+    } else {
+        for (int q = 0; q < per; q++) {
+            const int l = l0 + q;
+            if (l < m) {
+                ncol += RR[l] != 0.f ? 1u : 0u;
+                nrow += RM[l] != 0.f ? 1u : 0u;
+            }
+        }
+    }
+    auto wave_incl = [&](unsigned v) {
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned t = __shfl_up(v, o, 64);
+            if (lane >= o) v += t;
+        }
+        return v;
+    };
+    const unsigned ic = wave_incl(ncol), ir = wave_incl(nrow);
+    if (lane == 63) wsc[wave] = ic, wsr[wave] = ir;
+    __syncthreads();
+    unsigned pc = ic - ncol, pr = ir - nrow, tc = 0, tr = 0;
+    {  // (the 16 wave totals: one LDS read per lane and a wave scan)
+        const unsigned wc = lane < CK_TPB / 64 ? wsc[lane] : 0u, wr = lane < CK_TPB / 64 ? wsr[lane] : 0u;
+        const unsigned sc = wave_incl(wc), sr = wave_incl(wr);
+        pc += __shfl(sc - wc, wave, 64);
+        pr += __shfl(sr - wr, wave, 64);
+        tc = __shfl(sc, CK_TPB / 64 - 1, 64);
+        tr = __shfl(sr, CK_TPB / 64 - 1, 64);
+    }
+    if (reg) {
+#pragma unroll
+        for (int q = 0; q < CK_REG; q++) {
+            const int l = l0 + q;
+            if (q >= per || l >= m) continue;
+            if (vr[q] != 0.f) {
+                CC[pc * 3] = vx[q], CC[pc * 3 + 1] = vy[q], CC[pc * 3 + 2] = vz[q];
+                S3[pc] = vr[q];
+                S1[pc] = vm[q];
+                pc++;
+            }
+            if (vm[q] != 0.f) {
+                RW[pr++] = l;
+            } else if (ratioR_next) {
+                ratioR_next[(size_t)bi * stride + l] = 0.f;
+            }
+        }
+    } else {
+        for (int q = 0; q < per; q++) {
+            const int l = l0 + q;
+            if (l >= m) break;
+            const float rr = RR[l], rm = RM[l];
+            if (rr != 0.f) {
+                CC[pc * 3] = C[(size_t)l * 3], CC[pc * 3 + 1] = C[(size_t)l * 3 + 1], CC[pc * 3 + 2] = C[(size_t)l * 3 + 2];
+                S3[pc] = rr;
+                S1[pc] = rm;
+                pc++;
+            }
+            if (rm != 0.f) {
+                RW[pr++] = l;
+            } else if (ratioR_next) {
+                ratioR_next[(size_t)bi * stride + l] = 0.f;
+            }
+        }
+    }
+    const unsigned tcp = (tc + 2 * SUB - 1) / (2 * SUB) * (2 * SUB);
+    for (unsigned j = tc + tid; j < tcp + SUB; j += CK_TPB) {  // zero-scalar columns: the padding and the sweep's prefetch slack
+        CC[j * 3] = CC[j * 3 + 1] = CC[j * 3 + 2] = 0.f;
+        S3[j] = S1[j] = 0.f;
+    }
+    const unsigned trp = (tr + 127u) / 128u * 128u;
+    for (unsigned j = tr + tid; j < trp; j += CK_TPB) RW[j] = -1;
+    if (tid == 0) {
+        counts[bi * 4] = (int)tcp;
+        counts[bi * 4 + 1] = (int)tr;
+        counts[bi * 4 + 2] = (int)tc;
     }
 }
 
@@ -1637,6 +1777,9 @@ struct AmLayout {
     bool rowsort_ok;       // the dense sweeps of the sharp levels take their rows in the clouds' spatial order (am_rowk_kernel SKIP)
     bool fgt_ok;           // the broad levels by expansion (emd_fgt.hip): scratch reserved
     size_t off_fgt;
+    bool compact_ok;       // from the third level on the sweeps run over the LIVE columns / rows of set 2 only (am_compact_kernel)
+    size_t cstride;        // floats per sample of a packed column array
+    size_t off_cc, off_s3c, off_s1c, off_rows, off_cnt;
     size_t off_maskk, off_maskl;  // (rowsort_ok) the skipping sweeps' column lists, rows of set 1 / rows of set 2 (am_rowk_kernel MASK)
     int nsa, nsb;          // padded sizes of the two sorted sets
     size_t Vs;             // floats per sorted twin pair [L: nsa | R: nsb]
@@ -1702,6 +1845,23 @@ AmLayout am_layout(int b, int n, int m, int nlevels, bool allow_cull, int mode =
         L.off_fgt = off;
         off += (rfe::fgt_workspace_bytes(b, n > m ? n : m) + 3) / 4 + 64;
     }
+    // (by the clouds' sizes alone, never by b: what a sample's sweeps sum over must not depend on the batch it is called in)
+    L.compact_ok = !swept && n >= 512 && m >= 512;
+    L.cstride = (size_t)L.mpad + 64;
+    L.off_cc = L.off_s3c = L.off_s1c = L.off_rows = L.off_cnt = 0;
+    if (L.compact_ok) {
+        off = (off + 63) / 64 * 64;
+        L.off_cc = off;
+        off += (size_t)b * L.cstride * 3 + 64;
+        L.off_s3c = off;
+        off += (size_t)b * L.cstride + 64;
+        L.off_s1c = off;
+        off += (size_t)b * L.cstride + 64;
+        L.off_rows = off;
+        off += (size_t)b * L.mpad + 64;
+        L.off_cnt = off;
+        off += (size_t)b * 4 + 64;
+    }
     L.off_maskk = L.off_maskl = 0;
     if (L.rowsort_ok) {
         // per (wave of 64 or 128 sorted rows, column segment) a count and up to seglen 16-bit column numbers
@@ -1764,7 +1924,12 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
     auto sharp = [&](int v) { return (double)(-lc.c[v]) * 0.69314718055994530942; };
     int vF = nlevels;
     while (vF > 1 && lc.c[vF - 1] <= 0.f && sharp(vF - 1) <= (double)rfe::kFgtMaxA * 1.0001) vF--;
-    const bool fgt = L.fgt_ok && vF < nlevels && vF >= ncull + 1;
+    // Live columns (am_compact_kernel): from level vC on, every sweep runs over the columns / rows of set 2 whose scalars are not
+    // exactly 0 -- which, at the broad end of the schedule, is a few per cent of them: with it the broad levels cost less as
+    // sweeps than as expansions, so the expansion route is left to RF_EMD_EXPANDED.
+    const bool compact = L.compact_ok && ncull == 0 && nlevels >= 4 && mode != RF_EMD_EXPANDED;
+    constexpr int vC = 2;
+    const bool fgt = L.fgt_ok && vF < nlevels && vF >= ncull + 1 && !compact;
     void *fws = fgt ? (void *)(w + L.off_fgt) : nullptr;
     // (padded entries of every vector must read 0 -- they are column scalars of padded columns: am_init writes them; the same
     // launch carries the expansion's geometry pass, one more workgroup per batch element)
@@ -1825,6 +1990,8 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
                         n < 65536 && m < 65536 &&  // (16-bit column numbers ...
                         L.mpad / segk <= 65535 && L.npad / segl <= 65535;  // ... and 16-bit per-wave counts: a segment of 65536 columns, all listed, would wrap to 0)
     unsigned short *maskk = (unsigned short *)(w + L.off_maskk), *maskl = (unsigned short *)(w + L.off_maskl);
+    float *ccol = w + L.off_cc, *cs3 = w + L.off_s3c, *cs1 = w + L.off_s1c;
+    int *crows = (int *)(w + L.off_rows), *ccnt = (int *)(w + L.off_cnt);
     for (int v = 0; v < nlevels; v++) {
         float *ratioL = ratios + (size_t)v * L.V, *ratioR = ratioL + L.npad;
         const bool zero = lc.c[v] == 0.0f;  // e = exp2(d2 * 0) = 1 exactly: no exponential needed
@@ -1870,6 +2037,21 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
 #define AM_ROWK_ARGS(pR_, pL_, cprev)                                                                 \
     n, L.mpad / segk, xyz1, (const float *)x2p, (size_t)L.mpad * 3, pR_, (const float *)remainR, pL_,  \
         remainL, ratioL, L.bstride, cprev, lc.c[v], permA, L.nsa, tsk, skip_t(v - 1), gptr, 1
+        const bool live = compact && v >= vC && !skip;  // this level's sweeps run over the live columns / rows (packed after P2 of level v - 1)
+#define AM_ROWK_LIVE(pL_, cprev)                                                                                         \
+    n, 0, xyz1, (const float *)ccol, L.cstride * 3, (const float *)cs3, (const float *)cs1, pL_, remainL, ratioL, L.bstride, cprev, \
+        lc.c[v], (const int *)nullptr, 0, INFINITY, INFINITY, gptr, 1, (unsigned short *)nullptr, 0.f, (const int *)ccnt, L.cstride
+        if (live) {
+            const float *pL = ratios + (size_t)(v - 1) * L.V;
+            if (zero) {
+                RF_LAUNCH("am_p3p1", (am_rowk_kernel<true, 2, RPT, 0, 0, 1>), gk, dim3(64 * segk), 0, s, AM_ROWK_LIVE(pL, lc.c[v - 1]));
+            } else if (lc.c[v - 1] == lc.c[v]) {
+                RF_LAUNCH("am_p3p1", (am_rowk_kernel<true, 3, RPT, 0, 0, 1>), gk, dim3(64 * segk), 0, s, AM_ROWK_LIVE(pL, lc.c[v - 1]));
+            } else {
+                RF_LAUNCH("am_p3p1", (am_rowk_kernel<true, 1, RPT, 0, 0, 1>), gk, dim3(64 * segk), 0, s, AM_ROWK_LIVE(pL, lc.c[v - 1]));
+            }
+        } else
+#undef AM_ROWK_LIVE
         if (skip && v == 0 && masked) {  // ... and lists, per wave, the columns the next level's sweep will have to visit
             RF_LAUNCH("am_p1", (am_rowk_kernel<false, 1, RPT, 1, 1>), gks, dim3(64 * segk), 0, s,
                       AM_ROWK_ARGS((const float *)remainR, (const float *)remainL, 0.f), maskk, skip_t(1));
@@ -1906,6 +2088,20 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
             }
         }
 #undef AM_ROWK_ARGS
+        if (live) {
+            // (few rows are left: as many column segments as the columns allow, so that what is left is spread over more, shorter waves)
+            int segl = 1;
+            while (segl < 16 && L.npad / (segl * 2) >= 64 && (L.npad / (segl * 2)) % (2 * SUB) == 0) segl *= 2;
+            if (zero) {
+                RF_LAUNCH("am_p2", (am_rowl_kernel<RPT, true, false, 0, true>), gl, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
+                          (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR, L.bstride, lc.c[v],
+                          (const int *)crows, L.mpad, tsk, gptr, 1, (unsigned short *)nullptr, 0.f, (const int *)ccnt);
+            } else {
+                RF_LAUNCH("am_p2", (am_rowl_kernel<RPT, false, false, 0, true>), gl, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
+                          (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR, L.bstride, lc.c[v],
+                          (const int *)crows, L.mpad, tsk, gptr, 1, (unsigned short *)nullptr, 0.f, (const int *)ccnt);
+            }
+        } else
         if (zero) {
             RF_LAUNCH("am_p2", (am_rowl_kernel<RPT, true>), gl, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
                       (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR,
@@ -1928,6 +2124,11 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
             RF_LAUNCH("am_p2", (am_rowl_kernel<RPT, false>), gl, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
                       (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR,
                       L.bstride, lc.c[v], permB, L.nsb, tsk, gptr, 1);
+        }
+        if (compact && v + 1 >= vC && v + 1 < nlevels) {  // what is still live of set 2, for the next level's sweeps
+            float *ratioR_next = ratios + (size_t)(v + 1) * L.V + L.npad;
+            RF_LAUNCH("am_compact", am_compact_kernel, dim3(b), dim3(CK_TPB), 0, s, m, L.mpad, (const float *)x2p, (size_t)L.mpad * 3,
+                      (const float *)ratioR, (const float *)remainR, ratioR_next, L.bstride, ccol, cs3, cs1, crows, ccnt, L.cstride);
         }
     }
     return RF_OK;
