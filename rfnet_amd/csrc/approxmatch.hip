@@ -587,57 +587,45 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
     }
 }
 
-// The LIVE columns and rows of set 2 after P2 of a level (round 6).  P2 sets remainR[l] = max(0, remainR[l] - t): a column whose
-// demand reached its supply is EXACTLY +0 from then on -- 44 % of C4's columns after two levels, 68 / 80 / 87 / 92 / 97 % after
-// three .. seven -- and, with it, ratioR of every later level.  What the schedule still computes for such a column is
-// fma(e, +0, acc) = acc in P1 / P3 and a row of zeros in P2.  This kernel packs, per sample and in index order,
-//   * the columns with ratioR_v != 0 (a superset of remainR != 0) -- coordinates, ratioR_v, remainR -- for the fused P3(v) + P1(v+1)
-//     sweep (am_rowk_kernel CMP), padded with zero-scalar columns to a multiple of 16 plus one sub-chunk of prefetch slack;
-//   * the rows with remainR != 0 for P2(v+1) (am_rowl_kernel LIST), padded with -1 to a whole workgroup's 128;
-// and writes ratioR_{v+1} = 0 for the rows P2(v+1) will skip.  One workgroup per sample; a thread owns `per` consecutive entries.
+// The LIVE columns and rows of set 2 (round 6).  P2 sets remainR[l] = max(0, remainR[l] - t): a column whose demand reached its
+// supply is EXACTLY +0 from then on -- 44 % of C4's columns after two levels, 68 / 80 / 87 / 92 / 97 % after three .. seven -- and,
+// with it, ratioR of every later level.  What the schedule still computes for such a column is fma(e, +0, acc) = acc in P1 / P3
+// and a row of zeros in P2.  From level vC on the sweeps therefore run over PACKED SETS of the live points of set 2, kept in
+// index order (so every sum is over the same terms in the same order whatever the batch around the sample):
+//   struct of arrays per sample: cc (x, y, z), s3 = ratioR of the level, s1 = remainR, rows = original index, cnt[0] = entries
+//   padded to a multiple of 16 with zero-scalar entries (+ one sub-chunk of prefetch slack), cnt[1] = entries.
+// am_compact_kernel makes the first two sets after P2 of level vC - 1 (the last level swept the old way):
+//   set `cols`: the columns with ratioR != 0, for the fused P3(vC - 1) + P1(vC) sweep (am_rowk_kernel CMP);
+//   set `live`: the rows with remainR != 0 (a subset), which am_p2_live_kernel of level vC takes its rows from;
+// and writes ratioR = 0 at every later level for the rows that are dead already.  From then on am_p2_live_kernel maintains
+// the sets itself (each level's P2 packs its own rows, with their new scalars, into the other buffer): no launch in between.
+struct LiveSet {
+    float *cc, *s3, *s1;  // per sample: cstride * 3 / cstride / cstride floats
+    int *rows;            // per sample: cstride ints
+    int *cnt;             // per sample: 4 ints
+};
 constexpr int CK_TPB = 1024;
-__global__ __launch_bounds__(CK_TPB) void am_compact_kernel(int m, int mpad, const float *__restrict__ xyz2p, size_t xyz2p_stride,
+__global__ __launch_bounds__(CK_TPB) void am_compact_kernel(int m, const float *__restrict__ xyz2p, size_t xyz2p_stride,
                                                             const float *__restrict__ ratioR, const float *__restrict__ remainR,
-                                                            float *__restrict__ ratioR_next, size_t stride, float *__restrict__ cc,
-                                                            float *__restrict__ s3c, float *__restrict__ s1c, int *__restrict__ rows,
-                                                            int *__restrict__ counts, size_t cstride) {
+                                                            float *__restrict__ ratioR_later, size_t lv_stride, int nlater,
+                                                            size_t stride, LiveSet cols, LiveSet live, size_t cstride) {
     __shared__ unsigned wsc[CK_TPB / 64], wsr[CK_TPB / 64];
     const int bi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *__restrict__ C = xyz2p + (size_t)bi * xyz2p_stride;
     const float *__restrict__ RR = ratioR + (size_t)bi * stride;
     const float *__restrict__ RM = remainR + (size_t)bi * stride;
-    float *__restrict__ CC = cc + (size_t)bi * cstride * 3;
-    float *__restrict__ S3 = s3c + (size_t)bi * cstride;
-    float *__restrict__ S1 = s1c + (size_t)bi * cstride;
-    int *__restrict__ RW = rows + (size_t)bi * mpad;
+    float *__restrict__ CC = cols.cc + (size_t)bi * cstride * 3, *__restrict__ CS3 = cols.s3 + (size_t)bi * cstride,
+                        *__restrict__ CS1 = cols.s1 + (size_t)bi * cstride;
+    float *__restrict__ LC = live.cc + (size_t)bi * cstride * 3, *__restrict__ LS1 = live.s1 + (size_t)bi * cstride;
+    int *__restrict__ LR = live.rows + (size_t)bi * cstride;
     const int per = (m + CK_TPB - 1) / CK_TPB;
     const int l0 = tid * per;
     unsigned ncol = 0, nrow = 0;
-    // (a thread's entries and their coordinates in ONE round trip when it owns at most CK_REG of them -- clouds of up to 4096 points)
-    constexpr int CK_REG = 4;
-    float vr[CK_REG], vm[CK_REG], vx[CK_REG], vy[CK_REG], vz[CK_REG];
-    const bool reg = per <= CK_REG;
-    if (reg) {
-#pragma unroll
-        for (int q = 0; q < CK_REG; q++) {
-            const int l = min(l0 + q, m - 1);
-            const bool in = q < per && l0 + q < m;
-            vr[q] = in ? RR[l] : 0.f;
-            vm[q] = in ? RM[l] : 0.f;
-            vx[q] = C[(size_t)l * 3], vy[q] = C[(size_t)l * 3 + 1], vz[q] = C[(size_t)l * 3 + 2];
-        }
-#pragma unroll
-        for (int q = 0; q < CK_REG; q++) {
-            ncol += vr[q] != 0.f ? 1u : 0u;
-            nrow += vm[q] != 0.f ? 1u : 0u;
-        }
-    } else {
-        for (int q = 0; q < per; q++) {
-            const int l = l0 + q;
-            if (l < m) {
-                ncol += RR[l] != 0.f ? 1u : 0u;
-                nrow += RM[l] != 0.f ? 1u : 0u;
-            }
+    for (int q = 0; q < per; q++) {
+        const int l = l0 + q;
+        if (l < m) {
+            ncol += RR[l] != 0.f ? 1u : 0u;
+            nrow += RM[l] != 0.f ? 1u : 0u;
         }
     }
     auto wave_incl = [&](unsigned v) {
@@ -660,53 +648,266 @@ __global__ __launch_bounds__(CK_TPB) void am_compact_kernel(int m, int mpad, con
         tc = __shfl(sc, CK_TPB / 64 - 1, 64);
         tr = __shfl(sr, CK_TPB / 64 - 1, 64);
     }
-    if (reg) {
-#pragma unroll
-        for (int q = 0; q < CK_REG; q++) {
-            const int l = l0 + q;
-            if (q >= per || l >= m) continue;
-            if (vr[q] != 0.f) {
-                CC[pc * 3] = vx[q], CC[pc * 3 + 1] = vy[q], CC[pc * 3 + 2] = vz[q];
-                S3[pc] = vr[q];
-                S1[pc] = vm[q];
-                pc++;
-            }
-            if (vm[q] != 0.f) {
-                RW[pr++] = l;
-            } else if (ratioR_next) {
-                ratioR_next[(size_t)bi * stride + l] = 0.f;
-            }
+    for (int q = 0; q < per; q++) {
+        const int l = l0 + q;
+        if (l >= m) break;
+        const float rr = RR[l], rm = RM[l];
+        const float x = C[(size_t)l * 3], y = C[(size_t)l * 3 + 1], z = C[(size_t)l * 3 + 2];
+        if (rr != 0.f) {
+            CC[pc * 3] = x, CC[pc * 3 + 1] = y, CC[pc * 3 + 2] = z;
+            CS3[pc] = rr;
+            CS1[pc] = rm;
+            pc++;
         }
-    } else {
-        for (int q = 0; q < per; q++) {
-            const int l = l0 + q;
-            if (l >= m) break;
-            const float rr = RR[l], rm = RM[l];
-            if (rr != 0.f) {
-                CC[pc * 3] = C[(size_t)l * 3], CC[pc * 3 + 1] = C[(size_t)l * 3 + 1], CC[pc * 3 + 2] = C[(size_t)l * 3 + 2];
-                S3[pc] = rr;
-                S1[pc] = rm;
-                pc++;
-            }
-            if (rm != 0.f) {
-                RW[pr++] = l;
-            } else if (ratioR_next) {
-                ratioR_next[(size_t)bi * stride + l] = 0.f;
-            }
+        if (rm != 0.f) {
+            LC[pr * 3] = x, LC[pr * 3 + 1] = y, LC[pr * 3 + 2] = z;
+            LS1[pr] = rm;
+            LR[pr] = l;
+            pr++;
+        } else {
+            for (int u = 0; u < nlater; u++) ratioR_later[(size_t)u * lv_stride + (size_t)bi * stride + l] = 0.f;
         }
     }
     const unsigned tcp = (tc + 2 * SUB - 1) / (2 * SUB) * (2 * SUB);
-    for (unsigned j = tc + tid; j < tcp + SUB; j += CK_TPB) {  // zero-scalar columns: the padding and the sweep's prefetch slack
-        CC[j * 3] = CC[j * 3 + 1] = CC[j * 3 + 2] = 0.f;
-        S3[j] = S1[j] = 0.f;
+    for (unsigned e = tc + tid; e < tcp + SUB; e += CK_TPB) {  // zero-scalar columns: the padding and the sweep's prefetch slack
+        CC[e * 3] = CC[e * 3 + 1] = CC[e * 3 + 2] = 0.f;
+        CS3[e] = CS1[e] = 0.f;
     }
-    const unsigned trp = (tr + 127u) / 128u * 128u;
-    for (unsigned j = tr + tid; j < trp; j += CK_TPB) RW[j] = -1;
     if (tid == 0) {
-        counts[bi * 4] = (int)tcp;
-        counts[bi * 4 + 1] = (int)tr;
-        counts[bi * 4 + 2] = (int)tc;
+        cols.cnt[bi * 4] = (int)tcp;
+        cols.cnt[bi * 4 + 1] = (int)tc;
+        live.cnt[bi * 4] = (int)((tr + 2 * SUB - 1) / (2 * SUB) * (2 * SUB));
+        live.cnt[bi * 4 + 1] = (int)tr;
     }
+}
+
+// P2 of a level over the LIVE rows of set 2 (round 6; formulas: am_rowl_kernel).  Few rows are left at these levels (56 % of C4's
+// at level 2, 8 % at level 6, 0.3 % at the last): with a row per lane and the columns through scalar registers (am_rowl_kernel)
+// what is left is a handful of long waves, each a chain of scalar-load round trips nothing covers -- 18 us per launch however few
+// the rows.  Here the roles are turned round: a work item is PL_ROWS = 32 consecutive live rows, parked in LDS (few rows per
+// item: a launch with 70 rows left per sample still spreads over 96 CUs); each of its waves owns a
+// slice of the COLUMNS (set 1), PL_CPL per lane at a time in registers, walks the workgroup's PL_ROWS rows over them, reduces each row's terms
+// across the wave (DPP) and keeps row j's running sum in lane j.  Work ~ live rows x columns, in waves of equal length.
+//   prologue   the workgroup finds its rows itself: they are the survivors (s1 != 0) no. [32 bx, 32 bx + 32) of the previous
+//              level's packed set `in` (a scan of its s1 array: <= m floats) -- no compaction launch between the levels;
+//   epilogue   ratioR_v / remainR to the full vectors, and the rows with their new scalars into the other packed set `out`,
+//              which the fused P3(v) + P1(v + 1) sweep (am_rowk_kernel CMP) and the next level's P2 read; a row whose remainR
+//              reaches +0 here writes ratioR = 0 for every later level itself.
+// Sums: per lane over its columns in index order, then across the lanes, then across the waves in order -- another order than
+// am_rowl_kernel's (tolerance, not bits: tests/test_gpu_emd.py), the same for a sample whatever its batch.
+// (same device, C4: 16 / 32 / 64 rows per item 0.642 / 0.614 / 0.634 ms per approx_match + match_cost -- an item's prologue is two
+// round trips to memory whatever its rows; 512 threads x 4 columns per lane, unpacked: 0.671)
+constexpr int PL_TPB = 256, PL_NW = PL_TPB / 64, PL_ROWS = 32, PL_CPL = 8, PL_RU = 2;  // (PL_RU rows' chains side by side)
+static_assert(PL_CPL % 2 == 0, "the columns of a lane go through packed fp32 operations in pairs");
+static_assert(PL_ROWS % PL_RU == 0 && PL_ROWS <= 64, "a row per lane of the running sums");
+template <bool ZERO>
+__global__ __launch_bounds__(PL_TPB) void am_p2_live_kernel(int npad, const float *__restrict__ xyz1p, size_t xyz1p_stride,
+                                                            const float *__restrict__ ratioL, float *__restrict__ remainR,
+                                                            float *__restrict__ ratioR_out, size_t lv_stride, int nlater,
+                                                            size_t stride, float c_cur, LiveSet in, LiveSet out, size_t cstride, int cap, int b) {
+    __shared__ unsigned wsum[PL_NW];
+    __shared__ int rpos[PL_ROWS];            // this workgroup's rows: position in `in`
+    __shared__ float4 rowbuf[PL_ROWS];       // (x, y, z, remainR)
+    __shared__ float part[PL_NW][PL_ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // A FIXED grid walks the (chunk of rows, sample) items, chunk-major: how many chunks a sample still has is known on the device
+    // only, and one workgroup per possible chunk -- 4096 at C4, nearly all of which read their sample's count and leave -- cost a
+    // round trip to memory each, four residency rounds of them: an 8 us floor under a launch with 70 rows per sample left.  The
+    // counts of the items a workgroup walks past come out of the scalar cache after its first.
+    const int nitems = ((cap + PL_ROWS - 1) / PL_ROWS) * b;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int bx = item / b, bi = item - bx * b;
+    // Everything that does not depend on anything else is asked for FIRST and together -- the set's count, its s1 array (a thread's
+    // entries by the set's capacity, not by the count that is still on its way), the wave's first tile of columns: the launches of
+    // a level follow each other across XCDs, every one of these comes from memory (~2 us), and asked for one after the other they
+    // were a 19 us floor under this kernel however few its rows.
+    const int cin = ((const __attribute__((address_space(4))) int *)in.cnt)[bi * 4 + 1];  // entries of the previous set
+    if (bx != 0 && bx * PL_ROWS >= cin) continue;  // (uniform; survivors <= entries; chunk 0 always writes the new set's counts)
+    // what does not depend on anything else is asked for together: the set's s1 array (a thread's entries by the set's capacity)
+    // and the wave's first tile of columns -- every one of these comes from memory (~2 us: the launches of a level follow each
+    // other across XCDs)
+    const float *__restrict__ IS1 = in.s1 + (size_t)bi * cstride;
+    const float *__restrict__ C = xyz1p + (size_t)bi * xyz1p_stride;
+    const float *__restrict__ S = ratioL + (size_t)bi * stride;
+    const int per = (cap + PL_TPB - 1) / PL_TPB;  // (uniform; cap = the set's capacity: mpad)
+    const int e0 = tid * per;
+    float sv[8];
+    if (per <= 8) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) sv[q] = (q < per && e0 + q < cin) ? IS1[e0 + q] : 0.f;
+    }
+    const int slice = (npad / PL_NW + 63) / 64 * 64;  // (npad is a multiple of 128; the slices cover it, the last may be short)
+    const int k0 = wave * slice, k1 = min(npad, k0 + slice);
+    // (a lane's columns in PAIRS, the halves of packed fp32 operations -- v_pk_add / v_pk_mul / v_pk_fma, as am_rowl_kernel's two
+    // rows: per pair of terms 8 packed instructions and two exponentials instead of 18 scalar ones)
+    am_v2f cx[PL_CPL / 2], cy[PL_CPL / 2], cz[PL_CPL / 2], cs[PL_CPL / 2];
+#define RFA_PL_COLS(kb)                                                                  \
+    _Pragma("unroll") for (int q = 0; q < PL_CPL; q++) {                                 \
+        const int k = (kb) + q * 64 + lane;                                              \
+        const bool in_ = k < k1;                                                         \
+        const int kk = in_ ? k : 0;                                                      \
+        const float vx = C[(size_t)kk * 3], vy = C[(size_t)kk * 3 + 1], vz = C[(size_t)kk * 3 + 2]; \
+        const float vs = in_ ? S[kk] : 0.f; /* (padded columns of the set read 0 by themselves: am_init) */ \
+        if (q & 1) { cx[q / 2].y = vx, cy[q / 2].y = vy, cz[q / 2].y = vz, cs[q / 2].y = vs; }   \
+        else       { cx[q / 2].x = vx, cy[q / 2].x = vy, cz[q / 2].x = vz, cs[q / 2].x = vs; }   \
+    }
+    RFA_PL_COLS(k0)
+    // ---- the survivors' ranks: thread t owns `per` consecutive entries
+    unsigned mine = 0, alive = 0;  // (alive: bit q = entry e0 + q survives, for per <= 8 -- sets of up to 4096 entries)
+    if (per <= 8) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) alive |= (e0 + q < cin && sv[q] != 0.f) ? 1u << q : 0u;
+        mine = (unsigned)__builtin_popcount(alive);
+    } else {
+        for (int q = 0; q < per; q++) mine += (e0 + q < cin && IS1[e0 + q] != 0.f) ? 1u : 0u;
+    }
+    unsigned incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    if (tid < PL_ROWS) rpos[tid] = -1;
+    __syncthreads();
+    unsigned before = incl - mine, total = 0;
+#pragma unroll
+    for (int w = 0; w < PL_NW; w++) {
+        if (w < wave) before += wsum[w];
+        total += wsum[w];
+    }
+    const int lo = bx * PL_ROWS;
+    if (lo >= (int)total) {  // (uniform) no survivor left for this workgroup ...
+        if (bx == 0 && tid == 0) {  // ... (none at all: total == 0) the next sweeps see an empty set
+            out.cnt[bi * 4] = 0;
+            out.cnt[bi * 4 + 1] = 0;
+        }
+        if (bx == 0 && tid < SUB) {
+            float *oc = out.cc + (size_t)bi * cstride * 3;
+            oc[tid * 3] = oc[tid * 3 + 1] = oc[tid * 3 + 2] = 0.f;
+            out.s3[(size_t)bi * cstride + tid] = out.s1[(size_t)bi * cstride + tid] = 0.f;
+        }
+        __syncthreads();  // (wsum / rpos are rewritten by the next item)
+        continue;
+    }
+    {
+        unsigned r = before;
+        if (per <= 8) {
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                if (alive >> q & 1u) {
+                    if ((int)r >= lo && (int)r < lo + PL_ROWS) rpos[r - lo] = e0 + q;
+                    r++;
+                }
+        } else {
+            for (int q = 0; q < per; q++) {
+                const int e = e0 + q;
+                if (e < cin && IS1[e] != 0.f) {
+                    if ((int)r >= lo && (int)r < lo + PL_ROWS) rpos[r - lo] = e;
+                    r++;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int nrows = min(PL_ROWS, (int)total - lo);
+    int orig = -1;
+    if (tid < PL_ROWS) {
+        const int e = rpos[tid];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e >= 0) {
+            const float *ic = in.cc + (size_t)bi * cstride * 3 + (size_t)e * 3;
+            v = make_float4(ic[0], ic[1], ic[2], IS1[e]);
+            orig = in.rows[(size_t)bi * cstride + e];
+        }
+        rowbuf[tid] = v;
+    }
+    __syncthreads();
+    // ---- the sums: this wave's slice of the columns, PL_CPL per lane at a time (the first tile is in registers already)
+    float racc = 0.f;  // lane j: row j's sum over this wave's columns
+    for (int kb = k0; kb < k1; kb += 64 * PL_CPL) {
+        if (kb != k0) {
+            RFA_PL_COLS(kb)
+        }
+        for (int j0 = 0; j0 < nrows; j0 += PL_RU) {  // (rows behind the last hold zeros and are not kept)
+            float4 rw[PL_RU];
+            float a[PL_RU];
+#pragma unroll
+            for (int u = 0; u < PL_RU; u++) rw[u] = rowbuf[j0 + u];  // (broadcast reads)
+#pragma unroll
+            for (int u = 0; u < PL_RU; u++) {
+                am_v2f acc = {0.f, 0.f};
+                const am_v2f rx = {rw[u].x, rw[u].x}, ry = {rw[u].y, rw[u].y}, rz = {rw[u].z, rw[u].z};
+#pragma unroll
+                for (int q = 0; q < PL_CPL / 2; q++) {
+                    const am_v2f dx = rx - cx[q], dy = ry - cy[q], dz = rz - cz[q];
+                    const am_v2f d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));  // (rf::d2_fma's order)
+                    am_v2f e = {1.0f, 1.0f};
+                    if (!ZERO) {
+                        const am_v2f t = d2 * c_cur;
+                        e = am_v2f{fast_exp2(t.x), fast_exp2(t.y)};
+                    }
+                    acc = __builtin_elementwise_fma(e, cs[q], acc);
+                }
+                a[u] = acc.x + acc.y;
+            }
+            // the wave's sums: row shifts, then the two row broadcasts (lane 63 holds them)
+#define RFA_DPP_ADD(ctrl, rmask)                                                                                             \
+    _Pragma("unroll") for (int u = 0; u < PL_RU; u++)                                                                        \
+        a[u] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a[u]), ctrl, rmask, 0xf, false))
+            RFA_DPP_ADD(0x111, 0xf);
+            RFA_DPP_ADD(0x112, 0xf);
+            RFA_DPP_ADD(0x114, 0xf);
+            RFA_DPP_ADD(0x118, 0xf);
+            RFA_DPP_ADD(0x142, 0xa);
+            RFA_DPP_ADD(0x143, 0xc);
+#undef RFA_DPP_ADD
+#pragma unroll
+            for (int u = 0; u < PL_RU; u++) {
+                const float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a[u]), 63));
+                racc = lane == j0 + u ? racc + tot : racc;
+            }
+        }
+    }
+#undef RFA_PL_COLS
+    if (lane < PL_ROWS) part[wave][lane] = racc;
+    __syncthreads();
+    if (tid < PL_ROWS && tid < nrows) {
+        float sumr = part[0][tid];
+#pragma unroll
+        for (int w = 1; w < PL_NW; w++) sumr += part[w][tid];
+        const float4 rw = rowbuf[tid];
+        const float rem = rw.w;
+        const float t = sumr * rem;
+        const float cons = fminf(rem / (t + 1e-9f), 1.0f);
+        const float ro = rem * cons, rn = fmaxf(0.0f, rem - t);
+        const size_t o = (size_t)bi * stride + orig;
+        ratioR_out[o] = ro;
+        remainR[o] = rn;
+        if (rn == 0.f)
+            for (int u = 1; u <= nlater; u++) ratioR_out[o + (size_t)u * lv_stride] = 0.f;  // dead from here on
+        const size_t p = (size_t)bi * cstride + lo + tid;
+        float *oc = out.cc + (size_t)bi * cstride * 3 + (size_t)(lo + tid) * 3;
+        oc[0] = rw.x, oc[1] = rw.y, oc[2] = rw.z;
+        out.s3[p] = ro;
+        out.s1[p] = rn;
+        out.rows[p] = orig;
+    }
+    // the set's padding (zero-scalar entries up to a multiple of 16, + one sub-chunk) and its counts: the workgroup that holds its end
+    if (lo + PL_ROWS >= (int)total) {
+        const int tp = ((int)total + 2 * SUB - 1) / (2 * SUB) * (2 * SUB);
+        for (int e = (int)total + tid; e < tp + SUB; e += PL_TPB) {
+            float *oc = out.cc + (size_t)bi * cstride * 3 + (size_t)e * 3;
+            oc[0] = oc[1] = oc[2] = 0.f;
+            out.s3[(size_t)bi * cstride + e] = out.s1[(size_t)bi * cstride + e] = 0.f;
+        }
+        if (tid == 0) {
+            out.cnt[bi * 4] = tp;
+            out.cnt[bi * 4 + 1] = (int)total;
+        }
+    }
+    __syncthreads();  // (the LDS arrays are rewritten by the next item)
+    }  // items
 }
 
 // match[l][k] = sum over levels (in order) of fma(ratioL_lv[k]*e_lv, ratioR_lv[l], acc).
@@ -1779,7 +1980,7 @@ struct AmLayout {
     size_t off_fgt;
     bool compact_ok;       // from the third level on the sweeps run over the LIVE columns / rows of set 2 only (am_compact_kernel)
     size_t cstride;        // floats per sample of a packed column array
-    size_t off_cc, off_s3c, off_s1c, off_rows, off_cnt;
+    size_t off_live[2], live_floats;  // two packed sets (LiveSet), used in turn
     size_t off_maskk, off_maskl;  // (rowsort_ok) the skipping sweeps' column lists, rows of set 1 / rows of set 2 (am_rowk_kernel MASK)
     int nsa, nsb;          // padded sizes of the two sorted sets
     size_t Vs;             // floats per sorted twin pair [L: nsa | R: nsb]
@@ -1848,19 +2049,14 @@ AmLayout am_layout(int b, int n, int m, int nlevels, bool allow_cull, int mode =
     // (by the clouds' sizes alone, never by b: what a sample's sweeps sum over must not depend on the batch it is called in)
     L.compact_ok = !swept && n >= 512 && m >= 512;
     L.cstride = (size_t)L.mpad + 64;
-    L.off_cc = L.off_s3c = L.off_s1c = L.off_rows = L.off_cnt = 0;
+    L.off_live[0] = L.off_live[1] = 0;
+    L.live_floats = (size_t)b * L.cstride * 6 + (size_t)b * 4 + 64;  // cc (3) + s3 + s1 + rows, counts
     if (L.compact_ok) {
-        off = (off + 63) / 64 * 64;
-        L.off_cc = off;
-        off += (size_t)b * L.cstride * 3 + 64;
-        L.off_s3c = off;
-        off += (size_t)b * L.cstride + 64;
-        L.off_s1c = off;
-        off += (size_t)b * L.cstride + 64;
-        L.off_rows = off;
-        off += (size_t)b * L.mpad + 64;
-        L.off_cnt = off;
-        off += (size_t)b * 4 + 64;
+        for (int q = 0; q < 2; q++) {
+            off = (off + 63) / 64 * 64;
+            L.off_live[q] = off;
+            off += L.live_floats;
+        }
     }
     L.off_maskk = L.off_maskl = 0;
     if (L.rowsort_ok) {
@@ -1927,8 +2123,12 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
     // Live columns (am_compact_kernel): from level vC on, every sweep runs over the columns / rows of set 2 whose scalars are not
     // exactly 0 -- which, at the broad end of the schedule, is a few per cent of them: with it the broad levels cost less as
     // sweeps than as expansions, so the expansion route is left to RF_EMD_EXPANDED.
-    const bool compact = L.compact_ok && ncull == 0 && nlevels >= 4 && mode != RF_EMD_EXPANDED;
     constexpr int vC = 2;
+    bool compact = L.compact_ok && ncull == 0 && nlevels >= 4 && mode != RF_EMD_EXPANDED;
+    // (the packed sets are handed from level to level: a level from vC on that would take the skipping sweeps -- a schedule with
+    // more than two levels that sharp -- keeps the whole call on the old sweeps)
+    for (int v = vC; v < nlevels; v++)
+        if (lc.c[v] < 0.f && kSkipArg / -lc.c[v] <= kSkipMaxT) compact = false;
     const bool fgt = L.fgt_ok && vF < nlevels && vF >= ncull + 1 && !compact;
     void *fws = fgt ? (void *)(w + L.off_fgt) : nullptr;
     // (padded entries of every vector must read 0 -- they are column scalars of padded columns: am_init writes them; the same
@@ -1990,8 +2190,19 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
                         n < 65536 && m < 65536 &&  // (16-bit column numbers ...
                         L.mpad / segk <= 65535 && L.npad / segl <= 65535;  // ... and 16-bit per-wave counts: a segment of 65536 columns, all listed, would wrap to 0)
     unsigned short *maskk = (unsigned short *)(w + L.off_maskk), *maskl = (unsigned short *)(w + L.off_maskl);
-    float *ccol = w + L.off_cc, *cs3 = w + L.off_s3c, *cs1 = w + L.off_s1c;
-    int *crows = (int *)(w + L.off_rows), *ccnt = (int *)(w + L.off_cnt);
+    auto live_set = [&](int q) {
+        float *base = w + L.off_live[q];
+        LiveSet ls;
+        ls.cc = base;
+        ls.s3 = base + (size_t)b * L.cstride * 3;
+        ls.s1 = ls.s3 + (size_t)b * L.cstride;
+        ls.rows = (int *)(ls.s1 + (size_t)b * L.cstride);
+        ls.cnt = ls.rows + (size_t)b * L.cstride;
+        return ls;
+    };
+    const LiveSet setA = compact ? live_set(0) : LiveSet{}, setB = compact ? live_set(1) : LiveSet{};
+    // level v >= vC: P2 packs its rows into out(v) = (v - vC) even ? B : A, from in(v) = out(v - 1) (in(vC) = A: am_compact_kernel's
+    // live set); the fused sweep in front of it reads am_compact_kernel's column set (B) at vC, out(v - 1) after
     for (int v = 0; v < nlevels; v++) {
         float *ratioL = ratios + (size_t)v * L.V, *ratioR = ratioL + L.npad;
         const bool zero = lc.c[v] == 0.0f;  // e = exp2(d2 * 0) = 1 exactly: no exponential needed
@@ -2038,9 +2249,11 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
     n, L.mpad / segk, xyz1, (const float *)x2p, (size_t)L.mpad * 3, pR_, (const float *)remainR, pL_,  \
         remainL, ratioL, L.bstride, cprev, lc.c[v], permA, L.nsa, tsk, skip_t(v - 1), gptr, 1
         const bool live = compact && v >= vC && !skip;  // this level's sweeps run over the live columns / rows (packed after P2 of level v - 1)
+        const LiveSet p2out = ((v - vC) & 1) ? setA : setB, p2in = v == vC ? setA : (((v - vC) & 1) ? setB : setA);
+        const LiveSet kin = v == vC ? setB : p2in;
 #define AM_ROWK_LIVE(pL_, cprev)                                                                                         \
-    n, 0, xyz1, (const float *)ccol, L.cstride * 3, (const float *)cs3, (const float *)cs1, pL_, remainL, ratioL, L.bstride, cprev, \
-        lc.c[v], (const int *)nullptr, 0, INFINITY, INFINITY, gptr, 1, (unsigned short *)nullptr, 0.f, (const int *)ccnt, L.cstride
+    n, 0, xyz1, (const float *)kin.cc, L.cstride * 3, (const float *)kin.s3, (const float *)kin.s1, pL_, remainL, ratioL, L.bstride, cprev, \
+        lc.c[v], (const int *)nullptr, 0, INFINITY, INFINITY, gptr, 1, (unsigned short *)nullptr, 0.f, (const int *)kin.cnt, L.cstride
         if (live) {
             const float *pL = ratios + (size_t)(v - 1) * L.V;
             if (zero) {
@@ -2089,17 +2302,13 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
         }
 #undef AM_ROWK_ARGS
         if (live) {
-            // (few rows are left: as many column segments as the columns allow, so that what is left is spread over more, shorter waves)
-            int segl = 1;
-            while (segl < 16 && L.npad / (segl * 2) >= 64 && (L.npad / (segl * 2)) % (2 * SUB) == 0) segl *= 2;
+            const dim3 gp(min(rf::ceil_div(L.mpad, PL_ROWS) * b, 2048));  // (eight workgroups of four waves per CU: all resident)
             if (zero) {
-                RF_LAUNCH("am_p2", (am_rowl_kernel<RPT, true, false, 0, true>), gl, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
-                          (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR, L.bstride, lc.c[v],
-                          (const int *)crows, L.mpad, tsk, gptr, 1, (unsigned short *)nullptr, 0.f, (const int *)ccnt);
+                RF_LAUNCH("am_p2", am_p2_live_kernel<true>, gp, dim3(PL_TPB), 0, s, L.npad, (const float *)x1p, (size_t)L.npad * 3,
+                          (const float *)ratioL, remainR, ratioR, L.V, nlevels - 1 - v, L.bstride, lc.c[v], p2in, p2out, L.cstride, L.mpad, b);
             } else {
-                RF_LAUNCH("am_p2", (am_rowl_kernel<RPT, false, false, 0, true>), gl, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
-                          (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR, L.bstride, lc.c[v],
-                          (const int *)crows, L.mpad, tsk, gptr, 1, (unsigned short *)nullptr, 0.f, (const int *)ccnt);
+                RF_LAUNCH("am_p2", am_p2_live_kernel<false>, gp, dim3(PL_TPB), 0, s, L.npad, (const float *)x1p, (size_t)L.npad * 3,
+                          (const float *)ratioL, remainR, ratioR, L.V, nlevels - 1 - v, L.bstride, lc.c[v], p2in, p2out, L.cstride, L.mpad, b);
             }
         } else
         if (zero) {
@@ -2125,10 +2334,10 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
                       (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR,
                       L.bstride, lc.c[v], permB, L.nsb, tsk, gptr, 1);
         }
-        if (compact && v + 1 >= vC && v + 1 < nlevels) {  // what is still live of set 2, for the next level's sweeps
-            float *ratioR_next = ratios + (size_t)(v + 1) * L.V + L.npad;
-            RF_LAUNCH("am_compact", am_compact_kernel, dim3(b), dim3(CK_TPB), 0, s, m, L.mpad, (const float *)x2p, (size_t)L.mpad * 3,
-                      (const float *)ratioR, (const float *)remainR, ratioR_next, L.bstride, ccol, cs3, cs1, crows, ccnt, L.cstride);
+        if (compact && v + 1 == vC) {  // the first two packed sets (from here on every P2 packs the next one itself)
+            float *ratioR_later = ratios + (size_t)(v + 1) * L.V + L.npad;
+            RF_LAUNCH("am_compact", am_compact_kernel, dim3(b), dim3(CK_TPB), 0, s, m, (const float *)x2p, (size_t)L.mpad * 3,
+                      (const float *)ratioR, (const float *)remainR, ratioR_later, L.V, nlevels - 1 - v, L.bstride, setB, setA, L.cstride);
         }
     }
     return RF_OK;
