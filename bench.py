@@ -81,12 +81,15 @@ EMD_LAUNCH_MIX = {
     # v_pk_fma: 4th field = packed instructions per pair, two pairs per instruction): P2 8 packed per two pairs, the fused
     # P3 + P1 11, P3 alone 9; from level 2 (-4^5: a wave keeps 42 % of its columns) on the sweeps are dense -- packed, they beat
     # the skipping form there and the form with only its P3 part conditional
-    "am_p2, levels 2-6 (packed)": (5, 0, 1, 4.0),
+    # round 6: from the third level on the sweeps run over the LIVE columns / rows of set 2 only -- remainR is exactly +0 for
+    # 44 / 68 / 80 / 87 / 92 / 97 / 99 / 99.7 % of C4's columns after levels 1 .. 8 (the same kind of constant as the keep fractions
+    # above: measured on this workload by tools/experiments/emd_live_fractions.py, NOT counted in this run).  The fused P3(v) + P1(v+1)
+    # sweeps of level pairs 1+2 .. 8+9 visit 0.91 + 0.56 + 0.32 + 0.20 + 0.135 + 0.08 + 0.033 + 0.008 = 2.25 sweeps' worth of pairs
+    # (packed: 5.5 instructions per pair, two exponentials), P2 of levels 2 .. 9 0.56 + ... + 0.003 = 1.34 (am_p2_live_kernel: 4 packed per
+    # pair, one exponential, and the wave reduction of a row's terms -- 8 instructions per 8 pairs)
+    "am_p3p1 over the live columns, level pairs 1+2 .. 8+9 (packed)": (2.25, 0, 2, 5.5),
+    "am_p2 over the live rows, levels 2 .. 9 (packed)": (1.34, 1.0, 1, 4.0),
     "am_p3p1, levels 0+1 (skipping, P3 under its own test)": (1, 7 + 0.185 * 2 + 0.088 * 3, 0.185 + 0.088),
-    "am_p3p1, level pairs 1+2, 2+3, 3+4, 4+5, 5+6 (packed)": (5, 0, 2, 5.5),
-    # round 5, late: levels 7, 8 and 9 (-1, -0.25, 0) are not swept any more -- their row sums come from a truncated Taylor expansion
-    # about the clouds' centre (emd_fgt.hip: 7 small fp64 launches, `emd.roofline.expanded_levels`), so the P3 of level 6 runs alone
-    "am_p3 (level 6 alone, packed)": (1, 0, 1, 4.5),
     # round 5: levels 1, 3, 5, 7 take their weight from the next level's by two squarings (2 mul instead of mul + exp)
     # ... and the sharpest level is evaluated only where some column of the wave is within its cut-off of the row (14 % of the
     # (wave, row) pairs at C4: 1 - (1 - 0.0023)^64)
@@ -881,8 +884,8 @@ def main():
         del mt
         # (no kernel events -- a renamed kernel, events unavailable under a tool: fall back to the wall time, never divide by 0)
         am_kernel_ms = sum(am_k.values()) or am_ms
-        # the issue floor models the SWEPT launches (fp32 VALU + v_exp_f32) and the materialisation; the expanded levels' fp64 launches,
-        # the row sort and the init kernels are reported beside it
+        # the issue floor models the sweeps (fp32 VALU + v_exp_f32) and the materialisation; the row sort, the init and the packing
+        # kernels are reported beside it
         am_swept_ms = sum(v for k, v in am_k.items() if k in ("am_p1", "am_p2", "am_p3p1", "am_p3", "am_match")) or am_kernel_ms
         efl = emd_issue_floor_ms(eb, en, en)
         lane_ops = (efl["valu_per_pair"] if efl else 250.0) * eb * en * en
@@ -932,7 +935,7 @@ def main():
         dt_emd, dt_ns, dt_emdf, dt_x50 = (float(tmax[i].item()) for i in range(4))
         extras["emd"] = {
             "roofline": {
-                "bound": "valu+trans", "kernel": "am_p1 + am_p2 + am_p3p1 + am_p3 + am_match (approx_match: 15 swept launches; + 8 launches of the expanded levels, the row sort)",
+                "bound": "valu+trans", "kernel": "am_p1 + am_p2 + am_p3p1 + am_match (approx_match: 20 sweeps -- from the third level on over the live columns / rows of set 2 only -- + the materialisation; the row sort, one packing launch)",
                 "lane_ops_per_pair": efl["valu_per_pair"] if efl else None, "exp_per_pair": efl["exp_per_pair"] if efl else None,
                 "packed_instructions_per_pair": efl["packed_per_pair"] if efl else None,
                 "achieved": lane_ops / (am_kernel_ms * 1e-3) / 1e12, "unit": "T lane-ops/s",
@@ -942,17 +945,15 @@ def main():
                                       "profiles/issue_costs.json missing",
                 "frac": (efl["mix_ms"] / am_swept_ms) if efl else None,
                 "swept_kernel_sum_ms": am_swept_ms,
-                "expanded_levels": {"what": "levels -1, -0.25 and 0 of the schedule: row sums from one truncated Taylor expansion about the "
-                                            "clouds' centre (emd_fgt.hip, fp64, degree 10 / 8 / 0).  Every row's sum carries a certificate: an error bound from one "
-                                            "extra moment; a row whose bound exceeds 4e-6 of its sum is summed directly (C4: bound <= 2.5e-6, true error "
-                                            "<= 3.4e-7, no row fails; two clusters in opposite corners: every row fails and is summed directly); clouds "
-                                            "beyond a unit cube or with non-finite coordinates are refused per batch element on the device",
-                                    "kernels_ms": {k: v for k, v in am_k.items() if k.startswith("am_fgt")}},
+                "live_columns": "from the third level on the sweeps run over the columns / rows of set 2 whose remainR is not exactly +0 (a dead "
+                                "column adds fma(e, +0, acc) = acc): 56 % of C4's columns at level -1024, 3 % at level -1; every sum is over the same terms as "
+                                "the reference's (another order: tolerance).  Round 5's Taylor expansion of the three broadest levels is gone "
+                                "(tools/experiments/emd_fgt_route.patch.txt)",
                 "frac_of_fp32_peak": 2.0 * lane_ops / (am_kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
                 # against the CHIP, not the model above: the reference schedule's 30*B*n*m exponentials per call over the whole
                 # approx_match kernel time, against the transcendental issue roof (one v_exp_f32 wave-instruction per 8.14 cycles per
                 # SIMD x 1024 SIMDs x 64 lanes x 2.36 GHz = 1.9e13 exp/s); `chip_frac_executed` prices only the exponentials the
-                # kernels still execute (skipped columns, squared levels and expanded levels execute none)
+                # kernels still execute (skipped and dead columns and squared levels execute none)
                 "trans_roof_exp_per_s": TRANS_ROOF_EXP_PER_S,
                 "chip_frac": 30.0 * eb * en * en / (am_kernel_ms * 1e-3) / TRANS_ROOF_EXP_PER_S,
                 "chip_frac_executed": ((efl["exp_per_pair"] * eb * en * en / (am_kernel_ms * 1e-3) / TRANS_ROOF_EXP_PER_S) if efl else None),
@@ -963,8 +964,7 @@ def main():
                         "transcendental work); d2 via the |a|^2+|b|^2-2ab GEMM is ruled out because exp(-16384 d2) amplifies "
                         "its cancellation error to ~7e-4 relative (DESIGN.md 5.5, K=4 trial recorded there)",
                 "dense_equivalent": {"lane_ops_per_pair": 254, "exp_per_pair": 32,
-                                     "what": "the schedule with every pair of every level evaluated (round 5 before the skipping sweeps "
-                                             "and the expanded levels); the skipped terms are exact zeros"},
+                                     "what": "the schedule with every pair of every level evaluated; the terms left out are exact zeros"},
                 "note": "frac = issue floor derived from EXECUTED instructions (counted, with the model's keep fractions for the "
                         "skipping sweeps; a packed instruction = two fp32 operations per lane, counted once and priced at its own measured "
                         "issue cost; the 1.155 non-additivity factor was measured on the scalar column mix) x measured issue costs / measured kernel time; "

@@ -148,16 +148,14 @@ int rf_approxmatch_levels(int b, int n, int m, const float *xyz1, const float *x
 /* The same op with its route pinned.  The reference's kernel loops over the samples of a batch independently
  * (tf_approxmatch.cu:13), so a sample's match does not depend on the batch it is called in.  RF_EMD_AUTO (what rf_approxmatch /
  * rf_approxmatch_levels / rf_earth_mover pass) picks launch shapes and routes by the size of the WHOLE batch: from 6e7 pairs on
- * the sweeps take their rows in spatial order, from 8e7 pairs on the three broad levels come from an expansion, and the column
- * segments of a sweep follow b -- every route within the op's tolerances, but the bits of sample i differ between a call on the
- * batch and a call on that sample alone.  RF_EMD_SWEPT pins the route: every level a dense sweep over the clouds in the caller's
- * order, launch shapes those of a batch of one -- sample i's match (and rf_earth_mover_mode's cost) is bit-identical whatever the
- * batch around it or the shard it lands in (what a loss compared across differently sharded runs wants; C4 costs ~1.2x the
- * time).  RF_EMD_EXPANDED takes the sorted-row sweeps and the expansion wherever the SHAPES allow them (n, m >= 512), whatever the
- * batch: for tests of that route on small batches.  levels_host == NULL with nlevels == 0: the reference schedule. */
+ * the sharp levels' sweeps take their rows in spatial order and skip columns, and the column segments of a sweep follow b --
+ * every route within the op's tolerances, but the bits of sample i may differ between a call on the batch and a call on that
+ * sample alone.  RF_EMD_SWEPT pins the route: every level a dense sweep over the clouds in the caller's order, launch shapes
+ * those of a batch of one -- sample i's match (and rf_earth_mover_mode's cost) is bit-identical whatever the batch around it or
+ * the shard it lands in (what a loss compared across differently sharded runs wants; C4 costs ~1.5x the time).
+ * levels_host == NULL with nlevels == 0: the reference schedule. */
 #define RF_EMD_AUTO 0
 #define RF_EMD_SWEPT 1
-#define RF_EMD_EXPANDED 2
 size_t rf_approxmatch_mode_workspace_bytes(int b, int n, int m, int nlevels /* 0 = reference's 10 */, int mode);
 int rf_approxmatch_mode(int b, int n, int m, const float *xyz1, const float *xyz2, float *match,
                         const float *levels_host, int nlevels, void *workspace, size_t workspace_bytes,

@@ -316,7 +316,7 @@ def _emd_inputs(st, xyz1, xyz2, opname):
 
 
 # rf_approxmatch_mode / rf_earth_mover_mode (include/rfops.h): "swept" pins the route -- a sample's bits do not depend on the batch
-EMD_MODES = {"auto": 0, "swept": 1, "expanded": 2}
+EMD_MODES = {"auto": 0, "swept": 1}
 
 
 @H.on_input_device
@@ -324,7 +324,7 @@ def approx_match(xyz1, xyz2, levels=None, mode="auto"):
     """ApproxMatchGpuOp::Compute, pc_distance/tf_approxmatch.cpp:148-172 -> match (b,m,n).
 
     `levels` (optional, extension): explicit annealing schedule; default = the reference's 10.
-    `mode` (extension): "auto" | "swept" (batch-invariant bits per sample, as the reference's per-sample loop) | "expanded".
+    `mode` (extension): "auto" | "swept" (batch-invariant bits per sample, as the reference's per-sample loop).
     """
     if mode not in EMD_MODES:
         raise H.invalid(f"ApproxMatch: mode must be one of {sorted(EMD_MODES)}")

@@ -28,8 +28,6 @@
 
 #include "common.hpp"
 #include "nn_pruned.hpp"
-#include "emd_fgt.hpp"
-#include "emd_fgt_prep.hpp"
 
 namespace {
 
@@ -90,16 +88,10 @@ struct AmInit {
     float *vec;        // the vector region: per batch element `stride` floats = nslots slots of V = npad[0] + npad[1] floats
     size_t stride, V;  // slot s: [cloud 0's vector (npad[0]) | cloud 1's (npad[1])]
     int nslots, b;
-    rfe::Geom *geom;   // != nullptr: blocks (0, bi, 2) run the expansion's geometry pass (emd_fgt_prep.hpp) for element bi
-    double a_max;
 };
-constexpr int AI_TPB = 1024;  // (the geometry pass is one workgroup per batch element: 13 us with 256 threads, 8 with 1024)
+constexpr int AI_TPB = 1024;
 __global__ __launch_bounds__(AI_TPB) void am_init_kernel(AmInit a) {
     const int bi = blockIdx.y, c = blockIdx.z;
-    if (c == 2) {  // (uniform per workgroup)
-        if (blockIdx.x == 0) rfe::fgt_prep_block<AI_TPB>(bi, a.npts[0], a.npts[1], a.xyz[0], a.xyz[1], a.a_max, a.geom);
-        return;
-    }
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int npts = c ? a.npts[1] : a.npts[0], npad = c ? a.npad[1] : a.npad[0];
     if (bi == 0 && c == 0 && j < 64) a.vec[(size_t)a.b * a.stride + j] = 0.f;  // the slack behind the last element's vectors
@@ -162,8 +154,7 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
     static_assert(MASK == 0 || SKIP == 1, "column lists belong to the skipping sweeps");
     static_assert(CMP == 0 || (SKIP == 0 && MASK == 0), "the live-column form is a dense sweep over a shorter column set");
     __shared__ float part3[16][64 * RPT], part1[16][64 * RPT];
-    // (the broad levels: this sweep runs only when the expansion of emd_fgt.hip was refused for the call's clouds, or -- the
-    // P3-only form before the first expanded level -- only when it was accepted; guard = NULL: always)
+    // (guard: an optional device word that switches the launch off -- unused by the current routes)
     if (guard && (*guard != 0) != (guard_want != 0)) return;
     static_assert(SKIP == 0 || P1 == 1, "the skipping sweeps evaluate this level's own exponential");
     // (a sample's workgroups on ONE XCD, rf::xcd_contiguous: its columns are then read from HBM by one L2 instead of eight)
@@ -1976,8 +1967,6 @@ struct AmLayout {
     // culled sweeps (sizes known without the level values: room is reserved whenever the clouds qualify)
     bool cull_ok;
     bool rowsort_ok;       // the dense sweeps of the sharp levels take their rows in the clouds' spatial order (am_rowk_kernel SKIP)
-    bool fgt_ok;           // the broad levels by expansion (emd_fgt.hip): scratch reserved
-    size_t off_fgt;
     bool compact_ok;       // from the third level on the sweeps run over the LIVE columns / rows of set 2 only (am_compact_kernel)
     size_t cstride;        // floats per sample of a packed column array
     size_t off_live[2], live_floats;  // two packed sets (LiveSet), used in turn
@@ -1992,10 +1981,6 @@ constexpr int CULL_MAXLV = 8;  // at most this many leading levels are culled
 #define RFA_ROWSORT_MIN_PAIRS 6.0e7
 #endif
 constexpr double ROWSORT_MIN_PAIRS = RFA_ROWSORT_MIN_PAIRS;
-#ifndef RFA_FGT_MIN_PAIRS
-#define RFA_FGT_MIN_PAIRS 8.0e7
-#endif
-constexpr double FGT_MIN_PAIRS = RFA_FGT_MIN_PAIRS;
 
 int round_up_i(int v, int q) { return (v + q - 1) / q * q; }
 
@@ -2003,8 +1988,7 @@ int round_up_i(int v, int q) { return (v + q - 1) / q * q; }
 // must not carry the sorted sets and twin slots (about 50 MB at 32 x 16384^2) for nothing
 // mode (include/rfops.h): RF_EMD_AUTO -- the routes by the size of the whole batch (below); RF_EMD_SWEPT -- every level as a
 // dense sweep over the clouds in the caller's order and every launch shape taken as for b = 1: a sample's bits do not depend on
-// the batch it is called in (the reference is batch-independent per sample, tf_approxmatch.cu:13); RF_EMD_EXPANDED -- sorted rows,
-// skipping sweeps and the expanded broad levels wherever the SHAPES allow them, whatever the batch (small-batch tests of that route).
+// the batch it is called in (the reference is batch-independent per sample, tf_approxmatch.cu:13).
 AmLayout am_layout(int b, int n, int m, int nlevels, bool allow_cull, int mode = RF_EMD_AUTO) {
     AmLayout L;
     L.npad = round_up_i(n, CPAD);
@@ -2016,10 +2000,10 @@ AmLayout am_layout(int b, int n, int m, int nlevels, bool allow_cull, int mode =
     off += (size_t)b * L.npad * 3 + 64;
     L.off_x2 = off;
     off += (size_t)b * L.mpad * 3 + 64;
-    const bool swept = mode == RF_EMD_SWEPT, forced = mode == RF_EMD_EXPANDED;
+    const bool swept = mode == RF_EMD_SWEPT;
     L.cull_ok = !swept && allow_cull && n >= CULL_MIN_PTS && m >= CULL_MIN_PTS && rfp::pruned_supported(b, n, m);
     // (sizes alone decide; same device: 32 x 1024^2 = 3.4e7 pairs 0.324 ms with the sort against 0.316 without, 32 x 2048^2 = 1.3e8 pairs 1.026 against 1.057)
-    L.rowsort_ok = !swept && n >= 512 && m >= 512 && (forced || (double)b * n * m >= ROWSORT_MIN_PAIRS) && rfp::pruned_supported(b, n, m);
+    L.rowsort_ok = !swept && n >= 512 && m >= 512 && (double)b * n * m >= ROWSORT_MIN_PAIRS && rfp::pruned_supported(b, n, m);
     L.nsa = L.nsb = 0;
     L.Vs = L.tw_stride = L.off_sa = L.off_sb = L.off_tw = 0;
     if (L.cull_ok || L.rowsort_ok) {
@@ -2037,14 +2021,6 @@ AmLayout am_layout(int b, int n, int m, int nlevels, bool allow_cull, int mode =
         L.tw_stride = L.Vs * (size_t)(1 + CULL_MAXLV);
         L.off_tw = off;
         off += (size_t)b * L.tw_stride + 64;
-    }
-    // (from about 4e6 pairs per sweep on: below, five tiny dense sweeps are cheaper than the expansion's seven launches)
-    L.fgt_ok = !swept && n >= 512 && m >= 512 && (forced || (double)b * n * m >= FGT_MIN_PAIRS);
-    L.off_fgt = 0;
-    if (L.fgt_ok) {
-        off = (off + 63) / 64 * 64;
-        L.off_fgt = off;
-        off += (rfe::fgt_workspace_bytes(b, n > m ? n : m) + 3) / 4 + 64;
     }
     // (by the clouds' sizes alone, never by b: what a sample's sweeps sum over must not depend on the batch it is called in)
     L.compact_ok = !swept && n >= 512 && m >= 512;
@@ -2114,25 +2090,17 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
     float *x1p = w + L.off_x1, *x2p = w + L.off_x2;
     // the leading sharp levels run culled over spatially sorted (sort-tile-recursive) copies of the clouds (am_cull_kernel)
     const int ncull = allow_cull ? cull_levels(L, nlevels, lc) : 0;
-    // The broad tail of the schedule by expansion (emd_fgt.hip): every level from vF on has sharpness a = -c ln 2 <= kFgtMaxA
-    // (the reference schedule: levels -1, -0.25, 0 -> vF = 7).  The device decides per batch element whether the clouds' extent
-    // allows it (Geom::bad): a refused element's row sums are formed directly inside the expansion's own launches (direct_sum).
-    auto sharp = [&](int v) { return (double)(-lc.c[v]) * 0.69314718055994530942; };
-    int vF = nlevels;
-    while (vF > 1 && lc.c[vF - 1] <= 0.f && sharp(vF - 1) <= (double)rfe::kFgtMaxA * 1.0001) vF--;
     // Live columns (am_compact_kernel): from level vC on, every sweep runs over the columns / rows of set 2 whose scalars are not
-    // exactly 0 -- which, at the broad end of the schedule, is a few per cent of them: with it the broad levels cost less as
-    // sweeps than as expansions, so the expansion route is left to RF_EMD_EXPANDED.
+    // exactly 0 -- which, at the broad end of the schedule, is a few per cent of them.  (Round 5 took the three broadest levels
+    // from a truncated Taylor expansion about the clouds' centre instead of sweeping them: 121 us per call at C4 for what these
+    // sweeps now do in 40, exactly -- tools/experiments/emd_fgt_route.patch.txt.)
     constexpr int vC = 2;
-    bool compact = L.compact_ok && ncull == 0 && nlevels >= 4 && mode != RF_EMD_EXPANDED;
+    bool compact = L.compact_ok && ncull == 0 && nlevels >= 4;
     // (the packed sets are handed from level to level: a level from vC on that would take the skipping sweeps -- a schedule with
     // more than two levels that sharp -- keeps the whole call on the old sweeps)
     for (int v = vC; v < nlevels; v++)
         if (lc.c[v] < 0.f && kSkipArg / -lc.c[v] <= kSkipMaxT) compact = false;
-    const bool fgt = L.fgt_ok && vF < nlevels && vF >= ncull + 1 && !compact;
-    void *fws = fgt ? (void *)(w + L.off_fgt) : nullptr;
-    // (padded entries of every vector must read 0 -- they are column scalars of padded columns: am_init writes them; the same
-    // launch carries the expansion's geometry pass, one more workgroup per batch element)
+    // (padded entries of every vector must read 0 -- they are column scalars of padded columns: am_init writes them)
     {
         AmInit ai;
         ai.npts[0] = n, ai.npts[1] = m, ai.npad[0] = L.npad, ai.npad[1] = L.mpad;
@@ -2140,9 +2108,7 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
         ai.xyz[0] = xyz1, ai.xyz[1] = xyz2, ai.xyzp[0] = x1p, ai.xyzp[1] = x2p;
         ai.xyzp_stride[0] = (size_t)L.npad * 3, ai.xyzp_stride[1] = (size_t)L.mpad * 3;
         ai.vec = w, ai.stride = L.bstride, ai.V = L.V, ai.nslots = 1 + nlevels, ai.b = b;
-        ai.geom = fgt ? (rfe::Geom *)rfe::fgt_geom(fws, b, n > m ? n : m) : nullptr;
-        ai.a_max = fgt ? sharp(vF) : 0.0;
-        RF_LAUNCH("am_init", am_init_kernel, dim3(rf::ceil_div(max(L.npad, L.mpad), AI_TPB), b, fgt ? 3 : 2), dim3(AI_TPB), 0, s, ai);
+        RF_LAUNCH("am_init", am_init_kernel, dim3(rf::ceil_div(max(L.npad, L.mpad), AI_TPB), b, 2), dim3(AI_TPB), 0, s, ai);
     }
 
     L.tw_stride = L.Vs * (size_t)(1 + ncull);  // only the twin slots this schedule touches are laid out (and zero-filled)
@@ -2206,23 +2172,7 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
     for (int v = 0; v < nlevels; v++) {
         float *ratioL = ratios + (size_t)v * L.V, *ratioR = ratioL + L.npad;
         const bool zero = lc.c[v] == 0.0f;  // e = exp2(d2 * 0) = 1 exactly: no exponential needed
-        const int *gptr = nullptr;  // (the sweeps' guard word: unused since the expansion carries its own direct fallback)
-        if (fgt && v >= vF) {
-            const float *pL = ratios + (size_t)(v - 1) * L.V, *pR = pL + L.npad;
-            if (v == vF) {
-                // the P3 of the last swept level on its own (its P1 partner is an expanded level)
-                RF_LAUNCH("am_p3", (am_rowk_kernel<true, 0, RPT>), gk, dim3(64 * segk), 0, s, n, L.mpad / segk, xyz1,
-                          (const float *)x2p, (size_t)L.mpad * 3, pR, (const float *)remainR, pL, remainL, ratioL, L.bstride,
-                          lc.c[v - 1], lc.c[v], permA, L.nsa, INFINITY, INFINITY, gptr, 0);
-            }
-            if (int e = rfe::fgt_p3p1(b, n, m, xyz1, xyz2, v > vF, v > vF ? sharp(v - 1) : 0.0, sharp(v), pR, (const float *)remainR,
-                                      pL, remainL, ratioL, L.bstride, fws, s))
-                return e;
-            if (int e = rfe::fgt_p2(b, n, m, xyz1, xyz2, sharp(v), v + 1 < nlevels ? sharp(v + 1) : -1.0, (const float *)ratioL, remainR,
-                                    ratioR, L.bstride, fws, s))
-                return e;
-            continue;
-        }
+        const int *gptr = nullptr;  // (the sweeps' guard word: unused)
         const float tsk = skip_t(v);        // (a fused P3 of level v-1 is sharper or equal wherever this one is skippable)
         const bool skip = permA && tsk <= kSkipMaxT && (v == 0 || (lc.c[v - 1] < 0.f && lc.c[v - 1] <= lc.c[v]));
         if (v < ncull) {
@@ -2355,7 +2305,7 @@ int rf_probe_exp2(const float *x, float *y, int count, rf_stream_t stream) {
     return RF_OK;
 }
 
-static bool emd_mode_ok(int mode) { return mode == RF_EMD_AUTO || mode == RF_EMD_SWEPT || mode == RF_EMD_EXPANDED; }
+static bool emd_mode_ok(int mode) { return mode == RF_EMD_AUTO || mode == RF_EMD_SWEPT; }
 
 size_t rf_approxmatch_workspace_bytes(int b, int n, int m, int nlevels) {
     return rf_approxmatch_mode_workspace_bytes(b, n, m, nlevels, RF_EMD_AUTO);

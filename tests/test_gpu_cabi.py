@@ -108,7 +108,7 @@ def test_calls_are_independent_of_workspace_contents(orc):
         buf.fill_(0xFF)
     assert torch.equal(m1, R.approx_match(u, v))
     # the EMD state vectors are not cleared as a whole (am_init writes the padded entries only): ragged sizes on every route --
-    # plain sweeps, the fused op with gradients, and a batch large enough for sorted rows + the expanded broad levels
+    # plain sweeps, the fused op with gradients, and a batch large enough for sorted rows at the sharp levels
     e1 = [t.clone() for t in R.earth_mover(u, v, with_grad=True)]
     for buf in _host._ws_cache.values():
         buf.fill_(0xFF)

@@ -1,4 +1,4 @@
-"""approx_match + match_cost at C4 on the three routes of rf_approxmatch_mode (auto / swept / expanded), hipEvent-timed in one process,
+"""approx_match + match_cost at C4 on the two routes of rf_approxmatch_mode (auto / swept), hipEvent-timed in one process,
 with the per-kernel split of the default route.  usage: python tools/ab_emd_modes.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,7 +17,7 @@ def timed(fn, reps=20):
 rng = np.random.RandomState(100)
 a = torch.from_numpy((rng.random_sample((32, 2048, 3)) - 0.5).astype(np.float32)).cuda()
 c = torch.from_numpy((rng.random_sample((32, 2048, 3)) - 0.5).astype(np.float32)).cuda()
-for mode in ("auto", "swept", "expanded"):
+for mode in ("auto", "swept"):
     ms = timed(lambda: R.match_cost(a, c, R.approx_match(a, c, mode=mode)))
     mf = timed(lambda: R.earth_mover(a, c, mode=mode))
     print(f"C4 approx_match+match_cost {mode:9s} {ms:.4f} ms/call   fused earth_mover {mf:.4f} ms/call")

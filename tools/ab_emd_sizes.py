@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
-"""Same-device A/B of library builds on approx_match / earth_mover over a spread of shapes (where do the expanded broad levels
-of emd_fgt.hip pay, and what does a refused call cost): per shape and build the wall time of approx_match and of earth_mover.
-Clouds U(-0.5, 0.5) * scale; scale 4 is refused by the expansion's validity test and takes its direct sums.
+"""Same-device A/B of library builds on approx_match / earth_mover over a spread of shapes: per shape and build the wall time of
+approx_match and of earth_mover.  Clouds U(-0.5, 0.5) * scale (scale 4: every level sixteen-fold sharper).
 usage: python tools/ab_emd_sizes.py TAG [TAG ...]   ('base' = the product; others = rfnet_amd/variants/librfops_TAG.so)"""
 import os, subprocess, sys
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
