@@ -964,6 +964,7 @@ __global__ __launch_bounds__(TPB) void am_match_kernel(int n, int m, const float
     // ratios: [b][level][ (ratioL: npad) (ratioR: mpad) ]; roff = npad
     __shared__ float cxyz[LSEG][4];
     __shared__ float crr[LSEG][LVG];
+    __shared__ int cdl[LSEG];  // per row: its last level with ratioR != 0
     // (a sample's workgroups on ONE XCD, rf::xcd_contiguous: the sweeps' order)
     const unsigned per = gridDim.x * gridDim.y;
     const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
@@ -988,6 +989,13 @@ __global__ __launch_bounds__(TPB) void am_match_kernel(int n, int m, const float
         cxyz[i][2] = xyz2[(size_t)(l0 + i) * 3 + 2];
     }
     __syncthreads();
+    if (threadIdx.x < lcnt) {
+        int dl = 0;
+#pragma unroll
+        for (int v = 1; v < LVG; v++) dl = crr[threadIdx.x][v] != 0.f ? v : dl;
+        cdl[threadIdx.x] = dl;
+    }
+    __syncthreads();
     if (k >= n) return;
     const float x1 = xyz1[k * 3], y1 = xyz1[k * 3 + 1], z1 = xyz1[k * 3 + 2];
     if (NLV > 0) {
@@ -1002,7 +1010,31 @@ __global__ __launch_bounds__(TPB) void am_match_kernel(int n, int m, const float
             const float d2 = rf::d2_fma(cxyz[l][0] - x1, cxyz[l][1] - y1, cxyz[l][2] - z1);
             float e[NLV > 0 ? NLV : 1];
             float acc = 0.f;
-            if (SQ) {
+            if (SQ && NLV == 10 && LASTZERO) {
+                // (round 6) Row l's ratioR is exactly +0 from the level after its LAST LIVE one on (remainR reached +0 there:
+                // am_compact_kernel) -- 44 % of C4's rows are dead after level 1, 68 % after level 2 -- and a dead level's term is
+                // fma(p, +0, acc) = acc.  The weights come in pairs (an odd level's from the next even one's by two squarings), so
+                // pair (v, v + 1) is formed and added only while the row lives at v: wave-uniform branches on a per-row word,
+                // the same fma chain over the live levels -- same bits, 1.5 exponentials per entry instead of 4.
+                const int dl = cdl[l];  // (uniform) the row's last live level
+                const bool g1 = dl >= 1, g3 = dl >= 3, g5 = dl >= 5, g7 = dl >= 7;
+                if (g7) { e[8] = fast_exp2(d2 * cl[8]); const float q = e[8] * e[8]; e[7] = q * q; }
+                if (g5) { e[6] = fast_exp2(d2 * cl[6]); const float q = e[6] * e[6]; e[5] = q * q; }
+                if (g3) { e[4] = fast_exp2(d2 * cl[4]); const float q = e[4] * e[4]; e[3] = q * q; }
+                if (g1) { e[2] = fast_exp2(d2 * cl[2]); const float q = e[2] * e[2]; e[1] = q * q; }
+                if (__ballot(d2 < t0) != 0ull) {
+                    asm volatile("; level 0 kept");
+                    acc = fmaf(rl[0] * fast_exp2(d2 * cl[0]), crr[l][0], 0.f);
+                }
+                if (g1) { acc = fmaf(rl[1] * e[1], crr[l][1], acc); acc = fmaf(rl[2] * e[2], crr[l][2], acc); }
+                if (g3) { acc = fmaf(rl[3] * e[3], crr[l][3], acc); acc = fmaf(rl[4] * e[4], crr[l][4], acc); }
+                if (g5) { acc = fmaf(rl[5] * e[5], crr[l][5], acc); acc = fmaf(rl[6] * e[6], crr[l][6], acc); }
+                if (g7) {
+                    acc = fmaf(rl[7] * e[7], crr[l][7], acc);
+                    acc = fmaf(rl[8] * e[8], crr[l][8], acc);
+                    acc = fmaf(rl[9] * 1.0f, crr[l][9], acc);
+                }
+            } else if (SQ) {
                 // the sharpest level on its own: beyond t0 its weight is exactly +0 (v_exp_f32 returns +0 below -160), and a
                 // row l is beyond t0 of ALL 64 columns of the wave in 86 % of the cases at C4 (the cut-off is 0.082) -- then
                 // fma(rl * 0, rr, 0) = +0 = the accumulator's start: skipped by a wave-uniform branch, same bits
@@ -1672,6 +1704,9 @@ __global__ __launch_bounds__(TPB) void emd_fused_kernel(int n, int m, int mpad, 
                 const am_v2f d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));  // (rf::d2_fma's order)
                 am_v2f e[NLV];
                 am_v2f acc = {0.f, 0.f};
+                // (the per-column level guards of am_match_kernel do not pay here: a PAIR of columns is dead at a level only when both
+                // are -- 54 % of the pairs still need levels 3-4 at C4 against 32 % of the columns -- and the branches cost the
+                // packed chain more than the skipped exponentials return: 0.588 against 0.562 ms per call, same device)
                 if (SQ) {
                     level_weights2<NLV, LASTZERO, SQ, 1>(d2, cl, e);
                     if (__ballot(d2.x < t0 || d2.y < t0) != 0ull) {
@@ -1701,6 +1736,8 @@ __global__ __launch_bounds__(TPB) void emd_fused_kernel(int n, int m, int mpad, 
             const float d2 = rf::d2_fma(dx, dy, dz);
             float e[NLV];
             float acc = 0.f;
+            // (am_match_kernel's per-row level guards measured SLOWER here, 0.670 against 0.639 ms per call with gradients: this loop is
+            // unrolled four columns deep and the branches break that up)
             if (SQ) {  // the sharpest level under its own wave-uniform test (see am_match_kernel)
                 level_weights<NLV, LASTZERO, SQ, 1>(d2, cl, e);
                 if (__ballot(d2 < t0) != 0ull) {
@@ -2094,12 +2131,12 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
     // exactly 0 -- which, at the broad end of the schedule, is a few per cent of them.  (Round 5 took the three broadest levels
     // from a truncated Taylor expansion about the clouds' centre instead of sweeping them: 121 us per call at C4 for what these
     // sweeps now do in 40, exactly -- tools/experiments/emd_fgt_route.patch.txt.)
-    constexpr int vC = 2;
-    bool compact = L.compact_ok && ncull == 0 && nlevels >= 4;
-    // (the packed sets are handed from level to level: a level from vC on that would take the skipping sweeps -- a schedule with
-    // more than two levels that sharp -- keeps the whole call on the old sweeps)
-    for (int v = vC; v < nlevels; v++)
-        if (lc.c[v] < 0.f && kSkipArg / -lc.c[v] <= kSkipMaxT) compact = false;
+    // vC: the first level behind the last one that takes the skipping sweeps (the packed sets are handed from level to level),
+    // the third at the earliest (the reference schedule: 2; its 50-level stretching: 10)
+    int vC = 2;
+    for (int v = 2; v < nlevels; v++)
+        if (lc.c[v] < 0.f && kSkipArg / -lc.c[v] <= kSkipMaxT) vC = v + 1;
+    const bool compact = L.compact_ok && ncull == 0 && vC + 2 <= nlevels;
     // (padded entries of every vector must read 0 -- they are column scalars of padded columns: am_init writes them)
     {
         AmInit ai;

@@ -20,7 +20,8 @@ c = torch.from_numpy((rng.random_sample((32, 2048, 3)) - 0.5).astype(np.float32)
 for mode in ("auto", "swept"):
     ms = timed(lambda: R.match_cost(a, c, R.approx_match(a, c, mode=mode)))
     mf = timed(lambda: R.earth_mover(a, c, mode=mode))
-    print(f"C4 approx_match+match_cost {mode:9s} {ms:.4f} ms/call   fused earth_mover {mf:.4f} ms/call")
+    mg = timed(lambda: R.earth_mover(a, c, with_grad=True, mode=mode))
+    print(f"C4 approx_match+match_cost {mode:9s} {ms:.4f} ms/call   fused earth_mover {mf:.4f} ms/call   with gradients {mg:.4f} ms/call")
 _lib.profile_collect(); _lib.profile_enable(True)
 for _ in range(10): R.approx_match(a, c)
 torch.cuda.synchronize(); _lib.profile_enable(False)
