@@ -749,8 +749,14 @@ __global__ __launch_bounds__(PL_TPB) void am_p2_live_kernel(int npad, const floa
 #pragma unroll
         for (int q = 0; q < 8; q++) alive |= (e0 + q < cin && sv[q] != 0.f) ? 1u << q : 0u;
         mine = (unsigned)__builtin_popcount(alive);
-    } else {
-        for (int q = 0; q < per; q++) mine += (e0 + q < cin && IS1[e0 + q] != 0.f) ? 1u : 0u;
+    } else {  // (larger sets: eight entries in flight at a time)
+        for (int q0 = 0; q0 < per; q0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[q] = (q0 + q < per && e0 + q0 + q < cin) ? IS1[e0 + q0 + q] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; q++) mine += v[q] != 0.f ? 1u : 0u;
+        }
     }
     unsigned incl = mine;
 #pragma unroll
@@ -790,13 +796,17 @@ __global__ __launch_bounds__(PL_TPB) void am_p2_live_kernel(int npad, const floa
                     if ((int)r >= lo && (int)r < lo + PL_ROWS) rpos[r - lo] = e0 + q;
                     r++;
                 }
-        } else {
-            for (int q = 0; q < per; q++) {
-                const int e = e0 + q;
-                if (e < cin && IS1[e] != 0.f) {
-                    if ((int)r >= lo && (int)r < lo + PL_ROWS) rpos[r - lo] = e;
-                    r++;
-                }
+        } else if (before < (unsigned)(lo + PL_ROWS) && before + mine > (unsigned)lo) {  // (only the threads whose entries reach into this chunk look again)
+            for (int q0 = 0; q0 < per; q0 += 8) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) v[q] = (q0 + q < per && e0 + q0 + q < cin) ? IS1[e0 + q0 + q] : 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if (v[q] != 0.f) {
+                        if ((int)r >= lo && (int)r < lo + PL_ROWS) rpos[r - lo] = e0 + q0 + q;
+                        r++;
+                    }
             }
         }
     }
@@ -2136,7 +2146,8 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
     int vC = 2;
     for (int v = 2; v < nlevels; v++)
         if (lc.c[v] < 0.f && kSkipArg / -lc.c[v] <= kSkipMaxT) vC = v + 1;
-    const bool compact = L.compact_ok && ncull == 0 && vC + 2 <= nlevels;
+    if (vC < ncull) vC = ncull;  // (behind the culled levels too: they leave every vector in the original order as well)
+    const bool compact = L.compact_ok && vC + 2 <= nlevels;
     // (padded entries of every vector must read 0 -- they are column scalars of padded columns: am_init writes them)
     {
         AmInit ai;
@@ -2206,6 +2217,12 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
     const LiveSet setA = compact ? live_set(0) : LiveSet{}, setB = compact ? live_set(1) : LiveSet{};
     // level v >= vC: P2 packs its rows into out(v) = (v - vC) even ? B : A, from in(v) = out(v - 1) (in(vC) = A: am_compact_kernel's
     // live set); the fused sweep in front of it reads am_compact_kernel's column set (B) at vC, out(v - 1) after
+    auto pack_live = [&](int v, const float *ratioR_v) -> int {  // after P2 of level v = vC - 1
+        float *ratioR_later = ratios + (size_t)(v + 1) * L.V + L.npad;
+        RF_LAUNCH("am_compact", am_compact_kernel, dim3(b), dim3(CK_TPB), 0, s, m, (const float *)x2p, (size_t)L.mpad * 3, ratioR_v,
+                  (const float *)remainR, ratioR_later, L.V, nlevels - 1 - v, L.bstride, setB, setA, L.cstride);
+        return RF_OK;
+    };
     for (int v = 0; v < nlevels; v++) {
         float *ratioL = ratios + (size_t)v * L.V, *ratioR = ratioL + L.npad;
         const bool zero = lc.c[v] == 0.0f;  // e = exp2(d2 * 0) = 1 exactly: no exponential needed
@@ -2230,6 +2247,8 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
             RF_LAUNCH("am_p2c", am_cull_kernel<2>, gb, dim3(64 * CW), 0, s, SB, SA, Tcur, 0.f, lc.c[v],
                       (const float *)ratL_s, (const float *)ratL_s, L.tw_stride, (const float *)remR_s, remR_s, remainR,
                       ratR_s, ratioR, L.bstride);
+            if (compact && v + 1 == vC)
+                if (int e = pack_live(v, ratioR)) return e;
             continue;
         }
 #define AM_ROWK_ARGS(pR_, pL_, cprev)                                                                 \
@@ -2321,11 +2340,8 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
                       (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR,
                       L.bstride, lc.c[v], permB, L.nsb, tsk, gptr, 1);
         }
-        if (compact && v + 1 == vC) {  // the first two packed sets (from here on every P2 packs the next one itself)
-            float *ratioR_later = ratios + (size_t)(v + 1) * L.V + L.npad;
-            RF_LAUNCH("am_compact", am_compact_kernel, dim3(b), dim3(CK_TPB), 0, s, m, (const float *)x2p, (size_t)L.mpad * 3,
-                      (const float *)ratioR, (const float *)remainR, ratioR_later, L.V, nlevels - 1 - v, L.bstride, setB, setA, L.cstride);
-        }
+        if (compact && v + 1 == vC)  // the first two packed sets (from here on every P2 packs the next one itself)
+            if (int e = pack_live(v, ratioR)) return e;
     }
     return RF_OK;
 }

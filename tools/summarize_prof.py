@@ -12,8 +12,8 @@ def short(name):
     if "am_rowk_kernel<" in name:  # <P3, P1 mode, rows per lane>: one name per fused phase
         return "am_rowk<" + name.split("am_rowk_kernel<")[1].split(">")[0].replace(" ", "") + ">"
     for key in ("nnp_grad_sorted", "nnp_sweep", "nnp_sort_reg", "nnp_sort", "nn_sweep", "nn_pack", "nn_rowmerge", "nn_colresolve", "nn_resolve", "nn_grad", "pack_kernel",
-                "am_rowk_kernelILb1ELb1", "am_rowk_kernelILb0ELb1", "am_rowl", "am_match", "am_init", "mcg_kernel",
-                "mc_partial", "mc_final", "emd_fused", "emd_pack_cols", "am_cull", "fps_cluster", "fps_reg", "query_ball_boxes", "qx_flags", "query_ball_lanes", "query_ball", "three_nn_boxes", "three_nn", "three_interpolate_rows", "three_interpolate_grad_tile",
+                "am_rowk_kernelILb1ELb1", "am_rowk_kernelILb0ELb1", "am_rowl", "am_p2_live", "am_compact", "am_match", "am_init", "mcg_rows", "mcg_kernel",
+                "mc_partial", "mc_final", "emd_fused", "emd_pack_cols", "am_cull", "fps_sorted", "fps_reg", "rows_csr_build", "rows_csr_gather", "query_ball_boxes", "qx_flags", "query_ball_lanes", "query_ball", "three_nn_boxes", "three_nn", "three_interpolate_rows", "three_interpolate_grad_tile",
                 "group_point_grad", "group_point", "gather_kernel"):
         if key in name:
             return key
