@@ -146,3 +146,78 @@ def grid_order(P, variant):
 
 o = grid_order(P, "wave2x2x4 lane4x4x4").reshape(1024, 16)
 print("sort's own tables, key = wave cell 2x2x4 | lane cell 4x4x4 | z: touched waves %.2f of 16, touched lanes %.1f of 1024 per iteration" % simulate(P, o))
+
+# ---- what an iteration costs is the busiest SIMD, not the sum: wave w sits on SIMD w % 4 ----
+def simulate_simd(P, lane_pts, wave_of_cell=None):
+    X = P[lane_pts]
+    lo, hi = X.min(1), X.max(1)
+    td = np.full(lane_pts.shape, 1e38, np.float32)
+    old = 0
+    mx = tot = 0
+    for j in range(1, m):
+        s = P[old]
+        g = np.maximum(np.maximum(lo - s, s - hi), 0)
+        touched = (g * g).sum(1) < td.max(1)
+        wt = touched.reshape(16, 64).any(1)
+        ids = np.where(wt)[0] if wave_of_cell is None else wave_of_cell[np.where(wt)[0]]
+        mx += np.bincount(ids % 4, minlength=4).max() if len(ids) else 0
+        tot += wt.sum()
+        rows = np.repeat(wt, 64)
+        d = ((X[rows] - s) ** 2).sum(-1)
+        td[rows] = np.minimum(td[rows], d)
+        old = lane_pts.reshape(-1)[int(np.argmax(td.reshape(-1)))]
+    return tot / (m - 1), mx / (m - 1)
+
+print("busiest SIMD per iteration (touched waves on it), wave w on SIMD w % 4:")
+print("  product order:            touched %.2f, busiest SIMD %.2f" % simulate_simd(P, base))
+print("  sort's-tables grid order: touched %.2f, busiest SIMD %.2f" % simulate_simd(P, o))
+# the grid order with the 16 cells dealt to the SIMDs so that face neighbours differ: cell (x, y, z) of 2 x 2 x 4 -> SIMD (x + 2 y + z) % 4 ... wave = any of that SIMD's four
+cells = np.arange(16)
+cx, cy, cz = cells >> 3, (cells >> 2) & 1, cells & 3
+simd = (cx + 2 * cy + cz) % 4
+wave_of_cell = np.zeros(16, int)
+for s_ in range(4):
+    wave_of_cell[np.where(simd == s_)[0]] = s_ + 4 * np.arange((simd == s_).sum())
+print("  ... cells dealt so that neighbours sit on different SIMDs: touched %.2f, busiest SIMD %.2f" % simulate_simd(P, o, wave_of_cell))
+
+# ---- the same question for the PRODUCT's order: which of its 16 chunks of 1024 sorted points should share a SIMD? ----
+def touched_sets(P, lane_pts):
+    X = P[lane_pts]
+    lo, hi = X.min(1), X.max(1)
+    td = np.full(lane_pts.shape, 1e38, np.float32)
+    old = 0
+    out = []
+    for j in range(1, m):
+        s = P[old]
+        g = np.maximum(np.maximum(lo - s, s - hi), 0)
+        wt = ((g * g).sum(1) < td.max(1)).reshape(16, 64).any(1)
+        out.append(wt.copy())
+        rows = np.repeat(wt, 64)
+        d = ((X[rows] - s) ** 2).sum(-1)
+        td[rows] = np.minimum(td[rows], d)
+        old = lane_pts.reshape(-1)[int(np.argmax(td.reshape(-1)))]
+    return np.array(out)
+
+def busiest(T, simd_of_chunk):
+    return np.stack([(T[:, simd_of_chunk == s_]).sum(1) for s_ in range(4)], 1).max(1).mean()
+
+T = touched_sets(P, base)
+assign = np.arange(16) % 4
+best = busiest(T, assign)
+rs = np.random.RandomState(0)
+for it in range(4000):  # local search: swap the SIMDs of two chunks
+    i, j = rs.randint(0, 16, 2)
+    if assign[i] == assign[j]:
+        continue
+    assign[i], assign[j] = assign[j], assign[i]
+    v = busiest(T, assign)
+    if v < best:
+        best = v
+    else:
+        assign[i], assign[j] = assign[j], assign[i]
+print("product order, chunks dealt to SIMDs by local search on THIS cloud: busiest SIMD %.2f (round-robin %.2f); assignment %s" % (best, busiest(T, np.arange(16) % 4), assign.tolist()))
+# does one cloud's assignment carry to another?
+P2 = rng.random_sample((n, 3)).astype(np.float32)
+base2 = str_order(P2).reshape(1024, 16)
+T2 = touched_sets(P2, base2)
+print("  the same assignment on another uniform cloud: busiest %.2f (round-robin %.2f)" % (busiest(T2, assign), busiest(T2, np.arange(16) % 4)))
