@@ -268,7 +268,15 @@ __global__ __launch_bounds__(NT) void fps_sorted_kernel(int n, int m, int npad, 
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
     for (int s = 0; s < PPT; s++) {
-        const int c = t * PPT + s;
+        // Which CHUNK of 64 * PPT consecutive sorted points a wave takes (round 6).  An iteration costs what its BUSIEST SIMD scans, not
+        // the sum: wave w sits on SIMD w % 4, and with chunk = wave a new sample's 2.9 touched chunks -- spatial neighbours along and
+        // across the sort's slabs -- put 1.43 of them on the busiest SIMD; dealt so that the four chunks of a SIMD lie far apart it is
+        // 1.18 (tools/experiments/fps_region_model.py: a local search on one uniform cloud, the same table on another 1.20).  Same
+        // device, sort + kernel: 16384 points 0.852 -> 0.812 ms, 12000 0.787 -> 0.757, 8192 0.691 -> 0.668, 6000 +-0; clouds of up to
+        // 4096 points (2 or 4 points per lane: other slab counts, other neighbours) lose 1-3 % with this table and keep chunk = wave.
+        constexpr int kChunkOfWave[16] = {0, 1, 3, 4, 2, 6, 5, 7, 9, 10, 8, 11, 14, 12, 15, 13};
+        const int chunk = (NW == 16 && PPT >= 8) ? kChunkOfWave[wave & 15] : wave;
+        const int c = ((chunk << 6) | lane) * PPT + s;
         if (c < n) {
             // (the coordinates from the cloud itself, through the original index: the winners' coordinates are re-read from there
             // every iteration, and this pass is what brings the cloud into this XCD's L2 -- read from the sorted copy, a launch that
