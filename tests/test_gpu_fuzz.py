@@ -229,3 +229,48 @@ def test_fuzz_match_cost_grad_both_forms(orc, seed):
     o1, o2 = orc.match_cost_grad(a, c, mt)
     assert_rel(g1.cpu().numpy(), o1, 1e-4, 2e-6 * max(1, m // 256), what=f"seed {seed} {b}x{n}x{m} grad1")
     assert_rel(g2.cpu().numpy(), o2, 1e-4, 2e-6 * max(1, n // 256), what=f"seed {seed} {b}x{n}x{m} grad2")
+
+
+@pytest.mark.parametrize("seed", range(10 * FUZZ_SCALE))
+def test_fuzz_scatter_gradients_sorted_slots(orc, seed):
+    """group_point_grad / three_interpolate_grad on their sorted-slots route (scatter_rows.hip) at random shapes past the route's
+    threshold: against the oracle and against the atomic route; slot counts around the register-resident limit of the sort (32768
+    slots per sample), key spaces cut over 1..8 workgroups, channel counts with and without the 4-wide form, indices with long runs
+    on one row."""
+    from rfnet_amd import _raw
+    from rfnet_amd._lib import lib
+    rng = np.random.RandomState(7000 + seed)
+    if seed % 2 == 0:
+        n = _logint(rng, 64, 60000)
+        c = int(rng.choice([3, 8, 13, 32, 64, 67]))
+        ns = int(rng.choice([1, 8, 32, 64]))
+        m = _logint(rng, 64, 40000 // ns + 64)
+        b = max(1, int(np.ceil((1 << 22) / (m * ns * c))) + rng.randint(0, 3))
+        b = min(b, 64)
+        if b * m * ns * c < (1 << 22) and b * m * ns < (1 << 19):
+            pytest.skip("below the route's threshold")
+        idx = rng.randint(0, n, size=(b, m, ns)).astype(np.int32)
+        if seed % 4 == 0:
+            idx[:, : m // 3] = rng.randint(0, min(n, 5), size=(b, m // 3, ns))  # a few popular rows
+        go = rng.randn(b, m, ns, c).astype(np.float32)
+        assert lib.rf_grouppoint_grad_workspace_bytes(b, n, c, m, ns) > 0
+        pts = np.zeros((b, n, c), np.float32)
+        got = _raw.group_point_grad(cu(pts), cu(idx), cu(go)).cpu().numpy()
+        want = orc.group_point_grad(pts, idx, go)
+        scale = max(1.0, float(np.abs(want).max()))
+        assert np.abs(got - want).max() <= 1e-5 * scale + 1e-6, f"seed {seed} b={b} n={n} m={m} ns={ns} c={c}"
+        return
+    n = _logint(rng, 3000, 40000)   # unknown points
+    m = _logint(rng, 2100, 40000)   # known points: beyond the LDS tile
+    c = int(rng.choice([8, 13, 32, 64]))
+    b = min(32, max(1, int(np.ceil((1 << 22) / (n * 3 * c))) + rng.randint(0, 2)))
+    if lib.rf_threeinterpolate_grad_workspace_bytes(b, n, c, m) == 0:
+        pytest.skip("not the sorted-slots route")
+    idx = rng.randint(0, m, size=(b, n, 3)).astype(np.int32)
+    w = rng.rand(b, n, 3).astype(np.float32)
+    go = rng.randn(b, n, c).astype(np.float32)
+    pts = np.zeros((b, m, c), np.float32)
+    got = _raw.three_interpolate_grad(cu(pts), cu(idx), cu(w), cu(go)).cpu().numpy()
+    want = orc.three_interpolate_grad(pts, idx, w, go)
+    scale = max(1.0, float(np.abs(want).max()))
+    assert np.abs(got - want).max() <= 1e-5 * scale + 1e-6, f"seed {seed} b={b} n={n} m={m} c={c}"
