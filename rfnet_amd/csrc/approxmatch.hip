@@ -39,23 +39,14 @@ constexpr float kLog2e = 1.44269502f;  // 0x3FB8AA3B, the constant __expf multip
 // am_match's stores of `match` are non-temporal: the tensor (512 MiB at C4) is twice the memory-side cache and is read next by
 // another launch; written through the caches it leaves that launch competing with the write-back of its own input
 // (approx_match + match_cost 0.987 -> 0.956 ms same-device, am_match itself 139 -> 135.5 us)
-#ifndef RFA_MATCH_NT
-#define RFA_MATCH_NT 1
-#endif
 // match_cost reads `match` with non-temporal loads too: 88.4 -> 78.6 us alone, 87.7 -> 79.7 inside the sequence (a pure read of
 // 512 MiB: 83 us plain, 76 non-temporal -- tools/ubench/stream_rate.hip); the gradient pass behind it then finds less of the tensor's
 // head in the memory-side cache (85.8 -> 91.2 us): -3 us for the three ops together, -8 for approx_match + match_cost
-#ifndef RFA_MC_NT
-#define RFA_MC_NT 1
-#endif
 #ifndef RFA_PK
 #define RFA_PK 1
 #endif
 #ifndef RFA_PK_FUSED
 #define RFA_PK_FUSED 1  // emd_fused_kernel (cost only): two columns per step, packed
-#endif
-#ifndef RFA_XCD
-#define RFA_XCD 1
 #endif
 #ifndef RFA_SKIP_MASK
 #define RFA_SKIP_MASK 1  // level 0's skipping sweeps list the columns level 1's will need; level 1's visit only those (am_rowk_kernel MASK)
@@ -158,7 +149,7 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
     if (guard && (*guard != 0) != (guard_want != 0)) return;
     static_assert(SKIP == 0 || P1 == 1, "the skipping sweeps evaluate this level's own exponential");
     // (a sample's workgroups on ONE XCD, rf::xcd_contiguous: its columns are then read from HBM by one L2 instead of eight)
-    const unsigned lgc = RFA_XCD ? rf::xcd_contiguous(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y) : blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned lgc = rf::xcd_contiguous(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const int bi = lgc / gridDim.x, bx = lgc - bi * gridDim.x;
     const int lane = threadIdx.x & 63;
     const int seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -413,7 +404,7 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
     if (guard && (*guard != 0) != (guard_want != 0)) return;  // (see am_rowk_kernel)
     __shared__ float part[16][64 * RPT];
     // (a sample's workgroups on ONE XCD, rf::xcd_contiguous: its columns are then read from HBM by one L2 instead of eight)
-    const unsigned lgc = RFA_XCD ? rf::xcd_contiguous(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y) : blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned lgc = rf::xcd_contiguous(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const int bi = lgc / gridDim.x, bx = lgc - bi * gridDim.x;
     const int lane = threadIdx.x & 63;
     const int seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -978,7 +969,7 @@ __global__ __launch_bounds__(TPB) void am_match_kernel(int n, int m, const float
     // (a sample's workgroups on ONE XCD, rf::xcd_contiguous: the sweeps' order)
     const unsigned per = gridDim.x * gridDim.y;
     const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    const unsigned lgc = RFA_XCD ? rf::xcd_contiguous(lin, per * gridDim.z) : lin;
+    const unsigned lgc = rf::xcd_contiguous(lin, per * gridDim.z);
     const int bi = lgc / per;
     const unsigned rem = lgc - bi * per;
     const int by = rem / gridDim.x, bx = rem - by * gridDim.x;
@@ -1060,11 +1051,7 @@ __global__ __launch_bounds__(TPB) void am_match_kernel(int n, int m, const float
 #pragma unroll
                 for (int v = 0; v < NLV; v++) acc = fmaf(rl[v] * e[v], crr[l][v], acc);
             }
-#if RFA_MATCH_NT
             __builtin_nontemporal_store(acc, &match[(size_t)(l0 + l) * n + k]);
-#else
-            match[(size_t)(l0 + l) * n + k] = acc;
-#endif
         }
         return;
     }
@@ -1202,11 +1189,7 @@ __global__ __launch_bounds__(TPB) void mc_partial_kernel(int n, int m, const flo
 #pragma unroll 8
         for (int l = 0; l < lcnt; l++) {
             float d = sqrtf(rf::d2_fma(cxyz[l][0] - x1, cxyz[l][1] - y1, cxyz[l][2] - z1));
-#if RFA_MC_NT
             sum = fmaf(d, __builtin_nontemporal_load(&match[(size_t)(l0 + l) * n + k]), sum);
-#else
-            sum = fmaf(d, match[(size_t)(l0 + l) * n + k], sum);
-#endif
         }
     }
 #pragma unroll
@@ -1261,14 +1244,7 @@ __global__ void mc_final_kernel(const float *partial, int per_batch, float *cost
 #ifndef RFA_MG_LSPLIT
 #define RFA_MG_LSPLIT 4
 #endif
-#ifndef RFA_MG_NT
-#define RFA_MG_NT 1
-#endif
-#if RFA_MG_NT
 #define RFA_MG_LOAD(p) __builtin_nontemporal_load(p)  // (`match` is read once: see mr_load_row)
-#else
-#define RFA_MG_LOAD(p) (*(p))
-#endif
 constexpr int MG_TL = 32;
 constexpr int MG_LSPLIT = RFA_MG_LSPLIT;
 __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void mcg_kernel(int n, int m, int lspan,
@@ -1419,17 +1395,10 @@ constexpr int MR_DEPTH = 8;  // rows in flight per lane, 2 or 4 groups (16: +-2 
 // multiplication (their registers hold the range's last row).
 // `match` is read once, front to back: non-temporal loads (C4 same-device: mcg_rows 104.5 -> 94.3 us, 5.1 -> 5.7 TB/s; inside
 // the sequence approx_match -> match_cost -> match_cost_grad 97 -> 90 us)
-#ifndef RFA_MR_NT
-#define RFA_MR_NT 1
-#endif
 typedef float mr_v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 mr_load_row(const void *p) {
-#if RFA_MR_NT
     const mr_v4f v = __builtin_nontemporal_load((const mr_v4f *)p);
     return make_float4(v.x, v.y, v.z, v.w);
-#else
-    return *(const float4 *)p;
-#endif
 }
 template <bool FULL, bool TAIL, int G0>
 __device__ __forceinline__ void mr_group(const float4 (&mv)[MR_DEPTH], const float (&xs)[3 * MR_G], int lg, int lend, bool live,
@@ -1467,14 +1436,7 @@ __device__ __forceinline__ void mr_group(const float4 (&mv)[MR_DEPTH], const flo
 }
 
 // the group's 3 * MR_G per-lane sums reduced over the wave's 64 lanes and added to the workgroup's grad2 sums (the rows from lg on, below lend)
-#ifndef RFA_MR_F64
-#define RFA_MR_F64 1  // the workgroup's row sums in double: ds_add_f64 is 23x the rate of ds_add_f32 here (tools/ubench/lds_atomic_rate.hip)
-#endif
-#if RFA_MR_F64
 typedef double mr_sum_t;
-#else
-typedef float mr_sum_t;
-#endif
 __device__ __forceinline__ void mr_reduce_emit(const float (&S)[3 * MR_G], int lane, int lg, int lend, int lbeg, mr_sum_t *g2s) {
     // reduce-scatter: 3G -> 3G/2 (lanes >= 32 keep the upper half) -> 3G/4 (odd 16-lane rows keep the upper half)
     constexpr int NH = 3 * MR_G / 2, NQ = 3 * MR_G / 4;
@@ -1680,7 +1642,7 @@ __global__ __launch_bounds__(TPB) void emd_fused_kernel(int n, int m, int mpad, 
     // (a sample's workgroups on ONE XCD, rf::xcd_contiguous: the sweeps' order)
     const unsigned per_ = gridDim.x * gridDim.y;
     const unsigned lin_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    const unsigned lgc_ = RFA_XCD ? rf::xcd_contiguous(lin_, per_ * gridDim.z) : lin_;
+    const unsigned lgc_ = rf::xcd_contiguous(lin_, per_ * gridDim.z);
     const int bi = lgc_ / per_;
     const int by = (lgc_ - bi * per_) / gridDim.x, bx = (lgc_ - bi * per_) - by * gridDim.x;
     const int t = threadIdx.x;

@@ -109,34 +109,35 @@ __global__ __launch_bounds__(CB_TPB) void rows_csr_build_kernel(int n, int S, in
     if (tid == CB_TPB - 1) seg_end = run;
     __syncthreads();
     int *__restrict__ P = perm + (size_t)bi * S;
+    // this workgroup's rows are ONE contiguous segment of perm, [first, last): the slot numbers meet in LDS and leave as coalesced
+    // stores (scattered 4-byte stores from every lane were 7 of the kernel's 21 us); what a lopsided index distribution puts
+    // beyond the stage goes straight to memory
+    unsigned *stage = cb_cnt + nbl;
+    unsigned first = 0;
+    for (int w = 0; w < CB_TPB / 64; w++) first += lowsum[w];
+    const unsigned last = seg_end;
+    auto place = [&](int k, int slot) {
+        if (k >= lo && k < hi) {
+            const unsigned pos = atomicAdd(&cb_cnt[k - lo], 1u) - first;
+            if (pos < (unsigned)CB_STAGE) stage[pos] = (unsigned)slot;
+            else P[first + pos] = slot;
+        }
+    };
     if (REG) {
-        // this workgroup's rows are ONE contiguous segment of perm, [base, end): the slot numbers meet in LDS and leave as
-        // coalesced stores (scattered 4-byte stores from every lane were 7 of the kernel's 21 us); what a lopsided index
-        // distribution puts beyond the stage goes straight to memory
-        unsigned *stage = cb_cnt + nbl;
-        unsigned first = 0;
-        for (int w = 0; w < CB_TPB / 64; w++) first += lowsum[w];
-        const unsigned last = seg_end;
 #pragma unroll
-        for (int u = 0; u < CB_RPT; u++)
-            if (kr[u] >= lo && kr[u] < hi) {
-                const unsigned pos = atomicAdd(&cb_cnt[kr[u] - lo], 1u) - first;
-                if (pos < (unsigned)CB_STAGE) stage[pos] = (unsigned)(tid + u * CB_TPB);
-                else P[first + pos] = tid + u * CB_TPB;
-            }
-        __syncthreads();
-        const unsigned cnt = min(last - first, (unsigned)CB_STAGE);
-        for (unsigned j = tid; j < cnt; j += CB_TPB) P[first + j] = (int)stage[j];
+        for (int u = 0; u < CB_RPT; u++) place(kr[u], tid + u * CB_TPB);
     } else {
         for (int s0 = tid; s0 < S; s0 += 8 * CB_TPB) {
             int k[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) k[u] = s0 + u * CB_TPB < S ? I[s0 + u * CB_TPB] : -1;
 #pragma unroll
-            for (int u = 0; u < 8; u++)
-                if (k[u] >= lo && k[u] < hi) P[atomicAdd(&cb_cnt[k[u] - lo], 1u)] = s0 + u * CB_TPB;
+            for (int u = 0; u < 8; u++) place(k[u], s0 + u * CB_TPB);
         }
     }
+    __syncthreads();
+    const unsigned cnt = min(last - first, (unsigned)CB_STAGE);
+    for (unsigned j = tid; j < cnt; j += CB_TPB) P[first + j] = (int)stage[j];
 }
 
 typedef float cg_v4f __attribute__((ext_vector_type(4)));
@@ -273,7 +274,7 @@ int rows_csr_scatter(int b, int n, int c, long S, int K, const float *src, const
     if (S <= (long)CB_TPB * 32) {
         RFS_BUILD(32, CB_STAGE);
     } else {  // (48 slots per thread -- three_interpolate's 3 x 16384 -- spill: 128 registers is all a 1024-thread workgroup has)
-        RFS_BUILD(0, 0);
+        RFS_BUILD(0, CB_STAGE);
     }
 #undef RFS_BUILD
     const bool vec = c % 4 == 0 && rf::aligned16(src) && rf::aligned16(dst);
