@@ -678,7 +678,8 @@ __global__ __launch_bounds__(CK_TPB) void am_compact_kernel(int m, const float *
 // Sums: per lane over its columns in index order, then across the lanes, then across the waves in order -- another order than
 // am_rowl_kernel's (tolerance, not bits: tests/test_gpu_emd.py), the same for a sample whatever its batch.
 // (same device, C4: 16 / 32 / 64 rows per item 0.642 / 0.614 / 0.634 ms per approx_match + match_cost -- an item's prologue is two
-// round trips to memory whatever its rows; 512 threads x 4 columns per lane, unpacked: 0.671)
+// round trips to memory whatever its rows; 512 threads x 4 columns per lane, unpacked: 0.671; packed 0.597-0.604 against 0.574-0.580;
+// the kernel's 134 registers (three waves per SIMD) held to 128 (four): +-0; one row's chain at a time: am_p2 184 against 175 us)
 constexpr int PL_TPB = 256, PL_NW = PL_TPB / 64, PL_ROWS = 32, PL_CPL = 8, PL_RU = 2;  // (PL_RU rows' chains side by side)
 static_assert(PL_CPL % 2 == 0, "the columns of a lane go through packed fp32 operations in pairs");
 static_assert(PL_ROWS % PL_RU == 0 && PL_ROWS <= 64, "a row per lane of the running sums");
