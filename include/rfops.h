@@ -425,10 +425,9 @@ int rf_point_affine(int b, int n, int c, const float *y, const float *p, int kp,
 int rf_probe_memset_async(void *p, size_t bytes, rf_stream_t stream);
 
 /* y[i] = v_exp_f32(x[i]) for i < count, the instruction every EMD weight exp(level * d2) goes through
- * (pc_distance/tf_approxmatch.cu:49,77,110,146 use __expf = ex2.approx(x * log2e)).  The culled sweeps of the sharp
- * levels (the cost-only rf_earth_mover on clouds of >= 4096 points; rf_approxmatch* and the gradient form stay dense) skip pairs whose argument is <= -160 on the
- * ground that the instruction returns EXACTLY +0 there; this entry point lets a host (and tests/test_gpu_emd.py)
- * check that on the device it runs on. */
+ * (pc_distance/tf_approxmatch.cu:49,77,110,146 use __expf = ex2.approx(x * log2e)).  The skipping sweeps of the sharp
+ * levels leave out pairs whose argument is <= -160 on the ground that the instruction returns EXACTLY +0 there; this entry
+ * point lets a host (and tests/test_gpu_emd.py) check that on the device it runs on. */
 int rf_probe_exp2(const float *x, float *y, int count, rf_stream_t stream);
 
 /* ------------------------------------------------------------------ measurement hooks --- */

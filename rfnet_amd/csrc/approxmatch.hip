@@ -34,7 +34,7 @@ namespace {
 #ifndef RFA_TARGET_WAVES
 #define RFA_TARGET_WAVES 4096  // waves a level sweep is cut into at least (column segments per row block)
 #endif
-constexpr float kSkipArg = 161.f;  // d2 * |c| >= 161 => fl(d2 * c) <= -160 => v_exp_f32 = +0 (kCullArg below, with the product's rounding covered)
+constexpr float kSkipArg = 161.f;  // d2 * |c| >= 161 => fl(d2 * c) <= -160 => v_exp_f32 = +0 (with the product's rounding covered)
 constexpr float kLog2e = 1.44269502f;  // 0x3FB8AA3B, the constant __expf multiplies by
 // am_match's stores of `match` are non-temporal: the tensor (512 MiB at C4) is twice the memory-side cache and is read next by
 // another launch; written through the caches it leaves that launch competing with the write-back of its own input
@@ -1779,184 +1779,21 @@ __global__ __launch_bounds__(TPB) void emd_fused_kernel(int n, int m, int mpad, 
     }
 }
 
-// ---- the sharp levels of the schedule, culled ---------------------------------------------------------------
-// At level -4^7 (then -4^6, -4^5) the weight exp2(level*log2e * d2) of a pair is EXACTLY +0 once d2 passes a
-// threshold: v_exp_f32 returns +0 for every argument <= -160 (the true value is below half the smallest denormal:
-// whatever the denormal mode, the result is +0; tests/test_gpu_emd.py sweeps the instruction).  A pair with weight
-// 0 adds fma(0 * rl, s, acc) = acc to every sum of its level -- bit for bit nothing (ratios are finite: sums start
-// at 1e-9).  So for these levels the sweeps run over the spatially sorted (sort-tile-recursive) clouds of nn_pruned.hip: a workgroup owns 64
-// consecutive sorted rows, tests the box of every 16-record column block against the box of its rows with the
-// Chamfer sweep's bound (same instruction sequence on the per-axis gaps, hence <= the d2 of every pair between the
-// boxes), lists the blocks whose bound is below the threshold and streams only those through SGPRs.  What survives
-// depends on the density: the cut-off radius is 0.082 / 0.165 / 0.33 at levels -4^7 / -4^6 / -4^5, a 64-row group of
-// 16384 points in a unit cube is 0.16 across and a 16-column block 0.10, so ~5 / 15 / 50 % of the blocks survive; at
-// C4's 2048 points (0.31 and 0.20 across, mean spacing 0.08 = the sharpest cut-off itself) 30 / 60 / 100 % do and the
-// culled sweeps only break even -- the size rule below keeps those on the dense kernels.
-// The state vectors are kept in BOTH index orders while culled sweeps run (each writes its rows' results to the
-// sorted twin and, through the original index, to the vector the dense kernels use); the culled levels are a prefix
-// of the schedule, so the dense kernels never have to write a twin.  Sums run over columns in sorted order: the same
-// terms in another order, like the dense kernels' column segments -- inside the stated tolerance, not bit-identical.
-constexpr float kCullArg = 160.f;    // exp2(x) == +0 for x <= -160
+// ---- the sharp levels of the schedule ---------------------------------------------------------------------------
+// At level -4^7 (then -4^6, -4^5) the weight exp2(level*log2e * d2) of a pair is EXACTLY +0 once d2 passes a threshold: v_exp_f32
+// returns +0 for every argument <= -160 (tests/test_gpu_emd.py sweeps the instruction), and a pair with weight 0 adds
+// fma(0 * rl, s, acc) = acc to every sum of its level.  The skipping sweeps (am_rowk / am_rowl SKIP) use that in the DENSE column
+// order: they pay while a wave keeps few of its columns -- cut-offs up to d = 0.22 (levels -4^7 and -4^6: 9 / 19 % kept at C4); at
+// -4^5 (42 % kept) the packed dense sweep is faster (P2 33 us against 39).
+// (Rounds 3-5 also ran these levels CULLED over the sorted clouds' 16-record blocks for the cost-only rf_earth_mover of clouds of
+// >= 4096 points -- sums in sorted order.  Round 6 took that route out: with the live-column sweeps behind it, it only paid at
+// 16384^2 any more (2.90 against 3.11 ms; 4096^2 1.09 against 1.02), and a soak against the oracle found its COST 1.0e-5 .. 3.2e-5
+// off on 3 of 17 000 random large shapes, where the sweeps in column order stay within 8e-7:
+// tools/experiments/emd_cull_route.patch.txt, emd_cull_live_cost_oracle.py.)
 #ifndef RFA_SKIP_MAXT
 #define RFA_SKIP_MAXT 0.05f
 #endif
-// the DENSE-order skipping sweeps (am_rowk / am_rowl SKIP) pay while a wave keeps few of its columns: cut-offs up to d = 0.22
-// (levels -4^7 and -4^6: 9 / 19 % kept at C4); at -4^5 (42 % kept) the packed dense sweep is faster (P2 33 us against 39)
 constexpr float kSkipMaxT = RFA_SKIP_MAXT;
-constexpr float kCullMaxT = 0.2f;    // a sweep is culled when its threshold on d2 is at most this (d >= 0.45: pays
-                                     // for clouds of about unit extent, the reference's normalised shapes; always exact)
-#ifndef RFA_CULL_MIN_PTS
-#define RFA_CULL_MIN_PTS 4096  // both clouds at least this large (same-device A/B, tools/ab_emd_cull.py: 2048^2 +-0, 4096^2 -7 %,
-                               // 8192^2 -11 %, 16384^2 -15 % of the whole earth_mover call)
-#endif
-constexpr int CULL_MIN_PTS = RFA_CULL_MIN_PTS;
-constexpr int CW = 8;                // waves per row group: each takes every 8th listed block
-constexpr int CULL_MAXBLK = rfp::kMaxPoints / 16 + 8;
-
-struct CullSet {          // one spatially sorted set (rfp::Sorted) plus its size
-    const float *xyz;     // (b, npad, 3), padding = +inf
-    const int *orig;      // (b, npad), padding = -1
-    const float *box16;   // (b, npad / 64, 24)
-    const float *box64;   // (b, npad / 64, 8)
-    int npad;
-};
-
-__device__ __forceinline__ float cull_boxbox(const float *alo, const float *ahi, const float *b6) {
-    const float gx = fmaxf(fmaxf(b6[0] - ahi[0], alo[0] - b6[3]), 0.f);
-    const float gy = fmaxf(fmaxf(b6[1] - ahi[1], alo[1] - b6[4]), 0.f);
-    const float gz = fmaxf(fmaxf(b6[2] - ahi[2], alo[2] - b6[5]), 0.f);
-    return rf::d2_fma(gx, gy, gz);
-}
-
-// MODE 0: P1 of the first level      ratioL = remainL / (1e-9 + sum_l e_cur * remainR[l])
-// MODE 1: P3 of level v-1 + P1 of v  remainL = max(0, remainL - sum_l rl*e_prev*ratioR_prev[l]); ratioL as above
-// MODE 2: P2 (rows = set B)          sumr = sum_k e_cur * ratioL[k]; ratioR / remainR update as am_rowl_kernel
-// R = the rows' set, C = the columns' set.  Column scalars come from the SORTED twins (sc_a: ratioR_prev / ratioL,
-// sc_b: remainR); row state is read from the sorted twins and written to both orders.
-template <int MODE>
-__global__ __launch_bounds__(64 * CW) void am_cull_kernel(
-    CullSet R, CullSet C, float T, float c_prev, float c_cur, const float *__restrict__ sc_a,
-    const float *__restrict__ sc_b, size_t tw_stride, const float *__restrict__ row_in_s,
-    float *__restrict__ rem_s, float *__restrict__ rem_o, float *__restrict__ out_s, float *__restrict__ out_o,
-    size_t o_stride) {
-    __shared__ unsigned short list[CULL_MAXBLK];
-    __shared__ int wcount[CW + 1];
-    __shared__ float part_a[CW][64], part_b[CW][64];
-    const int bi = blockIdx.y, g = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = g * 64 + lane;  // sorted row
-    const float *__restrict__ rx = R.xyz + ((size_t)bi * R.npad + j) * 3;
-    const float x = rx[0], y = rx[1], z = rx[2];
-    const int ko = R.orig[(size_t)bi * R.npad + j];
-    const float rl = MODE == 1 ? row_in_s[(size_t)bi * tw_stride + j] : 0.f;
-    const float *gb = R.box64 + ((size_t)bi * (R.npad / 64) + g) * 8;
-    const float glo[3] = {gb[0], gb[1], gb[2]}, ghi[3] = {gb[4], gb[5], gb[6]};
-    const int nblk = C.npad / 16;
-    const float *__restrict__ cb16 = C.box16 + (size_t)bi * nblk * 6;  // 24 floats per superblock = 6 per block
-    // the blocks whose bound is below the threshold, in ascending order (the summation order is fixed)
-    int nl = 0;
-    for (int b0 = 0; b0 < nblk; b0 += 64 * CW) {
-        const int blk = b0 + tid;
-        bool keep = false;
-        if (blk < nblk) keep = !(cull_boxbox(glo, ghi, cb16 + (size_t)blk * 6) >= T);  // (NaN keeps)
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
-        if (lane == 0) wcount[w] = __builtin_popcountll(m);
-        __syncthreads();
-        int off = nl;
-        for (int q = 0; q < w; q++) off += wcount[q];
-        if (keep) list[off + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (unsigned short)blk;
-        int tot = 0;
-        for (int q = 0; q < CW; q++) tot += wcount[q];
-        nl += tot;
-        __syncthreads();
-    }
-    const float *__restrict__ cx = C.xyz + (size_t)bi * C.npad * 3;
-    const float *__restrict__ sa = sc_a + (size_t)bi * tw_stride;
-    const float *__restrict__ sb = sc_b + (size_t)bi * tw_stride;
-    float acc_a = 0.f, acc_b = (MODE != 2 && w == 0) ? 1e-9f : 0.f;
-    // this wave's blocks: entries w, w + CW, ...; 16 records = two halves of 8 through SGPRs, the next half in
-    // flight while this one is evaluated
-    constexpr int SUBC = 8;
-    float nb[3 * SUBC], na[SUBC], nbb[SUBC];
-    auto issue = [&](int blk, int h) {
-        const float *cp = cx + ((size_t)blk * 16 + h * SUBC) * 3;
-#pragma unroll
-        for (int i = 0; i < 3 * SUBC; i++) nb[i] = cp[i];
-#pragma unroll
-        for (int i = 0; i < SUBC; i++) {
-            na[i] = (MODE != 0) ? sa[blk * 16 + h * SUBC + i] : 0.f;
-            nbb[i] = (MODE != 2) ? sb[blk * 16 + h * SUBC + i] : 0.f;
-        }
-    };
-    int e = w;
-    if (e < nl) issue(__builtin_amdgcn_readfirstlane((int)list[e]), 0);
-    while (e < nl) {
-        const int blk = __builtin_amdgcn_readfirstlane((int)list[e]);
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            float cb[3 * SUBC], ca[SUBC], cbb[SUBC];
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 3 * SUBC; i++) cb[i] = nb[i];
-#pragma unroll
-            for (int i = 0; i < SUBC; i++) { ca[i] = na[i]; cbb[i] = nbb[i]; }
-            if (h == 0) {
-                issue(blk, 1);
-            } else if (e + CW < nl) {
-                issue(__builtin_amdgcn_readfirstlane((int)list[e + CW]), 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < SUBC; u++) {
-                const float d2 = rf::d2_fma(cb[u * 3] - x, cb[u * 3 + 1] - y, cb[u * 3 + 2] - z);
-                if (MODE == 1) acc_a = fmaf(rl * fast_exp2(d2 * c_prev), ca[u], acc_a);
-                if (MODE == 2) acc_a = fmaf(fast_exp2(d2 * c_cur), ca[u], acc_a);
-                if (MODE != 2) acc_b = fmaf(fast_exp2(d2 * c_cur), cbb[u], acc_b);
-            }
-        }
-        e += CW;
-    }
-    part_a[w][lane] = acc_a;
-    part_b[w][lane] = acc_b;
-    __syncthreads();
-    if (w != 0 || ko < 0) return;
-    float ta = part_a[0][lane], tb = part_b[0][lane];
-#pragma unroll
-    for (int q = 1; q < CW; q++) {
-        ta += part_a[q][lane];
-        tb += part_b[q][lane];
-    }
-    const size_t js = (size_t)bi * tw_stride + j, jo = (size_t)bi * o_stride + ko;
-    float rem = rem_s[js];
-    if (MODE == 2) {
-        const float t = ta * rem;
-        const float cons = fminf(rem / (t + 1e-9f), 1.0f);
-        const float ro = rem * cons, rn = fmaxf(0.0f, rem - t);
-        out_s[js] = ro;
-        out_o[jo] = ro;
-        rem_s[js] = rn;
-        rem_o[jo] = rn;
-    } else {
-        if (MODE == 1) {
-            rem = fmaxf(0.0f, rem - ta);
-            rem_s[js] = rem;
-            rem_o[jo] = rem;
-        }
-        const float ro = rem / tb;
-        out_s[js] = ro;
-        out_o[jo] = ro;
-    }
-}
-
-// the sorted twins of the two remain vectors (padding records hold 0: they are column scalars of padding columns)
-__global__ void am_cull_init_kernel(int npad, const int *__restrict__ orig, float fill, float *__restrict__ rem_s,
-                                    size_t tw_stride) {
-    const int bi = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= npad) return;
-    rem_s[(size_t)bi * tw_stride + j] = orig[(size_t)bi * npad + j] >= 0 ? fill : 0.f;
-}
 
 __global__ void probe_exp2_kernel(const float *__restrict__ x, float *__restrict__ y, int count) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1974,19 +1811,14 @@ struct AmLayout {
     size_t V;        // floats per vector pair [L: npad | R: mpad]
     size_t bstride;  // floats per batch element in the vector region: (1 + nlevels) * V
     size_t off_x1, off_x2, total;  // in floats
-    // culled sweeps (sizes known without the level values: room is reserved whenever the clouds qualify)
-    bool cull_ok;
     bool rowsort_ok;       // the dense sweeps of the sharp levels take their rows in the clouds' spatial order (am_rowk_kernel SKIP)
     bool compact_ok;       // from the third level on the sweeps run over the LIVE columns / rows of set 2 only (am_compact_kernel)
     size_t cstride;        // floats per sample of a packed column array
     size_t off_live[2], live_floats;  // two packed sets (LiveSet), used in turn
     size_t off_maskk, off_maskl;  // (rowsort_ok) the skipping sweeps' column lists, rows of set 1 / rows of set 2 (am_rowk_kernel MASK)
     int nsa, nsb;          // padded sizes of the two sorted sets
-    size_t Vs;             // floats per sorted twin pair [L: nsa | R: nsb]
-    size_t tw_stride;      // floats per batch element of the twin region: (1 + CULL_MAXLV) * Vs
-    size_t off_sa, off_sb, off_tw;
+    size_t off_sa, off_sb;
 };
-constexpr int CULL_MAXLV = 8;  // at most this many leading levels are culled
 #ifndef RFA_ROWSORT_MIN_PAIRS
 #define RFA_ROWSORT_MIN_PAIRS 6.0e7
 #endif
@@ -1994,12 +1826,10 @@ constexpr double ROWSORT_MIN_PAIRS = RFA_ROWSORT_MIN_PAIRS;
 
 int round_up_i(int v, int q) { return (v + q - 1) / q * q; }
 
-// allow_cull: only the cost-only rf_earth_mover ever runs culled levels; rf_approxmatch(_levels) and the gradient form
-// must not carry the sorted sets and twin slots (about 50 MB at 32 x 16384^2) for nothing
 // mode (include/rfops.h): RF_EMD_AUTO -- the routes by the size of the whole batch (below); RF_EMD_SWEPT -- every level as a
 // dense sweep over the clouds in the caller's order and every launch shape taken as for b = 1: a sample's bits do not depend on
 // the batch it is called in (the reference is batch-independent per sample, tf_approxmatch.cu:13).
-AmLayout am_layout(int b, int n, int m, int nlevels, bool allow_cull, int mode = RF_EMD_AUTO) {
+AmLayout am_layout(int b, int n, int m, int nlevels, int mode = RF_EMD_AUTO) {
     AmLayout L;
     L.npad = round_up_i(n, CPAD);
     L.mpad = round_up_i(m, CPAD);
@@ -2011,12 +1841,11 @@ AmLayout am_layout(int b, int n, int m, int nlevels, bool allow_cull, int mode =
     L.off_x2 = off;
     off += (size_t)b * L.mpad * 3 + 64;
     const bool swept = mode == RF_EMD_SWEPT;
-    L.cull_ok = !swept && allow_cull && n >= CULL_MIN_PTS && m >= CULL_MIN_PTS && rfp::pruned_supported(b, n, m);
     // (sizes alone decide; same device: 32 x 1024^2 = 3.4e7 pairs 0.324 ms with the sort against 0.316 without, 32 x 2048^2 = 1.3e8 pairs 1.026 against 1.057)
     L.rowsort_ok = !swept && n >= 512 && m >= 512 && (double)b * n * m >= ROWSORT_MIN_PAIRS && rfp::pruned_supported(b, n, m);
     L.nsa = L.nsb = 0;
-    L.Vs = L.tw_stride = L.off_sa = L.off_sb = L.off_tw = 0;
-    if (L.cull_ok || L.rowsort_ok) {
+    L.off_sa = L.off_sb = 0;
+    if (L.rowsort_ok) {
         L.nsa = rfp::sorted_view(b, n, nullptr).npad;
         L.nsb = rfp::sorted_view(b, m, nullptr).npad;
         off = (off + 63) / 64 * 64;  // 256-byte alignment of the sorted sets
@@ -2025,12 +1854,6 @@ AmLayout am_layout(int b, int n, int m, int nlevels, bool allow_cull, int mode =
         off = (off + 63) / 64 * 64;
         L.off_sb = off;
         off += (rfp::sorted_bytes(b, m) + 3) / 4 + 64;
-    }
-    if (L.cull_ok) {
-        L.Vs = (size_t)L.nsa + L.nsb;
-        L.tw_stride = L.Vs * (size_t)(1 + CULL_MAXLV);
-        L.off_tw = off;
-        off += (size_t)b * L.tw_stride + 64;
     }
     // (by the clouds' sizes alone, never by b: what a sample's sweeps sum over must not depend on the batch it is called in)
     L.compact_ok = !swept && n >= 512 && m >= 512;
@@ -2059,14 +1882,6 @@ AmLayout am_layout(int b, int n, int m, int nlevels, bool allow_cull, int mode =
     return L;
 }
 
-// how many leading levels are run as culled sweeps: those whose weight is exactly 0 beyond d2 = T <= kCullMaxT
-int cull_levels(const AmLayout &L, int nlevels, const LevelConsts &lc) {
-    if (!L.cull_ok) return 0;
-    int k = 0;
-    while (k < nlevels && k < CULL_MAXLV && lc.c[k] < 0.f && kCullArg / -lc.c[k] <= kCullMaxT) k++;
-    return k;
-}
-
 // waves per workgroup (= column segments): the smallest power of two that gives >= 4096 waves,
 // keeping >= 64 columns per segment
 int pick_nseg(int b, int rows, int cols_pad, int rpt) {
@@ -2086,20 +1901,14 @@ void am_multipliers(int n, int m, float &multiL, float &multiR) {
 // The level pipeline (P1 / P2 / fused P3+P1 launches) of the large-cloud path: fills the
 // workspace's per-level ratio vectors.  Shared by rf_approxmatch_levels (which then materialises
 // match) and rf_earth_mover (which does not).
-// allow_cull: the sharp leading levels may run as culled sweeps over sorted copies (sums in another order: the EMD
-// COST keeps its 1e-5, but single match entries follow the oracle's sequential sums less closely -- at 4096^2 230
-// of 16.7 M entries leave the abs 1e-6 + rel 1e-4 bar, up to 5.6e-4, against 5 up to 5e-6 for the dense sweeps,
-// tools/experiments/emd_cull_vs_dense_error.py -- so only the cost-only rf_earth_mover, which never materialises match, asks for it).
 int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int nlevels,
                   const LevelConsts &lc, float multiL, float multiR, void *workspace, hipStream_t s,
-                  bool allow_cull, int mode = RF_EMD_AUTO) {
-    AmLayout L = am_layout(b, n, m, nlevels, allow_cull, mode);
+                  int mode = RF_EMD_AUTO) {
+    AmLayout L = am_layout(b, n, m, nlevels, mode);
     float *w = (float *)workspace;
     float *remainL = w, *remainR = w + L.npad;          // slot 0 of the vector region
     float *ratios = w + L.V;                            // slot 1+v: [ratioL npad | ratioR mpad]
     float *x1p = w + L.off_x1, *x2p = w + L.off_x2;
-    // the leading sharp levels run culled over spatially sorted (sort-tile-recursive) copies of the clouds (am_cull_kernel)
-    const int ncull = allow_cull ? cull_levels(L, nlevels, lc) : 0;
     // Live columns (am_compact_kernel): from level vC on, every sweep runs over the columns / rows of set 2 whose scalars are not
     // exactly 0 -- which, at the broad end of the schedule, is a few per cent of them.  (Round 5 took the three broadest levels
     // from a truncated Taylor expansion about the clouds' centre instead of sweeping them: 121 us per call at C4 for what these
@@ -2109,7 +1918,6 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
     int vC = 2;
     for (int v = 2; v < nlevels; v++)
         if (lc.c[v] < 0.f && kSkipArg / -lc.c[v] <= kSkipMaxT) vC = v + 1;
-    if (vC < ncull) vC = ncull;  // (behind the culled levels too: they leave every vector in the original order as well)
     const bool compact = L.compact_ok && vC + 2 <= nlevels;
     // (padded entries of every vector must read 0 -- they are column scalars of padded columns: am_init writes them)
     {
@@ -2122,29 +1930,11 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
         RF_LAUNCH("am_init", am_init_kernel, dim3(rf::ceil_div(max(L.npad, L.mpad), AI_TPB), b, 2), dim3(AI_TPB), 0, s, ai);
     }
 
-    L.tw_stride = L.Vs * (size_t)(1 + ncull);  // only the twin slots this schedule touches are laid out (and zero-filled)
-    CullSet SA{}, SB{};
-    float *tw = w + L.off_tw;  // twins: slot 0 = [remainL_s nsa | remainR_s nsb], slot 1+v = [ratioL_s | ratioR_s]
-    if (ncull > 0) {
-        const rfp::Sorted so[2] = {rfp::sorted_view(b, n, w + L.off_sa), rfp::sorted_view(b, m, w + L.off_sb)};
-        const int nn[2] = {n, m};
-        const float *src[2] = {xyz1, xyz2};
-        if (int e = rfp::sort_sets(b, 2, nn, src, so, s, nullptr)) return e;
-        SA = CullSet{so[0].xyz, so[0].orig, so[0].box16, so[0].box64, so[0].npad};
-        SB = CullSet{so[1].xyz, so[1].orig, so[1].box16, so[1].box64, so[1].npad};
-        // padding records of every twin must read 0 (column scalars of padding columns: 0 * e, never garbage * e)
-        RF_ZERO(tw, sizeof(float) * ((size_t)b * L.tw_stride + 64), s);
-        RF_LAUNCH("am_init", am_cull_init_kernel, dim3(rf::ceil_div(L.nsa, 256), b), dim3(256), 0, s, L.nsa, so[0].orig,
-                  multiL, tw, L.tw_stride);
-        RF_LAUNCH("am_init", am_cull_init_kernel, dim3(rf::ceil_div(L.nsb, 256), b), dim3(256), 0, s, L.nsb, so[1].orig,
-                  multiR, tw + L.nsa, L.tw_stride);
-    }
-    float *remL_s = tw, *remR_s = tw + L.nsa;
     // the sharp levels that stay on the dense sweeps: rows in the clouds' spatial order, columns with all-zero weights skipped
-    // (am_rowk_kernel SKIP; bit-identical sums).  Level v qualifies when its weight is exactly 0 from a d2 of at most kCullMaxT on.
+    // (am_rowk_kernel SKIP; bit-identical sums).  Level v qualifies when its weight is exactly 0 from a d2 of at most kSkipMaxT on.
     auto skip_t = [&](int v) { return (v >= 0 && v < nlevels && lc.c[v] < 0.f) ? kSkipArg / -lc.c[v] : INFINITY; };
     const int *permA = nullptr, *permB = nullptr;
-    if (ncull == 0 && L.rowsort_ok && skip_t(0) <= kSkipMaxT) {
+    if (L.rowsort_ok && skip_t(0) <= kSkipMaxT) {
         const rfp::Sorted so[2] = {rfp::sorted_view(b, n, w + L.off_sa), rfp::sorted_view(b, m, w + L.off_sb)};
         const int nn[2] = {n, m};
         const float *src[2] = {xyz1, xyz2};
@@ -2192,28 +1982,6 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
         const int *gptr = nullptr;  // (the sweeps' guard word: unused)
         const float tsk = skip_t(v);        // (a fused P3 of level v-1 is sharper or equal wherever this one is skippable)
         const bool skip = permA && tsk <= kSkipMaxT && (v == 0 || (lc.c[v - 1] < 0.f && lc.c[v - 1] <= lc.c[v]));
-        if (v < ncull) {
-            float *ratL_s = tw + (size_t)(1 + v) * L.Vs, *ratR_s = ratL_s + L.nsa;
-            const float Tcur = kCullArg / -lc.c[v];
-            const dim3 ga(L.nsa / 64, b), gb(L.nsb / 64, b);
-            if (v == 0) {
-                RF_LAUNCH("am_p1c", am_cull_kernel<0>, ga, dim3(64 * CW), 0, s, SA, SB, Tcur, 0.f, lc.c[v],
-                          (const float *)remR_s, (const float *)remR_s, L.tw_stride, (const float *)remL_s, remL_s,
-                          remainL, ratL_s, ratioL, L.bstride);
-            } else {
-                const float *pL_s = tw + (size_t)v * L.Vs, *pR_s = pL_s + L.nsa;  // level v-1's twins
-                const float Tprev = kCullArg / -lc.c[v - 1];
-                RF_LAUNCH("am_p3p1c", am_cull_kernel<1>, ga, dim3(64 * CW), 0, s, SA, SB, Tcur > Tprev ? Tcur : Tprev,
-                          lc.c[v - 1], lc.c[v], pR_s, (const float *)remR_s, L.tw_stride, pL_s, remL_s, remainL, ratL_s,
-                          ratioL, L.bstride);
-            }
-            RF_LAUNCH("am_p2c", am_cull_kernel<2>, gb, dim3(64 * CW), 0, s, SB, SA, Tcur, 0.f, lc.c[v],
-                      (const float *)ratL_s, (const float *)ratL_s, L.tw_stride, (const float *)remR_s, remR_s, remainR,
-                      ratR_s, ratioR, L.bstride);
-            if (compact && v + 1 == vC)
-                if (int e = pack_live(v, ratioR)) return e;
-            continue;
-        }
 #define AM_ROWK_ARGS(pR_, pL_, cprev)                                                                 \
     n, L.mpad / segk, xyz1, (const float *)x2p, (size_t)L.mpad * 3, pR_, (const float *)remainR, pL_,  \
         remainL, ratioL, L.bstride, cprev, lc.c[v], permA, L.nsa, tsk, skip_t(v - 1), gptr, 1
@@ -2330,7 +2098,7 @@ size_t rf_approxmatch_workspace_bytes(int b, int n, int m, int nlevels) {
 size_t rf_approxmatch_mode_workspace_bytes(int b, int n, int m, int nlevels, int mode) {
     if (b <= 0 || n <= 0 || m <= 0 || !emd_mode_ok(mode)) return 0;
     if (nlevels <= 0) nlevels = 10;
-    return am_layout(b, n, m, nlevels, false, mode).total * sizeof(float);
+    return am_layout(b, n, m, nlevels, mode).total * sizeof(float);
 }
 
 int rf_approxmatch_levels(int b, int n, int m, const float *xyz1, const float *xyz2, float *match,
@@ -2366,10 +2134,10 @@ int rf_approxmatch_mode(int b, int n, int m, const float *xyz1, const float *xyz
     LevelConsts lc;
     for (int v = 0; v < MAX_LEVELS; v++) lc.c[v] = v < nlevels ? levels_host[v] * kLog2e : 0.f;
     {
-        const int st = am_run_levels(b, n, m, xyz1, xyz2, nlevels, lc, multiL, multiR, workspace, s, false, mode);
+        const int st = am_run_levels(b, n, m, xyz1, xyz2, nlevels, lc, multiL, multiR, workspace, s, mode);
         if (st != RF_OK) return st;
     }
-    const AmLayout L = am_layout(b, n, m, nlevels, false, mode);
+    const AmLayout L = am_layout(b, n, m, nlevels, mode);
     const float *ratios = (const float *)workspace + L.V;
     // P3 of the last level only updates remainL, which nothing reads afterwards: not launched.
     const dim3 gm(rf::ceil_div(n, TPB), rf::ceil_div(m, LSEG), b);
@@ -2484,7 +2252,7 @@ EmdLayout emd_layout(int b, int n, int m, int mode = RF_EMD_AUTO) {
         E.off_rec = E.off_partial = 0;
         return E;
     }
-    const AmLayout L = am_layout(b, n, m, 10, true, mode);  // (one size for both forms of rf_earth_mover: the cost-only one culls)
+    const AmLayout L = am_layout(b, n, m, 10, mode);
     // enough workgroups to fill the chip: >= 4096 of 4 waves, l-spans of whole 32-column tiles
     // (the l-spans fix the order of the cost's partial sums: under RF_EMD_SWEPT they are those of a batch of one)
     const long base = (long)(mode == RF_EMD_SWEPT ? 1 : b) * rf::ceil_div(n, TPB);
@@ -2560,12 +2328,10 @@ int rf_earth_mover_mode(int b, int n, int m, const float *xyz1, const float *xyz
         return RF_OK;
     }
     {
-        // (cost only: with gradients asked for, the dense sweeps -- gradients are sums of match entries and follow
-        // them: 7 of 12288 components of a 4096^2 case left rel 1e-4 + abs 1e-4 with the culled levels, by up to 5e-4)
-        const int st = am_run_levels(b, n, m, xyz1, xyz2, nl, lc, multiL, multiR, workspace, s, !want_grad, mode);
+        const int st = am_run_levels(b, n, m, xyz1, xyz2, nl, lc, multiL, multiR, workspace, s, mode);
         if (st != RF_OK) return st;
     }
-    const AmLayout L = am_layout(b, n, m, nl, !want_grad, mode);
+    const AmLayout L = am_layout(b, n, m, nl, mode);
     const float *ratios = w + L.V;
     float *rec = w + E.off_rec, *partial = w + E.off_partial;
     RF_LAUNCH("emd_pack_cols", emd_pack_cols_kernel, dim3(rf::ceil_div(L.mpad, 256), b), dim3(256), 0, s, m,

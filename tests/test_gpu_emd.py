@@ -262,7 +262,7 @@ def test_earth_mover_fused_eval_size_16384():
 
 
 def test_exp2_is_exactly_zero_below_the_cull_argument():
-    """What the culled sweeps of the sharp levels rest on (approxmatch.hip kCullArg): v_exp_f32(x) == +0 for every
+    """What the skipping sweeps of the sharp levels rest on (approxmatch.hip kSkipArg): v_exp_f32(x) == +0 for every
     x <= -160, bit for bit, so a skipped pair would have added fma(0, s, acc) = acc."""
     from rfnet_amd._lib import check, lib
     x = np.concatenate([-np.linspace(160.0, 400.0, 200001), -np.logspace(np.log10(160.0), 30.0, 20000),
@@ -281,11 +281,10 @@ def test_exp2_is_exactly_zero_below_the_cull_argument():
 
 @pytest.mark.parametrize("b,n,m", [(1, 4096, 4096), (1, 4096, 5000), (2, 6000, 4100)])
 def test_earth_mover_culled_sharp_levels(orc, b, n, m):
-    """The cost-only rf_earth_mover on clouds of >= 4096 points runs the three sharpest levels as culled sweeps
-    over spatially sorted (sort-tile-recursive) copies (approxmatch.hip am_cull_kernel): same schedule, pairs whose weight is exactly 0
-    skipped, sums in sorted column order.  Cost against the oracle's chain (approx_match -> match_cost,
-    tf_approxmatch.cu restated) within 1e-5; the gradient form and approx_match itself (the ops that hand out
-    per-entry results) stay on the dense sweeps and keep their tolerances."""
+    """rf_earth_mover on clouds of >= 4096 points: cost against the oracle's chain (approx_match -> match_cost, tf_approxmatch.cu
+    restated) within 1e-5, with and without gradients, and the unfused chain.  (The name is rounds 3-5's, when the cost-only form ran
+    its three sharpest levels CULLED over sorted copies, sums in sorted order; round 6 took that route out -- a soak found its cost
+    1e-5 .. 3e-5 off the oracle's on rare large shapes: tools/experiments/emd_cull_route.patch.txt.)"""
     from rfnet_amd import _raw as R
     rng = np.random.RandomState(n + m)
     a = (rng.random_sample((b, n, 3)) - 0.5).astype(np.float32)
@@ -297,7 +296,7 @@ def test_earth_mover_culled_sharp_levels(orc, b, n, m):
     assert_rel(cost.cpu().numpy(), oc, 1e-5, what="cost (with_grad)")
     o1, o2 = orc.match_cost_grad(a, c, om)
     multiL, multiR = (1.0, float(n // m)) if n >= m else (float(m // n), 1.0)
-    # (the gradient form runs the DENSE sweeps; at these sizes -- twice to three times test_earth_mover_fused's -- the
+    # (at these sizes -- twice to three times test_earth_mover_fused's -- the
     # fast-exp noise of single match entries reaches 1.2e-4 of a unit mass in one component of 36000)
     assert_rel(g1.cpu().numpy(), o1, 1e-4, 2e-4 * multiL, what="grad1")
     assert_rel(g2.cpu().numpy(), o2, 1e-4, 2e-4 * multiR, what="grad2")
