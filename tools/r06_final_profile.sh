@@ -16,6 +16,9 @@ timeout 200 python3 tools/ab_emd_modes.py > "$O/ab_emd_modes.txt" 2>&1; cat "$O/
 timeout 300 python3 tools/ab_group_grad.py > "$O/ab_group_grad.txt" 2>&1; cut -c1-260 "$O/ab_group_grad.txt"
 timeout 200 python3 tools/ab_c3.py > "$O/ab_c3.txt" 2>&1; cat "$O/ab_c3.txt"
 timeout 300 python3 tools/soak_emd_live.py 120 6 > "$O/soak_emd_live.txt" 2>&1; tail -2 "$O/soak_emd_live.txt"
+timeout 300 python3 tools/soak_emd_live.py 60 3 large > "$O/soak_emd_large.txt" 2>&1; tail -2 "$O/soak_emd_large.txt"
+timeout 300 python3 tools/soak_emd_live.py 60 5 batch > "$O/soak_emd_batch.txt" 2>&1; tail -2 "$O/soak_emd_batch.txt"
+timeout 200 python3 tools/ab_emd_cull.py base > "$O/emd_sizes.txt" 2>&1; cut -c1-200 "$O/emd_sizes.txt"
 timeout 300 python3 tools/soak_step.py 100 > "$O/soak_step.txt" 2>&1; tail -2 "$O/soak_step.txt"
 timeout 300 python3 tools/soak_culled.py 60 > "$O/soak_culled.txt" 2>&1; tail -2 "$O/soak_culled.txt"
 timeout 300 python3 tools/soak_three_nn.py 60 3 > "$O/soak_three_nn.txt" 2>&1; tail -2 "$O/soak_three_nn.txt"

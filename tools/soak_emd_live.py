@@ -7,7 +7,9 @@ Per case: the two routes' costs within rel 1e-5 (the op's tolerance), every matc
 outside abs 1e-6 + rel 1e-4 counted (clamp flips: tests/test_oracle_golden.py::test_match_bar_is_ill_conditioned); the fused
 earth_mover cost and its gradients on both routes.  `large`: clouds of 4096 .. 9000 points (where rounds 3-5's cost-only earth_mover ran
 its sharp levels culled: this soak is what found that route 1e-5 .. 3e-5 off).
-usage: python tools/soak_emd_live.py [seconds] [seed] [large]"""
+`batch`: batches of 8 .. 24 clouds of 1500 .. 2600 points -- past the 6e7 pairs per call from which the default route sorts the rows of
+the sharp levels spatially, skips columns and hands level 1 the column lists of level 0.
+usage: python tools/soak_emd_live.py [seconds] [seed] [large | batch]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -16,7 +18,8 @@ from rfnet_amd import _raw as R
 T = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 LARGE = len(sys.argv) > 3 and sys.argv[3] == "large"
-LO, HI = (4096, 9000) if LARGE else (512, 3000)
+BATCH = len(sys.argv) > 3 and sys.argv[3] == "batch"
+LO, HI = (4096, 9000) if LARGE else ((1500, 2600) if BATCH else (512, 3000))
 t0 = time.time()
 cases = bad_cost = bad_entry = 0
 strays = entries = 0
@@ -39,7 +42,7 @@ def cloud(b, n, kind):
 
 
 while time.time() - t0 < T:
-    b = rng.randint(1, 3 if LARGE else 5)
+    b = rng.randint(8, 25) if BATCH else rng.randint(1, 3 if LARGE else 5)
     n = int(round(np.exp(rng.uniform(np.log(LO), np.log(HI)))))
     m = n if rng.rand() < 0.4 else int(round(np.exp(rng.uniform(np.log(LO), np.log(HI)))))
     ka, kc = rng.randint(0, 5), rng.randint(0, 5)
