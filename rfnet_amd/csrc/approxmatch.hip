@@ -42,18 +42,6 @@ constexpr float kLog2e = 1.44269502f;  // 0x3FB8AA3B, the constant __expf multip
 // match_cost reads `match` with non-temporal loads too: 88.4 -> 78.6 us alone, 87.7 -> 79.7 inside the sequence (a pure read of
 // 512 MiB: 83 us plain, 76 non-temporal -- tools/ubench/stream_rate.hip); the gradient pass behind it then finds less of the tensor's
 // head in the memory-side cache (85.8 -> 91.2 us): -3 us for the three ops together, -8 for approx_match + match_cost
-#ifndef RFA_PK
-#define RFA_PK 1
-#endif
-#ifndef RFA_PK_FUSED
-#define RFA_PK_FUSED 1  // emd_fused_kernel (cost only): two columns per step, packed
-#endif
-#ifndef RFA_SKIP_MASK
-#define RFA_SKIP_MASK 1  // level 0's skipping sweeps list the columns level 1's will need; level 1's visit only those (am_rowk_kernel MASK)
-#endif
-#ifndef RFA_PP_DENSE
-#define RFA_PP_DENSE 1  // the packed sweeps take their column operands through two scalar register sets in turn, as the skipping sweeps
-#endif
 typedef float am_v2f __attribute__((ext_vector_type(2)));
 constexpr int TPB = 256;
 constexpr int LVG = 16;             // levels per group in the materialisation kernel
@@ -180,11 +168,11 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
         c1 = min(c0 + slen, cnt);
     }
     // one column (its coordinates and scalars wave-uniform) against the lane's RPT rows
-    // (RFA_PK: the lane's two rows as the halves of packed fp32 operations, as in am_rowl_kernel -- bit-identical sums -- together
+    // (PK: the lane's two rows as the halves of packed fp32 operations, as in am_rowl_kernel -- bit-identical sums -- together
     // with the column operands through two scalar register sets in turn: the dense fused P3 + P1 sweep 61.8 -> 47.5 us at C4, P3
     // alone 41.6 -> 33; packed alone the fused sweep got 6 % SLOWER, the two register sets alone 3 %.  The skipping sweeps keep
     // the scalar form: most of their columns end after the distance and its test, packed 41.6 / 53.4 for 35.9 / 47.1 us.)
-    constexpr bool PK = RPT == 2 && RFA_PK != 0 && SKIP == 0;
+    constexpr bool PK = RPT == 2 && SKIP == 0;
     am_v2f X1 = {x1[0], x1[RPT - 1]}, Y1 = {y1[0], y1[RPT - 1]}, Z1 = {z1[0], z1[RPT - 1]}, RL = {rl[0], rl[RPT - 1]};
     am_v2f ACC3 = {acc3[0], acc3[RPT - 1]}, ACC1 = {acc1[0], acc1[RPT - 1]};
     int nlisted = 0;                       // (MASK == 1, uniform) columns listed so far
@@ -258,7 +246,7 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
             if (HAS_P1) acc1[r] = fmaf(P1 == 2 ? 1.0f : (P1 == 3 ? e3 : fast_exp2(d2[r] * c_cur)), s1u, acc1[r]);
         }
     };
-    if constexpr (SKIP != 0 || (RFA_PP_DENSE && PK)) {
+    if constexpr (SKIP != 0 || PK) {
         // The skipping sweeps issue 14 VALU per column and lane pair against ~10 scalar instructions -- and a CU has ONE scalar
         // unit for its 16 waves: they are bound by IT (an x-only pre-test that removed 4 VALU from 50 % of the columns changed
         // nothing).  So here the column operands go through TWO scalar register sets used in turn instead of load-then-copy (5
@@ -425,9 +413,9 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
     const float *__restrict__ C = xyz1p + (size_t)bi * xyz1p_stride;
     const float *__restrict__ S = ratioL + (size_t)bi * stride;
     const int c0 = seg * seglen, c1 = c0 + seglen;
-    // RFA_PK: the lane's two rows as the two halves of packed fp32 operations (v_pk_add / v_pk_mul / v_pk_fma: the same IEEE
+    // PKL: the lane's two rows as the two halves of packed fp32 operations (v_pk_add / v_pk_mul / v_pk_fma: the same IEEE
     // operations in the same order -- bit-identical sums): 6 instead of 16 vector instructions per column beside the exponentials
-    constexpr bool PKL = RPT == 2 && RFA_PK != 0 && !SKIP;
+    constexpr bool PKL = RPT == 2 && !SKIP;
     am_v2f X2 = {x2[0], x2[RPT - 1]}, Y2 = {y2[0], y2[RPT - 1]}, Z2 = {z2[0], z2[RPT - 1]}, ACC = {0.f, 0.f};
     int nlisted = 0;                            // (MASK == 1, uniform)
     unsigned short *__restrict__ lst = nullptr;  // (MASK != 0) this wave's list: [0] = count, then the columns
@@ -470,7 +458,7 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
 #pragma unroll
         for (int r = 0; r < RPT; r++) acc[r] = fmaf(ZERO ? 1.0f : fast_exp2(d2[r] * c_cur), su, acc[r]);
     };
-    if constexpr (SKIP || (RFA_PP_DENSE && PKL)) {  // two scalar register sets in turn (am_rowk_kernel)
+    if constexpr (SKIP || PKL) {  // two scalar register sets in turn (am_rowk_kernel)
         const cfloat *Cc = (const cfloat *)C, *Sc = (const cfloat *)S;
         float xa[3 * SUB], sa[SUB], xb[3 * SUB], sb[SUB];
 #define RFA_FETCH_L(xs, ts, c)                                                               \
@@ -1666,7 +1654,7 @@ __global__ __launch_bounds__(TPB) void emd_fused_kernel(int n, int m, int mpad, 
     const int lend = min(mpad, lbeg + lspan);  // multiples of MG_TL; records beyond m are zero
     const int bl = t & (MG_TL - 1);
     const int br = t / MG_TL;
-    if constexpr (!GRAD && RFA_PK_FUSED != 0) {
+    if constexpr (!GRAD) {
         // cost only: two columns per step as the halves of packed fp32 operations, their operands in scalar register pairs (the
         // pair layout of emd_pack_cols_kernel); per entry the same operations in the same order, the cost summed column by column
         for (int l0 = lbeg; l0 < lend; l0 += MG_TL) {
@@ -1952,8 +1940,8 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
     const dim3 gk(rf::ceil_div(n, 64 * RPT), b), gl(rf::ceil_div(m, 64 * RPT), b);
     const dim3 gks(rf::ceil_div(L.nsa, 64 * RPT), b), gls(rf::ceil_div(L.nsb, 64 * RPT), b);  // SKIP: over the sorted positions
     // levels 0 and 1 both on the skipping sweeps (sharper cut-off first): level 0's launches list, per wave, the columns within level
-    // 1's cut-off; level 1's launches visit only those (RFA_SKIP_MASK)
-    const bool masked = RFA_SKIP_MASK && permA && permB && nlevels > 2 && lc.c[0] < lc.c[1] && lc.c[1] < 0.f && skip_t(1) <= kSkipMaxT &&
+    // 1's cut-off; level 1's launches visit only those (am_rowk_kernel MASK)
+    const bool masked = permA && permB && nlevels > 2 && lc.c[0] < lc.c[1] && lc.c[1] < 0.f && skip_t(1) <= kSkipMaxT &&
                         n < 65536 && m < 65536 &&  // (16-bit column numbers ...
                         L.mpad / segk <= 65535 && L.npad / segl <= 65535;  // ... and 16-bit per-wave counts: a segment of 65536 columns, all listed, would wrap to 0)
     unsigned short *maskk = (unsigned short *)(w + L.off_maskk), *maskl = (unsigned short *)(w + L.off_maskl);
@@ -2193,15 +2181,12 @@ int rf_matchcost(int b, int n, int m, const float *xyz1, const float *xyz2, cons
 }
 
 // The gradient pass over `match` (outputs zero-filled by the caller): whole rows per workgroup where the layout allows it.
-#ifndef RFA_MCG_ROWS
-#define RFA_MCG_ROWS 1
-#endif
 constexpr int MCG_ROWS_WG = 1024;  // workgroups the l-ranges are cut for: four per CU (1536 / 2048 at 6 waves per SIMD: +3 .. +6 %)
 static int mcg_launch(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match, float *grad1,
                        float *grad2, hipStream_t s) {
     const int kspan = TPB * MR_KPL;
     // (a last k-block that is mostly dead lanes costs more than the tile form's padding: 32 x 1028 x 1000 46-49 vs 44.6 us)
-    if (RFA_MCG_ROWS && n % MR_KPL == 0 && 4 * (long)n >= 3L * rf::ceil_div(n, kspan) * kspan && m >= 2 * MR_DEPTH &&
+    if (n % MR_KPL == 0 && 4 * (long)n >= 3L * rf::ceil_div(n, kspan) * kspan && m >= 2 * MR_DEPTH &&
         (((uintptr_t)xyz1 | (uintptr_t)match) & 15) == 0) {
         const int kb = rf::ceil_div(n, kspan);
         int lsplit = rf::ceil_div(MCG_ROWS_WG, b * kb);
@@ -2335,7 +2320,7 @@ int rf_earth_mover_mode(int b, int n, int m, const float *xyz1, const float *xyz
     const float *ratios = w + L.V;
     float *rec = w + E.off_rec, *partial = w + E.off_partial;
     RF_LAUNCH("emd_pack_cols", emd_pack_cols_kernel, dim3(rf::ceil_div(L.mpad, 256), b), dim3(256), 0, s, m,
-              L.mpad, nl, xyz2, ratios, L.V, L.bstride, L.npad, rec, (RFA_PK_FUSED && !want_grad) ? 1 : 0);
+              L.mpad, nl, xyz2, ratios, L.V, L.bstride, L.npad, rec, want_grad ? 0 : 1);
     const dim3 g(rf::ceil_div(n, TPB), E.lsplit, b);
     const bool sq = quarter_chain(lc.c, 10, true);
     if (want_grad && sq) {

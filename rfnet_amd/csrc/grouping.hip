@@ -298,10 +298,6 @@ __global__ __launch_bounds__(64 * QS) void query_ball_lanes_kernel(int n, int m,
 // whatever the radius: results are bit-identical to the scan kernels' (tests/test_gpu_sampling_grouping.py).
 constexpr int QX_LIST = 128;  // surviving superblocks a boxed query may hold: max(16, G / 8) <= 128 for G <= 1024
 constexpr int QX_STAGE = 64;  // nsample <= 64
-#ifndef RFG_QX_XCD
-#define RFG_QX_XCD 1
-#endif
-constexpr int QX_XCD = RFG_QX_XCD;
 #ifndef RFG_QX_BATCH
 #define RFG_QX_BATCH 4
 #endif
@@ -350,7 +346,7 @@ __global__ __launch_bounds__(1024) void query_ball_boxes_kernel(
     const int wpb = blockDim.x >> 6;
     // a sample's workgroups on ONE XCD (rf::xcd_contiguous): its sorted records and boxes (270 KB at 16384 points) then stay in
     // that XCD's L2 -- spread over all eight, 32 samples are 8.6 MB per 4 MB L2
-    const unsigned logical = QX_XCD ? rf::xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+    const unsigned logical = rf::xcd_contiguous(blockIdx.x, gridDim.x);
     const int bpb = (m + wpb - 1) / wpb;  // workgroups per sample
     const int bi = logical / bpb;
     const int q = (logical - bi * bpb) * wpb + wib;
@@ -517,21 +513,17 @@ __global__ void group_point3_kernel(int n, int per_batch, const float *__restric
 // Any c: a thread row per (query, sample) slot -- its index loaded once -- and the channels as VEC-wide vectors over the row's
 // lanes, 32-bit arithmetic, the batch element from the grid (the element-per-thread kernels below pay two 64-bit divisions per
 // ELEMENT; they remain for what does not fit 32 bits).  GRAD: the same walk, adding grad_out into grad_points.
-#ifndef RFG_XCD
-#define RFG_XCD 1  // a sample's workgroups on one XCD (rf::xcd_contiguous)
-#endif
 constexpr int GPR_TPB = 256;
 constexpr int GPR_PP = 4;  // slots per thread row and block
 typedef float gpr_v4f __attribute__((ext_vector_type(4)));
 template <int VEC, bool GRAD>
 __global__ __launch_bounds__(GPR_TPB) void group_point_rows_kernel(int n, int c, int per_batch, int tx_log2, int bpb /* blocks per sample */,
-                                                                   int xcd_contiguous,
                                                                    const float *__restrict__ src /* points | grad_out */,
                                                                    const int *__restrict__ idx,
                                                                    float *__restrict__ dst /* out | grad_points */) {
     typedef typename std::conditional<VEC == 4, gpr_v4f, float>::type V;
     // (a sample's blocks on ONE XCD: the rows it gathers cross the fabric once instead of eight times)
-    const unsigned logical = xcd_contiguous ? rf::xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+    const unsigned logical = rf::xcd_contiguous(blockIdx.x, gridDim.x);  // a sample's workgroups on one XCD
     const size_t bi = logical / bpb;
     const int bx = logical - (unsigned)bi * bpb;
     const int TX = 1 << tx_log2, TY = GPR_TPB >> tx_log2;
@@ -581,17 +573,14 @@ static int group_rows_launch(int b, int n, int c, long per_batch, const float *s
     const long bpb = (per_batch + spb - 1) / spb;
     const dim3 grid((unsigned)(bpb * b));
     if (vec) {
-        RF_LAUNCH(name, (group_point_rows_kernel<4, GRAD>), grid, dim3(GPR_TPB), 0, s, n, c, (int)per_batch, tx_log2, (int)bpb, RFG_XCD, src, idx, dst);
+        RF_LAUNCH(name, (group_point_rows_kernel<4, GRAD>), grid, dim3(GPR_TPB), 0, s, n, c, (int)per_batch, tx_log2, (int)bpb, src, idx, dst);
     } else {
-        RF_LAUNCH(name, (group_point_rows_kernel<1, GRAD>), grid, dim3(GPR_TPB), 0, s, n, c, (int)per_batch, tx_log2, (int)bpb, RFG_XCD, src, idx, dst);
+        RF_LAUNCH(name, (group_point_rows_kernel<1, GRAD>), grid, dim3(GPR_TPB), 0, s, n, c, (int)per_batch, tx_log2, (int)bpb, src, idx, dst);
     }
     return RF_OK;
 }
-#ifndef RFG_ROWS
-#define RFG_ROWS 1
-#endif
 static bool group_rows_ok(int b, int n, int c, long per_batch) {
-    return RFG_ROWS && b <= 65535 && per_batch * b < (1L << 31) && per_batch * c < (1L << 31) && (long)n * c < (1L << 31) && per_batch < (1L << 30);
+    return b <= 65535 && per_batch * b < (1L << 31) && per_batch * c < (1L << 31) && (long)n * c < (1L << 31) && per_batch < (1L << 30);
 }
 
 __global__ void group_point_grad_kernel(int n, int c, long per_batch, long total,

@@ -107,9 +107,6 @@ __global__ __launch_bounds__(TN_TPB) void three_nn_kernel(int n, int m,
 #ifndef RFI_TB_WAVES
 #define RFI_TB_WAVES 4
 #endif
-#ifndef RFI_TB_XCD
-#define RFI_TB_XCD 1
-#endif
 constexpr int TB_WAVES = RFI_TB_WAVES;  // waves per workgroup, each on its own (no barrier)
 
 #define TB_ROW(OP, N) asm volatile("s_nop 1\n\t" OP " %0, %0, %0 row_ror:" #N " row_mask:0xf bank_mask:0xf" : "+v"(v))
@@ -153,7 +150,7 @@ __global__ __launch_bounds__(64 * TB_WAVES) void three_nn_boxes_kernel(
     const int lane = threadIdx.x & 63;
     // a sample's workgroups on the XCD that sorted it (rf::xcd_contiguous, as nnp_sort): its records are still in that L2
     const int bpb = ((npq >> 6) + TB_WAVES - 1) / TB_WAVES;  // workgroups per sample
-    const unsigned logical = RFI_TB_XCD ? rf::xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+    const unsigned logical = rf::xcd_contiguous(blockIdx.x, gridDim.x);  // a sample's workgroups on one XCD
     const int bi = logical / bpb;
     const int group = (logical - bi * bpb) * TB_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (group * 64 >= npq) return;  // (uniform)
@@ -353,14 +350,13 @@ struct TiVec<1> {
 
 template <int VEC>
 __global__ __launch_bounds__(TI_TPB) void three_interpolate_rows_kernel(int m, int c, int n, int tx_log2, int bpb /* blocks per sample */,
-                                                                        int xcd_contiguous,
                                                                         const float *__restrict__ points,
                                                                         const int *__restrict__ idx,
                                                                         const float *__restrict__ weight,
                                                                         float *__restrict__ out) {
     typedef typename TiVec<VEC>::T V;
     // (a sample's blocks on ONE XCD: its rows of `points` then cross the fabric once instead of eight times -- FETCH_SIZE 71 -> 14 MB, 68 -> 57 us)
-    const unsigned logical = xcd_contiguous ? rf::xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+    const unsigned logical = rf::xcd_contiguous(blockIdx.x, gridDim.x);  // a sample's workgroups on one XCD
     const int bi = logical / bpb, bx = logical - bi * bpb;
     const int TX = 1 << tx_log2, TY = TI_TPB >> tx_log2;
     const int lx = threadIdx.x & (TX - 1), ly = threadIdx.x >> tx_log2;
@@ -399,12 +395,6 @@ __global__ __launch_bounds__(TI_TPB) void three_interpolate_rows_kernel(int m, i
 // runs at 18 lane-operations per ns and CU against 0.8 for ds_add_f32 (tools/ubench/lds_atomic_rate.hip), and L2 atomics from
 // every element (the kernel below) reach 0.3 per ns and CU -- and walks a part of the unknown points: grad_out is read once,
 // cs * 4 bytes per point and workgroup; the tile leaves as plain stores (one part) or atomic adds (several).
-#ifndef RFI_XCD
-#define RFI_XCD 1  // a sample's workgroups on one XCD (rf::xcd_contiguous)
-#endif
-#ifndef RFI_TG_VEC
-#define RFI_TG_VEC 1
-#endif
 #ifndef RFI_TG_WGS
 #define RFI_TG_WGS 256
 #endif
@@ -413,7 +403,7 @@ constexpr int TG_U = 4;  // points per thread row in flight
 
 template <int VEC, bool POW2>  // POW2: cs is a power of two (shifts instead of multiplications and a division)
 __global__ __launch_bounds__(TG_TPB) void three_interpolate_grad_tile_kernel(int m, int c, int n, int cs, int tx_log2,
-                                                                             int nslices, int parts, int xcd_contiguous,
+                                                                             int nslices, int parts,
                                                                              const float *__restrict__ grad_out,
                                                                              const int *__restrict__ idx,
                                                                              const float *__restrict__ weight,
@@ -421,7 +411,7 @@ __global__ __launch_bounds__(TG_TPB) void three_interpolate_grad_tile_kernel(int
     typedef typename TiVec<VEC>::T V;
     extern __shared__ __attribute__((aligned(16))) double ti_tile[];  // [m * cs]; cs = VEC << tx_log2, or (VEC == 1) any cs <= 1 << tx_log2
     // (a sample's slices and parts on ONE XCD: neighbouring slices share the cache lines of grad_out's rows)
-    const unsigned logical = xcd_contiguous ? rf::xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+    const unsigned logical = rf::xcd_contiguous(blockIdx.x, gridDim.x);  // a sample's workgroups on one XCD
     const int wps = nslices * parts;  // workgroups per sample
     const int bi = logical / wps, bx = logical - bi * wps;
     const int slice = bx % nslices, part = bx / nslices;
@@ -606,10 +596,10 @@ int rf_threeinterpolate(int b, int m, int c, int n, const float *points, const i
             const dim3 grid((unsigned)(bpb * b));
             if (vec) {
                 RF_LAUNCH("three_interpolate", three_interpolate_rows_kernel<4>, grid, dim3(TI_TPB), 0, (hipStream_t)stream, m, c, n,
-                          tx_log2, (int)bpb, RFI_XCD, points, idx, weight, out);
+                          tx_log2, (int)bpb, points, idx, weight, out);
             } else {
                 RF_LAUNCH("three_interpolate", three_interpolate_rows_kernel<1>, grid, dim3(TI_TPB), 0, (hipStream_t)stream, m, c, n,
-                          tx_log2, (int)bpb, RFI_XCD, points, idx, weight, out);
+                          tx_log2, (int)bpb, points, idx, weight, out);
             }
             return RF_OK;
         }
@@ -661,7 +651,7 @@ int rf_threeinterpolate_grad_ws(int b, int n, int c, int m, const float *grad_ou
                                      "three_interpolate_grad", s);
     if (cs > 0) {
         const bool pow2 = (cs & (cs - 1)) == 0 && cs >= 8;
-        const bool vec = RFI_TG_VEC && pow2 && rf::aligned16(grad_out);  // (rows of a slice start 16-byte aligned when the tensor does)
+        const bool vec = pow2 && rf::aligned16(grad_out);  // (rows of a slice start 16-byte aligned when the tensor does)
         const int nslices = c / cs;
         int tx_log2 = 0;
         while ((1 << tx_log2) < (vec ? cs / 4 : cs)) tx_log2++;
@@ -673,7 +663,7 @@ int rf_threeinterpolate_grad_ws(int b, int n, int c, int m, const float *grad_ou
         const dim3 grid((unsigned)(nslices * parts * b));
 #define TG_GO(KERNEL)                                                                                                      \
     RF_HIP(hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));                 \
-    RF_LAUNCH("three_interpolate_grad", KERNEL, grid, dim3(TG_TPB), lds, s, m, c, n, cs, tx_log2, nslices, parts, RFI_XCD, grad_out, idx, \
+    RF_LAUNCH("three_interpolate_grad", KERNEL, grid, dim3(TG_TPB), lds, s, m, c, n, cs, tx_log2, nslices, parts, grad_out, idx, \
               weight, grad_points)
         if (vec) {
             TG_GO((three_interpolate_grad_tile_kernel<4, true>));

@@ -477,14 +477,7 @@ struct GradArgs {
 template <bool LOSS>
 __global__ __launch_bounds__(GTPB) void nn_grad_kernel(GradArgs a) {
     // the tile's sums in DOUBLE: ds_add_f64 runs at 18 lane-operations per ns and CU, ds_add_f32 at 0.8 (tools/ubench/lds_atomic_rate.hip)
-#ifndef RFN_GRAD_F64
-#define RFN_GRAD_F64 1
-#endif
-#if RFN_GRAD_F64
     typedef double acc_t;
-#else
-    typedef float acc_t;
-#endif
     __shared__ acc_t acc[GT * 3];
     int bid = blockIdx.x;
     const int which = bid >= a.nblk0;

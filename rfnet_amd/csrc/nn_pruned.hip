@@ -84,17 +84,11 @@ namespace {
 #ifndef RFP_QSAMPLE
 #define RFP_QSAMPLE 3  // the quantile histograms take every (RFP_QSAMPLE + 1)-th point: 3 = a quarter of the cloud
 #endif
-#ifndef RFP_HAGG
-#define RFP_HAGG 1  // the sort's quantile histograms sample 4x fewer lanes in waves whose points crowd into few bins (collapsed clouds)
-#endif
 #ifndef RFP_STR_SMALL_N
 #define RFP_STR_SMALL_N 4096
 #endif
 #ifndef RFP_CROWD_DIV
 #define RFP_CROWD_DIV 4  // a cloud is flagged crowded when more than 1 / RFP_CROWD_DIV of its sort's waves are
-#endif
-#ifndef RFP_ZSPREAD
-#define RFP_ZSPREAD 1    // crowded waves spread a spot's copies over 16 adjacent z ranks
 #endif
 #ifndef RFP_STR_LARGE_LEAF
 #define RFP_STR_LARGE_LEAF 48
@@ -401,7 +395,7 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
         const int w3 = wave & RFP_QSAMPLE;
         const float x0 = w3 == 0 ? px[0] : (w3 == 3 ? px[1] : (w3 == 2 ? px[2] : px[3]));
         const int k0 = (4 - w3) & 3;
-        dense = RFP_HAGG && RFP_QSAMPLE == 3 && hist_is_dense((unsigned)axis_bin(x0, fl[0], fs[0]), tid + k0 * STPB < n);
+        dense = RFP_QSAMPLE == 3 && hist_is_dense((unsigned)axis_bin(x0, fl[0], fs[0]), tid + k0 * STPB < n);
     }
     const bool feeds = !dense || (lane & 3) == 0;  // (a crowded wave: a quarter of its lanes feed the quantile histograms)
     if (dense && lane == 0) atomicAdd(&ncrowded, 1u);
@@ -502,7 +496,7 @@ __global__ __launch_bounds__(STPB) void nnp_sort_reg_kernel(SortArgs a) {
         // a crowded wave (near-copies on a few spots) spreads its points over 16 adjacent z ranks by lane: the key
         // histogram and the positions are exact and their same-address LDS atomics serialise -- 46 of 64 lanes on one
         // bin otherwise; copies of one spot are the same place, so the ORDER among them is free and culling loses nothing
-        if (RFP_ZSPREAD && dense) zq = (zq & ~15u) | (unsigned)(lane & 15);
+        if (dense) zq = (zq & ~15u) | (unsigned)(lane & 15);
         const unsigned key = ((unsigned)col << 9) | ((col & 1) ? 511u - zq : zq);
         int slice = col >= cs1;  // (two workgroups per cloud, the product's split: one comparison)
         if (H > 2) slice += (col >= cs2) + (col >= cs3);  // (uniform)
