@@ -892,8 +892,19 @@ __global__ __launch_bounds__(PL_TPB) void am_p2_live_kernel(int npad, const floa
 }
 
 // match[l][k] = sum over levels (in order) of fma(ratioL_lv[k]*e_lv, ratioR_lv[l], acc).
-// thread <-> k (coalesced 256-B stores per wave per l); workgroup = 256 k x LSEG l.
-constexpr int LSEG = 64;
+// thread <-> k (coalesced 256-B stores per wave per l); workgroup = AMM_TPB k x LSEG l.
+// The kernel sits on its STORES (512 MiB at C4; the same stores of a value that costs nothing take as long), and how long they
+// take depends on the rows a thread walks, not on the workgroup's width: same device, C4, 256 threads x 64 rows (rounds 1-5) 117 us,
+// x 32 rows 95, x 16 rows 106, 24 / 40 / 48 rows 109 / 101 / 108; 512 or 1024 threads x 32 rows 94-96 (a linear fill of the tensor:
+// 89-95, profiles/r05_stream_rate.txt); two or four entries of a row per thread 110-121 (tools/experiments/
+// am_match_entries_per_thread.patch.txt).  approx_match + match_cost 0.577 -> 0.557 ms with 1024 x 32 (profiles/r06_ab_am_match.txt).
+#ifndef RFA_MATCH_TPB
+#define RFA_MATCH_TPB 1024
+#endif
+#ifndef RFA_MATCH_LSEG
+#define RFA_MATCH_LSEG 32
+#endif
+constexpr int LSEG = RFA_MATCH_LSEG, AMM_TPB = RFA_MATCH_TPB;
 struct LevelConsts {
     float c[MAX_LEVELS];  // level * log2e
 };
@@ -946,7 +957,7 @@ inline bool quarter_chain(const float *c, int nlv, bool lastzero) {
 }
 
 template <int NLV, bool LASTZERO = false, bool SQ = false>
-__global__ __launch_bounds__(TPB) void am_match_kernel(int n, int m, const float *xyz1,
+__global__ __launch_bounds__(AMM_TPB) void am_match_kernel(int n, int m, const float *xyz1,
                                                        const float *xyz2, const float *ratios,
                                                        size_t lv_stride, size_t b_stride, int roff,
                                                        int lv0, int nlv, LevelConsts lc,
@@ -962,18 +973,18 @@ __global__ __launch_bounds__(TPB) void am_match_kernel(int n, int m, const float
     const int bi = lgc / per;
     const unsigned rem = lgc - bi * per;
     const int by = rem / gridDim.x, bx = rem - by * gridDim.x;
-    const int k = bx * TPB + threadIdx.x;
+    const int k = bx * AMM_TPB + threadIdx.x;
     const int l0 = by * LSEG;
     const int lcnt = min(LSEG, m - l0);
     xyz1 += (size_t)bi * n * 3;
     xyz2 += (size_t)bi * m * 3;
     ratios += (size_t)bi * b_stride + (size_t)lv0 * lv_stride;
     match += (size_t)bi * n * m;
-    for (int i = threadIdx.x; i < lcnt * LVG; i += TPB) {
+    for (int i = threadIdx.x; i < lcnt * LVG; i += AMM_TPB) {
         int l = i / LVG, v = i % LVG;
         crr[l][v] = v < nlv ? ratios[(size_t)v * lv_stride + roff + l0 + l] : 0.f;
     }
-    for (int i = threadIdx.x; i < lcnt; i += TPB) {
+    for (int i = threadIdx.x; i < lcnt; i += AMM_TPB) {
         cxyz[i][0] = xyz2[(size_t)(l0 + i) * 3 + 0];
         cxyz[i][1] = xyz2[(size_t)(l0 + i) * 3 + 1];
         cxyz[i][2] = xyz2[(size_t)(l0 + i) * 3 + 2];
@@ -2128,20 +2139,20 @@ int rf_approxmatch_mode(int b, int n, int m, const float *xyz1, const float *xyz
     const AmLayout L = am_layout(b, n, m, nlevels, mode);
     const float *ratios = (const float *)workspace + L.V;
     // P3 of the last level only updates remainL, which nothing reads afterwards: not launched.
-    const dim3 gm(rf::ceil_div(n, TPB), rf::ceil_div(m, LSEG), b);
+    const dim3 gm(rf::ceil_div(n, AMM_TPB), rf::ceil_div(m, LSEG), b);
     if (nlevels == 10 && lc.c[9] == 0.0f && quarter_chain(lc.c, 10, true)) {  // the reference schedule
-        RF_LAUNCH("am_match", (am_match_kernel<10, true, true>), gm, dim3(TPB), 0, s, n, m, xyz1, xyz2,
+        RF_LAUNCH("am_match", (am_match_kernel<10, true, true>), gm, dim3(AMM_TPB), 0, s, n, m, xyz1, xyz2,
                   (const float *)ratios, L.V, L.bstride, L.npad, 0, 10, lc, match);
     } else if (nlevels == 10 && lc.c[9] == 0.0f) {
-        RF_LAUNCH("am_match", (am_match_kernel<10, true>), gm, dim3(TPB), 0, s, n, m, xyz1, xyz2,
+        RF_LAUNCH("am_match", (am_match_kernel<10, true>), gm, dim3(AMM_TPB), 0, s, n, m, xyz1, xyz2,
                   (const float *)ratios, L.V, L.bstride, L.npad, 0, 10, lc, match);
     } else if (nlevels == 10) {
-        RF_LAUNCH("am_match", (am_match_kernel<10, false>), gm, dim3(TPB), 0, s, n, m, xyz1, xyz2,
+        RF_LAUNCH("am_match", (am_match_kernel<10, false>), gm, dim3(AMM_TPB), 0, s, n, m, xyz1, xyz2,
                   (const float *)ratios, L.V, L.bstride, L.npad, 0, 10, lc, match);
     } else {
         for (int lv0 = 0; lv0 < nlevels; lv0 += LVG) {
             int nlv = nlevels - lv0 < LVG ? nlevels - lv0 : LVG;
-            RF_LAUNCH("am_match", (am_match_kernel<0, false>), gm, dim3(TPB), 0, s, n, m, xyz1, xyz2,
+            RF_LAUNCH("am_match", (am_match_kernel<0, false>), gm, dim3(AMM_TPB), 0, s, n, m, xyz1, xyz2,
                       (const float *)ratios, L.V, L.bstride, L.npad, lv0, nlv, lc, match);
         }
     }
