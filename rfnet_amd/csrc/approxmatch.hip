@@ -910,7 +910,7 @@ struct LevelConsts {
 };
 
 // NLV > 0: exactly NLV levels starting at level 0, fully unrolled with no per-level branch (the
-// reference schedule is NLV = 10); NLV = 0: generic group of up to LVG levels, predicated.
+// reference schedule is NLV = 10).
 // LASTZERO: level NLV-1 has multiplier 0 (e = 1.0 exactly): its exponential is not evaluated.
 // SQ: every odd level below the last has exactly four times the multiplier of the level after it (the reference
 // schedule: levels -4^7 ... -4^-1, 0: tf_approxmatch.cu:36), so d2*c[v] == 4*(d2*c[v+1]) exactly and its weight is the
@@ -1055,20 +1055,93 @@ __global__ __launch_bounds__(AMM_TPB) void am_match_kernel(int n, int m, const f
         }
         return;
     }
-    float rl[LVG];
+}
+
+// Any other schedule (up to MAX_LEVELS levels; BASELINE configs[3]: the ten reference levels five times each = 50): ALL its levels
+// in ONE pass over `match` -- NG groups of LVG levels, a thread's ratioL of every level in registers (LVG * NG of them), the
+// rows' ratioR in LDS.  (Rounds 1-5 took LVG levels per launch and read the tensor back for the next group: four launches and
+// 3.5 GiB of traffic for the 50-level schedule at C4, 1.6 ms of its 2.9.)  The same fma chain in level order, so the same bits:
+//   * a level with the multiplier of the one before it reuses its weight (the same argument: the same v_exp_f32 result) -- which
+//     levels need a new one is a 64-bit word from the host;
+//   * a row's levels behind its LAST LIVE one are not formed (ratioR is exactly +0 there and fma(p, +0, acc) = acc -- p is finite);
+//     the guard is per group of four levels, wave-uniform.
+// REP > 0: a schedule that takes every multiplier REP times in a row (configs[3]: REP = 5) -- one guard, one exponential and REP
+// terms per run instead of a test per level: the branches were what the general form spent its time on (0.40 -> see below).
+template <int NG, int REP = 0>
+__global__ __launch_bounds__(AMM_TPB) void am_match_any_kernel(int n, int m, const float *xyz1, const float *xyz2,
+                                                               const float *ratios, size_t lv_stride, size_t b_stride,
+                                                               int roff, int nlv, LevelConsts lc, unsigned long long fresh,
+                                                               float *match) {
+    constexpr int NL = LVG * NG;
+    __shared__ float cxyz[LSEG][4];
+    __shared__ __attribute__((aligned(16))) float crr[LSEG][NL];
+    __shared__ int cdl[LSEG];  // per row: its last level with ratioR != 0
+    const unsigned per = gridDim.x * gridDim.y;
+    const unsigned lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const unsigned lgc = rf::xcd_contiguous(lin, per * gridDim.z);
+    const int bi = lgc / per;
+    const unsigned rem = lgc - bi * per;
+    const int by = rem / gridDim.x, bx = rem - by * gridDim.x;
+    const int k = bx * AMM_TPB + threadIdx.x;
+    const int l0 = by * LSEG;
+    const int lcnt = min(LSEG, m - l0);
+    xyz1 += (size_t)bi * n * 3;
+    xyz2 += (size_t)bi * m * 3;
+    ratios += (size_t)bi * b_stride;
+    match += (size_t)bi * n * m;
+    for (int i = threadIdx.x; i < lcnt * NL; i += AMM_TPB) {
+        const int l = i / NL, v = i % NL;
+        crr[l][v] = v < nlv ? ratios[(size_t)v * lv_stride + roff + l0 + l] : 0.f;
+    }
+    for (int i = threadIdx.x; i < lcnt; i += AMM_TPB) {
+        cxyz[i][0] = xyz2[(size_t)(l0 + i) * 3 + 0];
+        cxyz[i][1] = xyz2[(size_t)(l0 + i) * 3 + 1];
+        cxyz[i][2] = xyz2[(size_t)(l0 + i) * 3 + 2];
+    }
+    __syncthreads();
+    if (threadIdx.x < lcnt) {
+        int dl = 0;
+        for (int v = 1; v < NL; v++) dl = crr[threadIdx.x][v] != 0.f ? v : dl;
+        cdl[threadIdx.x] = dl;
+    }
+    __syncthreads();
+    if (k >= n) return;
+    const float x1 = xyz1[k * 3], y1 = xyz1[k * 3 + 1], z1 = xyz1[k * 3 + 2];
+    float rl[NL];
 #pragma unroll
-    for (int v = 0; v < LVG; v++) rl[v] = v < nlv ? ratios[(size_t)v * lv_stride + k] : 0.f;
+    for (int v = 0; v < NL; v++) rl[v] = v < nlv ? ratios[(size_t)v * lv_stride + k] : 0.f;
     for (int l = 0; l < lcnt; l++) {
-        float d2 = rf::d2_fma(cxyz[l][0] - x1, cxyz[l][1] - y1, cxyz[l][2] - z1);
-        float acc = lv0 == 0 ? 0.f : match[(size_t)(l0 + l) * n + k];
+        const float d2 = rf::d2_fma(cxyz[l][0] - x1, cxyz[l][1] - y1, cxyz[l][2] - z1);
+        const int last = min(cdl[l], nlv - 1);  // (uniform)
+        float acc = 0.f, e = 0.f;
+        if constexpr (REP > 0) {
+            // every multiplier REP times in a row (the host checked): a run is one exponential, one guard, REP terms
 #pragma unroll
-        for (int v = 0; v < LVG; v++) {
-            if (v < nlv) {
-                float p = rl[v] * fast_exp2(d2 * lc.c[lv0 + v]);
-                acc = fmaf(p, crr[l][v], acc);
+            for (int g = 0; g < NL / REP; g++) {
+                if (REP * g <= last) {  // (uniform) the row lives at this run's first level
+                    e = fast_exp2(d2 * lc.c[REP * g]);
+#pragma unroll
+                    for (int u = 0; u < REP; u++) acc = fmaf(rl[REP * g + u] * e, crr[l][REP * g + u], acc);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < NL / 4; g++) {
+                if (4 * g <= last) {  // (uniform) the row lives at this group's first level
+                    const float4 rr = *(const float4 *)&crr[l][4 * g];  // (one broadcast read for the group's four levels)
+                    const float r4[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int v = 4 * g + u;
+                        // (uniform) a NEW weight only where the multiplier changes (`fresh`: bit v, from the host); otherwise the level
+                        // before it left the same argument's v_exp_f32 in `e` -- across groups too: last >= 4 g, so group g - 1 ran
+                        if (fresh >> v & 1ull) e = fast_exp2(d2 * lc.c[v]);
+                        acc = fmaf(rl[v] * e, r4[u], acc);
+                    }
+                }
             }
         }
-        match[(size_t)(l0 + l) * n + k] = acc;
+        __builtin_nontemporal_store(acc, &match[(size_t)(l0 + l) * n + k]);
     }
 }
 
@@ -2149,12 +2222,32 @@ int rf_approxmatch_mode(int b, int n, int m, const float *xyz1, const float *xyz
     } else if (nlevels == 10) {
         RF_LAUNCH("am_match", (am_match_kernel<10, false>), gm, dim3(AMM_TPB), 0, s, n, m, xyz1, xyz2,
                   (const float *)ratios, L.V, L.bstride, L.npad, 0, 10, lc, match);
-    } else {
-        for (int lv0 = 0; lv0 < nlevels; lv0 += LVG) {
-            int nlv = nlevels - lv0 < LVG ? nlevels - lv0 : LVG;
-            RF_LAUNCH("am_match", (am_match_kernel<0, false>), gm, dim3(AMM_TPB), 0, s, n, m, xyz1, xyz2,
-                      (const float *)ratios, L.V, L.bstride, L.npad, lv0, nlv, lc, match);
+    } else {  // any other schedule: every level in one pass (am_match_any_kernel)
+#define AM_MATCH_ANY(NG)                                                                                              \
+    RF_LAUNCH("am_match", (am_match_any_kernel<NG>), gm, dim3(AMM_TPB), 0, s, n, m, xyz1, xyz2, (const float *)ratios, \
+              L.V, L.bstride, L.npad, nlevels, lc, fresh, match)
+        unsigned long long fresh = 1ull;  // bit v: level v's multiplier differs from level v - 1's (a new exponential)
+        for (int v = 1; v < nlevels; v++) fresh |= (lc.c[v] != lc.c[v - 1]) ? 1ull << v : 0ull;
+        static_assert(MAX_LEVELS == 4 * LVG, "the four instantiations below cover every admissible schedule");
+        int rep = 0;  // every multiplier exactly `rep` times in a row?
+        for (int r = 2; r <= 8 && !rep; r++) {
+            bool ok = nlevels % r == 0;
+            for (int v = 0; ok && v < nlevels; v++) ok = ((fresh >> v & 1ull) != 0ull) == (v % r == 0);
+            if (ok) rep = r;
         }
+        if (rep == 5 && nlevels <= 60) {  // (BASELINE configs[3])
+            RF_LAUNCH("am_match", (am_match_any_kernel<4, 5>), gm, dim3(AMM_TPB), 0, s, n, m, xyz1, xyz2, (const float *)ratios,
+                      L.V, L.bstride, L.npad, nlevels, lc, fresh, match);
+        } else if (nlevels <= LVG) {
+            AM_MATCH_ANY(1);
+        } else if (nlevels <= 2 * LVG) {
+            AM_MATCH_ANY(2);
+        } else if (nlevels <= 3 * LVG) {
+            AM_MATCH_ANY(3);
+        } else {
+            AM_MATCH_ANY(4);
+        }
+#undef AM_MATCH_ANY
     }
     return RF_OK;
 }

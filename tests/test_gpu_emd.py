@@ -101,6 +101,43 @@ def test_extended_schedule_50_levels(orc):
     assert_rel(got.cpu().numpy(), orc.approx_match(a, c, levels=lv), 1e-4, 1e-6)
 
 
+@pytest.mark.parametrize("nlv, kind", [(13, "irregular"), (20, "irregular"), (30, "pairs"), (37, "irregular"), (50, "fives"),
+                                       (50, "irregular"), (64, "irregular"), (40, "eights")])
+def test_any_schedule_is_materialised_in_one_pass(orc, nlv, kind):
+    """Schedules other than the reference's ten levels go through am_match_any_kernel: every level in one pass over `match`, a
+    repeated multiplier reusing its weight, a row's levels behind its last live one not formed (1, 2, 3 or 4 groups of sixteen
+    levels; runs of five as their own instantiation).  Against the oracle on the same schedule, above the small-cloud kernel's
+    size, with ragged sizes; rounds 1-5 took sixteen levels per launch and read the tensor back in between."""
+    from pc_distance.tf_approxmatch import approx_match_levels, match_cost
+    rng = np.random.RandomState(1000 + nlv)
+    base = np.asarray(orc.default_levels(), np.float32)
+    if kind == "fives":
+        lv = np.repeat(base, 5)
+    elif kind == "pairs":
+        lv = np.repeat(np.concatenate([base, base[-5:]]), 2)
+    elif kind == "eights":
+        lv = np.repeat(base[[0, 2, 4, 6, 9]], 8)
+    else:  # runs of 1..4 of a descending ladder that ends at 0
+        ladder = np.abs(np.concatenate([base[:-1], base[:-1] * 0.5, base[:-1] * 0.3]))
+        lv, i = [], 0
+        while len(lv) < nlv - 1:
+            lv += [-float(ladder[i % len(ladder)])] * int(rng.randint(1, 5))
+            i += 1
+        lv = np.asarray(sorted(lv[:nlv - 1]) + [0.0], np.float32)
+    assert len(lv) == nlv
+    b, n, m = 2, 300 + nlv, 417
+    a = (rng.random_sample((b, n, 3)) - 0.5).astype(np.float32)
+    c = (rng.random_sample((b, m, 3)) - 0.5).astype(np.float32)
+    ta, tc = cu(a), cu(c)
+    got = approx_match_levels(ta, tc, lv.tolist())
+    want = orc.approx_match(a, c, levels=lv)
+    g = got.cpu().numpy()
+    bad = np.abs(g - want) > 1e-6 + 1e-4 * np.abs(want)
+    assert bad.mean() <= 1e-3, f"{int(bad.sum())} of {bad.size} entries outside the strict bar"  # (the ill-conditioned few: test_oracle_golden.py)
+    np.testing.assert_allclose(g.sum(1), want.sum(1), rtol=0, atol=2e-4)
+    assert_rel(match_cost(ta, tc, got).cpu().numpy(), orc.match_cost(a, c, want), 1e-5, what=f"cost, {nlv} levels ({kind})")
+
+
 def test_extended_schedule_50_levels_c4_size(orc):
     """SURVEY 8(d) C4's secondary run at ITS size: the 50-level schedule (10 reference levels x 5) at 2048 vs 2048, one
     sample against the oracle on the same schedule (6.3e8 exp evaluations on the host), marginals on all of the
