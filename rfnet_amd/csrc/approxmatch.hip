@@ -2023,11 +2023,17 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
     const int segk = pick_nseg(bseg, n, L.mpad, RPT), segl = pick_nseg(bseg, m, L.npad, RPT);
     const dim3 gk(rf::ceil_div(n, 64 * RPT), b), gl(rf::ceil_div(m, 64 * RPT), b);
     const dim3 gks(rf::ceil_div(L.nsa, 64 * RPT), b), gls(rf::ceil_div(L.nsb, 64 * RPT), b);  // SKIP: over the sorted positions
-    // levels 0 and 1 both on the skipping sweeps (sharper cut-off first): level 0's launches list, per wave, the columns within level
-    // 1's cut-off; level 1's launches visit only those (am_rowk_kernel MASK)
-    const bool masked = permA && permB && nlevels > 2 && lc.c[0] < lc.c[1] && lc.c[1] < 0.f && skip_t(1) <= kSkipMaxT &&
-                        n < 65536 && m < 65536 &&  // (16-bit column numbers ...
+    // The leading run of levels on the skipping sweeps (vE of them: 2 on the reference schedule, 10 on its 50-level stretching):
+    // level 0's launches list, per wave, the columns within the BROADEST of these levels' cut-offs; the launches of levels
+    // 1 .. vE - 1 visit only the listed columns (am_rowk_kernel MASK) -- the geometry does not change between the levels of a call.
+    int vE = 0;
+    for (int v = 0; v < nlevels && permA && permB; v++) {
+        if (!(skip_t(v) <= kSkipMaxT && (v == 0 || (lc.c[v - 1] < 0.f && lc.c[v - 1] <= lc.c[v])))) break;
+        vE = v + 1;
+    }
+    const bool masked = vE >= 2 && nlevels > 2 && n < 65536 && m < 65536 &&  // (16-bit column numbers ...
                         L.mpad / segk <= 65535 && L.npad / segl <= 65535;  // ... and 16-bit per-wave counts: a segment of 65536 columns, all listed, would wrap to 0)
+    const float tmaskE = vE >= 1 ? skip_t(vE - 1) : 0.f;
     unsigned short *maskk = (unsigned short *)(w + L.off_maskk), *maskl = (unsigned short *)(w + L.off_maskl);
     auto live_set = [&](int q) {
         float *base = w + L.off_live[q];
@@ -2076,11 +2082,12 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
 #undef AM_ROWK_LIVE
         if (skip && v == 0 && masked) {  // ... and lists, per wave, the columns the next level's sweep will have to visit
             RF_LAUNCH("am_p1", (am_rowk_kernel<false, 1, RPT, 1, 1>), gks, dim3(64 * segk), 0, s,
-                      AM_ROWK_ARGS((const float *)remainR, (const float *)remainL, 0.f), maskk, skip_t(1));
+                      AM_ROWK_ARGS((const float *)remainR, (const float *)remainL, 0.f), maskk, tmaskE);
         } else if (skip && v == 0) {
             RF_LAUNCH("am_p1", (am_rowk_kernel<false, 1, RPT, 1>), gks, dim3(64 * segk), 0, s,
                       AM_ROWK_ARGS((const float *)remainR, (const float *)remainL, 0.f));
-        } else if (skip && v == 1 && masked) {  // only the columns level 0's sweep listed
+        } else if (skip && v >= 1 && v < vE && masked) {  // only the columns level 0's sweep listed (a repeated multiplier: the two
+                                                           // exponentials have the same argument -- the same bits as the shared one)
             const float *pL = ratios + (size_t)(v - 1) * L.V, *pR = pL + L.npad;
             RF_LAUNCH("am_p3p1", (am_rowk_kernel<true, 1, RPT, 1, 2>), gks, dim3(64 * segk), 0, s,
                       AM_ROWK_ARGS(pR, pL, lc.c[v - 1]), maskk, 0.f);
@@ -2124,11 +2131,11 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
             RF_LAUNCH("am_p2", (am_rowl_kernel<RPT, true>), gl, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
                       (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR,
                       L.bstride, lc.c[v], permB, L.nsb, tsk, gptr, 1);
-        } else if (permB && tsk <= kSkipMaxT && masked && v <= 1) {
+        } else if (permB && tsk <= kSkipMaxT && masked && v < vE) {
             if (v == 0) {
                 RF_LAUNCH("am_p2", (am_rowl_kernel<RPT, false, true, 1>), gls, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
                           (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR,
-                          L.bstride, lc.c[v], permB, L.nsb, tsk, gptr, 1, maskl, skip_t(1));
+                          L.bstride, lc.c[v], permB, L.nsb, tsk, gptr, 1, maskl, tmaskE);
             } else {
                 RF_LAUNCH("am_p2", (am_rowl_kernel<RPT, false, true, 2>), gls, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
                           (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR,

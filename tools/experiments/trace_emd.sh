@@ -1,7 +1,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/r06_emd_trace; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/stats" -- python3 "$R/tools/run_emd_once.py" > /dev/null 2> "$OUT/err.txt"
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/stats" -- python3 "$R/tools/run_emd_once.py" $1 > /dev/null 2> "$OUT/err.txt"
 python3 - <<PY
 import csv,glob,collections
 f=glob.glob("$OUT/stats/**/*kernel_trace.csv",recursive=True)[0]
@@ -14,6 +14,7 @@ def short(n):
     m=re.search(r"(am_row[kl]_kernel<[^>]*>|am_match_kernel<[^>]*>|fgt_\w+|nnp_sort\w*|mc_\w+|am_init\w*|zero_kernel|am_\w+)",n)
     return m.group(1) if m else n[:40]
 # take the last 40 kernels
-for n,d in seq[-34:]:
+import sys
+for n,d in seq[-(int('${2:-34}')):]:
     print(f"{short(n):50s} {d/1e3:8.1f} us")
 PY
