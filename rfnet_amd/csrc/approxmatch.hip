@@ -129,7 +129,7 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
     float *__restrict__ ratioL_out, size_t stride, float c_prev, float c_cur, const int *__restrict__ perm,
     int perm_stride, float tskip, float tskip_prev, const int *__restrict__ guard, int guard_want,
     unsigned short *__restrict__ mask = nullptr, float tmask = 0.f, const int *__restrict__ counts = nullptr,
-    size_t cstride = 0) {
+    size_t cstride = 0, const float *__restrict__ rowbox = nullptr) {
     static_assert(MASK == 0 || SKIP == 1, "column lists belong to the skipping sweeps");
     static_assert(CMP == 0 || (SKIP == 0 && MASK == 0), "the live-column form is a dense sweep over a shorter column set");
     __shared__ float part3[16][64 * RPT], part1[16][64 * RPT];
@@ -293,6 +293,63 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
                     column(v.x, v.y, v.z, v.w, cb[u][4]);
                 }
             }
+        } else if constexpr (MASK == 1) {
+            // The LISTING launch (round 6, late): 64 columns at a time, one per lane, against the BOX of the wave's rows first -- the
+            // two superblocks of the sorted set the rows come from (rfp::Sorted::box64; the same operations on the per-axis gaps as
+            // d2 on the differences: never above the d2 of any row in the box, fps_sorted_kernel's argument) -- and only the columns
+            // whose bound is inside the listing cut-off go through the exact per-row test, in column order, their operands parked
+            // in LDS and read back as broadcasts (MASK == 2's gather).  At C4 a wave's box passes 2 of 5 columns; testing every
+            // column against every row was 31 us of a 0.56 ms call, twice (here and in am_rowl_kernel).
+            __shared__ float colbuf1[16][64][8];
+            float(*cb)[8] = colbuf1[seg];
+            float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            {
+                const int nsb = perm_stride >> 6;
+                const cfloat *BX = (const cfloat *)(rowbox + (size_t)bi * nsb * 8);
+#pragma unroll
+                for (int r = 0; r < RPT; r++) {
+                    const int sb = bx * RPT + r;
+                    if (sb < nsb) {  // (uniform)
+#pragma unroll
+                        for (int a = 0; a < 3; a++) blo[a] = fminf(blo[a], BX[sb * 8 + a]), bhi[a] = fmaxf(bhi[a], BX[sb * 8 + 4 + a]);
+                    }
+                }
+            }
+            for (int base = c0; base < c1; base += 64) {
+                const int j = base + lane;
+                const bool in = j < c1;
+                const int jj = in ? j : c0;
+                const float cx = C[(size_t)jj * 3], cy = C[(size_t)jj * 3 + 1], cz = C[(size_t)jj * 3 + 2];
+                const float s3v = HAS_P3 ? S3[jj] : 0.f, s1v = HAS_P1 ? S1[jj] : 0.f;
+                const float gx = fmaxf(fmaxf(blo[0] - cx, cx - bhi[0]), 0.f), gy = fmaxf(fmaxf(blo[1] - cy, cy - bhi[1]), 0.f),
+                            gz = fmaxf(fmaxf(blo[2] - cz, cz - bhi[2]), 0.f);
+                unsigned long long M = __ballot(in && rf::d2_fma(gx, gy, gz) < tmask);
+                if (M == 0ull) continue;  // (uniform)
+                *(float4 *)cb[lane] = make_float4(cx, cy, cz, s3v);
+                cb[lane][4] = s1v;
+                // (a wave's own LDS writes are visible to it without a barrier: in-order LDS queue)
+                while (M != 0ull) {  // four records in flight: one LDS round trip per four columns
+                    int uu[4], nb = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        if (M != 0ull) {
+                            uu[q] = __builtin_ctzll(M);
+                            M &= M - 1ull;
+                            nb = q + 1;
+                        } else {
+                            uu[q] = uu[0];
+                        }
+                    }
+                    float4 v[4];
+                    float w[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) v[q] = *(const float4 *)cb[uu[q]], w[q] = cb[uu[q]][4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (q < nb) column(v[q].x, v[q].y, v[q].z, v[q].w, w[q], base - c0 + uu[q]);
+                }
+            }
+            if (lane == 0) lst[0] = (unsigned short)nlisted;
         } else {
         RFA_FETCH_K(xa, a3, a1, c0);
         for (int c = c0; c < c1; c += 2 * SUB) {
@@ -310,7 +367,6 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
 #pragma unroll
             for (int u = 0; u < SUB; u++) column(xb[u * 3], xb[u * 3 + 1], xb[u * 3 + 2], b3[u], b1[u], c + SUB - c0 + u);
         }
-        if (MASK == 1 && lane == 0) lst[0] = (unsigned short)nlisted;
         }
 #undef RFA_FETCH_K
     } else {
@@ -386,7 +442,7 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
     size_t xyz1p_stride, const float *__restrict__ ratioL, float *__restrict__ remainR,
     float *__restrict__ ratioR_out, size_t stride, float c_cur, const int *__restrict__ perm, int perm_stride,
     float tskip, const int *__restrict__ guard, int guard_want, unsigned short *__restrict__ mask = nullptr,
-    float tmask = 0.f, const int *__restrict__ counts = nullptr) {
+    float tmask = 0.f, const int *__restrict__ counts = nullptr, const float *__restrict__ rowbox = nullptr) {
     static_assert(MASK == 0 || SKIP, "column lists belong to the skipping sweeps (am_rowk_kernel MASK)");
     static_assert(!LIST || (!SKIP && MASK == 0), "the live-row form is a dense sweep over fewer rows");
     if (guard && (*guard != 0) != (guard_want != 0)) return;  // (see am_rowk_kernel)
@@ -491,6 +547,53 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
                     column(v.x, v.y, v.z, v.w);
                 }
             }
+        } else if constexpr (MASK == 1) {  // the listing launch: the columns against the box of the wave's rows first (am_rowk_kernel)
+            __shared__ float colbuf1[16][64][4];
+            float(*cb)[4] = colbuf1[seg];
+            float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            {
+                const int nsb = perm_stride >> 6;
+                const cfloat *BX = (const cfloat *)(rowbox + (size_t)bi * nsb * 8);
+#pragma unroll
+                for (int r = 0; r < RPT; r++) {
+                    const int sb = bx * RPT + r;
+                    if (sb < nsb) {  // (uniform)
+#pragma unroll
+                        for (int a = 0; a < 3; a++) blo[a] = fminf(blo[a], BX[sb * 8 + a]), bhi[a] = fmaxf(bhi[a], BX[sb * 8 + 4 + a]);
+                    }
+                }
+            }
+            for (int base = c0; base < c1; base += 64) {
+                const int j = base + lane;
+                const bool in = j < c1;
+                const int jj = in ? j : c0;
+                const float cx = C[(size_t)jj * 3], cy = C[(size_t)jj * 3 + 1], cz = C[(size_t)jj * 3 + 2], sv = S[jj];
+                const float gx = fmaxf(fmaxf(blo[0] - cx, cx - bhi[0]), 0.f), gy = fmaxf(fmaxf(blo[1] - cy, cy - bhi[1]), 0.f),
+                            gz = fmaxf(fmaxf(blo[2] - cz, cz - bhi[2]), 0.f);
+                unsigned long long M = __ballot(in && rf::d2_fma(gx, gy, gz) < tmask);
+                if (M == 0ull) continue;  // (uniform)
+                *(float4 *)cb[lane] = make_float4(cx, cy, cz, sv);
+                while (M != 0ull) {
+                    int uu[4], nb = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        if (M != 0ull) {
+                            uu[q] = __builtin_ctzll(M);
+                            M &= M - 1ull;
+                            nb = q + 1;
+                        } else {
+                            uu[q] = uu[0];
+                        }
+                    }
+                    float4 v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) v[q] = *(const float4 *)cb[uu[q]];
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (q < nb) column(v[q].x, v[q].y, v[q].z, v[q].w, base - c0 + uu[q]);
+                }
+            }
+            if (lane == 0) lst[0] = (unsigned short)nlisted;
         } else {
         RFA_FETCH_L(xa, sa, c0);
         for (int c = c0; c < c1; c += 2 * SUB) {
@@ -508,7 +611,6 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
 #pragma unroll
             for (int u = 0; u < SUB; u++) column(xb[u * 3], xb[u * 3 + 1], xb[u * 3 + 2], sb[u], c + SUB - c0 + u);
         }
-        if (MASK == 1 && lane == 0) lst[0] = (unsigned short)nlisted;
         }
 #undef RFA_FETCH_L
     } else {
@@ -2006,6 +2108,7 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
     // (am_rowk_kernel SKIP; bit-identical sums).  Level v qualifies when its weight is exactly 0 from a d2 of at most kSkipMaxT on.
     auto skip_t = [&](int v) { return (v >= 0 && v < nlevels && lc.c[v] < 0.f) ? kSkipArg / -lc.c[v] : INFINITY; };
     const int *permA = nullptr, *permB = nullptr;
+    const float *boxA = nullptr, *boxB = nullptr;  // the sorted sets' superblock boxes (the listing launches' first test)
     if (L.rowsort_ok && skip_t(0) <= kSkipMaxT) {
         const rfp::Sorted so[2] = {rfp::sorted_view(b, n, w + L.off_sa), rfp::sorted_view(b, m, w + L.off_sb)};
         const int nn[2] = {n, m};
@@ -2013,6 +2116,8 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
         if (int e = rfp::sort_sets(b, 2, nn, src, so, s, nullptr)) return e;
         permA = so[0].orig;
         permB = so[1].orig;
+        boxA = so[0].box64;
+        boxB = so[1].box64;
     }
 
     // 2 rows per lane (measured best of 1 / 2 / 4: longer compute per scalar prefetch covers the L2
@@ -2082,7 +2187,7 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
 #undef AM_ROWK_LIVE
         if (skip && v == 0 && masked) {  // ... and lists, per wave, the columns the next level's sweep will have to visit
             RF_LAUNCH("am_p1", (am_rowk_kernel<false, 1, RPT, 1, 1>), gks, dim3(64 * segk), 0, s,
-                      AM_ROWK_ARGS((const float *)remainR, (const float *)remainL, 0.f), maskk, tmaskE);
+                      AM_ROWK_ARGS((const float *)remainR, (const float *)remainL, 0.f), maskk, tmaskE, (const int *)nullptr, (size_t)0, boxA);
         } else if (skip && v == 0) {
             RF_LAUNCH("am_p1", (am_rowk_kernel<false, 1, RPT, 1>), gks, dim3(64 * segk), 0, s,
                       AM_ROWK_ARGS((const float *)remainR, (const float *)remainL, 0.f));
@@ -2135,7 +2240,7 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
             if (v == 0) {
                 RF_LAUNCH("am_p2", (am_rowl_kernel<RPT, false, true, 1>), gls, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
                           (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR,
-                          L.bstride, lc.c[v], permB, L.nsb, tsk, gptr, 1, maskl, tmaskE);
+                          L.bstride, lc.c[v], permB, L.nsb, tsk, gptr, 1, maskl, tmaskE, (const int *)nullptr, boxB);
             } else {
                 RF_LAUNCH("am_p2", (am_rowl_kernel<RPT, false, true, 2>), gls, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
                           (const float *)x1p, (size_t)L.npad * 3, (const float *)ratioL, remainR, ratioR,
