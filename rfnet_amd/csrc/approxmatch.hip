@@ -681,7 +681,12 @@ __global__ __launch_bounds__(CK_TPB) void am_compact_kernel(int m, const float *
                                                             const float *__restrict__ ratioR, const float *__restrict__ remainR,
                                                             float *__restrict__ ratioR_later, size_t lv_stride, int nlater,
                                                             size_t stride, LiveSet cols, LiveSet live, size_t cstride) {
-    __shared__ unsigned wsc[CK_TPB / 64], wsr[CK_TPB / 64];
+    // The sample in ROWS of CK_TPB consecutive entries, an entry per thread: loads and -- the survivors of a wave land side by
+    // side -- stores of whole cache lines.  (A thread owning consecutive entries, as this kernel first had it, scatters every store
+    // of a wave over 64 lines: 9 us at 2048 points, 110 us at 16384 where four workgroups do all of it.)  An entry's place in a
+    // set = the set's count before this row + the waves before this one (LDS, double-buffered: one barrier per row) + the lanes
+    // before this one (ballot).
+    __shared__ unsigned wsc[2][CK_TPB / 64], wsr[2][CK_TPB / 64];
     const int bi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *__restrict__ C = xyz2p + (size_t)bi * xyz2p_stride;
     const float *__restrict__ RR = ratioR + (size_t)bi * stride;
@@ -690,53 +695,35 @@ __global__ __launch_bounds__(CK_TPB) void am_compact_kernel(int m, const float *
                         *__restrict__ CS1 = cols.s1 + (size_t)bi * cstride;
     float *__restrict__ LC = live.cc + (size_t)bi * cstride * 3, *__restrict__ LS1 = live.s1 + (size_t)bi * cstride;
     int *__restrict__ LR = live.rows + (size_t)bi * cstride;
-    const int per = (m + CK_TPB - 1) / CK_TPB;
-    const int l0 = tid * per;
-    unsigned ncol = 0, nrow = 0;
-    for (int q = 0; q < per; q++) {
-        const int l = l0 + q;
-        if (l < m) {
-            ncol += RR[l] != 0.f ? 1u : 0u;
-            nrow += RM[l] != 0.f ? 1u : 0u;
-        }
-    }
-    auto wave_incl = [&](unsigned v) {
+    unsigned tc = 0, tr = 0;  // (uniform) the sets' counts so far
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int row0 = 0, it = 0; row0 < m; row0 += CK_TPB, it++) {
+        const int l = row0 + tid;
+        const bool in = l < m;
+        const int ll = in ? l : 0;
+        const float rr = in ? RR[ll] : 0.f, rm = in ? RM[ll] : 0.f;
+        const float x = C[(size_t)ll * 3], y = C[(size_t)ll * 3 + 1], z = C[(size_t)ll * 3 + 2];
+        const unsigned long long bc = __ballot(rr != 0.f), br = __ballot(rm != 0.f);
+        const int buf = it & 1;
+        if (lane == 0) wsc[buf][wave] = (unsigned)__builtin_popcountll(bc), wsr[buf][wave] = (unsigned)__builtin_popcountll(br);
+        __syncthreads();
+        unsigned pc = tc + (unsigned)__builtin_popcountll(bc & below), pr = tr + (unsigned)__builtin_popcountll(br & below);
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned t = __shfl_up(v, o, 64);
-            if (lane >= o) v += t;
+        for (int w = 0; w < CK_TPB / 64; w++) {
+            const unsigned c = wsc[buf][w], r = wsr[buf][w];
+            pc += w < wave ? c : 0u, pr += w < wave ? r : 0u;
+            tc += c, tr += r;
         }
-        return v;
-    };
-    const unsigned ic = wave_incl(ncol), ir = wave_incl(nrow);
-    if (lane == 63) wsc[wave] = ic, wsr[wave] = ir;
-    __syncthreads();
-    unsigned pc = ic - ncol, pr = ir - nrow, tc = 0, tr = 0;
-    {  // (the 16 wave totals: one LDS read per lane and a wave scan)
-        const unsigned wc = lane < CK_TPB / 64 ? wsc[lane] : 0u, wr = lane < CK_TPB / 64 ? wsr[lane] : 0u;
-        const unsigned sc = wave_incl(wc), sr = wave_incl(wr);
-        pc += __shfl(sc - wc, wave, 64);
-        pr += __shfl(sr - wr, wave, 64);
-        tc = __shfl(sc, CK_TPB / 64 - 1, 64);
-        tr = __shfl(sr, CK_TPB / 64 - 1, 64);
-    }
-    for (int q = 0; q < per; q++) {
-        const int l = l0 + q;
-        if (l >= m) break;
-        const float rr = RR[l], rm = RM[l];
-        const float x = C[(size_t)l * 3], y = C[(size_t)l * 3 + 1], z = C[(size_t)l * 3 + 2];
         if (rr != 0.f) {
             CC[pc * 3] = x, CC[pc * 3 + 1] = y, CC[pc * 3 + 2] = z;
             CS3[pc] = rr;
             CS1[pc] = rm;
-            pc++;
         }
         if (rm != 0.f) {
             LC[pr * 3] = x, LC[pr * 3 + 1] = y, LC[pr * 3 + 2] = z;
             LS1[pr] = rm;
             LR[pr] = l;
-            pr++;
-        } else {
+        } else if (in) {
             for (int u = 0; u < nlater; u++) ratioR_later[(size_t)u * lv_stride + (size_t)bi * stride + l] = 0.f;
         }
     }
@@ -771,23 +758,29 @@ __global__ __launch_bounds__(CK_TPB) void am_compact_kernel(int m, const float *
 // round trips to memory whatever its rows; 512 threads x 4 columns per lane, unpacked: 0.671; packed 0.597-0.604 against 0.574-0.580;
 // the kernel's 134 registers (three waves per SIMD) held to 128 (four): +-0; one row's chain at a time: am_p2 184 against 175 us)
 constexpr int PL_TPB = 256, PL_NW = PL_TPB / 64, PL_ROWS = 32, PL_CPL = 8, PL_RU = 2;  // (PL_RU rows' chains side by side)
+// An item walks its rows over ALL columns: at 16384 columns an item of 32 rows is 46 us long however few items a late level has
+// left (`tools/experiments/trace_emd.sh big`) -- clouds of more than PL_BIG_N points take their rows in items of PL_ROWS_BIG.
+#ifndef RFA_PL_ROWS_BIG
+#define RFA_PL_ROWS_BIG 8
+#endif
+constexpr int PL_ROWS_BIG = RFA_PL_ROWS_BIG, PL_BIG_N = 4096;
 static_assert(PL_CPL % 2 == 0, "the columns of a lane go through packed fp32 operations in pairs");
-static_assert(PL_ROWS % PL_RU == 0 && PL_ROWS <= 64, "a row per lane of the running sums");
-template <bool ZERO>
+static_assert(PL_ROWS % PL_RU == 0 && PL_ROWS <= 64 && PL_ROWS_BIG % PL_RU == 0, "a row per lane of the running sums");
+template <bool ZERO, int ROWS = PL_ROWS>
 __global__ __launch_bounds__(PL_TPB) void am_p2_live_kernel(int npad, const float *__restrict__ xyz1p, size_t xyz1p_stride,
                                                             const float *__restrict__ ratioL, float *__restrict__ remainR,
                                                             float *__restrict__ ratioR_out, size_t lv_stride, int nlater,
                                                             size_t stride, float c_cur, LiveSet in, LiveSet out, size_t cstride, int cap, int b) {
     __shared__ unsigned wsum[PL_NW];
-    __shared__ int rpos[PL_ROWS];            // this workgroup's rows: position in `in`
-    __shared__ float4 rowbuf[PL_ROWS];       // (x, y, z, remainR)
-    __shared__ float part[PL_NW][PL_ROWS];
+    __shared__ int rpos[ROWS];            // this workgroup's rows: position in `in`
+    __shared__ float4 rowbuf[ROWS];       // (x, y, z, remainR)
+    __shared__ float part[PL_NW][ROWS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // A FIXED grid walks the (chunk of rows, sample) items, chunk-major: how many chunks a sample still has is known on the device
     // only, and one workgroup per possible chunk -- 4096 at C4, nearly all of which read their sample's count and leave -- cost a
     // round trip to memory each, four residency rounds of them: an 8 us floor under a launch with 70 rows per sample left.  The
     // counts of the items a workgroup walks past come out of the scalar cache after its first.
-    const int nitems = ((cap + PL_ROWS - 1) / PL_ROWS) * b;
+    const int nitems = ((cap + ROWS - 1) / ROWS) * b;
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
     const int bx = item / b, bi = item - bx * b;
     // Everything that does not depend on anything else is asked for FIRST and together -- the set's count, its s1 array (a thread's
@@ -795,14 +788,18 @@ __global__ __launch_bounds__(PL_TPB) void am_p2_live_kernel(int npad, const floa
     // a level follow each other across XCDs, every one of these comes from memory (~2 us), and asked for one after the other they
     // were a 19 us floor under this kernel however few its rows.
     const int cin = ((const __attribute__((address_space(4))) int *)in.cnt)[bi * 4 + 1];  // entries of the previous set
-    if (bx != 0 && bx * PL_ROWS >= cin) continue;  // (uniform; survivors <= entries; chunk 0 always writes the new set's counts)
+    if (bx != 0 && bx * ROWS >= cin) continue;  // (uniform; survivors <= entries; chunk 0 always writes the new set's counts)
     // what does not depend on anything else is asked for together: the set's s1 array (a thread's entries by the set's capacity)
     // and the wave's first tile of columns -- every one of these comes from memory (~2 us: the launches of a level follow each
     // other across XCDs)
     const float *__restrict__ IS1 = in.s1 + (size_t)bi * cstride;
     const float *__restrict__ C = xyz1p + (size_t)bi * xyz1p_stride;
     const float *__restrict__ S = ratioL + (size_t)bi * stride;
-    const int per = (cap + PL_TPB - 1) / PL_TPB;  // (uniform; cap = the set's capacity: mpad)
+    // (uniform) entries per thread: by the set's CAPACITY (mpad) while that is one batch of eight loads -- they are then asked for
+    // before the count has arrived --, by the set's count beyond (clouds of more than 2048 points: with 64 entries per thread by
+    // capacity, a late level's few hundred entries sat in a handful of threads that walked them in eight dependent rounds, twice:
+    // a 60 us floor under every launch at 16384 points)
+    const int per = cap <= 8 * PL_TPB ? (cap + PL_TPB - 1) / PL_TPB : max(1, (cin + PL_TPB - 1) / PL_TPB);
     const int e0 = tid * per;
     float sv[8];
     if (per <= 8) {
@@ -847,7 +844,7 @@ __global__ __launch_bounds__(PL_TPB) void am_p2_live_kernel(int npad, const floa
         if (lane >= o) incl += t;
     }
     if (lane == 63) wsum[wave] = incl;
-    if (tid < PL_ROWS) rpos[tid] = -1;
+    if (tid < ROWS) rpos[tid] = -1;
     __syncthreads();
     unsigned before = incl - mine, total = 0;
 #pragma unroll
@@ -855,7 +852,7 @@ __global__ __launch_bounds__(PL_TPB) void am_p2_live_kernel(int npad, const floa
         if (w < wave) before += wsum[w];
         total += wsum[w];
     }
-    const int lo = bx * PL_ROWS;
+    const int lo = bx * ROWS;
     if (lo >= (int)total) {  // (uniform) no survivor left for this workgroup ...
         if (bx == 0 && tid == 0) {  // ... (none at all: total == 0) the next sweeps see an empty set
             out.cnt[bi * 4] = 0;
@@ -875,10 +872,10 @@ __global__ __launch_bounds__(PL_TPB) void am_p2_live_kernel(int npad, const floa
 #pragma unroll
             for (int q = 0; q < 8; q++)
                 if (alive >> q & 1u) {
-                    if ((int)r >= lo && (int)r < lo + PL_ROWS) rpos[r - lo] = e0 + q;
+                    if ((int)r >= lo && (int)r < lo + ROWS) rpos[r - lo] = e0 + q;
                     r++;
                 }
-        } else if (before < (unsigned)(lo + PL_ROWS) && before + mine > (unsigned)lo) {  // (only the threads whose entries reach into this chunk look again)
+        } else if (before < (unsigned)(lo + ROWS) && before + mine > (unsigned)lo) {  // (only the threads whose entries reach into this chunk look again)
             for (int q0 = 0; q0 < per; q0 += 8) {
                 float v[8];
 #pragma unroll
@@ -886,16 +883,16 @@ __global__ __launch_bounds__(PL_TPB) void am_p2_live_kernel(int npad, const floa
 #pragma unroll
                 for (int q = 0; q < 8; q++)
                     if (v[q] != 0.f) {
-                        if ((int)r >= lo && (int)r < lo + PL_ROWS) rpos[r - lo] = e0 + q0 + q;
+                        if ((int)r >= lo && (int)r < lo + ROWS) rpos[r - lo] = e0 + q0 + q;
                         r++;
                     }
             }
         }
     }
     __syncthreads();
-    const int nrows = min(PL_ROWS, (int)total - lo);
+    const int nrows = min(ROWS, (int)total - lo);
     int orig = -1;
-    if (tid < PL_ROWS) {
+    if (tid < ROWS) {
         const int e = rpos[tid];
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (e >= 0) {
@@ -953,9 +950,9 @@ __global__ __launch_bounds__(PL_TPB) void am_p2_live_kernel(int npad, const floa
         }
     }
 #undef RFA_PL_COLS
-    if (lane < PL_ROWS) part[wave][lane] = racc;
+    if (lane < ROWS) part[wave][lane] = racc;
     __syncthreads();
-    if (tid < PL_ROWS && tid < nrows) {
+    if (tid < ROWS && tid < nrows) {
         float sumr = part[0][tid];
 #pragma unroll
         for (int w = 1; w < PL_NW; w++) sumr += part[w][tid];
@@ -977,7 +974,7 @@ __global__ __launch_bounds__(PL_TPB) void am_p2_live_kernel(int npad, const floa
         out.rows[p] = orig;
     }
     // the set's padding (zero-scalar entries up to a multiple of 16, + one sub-chunk) and its counts: the workgroup that holds its end
-    if (lo + PL_ROWS >= (int)total) {
+    if (lo + ROWS >= (int)total) {
         const int tp = ((int)total + 2 * SUB - 1) / (2 * SUB) * (2 * SUB);
         for (int e = (int)total + tid; e < tp + SUB; e += PL_TPB) {
             float *oc = out.cc + (size_t)bi * cstride * 3 + (size_t)e * 3;
@@ -1953,6 +1950,212 @@ __global__ __launch_bounds__(TPB) void emd_fused_kernel(int n, int m, int mpad, 
     }
 }
 
+// ---- the cost alone, columns in the order of their LAST LIVE LEVEL (round 6, late) -------------------------------------------
+// A column of set 2 is exactly +0 in ratioR from the level after its last live one on (am_compact_kernel), and the cost does
+// not care in which order the columns are summed.  emd_pack_cols_sorted_kernel therefore lays a sample's column records out by
+// CLASS -- last live level 0 | 1-2 | 3-4 | 5-6 | 7-9, index order inside a class (a function of the sample alone), every class
+// padded to an even count with an all-zero record -- and emd_fused_cls_kernel walks a class with exactly the level pairs it needs:
+// no test per column, the packed two-column step intact.  At C4 59 % of the columns end at levels 1-2 and 9 % at level 0: 1.4
+// exponentials and 2.8 terms per entry instead of 4 and 9; the terms left out are fma(p, +0, acc) = acc.  (The same guards PER
+// COLUMN PAIR inside emd_fused_kernel measured slower: a pair is dead only when both columns are, and the branches break the chain.)
+constexpr int EF_NCLS = 5;  // (ten levels: the reference schedule)
+__device__ __forceinline__ int ef_class_of(int dl) { return dl == 0 ? 0 : (dl >= 7 ? 4 : (dl + 1) >> 1); }
+// Two launches, a workgroup per EP_TPB consecutive columns (one workgroup per sample walking all of them took 150 us at 16384
+// points, its 64-byte records scattered over the class segments): emd_class_count_kernel leaves every workgroup's class counts,
+// emd_pack_cols_sorted_kernel turns the counts before it into its bases and places its columns -- class base + the workgroups
+// before + the waves before (LDS) + the lanes before (ballot): index order inside a class.
+constexpr int EP_TPB = 1024;
+__device__ __forceinline__ int ef_column_class(int l, int m, int mpad, const float *__restrict__ RR, size_t lv_stride, float (&r)[EF_REC]) {
+    // r[4 + v] = ratioR of level v (a column beyond m: zeros, class 0; beyond mpad: no class)
+    if (l >= mpad) return -1;
+    if (l >= m) return 0;
+#pragma unroll
+    for (int v = 0; v < 10; v++) r[4 + v] = RR[(size_t)v * lv_stride + l];
+    int dl = 0;
+#pragma unroll
+    for (int v = 1; v < 10; v++) dl = r[4 + v] != 0.f ? v : dl;
+    return ef_class_of(dl);
+}
+__global__ __launch_bounds__(EP_TPB) void emd_class_count_kernel(int m, int mpad, const float *__restrict__ ratios, size_t lv_stride,
+                                                                size_t b_stride, int roff, int *__restrict__ wgcnt) {
+    __shared__ unsigned wtot[EP_TPB / 64][EF_NCLS];
+    const int bi = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float r[EF_REC];
+#pragma unroll
+    for (int i = 0; i < EF_REC; i++) r[i] = 0.f;
+    const int c = ef_column_class(g * EP_TPB + tid, m, mpad, ratios + (size_t)bi * b_stride + roff, lv_stride, r);
+#pragma unroll
+    for (int k = 0; k < EF_NCLS; k++) {
+        const unsigned long long bk = __ballot(c == k);
+        if (lane == 0) wtot[wave][k] = (unsigned)__builtin_popcountll(bk);
+    }
+    __syncthreads();
+    if (tid < EF_NCLS) {
+        unsigned tot = 0;
+        for (int w = 0; w < EP_TPB / 64; w++) tot += wtot[w][tid];
+        wgcnt[((size_t)bi * gridDim.x + g) * 8 + tid] = (int)tot;
+    }
+}
+__global__ __launch_bounds__(EP_TPB) void emd_pack_cols_sorted_kernel(int m, int mpad, const float *__restrict__ xyz2,
+                                                                     const float *__restrict__ ratios, size_t lv_stride,
+                                                                     size_t b_stride, int roff, const int *__restrict__ wgcnt,
+                                                                     float *__restrict__ rec, size_t rstride, int *__restrict__ coff) {
+    __shared__ unsigned wtot[EP_TPB / 64][EF_NCLS];
+    __shared__ unsigned cbase[EF_NCLS + 1], ctot[EF_NCLS], mybase[EF_NCLS];
+    const int bi = blockIdx.y, g = blockIdx.x, G = gridDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *__restrict__ R = rec + (size_t)bi * rstride * EF_REC;
+    if (tid < EF_NCLS) {  // this class over the sample's workgroups: its total, and what lies before this workgroup
+        unsigned tot = 0, bef = 0;
+        for (int q = 0; q < G; q++) {
+            const unsigned v = (unsigned)wgcnt[((size_t)bi * G + q) * 8 + tid];
+            bef += q < g ? v : 0u;
+            tot += v;
+        }
+        ctot[tid] = tot;
+        mybase[tid] = bef;
+    }
+    float r[EF_REC];
+#pragma unroll
+    for (int i = 0; i < EF_REC; i++) r[i] = 0.f;
+    const int l = g * EP_TPB + tid;
+    const int c = ef_column_class(l, m, mpad, ratios + (size_t)bi * b_stride + roff, lv_stride, r);
+    if (l < m) {
+        const float *pt = xyz2 + ((size_t)bi * m + l) * 3;
+        r[0] = pt[0], r[1] = pt[1], r[2] = pt[2];
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    unsigned mine = 0;  // lanes of this wave before this one in the same class
+#pragma unroll
+    for (int k = 0; k < EF_NCLS; k++) {
+        const unsigned long long bk = __ballot(c == k);
+        if (lane == 0) wtot[wave][k] = (unsigned)__builtin_popcountll(bk);
+        if (c == k) mine = (unsigned)__builtin_popcountll(bk & below);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned off = 0;
+        for (int k = 0; k < EF_NCLS; k++) {
+            cbase[k] = off;
+            off += (ctot[k] + 1u) & ~1u;
+        }
+        cbase[EF_NCLS] = off;
+        if (g == 0)
+            for (int k = 0; k <= EF_NCLS; k++) coff[bi * 8 + k] = (int)cbase[k];
+    }
+    __syncthreads();
+    auto put = [&](unsigned p, const float (&rr)[EF_REC]) {  // (the pair layout of emd_pack_cols_kernel)
+        float *q = R + (size_t)(p & ~1u) * EF_REC + (p & 1u);
+#pragma unroll
+        for (int i = 0; i < EF_REC; i++) q[2 * i] = rr[i];
+    };
+    if (c >= 0) {
+        unsigned p = mine;
+#pragma unroll
+        for (int k = 0; k < EF_NCLS; k++) {
+            unsigned bef = 0;
+#pragma unroll
+            for (int w = 0; w < EP_TPB / 64; w++) bef += w < wave ? wtot[w][k] : 0u;
+            if (c == k) p += cbase[k] + mybase[k] + bef;
+        }
+        put(p, r);
+    }
+    if (g == 0 && tid < EF_NCLS && (ctot[tid] & 1u)) {  // the all-zero record that makes a class's count even
+        float z[EF_REC];
+#pragma unroll
+        for (int i = 0; i < EF_REC; i++) z[i] = 0.f;
+        put(cbase[tid] + ctot[tid], z);
+    }
+}
+
+// one two-column step of class CLS (the columns' records c: pair layout); the level-ordered fma chain of am_match_kernel over the
+// class's levels -- weights of odd levels from the next even one's by two squarings, level 9's is 1.0
+template <int CLS>
+__device__ __forceinline__ void ef_pair_step(const am_v2f *__restrict__ c, float x1, float y1, float z1, const float (&rl)[10],
+                                             const float (&cl)[10], float t0, float &csum) {
+    const am_v2f dx = c[0] - x1, dy = c[1] - y1, dz = c[2] - z1;
+    const am_v2f d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));  // (rf::d2_fma's order)
+    auto ex2 = [](am_v2f a) { return am_v2f{fast_exp2(a.x), fast_exp2(a.y)}; };
+    am_v2f e1 = {0.f, 0.f}, e2 = e1, e3 = e1, e4 = e1, e5 = e1, e6 = e1, e7 = e1, e8 = e1;
+    if (CLS >= 4) { e8 = ex2(d2 * cl[8]); const am_v2f q = e8 * e8; e7 = q * q; }
+    if (CLS >= 3) { e6 = ex2(d2 * cl[6]); const am_v2f q = e6 * e6; e5 = q * q; }
+    if (CLS >= 2) { e4 = ex2(d2 * cl[4]); const am_v2f q = e4 * e4; e3 = q * q; }
+    if (CLS >= 1) { e2 = ex2(d2 * cl[2]); const am_v2f q = e2 * e2; e1 = q * q; }
+    am_v2f acc = {0.f, 0.f};
+    if (__ballot(d2.x < t0 || d2.y < t0) != 0ull) {  // (uniform) the sharpest level: beyond t0 its weight is exactly +0
+        asm volatile("; level 0 kept");
+        acc = __builtin_elementwise_fma(rl[0] * ex2(d2 * cl[0]), c[4], acc);
+    }
+    if (CLS >= 1) { acc = __builtin_elementwise_fma(rl[1] * e1, c[5], acc); acc = __builtin_elementwise_fma(rl[2] * e2, c[6], acc); }
+    if (CLS >= 2) { acc = __builtin_elementwise_fma(rl[3] * e3, c[7], acc); acc = __builtin_elementwise_fma(rl[4] * e4, c[8], acc); }
+    if (CLS >= 3) { acc = __builtin_elementwise_fma(rl[5] * e5, c[9], acc); acc = __builtin_elementwise_fma(rl[6] * e6, c[10], acc); }
+    if (CLS >= 4) {
+        acc = __builtin_elementwise_fma(rl[7] * e7, c[11], acc);
+        acc = __builtin_elementwise_fma(rl[8] * e8, c[12], acc);
+        acc = __builtin_elementwise_fma(rl[9] * am_v2f{1.0f, 1.0f}, c[13], acc);
+    }
+    csum = fmaf(sqrtf(d2.x), acc.x, csum);
+    csum = fmaf(sqrtf(d2.y), acc.y, csum);
+}
+
+// cost only, the reference schedule (ten levels, the last 0, quarter chain): a thread <-> EF_KPT rows k (TPB apart), a workgroup's
+// span of the class-sorted records [by * lspan, by * lspan + lspan) cut at the class boundaries.  (EF_KPT = 2 -- a step's 128
+// bytes of scalar loads serving 128 rows -- measured SLOWER: fused earth_mover at C4 0.525 against 0.513 ms, 4 x 16384^2 911 against
+// 864 us for this kernel: 84 registers, five waves per SIMD.)
+#ifndef RFA_EF_KPT
+#define RFA_EF_KPT 1
+#endif
+constexpr int EF_KPT = RFA_EF_KPT;
+__global__ __launch_bounds__(TPB) void emd_fused_cls_kernel(int n, int lspan, const float *__restrict__ xyz1,
+                                                            const float *__restrict__ rec, size_t rstride,
+                                                            const int *__restrict__ coff, const float *__restrict__ ratios,
+                                                            size_t lv_stride, size_t b_stride, LevelConsts lc,
+                                                            float *__restrict__ partial) {
+    __shared__ float wsum[TPB / 64];
+    const unsigned per_ = gridDim.x * gridDim.y;
+    const unsigned lin_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const unsigned lgc_ = rf::xcd_contiguous(lin_, per_ * gridDim.z);
+    const int bi = lgc_ / per_;
+    const int by = (lgc_ - bi * per_) / gridDim.x, bx = (lgc_ - bi * per_) - by * gridDim.x;
+    const int t = threadIdx.x;
+    const float *__restrict__ A = xyz1 + (size_t)bi * n * 3;
+    const float *__restrict__ R = rec + (size_t)bi * rstride * EF_REC;
+    float x1[EF_KPT], y1[EF_KPT], z1[EF_KPT], rl[EF_KPT][10], cl[10];
+#pragma unroll
+    for (int j = 0; j < EF_KPT; j++) {
+        const int k = (bx * EF_KPT + j) * TPB + t;
+        const bool live = k < n;
+        const int kk = live ? k : n - 1;
+        x1[j] = A[kk * 3], y1[j] = A[kk * 3 + 1], z1[j] = A[kk * 3 + 2];
+#pragma unroll
+        for (int v = 0; v < 10; v++) rl[j][v] = live ? ratios[(size_t)bi * b_stride + (size_t)v * lv_stride + kk] : 0.f;  // (a row beyond n: every term 0)
+    }
+#pragma unroll
+    for (int v = 0; v < 10; v++) cl[v] = lc.c[v];
+    const float t0 = cl[0] < 0.f ? kSkipArg / -cl[0] : INFINITY;  // (uniform)
+    const int *__restrict__ co = coff + bi * 8;
+    const int lbeg = by * lspan, lend = lbeg + lspan;  // (even; the class boundaries are even too)
+    float csum = 0.f;
+#define EF_CLASS(CLS)                                                                                              \
+    {                                                                                                              \
+        const int a_ = max(lbeg, co[CLS]), e_ = min(lend, co[CLS + 1]);                                            \
+        for (int l = a_; l < e_; l += 2) {                                                                         \
+            const am_v2f *__restrict__ c_ = (const am_v2f *)(R + (size_t)l * EF_REC);                              \
+            _Pragma("unroll") for (int j = 0; j < EF_KPT; j++) ef_pair_step<CLS>(c_, x1[j], y1[j], z1[j], rl[j], cl, t0, csum); \
+        }                                                                                                          \
+    }
+    EF_CLASS(0)
+    EF_CLASS(1)
+    EF_CLASS(2)
+    EF_CLASS(3)
+    EF_CLASS(4)
+#undef EF_CLASS
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) csum += __shfl_down(csum, o, 64);
+    if ((t & 63) == 0) wsum[t >> 6] = csum;
+    __syncthreads();
+    if (t == 0) partial[((size_t)bi * gridDim.y + by) * gridDim.x + bx] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
 // ---- the sharp levels of the schedule ---------------------------------------------------------------------------
 // At level -4^7 (then -4^6, -4^5) the weight exp2(level*log2e * d2) of a pair is EXACTLY +0 once d2 passes a threshold: v_exp_f32
 // returns +0 for every argument <= -160 (tests/test_gpu_emd.py sweeps the instruction), and a pair with weight 0 adds
@@ -2223,14 +2426,22 @@ int am_run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, int
         }
 #undef AM_ROWK_ARGS
         if (live) {
-            const dim3 gp(min(rf::ceil_div(L.mpad, PL_ROWS) * b, 2048));  // (eight workgroups of four waves per CU: all resident)
-            if (zero) {
-                RF_LAUNCH("am_p2", am_p2_live_kernel<true>, gp, dim3(PL_TPB), 0, s, L.npad, (const float *)x1p, (size_t)L.npad * 3,
-                          (const float *)ratioL, remainR, ratioR, L.V, nlevels - 1 - v, L.bstride, lc.c[v], p2in, p2out, L.cstride, L.mpad, b);
+            // (the first two live levels still have rows enough for the long items: 122 / 89 us against 141 / 102 with the short ones)
+            const int prows = (n > PL_BIG_N && v >= vC + 2) ? PL_ROWS_BIG : PL_ROWS;
+            const dim3 gp(min(rf::ceil_div(L.mpad, prows) * b, 2048));  // (eight workgroups of four waves per CU: all resident)
+#define AM_P2_LIVE(Z, ROWS_)                                                                                                      \
+    RF_LAUNCH("am_p2", (am_p2_live_kernel<Z, ROWS_>), gp, dim3(PL_TPB), 0, s, L.npad, (const float *)x1p, (size_t)L.npad * 3,         \
+              (const float *)ratioL, remainR, ratioR, L.V, nlevels - 1 - v, L.bstride, lc.c[v], p2in, p2out, L.cstride, L.mpad, b)
+            if (zero && prows == PL_ROWS) {
+                AM_P2_LIVE(true, PL_ROWS);
+            } else if (zero) {
+                AM_P2_LIVE(true, PL_ROWS_BIG);
+            } else if (prows == PL_ROWS) {
+                AM_P2_LIVE(false, PL_ROWS);
             } else {
-                RF_LAUNCH("am_p2", am_p2_live_kernel<false>, gp, dim3(PL_TPB), 0, s, L.npad, (const float *)x1p, (size_t)L.npad * 3,
-                          (const float *)ratioL, remainR, ratioR, L.V, nlevels - 1 - v, L.bstride, lc.c[v], p2in, p2out, L.cstride, L.mpad, b);
+                AM_P2_LIVE(false, PL_ROWS_BIG);
             }
+#undef AM_P2_LIVE
         } else
         if (zero) {
             RF_LAUNCH("am_p2", (am_rowl_kernel<RPT, true>), gl, dim3(64 * segl), 0, s, m, L.npad / segl, xyz2,
@@ -2439,7 +2650,8 @@ int rf_matchcost_grad(int b, int n, int m, const float *xyz1, const float *xyz2,
 namespace {
 struct EmdLayout {
     bool small;
-    size_t off_rec, off_partial, off_match, off_mc, total;  // floats
+    size_t off_rec, off_partial, off_match, off_mc, off_coff, total;  // floats
+    size_t rstride;  // records per sample in the column-record array (mpad + the class padding)
     int lsplit, lspan;
 };
 EmdLayout emd_layout(int b, int n, int m, int mode = RF_EMD_AUTO) {
@@ -2450,7 +2662,8 @@ EmdLayout emd_layout(int b, int n, int m, int mode = RF_EMD_AUTO) {
         E.off_match = 0;
         E.off_mc = (size_t)b * n * m;
         E.total = E.off_mc + rf_matchcost_workspace_bytes(b, n, m) / sizeof(float);
-        E.off_rec = E.off_partial = 0;
+        E.off_rec = E.off_partial = E.off_coff = 0;
+        E.rstride = 0;
         return E;
     }
     const AmLayout L = am_layout(b, n, m, 10, mode);
@@ -2459,11 +2672,14 @@ EmdLayout emd_layout(int b, int n, int m, int mode = RF_EMD_AUTO) {
     const long base = (long)(mode == RF_EMD_SWEPT ? 1 : b) * rf::ceil_div(n, TPB);
     int lsplit = 1;
     while (lsplit < 64 && base * lsplit < 4096 && L.mpad / (lsplit * 2) >= 2 * MG_TL) lsplit *= 2;
-    E.lspan = round_up_i(rf::ceil_div(L.mpad, lsplit), MG_TL);
-    E.lsplit = rf::ceil_div(L.mpad, E.lspan);
+    // (the spans cover the class-sorted records of the cost-only form: up to mpad + one padding record per class)
+    E.rstride = (size_t)L.mpad + 64;
+    E.lspan = round_up_i(rf::ceil_div(L.mpad + 2 * EF_NCLS, lsplit), MG_TL);
+    E.lsplit = rf::ceil_div(L.mpad + 2 * EF_NCLS, E.lspan);
     E.off_rec = L.total;
-    E.off_partial = E.off_rec + (size_t)b * L.mpad * EF_REC + 64;
-    E.total = E.off_partial + (size_t)b * rf::ceil_div(n, TPB) * E.lsplit;
+    E.off_partial = E.off_rec + (size_t)b * E.rstride * EF_REC + 64;
+    E.off_coff = E.off_partial + (size_t)b * rf::ceil_div(n, TPB) * E.lsplit;
+    E.total = E.off_coff + (size_t)b * 8 + (size_t)b * rf::ceil_div(L.mpad, EP_TPB) * 8 + 64;  // class offsets, then the workgroups' class counts
     E.off_match = E.off_mc = 0;
     return E;
 }
@@ -2535,22 +2751,33 @@ int rf_earth_mover_mode(int b, int n, int m, const float *xyz1, const float *xyz
     const AmLayout L = am_layout(b, n, m, nl, mode);
     const float *ratios = w + L.V;
     float *rec = w + E.off_rec, *partial = w + E.off_partial;
-    RF_LAUNCH("emd_pack_cols", emd_pack_cols_kernel, dim3(rf::ceil_div(L.mpad, 256), b), dim3(256), 0, s, m,
-              L.mpad, nl, xyz2, ratios, L.V, L.bstride, L.npad, rec, want_grad ? 0 : 1);
     const dim3 g(rf::ceil_div(n, TPB), E.lsplit, b);
     const bool sq = quarter_chain(lc.c, 10, true);
-    if (want_grad && sq) {
-        RF_LAUNCH("emd_fused_grad", (emd_fused_kernel<10, true, true, true>), g, dim3(TPB), 0, s, n, m, L.mpad, E.lspan,
-                  xyz1, (const float *)rec, ratios, L.V, L.bstride, lc, partial, grad1, grad2);
-    } else if (want_grad) {
-        RF_LAUNCH("emd_fused_grad", (emd_fused_kernel<10, true, true, false>), g, dim3(TPB), 0, s, n, m, L.mpad, E.lspan,
-                  xyz1, (const float *)rec, ratios, L.V, L.bstride, lc, partial, grad1, grad2);
-    } else if (sq) {
-        RF_LAUNCH("emd_fused", (emd_fused_kernel<10, false, true, true>), g, dim3(TPB), 0, s, n, m, L.mpad, E.lspan, xyz1,
-                  (const float *)rec, ratios, L.V, L.bstride, lc, partial, grad1, grad2);
+    if (!want_grad && sq) {  // the cost alone: the columns by the class of their last live level (emd_fused_cls_kernel)
+        int *coff = (int *)(w + E.off_coff);
+        int *wgcnt = coff + (size_t)b * 8;
+        const dim3 gp(rf::ceil_div(L.mpad, EP_TPB), b);
+        RF_LAUNCH("emd_pack_cols", emd_class_count_kernel, gp, dim3(EP_TPB), 0, s, m, L.mpad, ratios, L.V, L.bstride, L.npad, wgcnt);
+        RF_LAUNCH("emd_pack_cols", emd_pack_cols_sorted_kernel, gp, dim3(EP_TPB), 0, s, m, L.mpad, xyz2, ratios, L.V, L.bstride,
+                  L.npad, (const int *)wgcnt, rec, E.rstride, coff);
+        const dim3 gc(rf::ceil_div(n, TPB * EF_KPT), E.lsplit, b);
+        RF_LAUNCH("emd_fused", emd_fused_cls_kernel, gc, dim3(TPB), 0, s, n, E.lspan, xyz1, (const float *)rec, E.rstride,
+                  (const int *)coff, ratios, L.V, L.bstride, lc, partial);
+        RF_LAUNCH("mc_final", mc_final_kernel, dim3(b), dim3(256), 0, s, (const float *)partial, (int)(gc.x * gc.y), cost);
+        return RF_OK;
     } else {
-        RF_LAUNCH("emd_fused", (emd_fused_kernel<10, false, true, false>), g, dim3(TPB), 0, s, n, m, L.mpad, E.lspan, xyz1,
-                  (const float *)rec, ratios, L.V, L.bstride, lc, partial, grad1, grad2);
+        RF_LAUNCH("emd_pack_cols", emd_pack_cols_kernel, dim3(rf::ceil_div(L.mpad, 256), b), dim3(256), 0, s, m,
+                  L.mpad, nl, xyz2, ratios, L.V, L.bstride, L.npad, rec, want_grad ? 0 : 1);
+        if (want_grad && sq) {
+            RF_LAUNCH("emd_fused_grad", (emd_fused_kernel<10, true, true, true>), g, dim3(TPB), 0, s, n, m, L.mpad, E.lspan,
+                      xyz1, (const float *)rec, ratios, L.V, L.bstride, lc, partial, grad1, grad2);
+        } else if (want_grad) {
+            RF_LAUNCH("emd_fused_grad", (emd_fused_kernel<10, true, true, false>), g, dim3(TPB), 0, s, n, m, L.mpad, E.lspan,
+                      xyz1, (const float *)rec, ratios, L.V, L.bstride, lc, partial, grad1, grad2);
+        } else {
+            RF_LAUNCH("emd_fused", (emd_fused_kernel<10, false, true, false>), g, dim3(TPB), 0, s, n, m, L.mpad, E.lspan, xyz1,
+                      (const float *)rec, ratios, L.V, L.bstride, lc, partial, grad1, grad2);
+        }
     }
     RF_LAUNCH("mc_final", mc_final_kernel, dim3(b), dim3(256), 0, s, (const float *)partial,
               (int)(g.x * g.y), cost);
