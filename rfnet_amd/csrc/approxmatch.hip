@@ -2069,32 +2069,37 @@ __global__ __launch_bounds__(EP_TPB) void emd_pack_cols_sorted_kernel(int m, int
 
 // one two-column step of class CLS (the columns' records c: pair layout); the level-ordered fma chain of am_match_kernel over the
 // class's levels -- weights of odd levels from the next even one's by two squarings, level 9's is 1.0
+// (`f`: the first EF_NEED(CLS) floats of the pair's record, wave-uniform -- scalar registers)
+constexpr int ef_need(int cls) { return 8 + 2 * (cls == 0 ? 1 : (cls == 4 ? 10 : 2 * cls + 1)); }  // xyz pairs, pad, the class's ratioR pairs
 template <int CLS>
-__device__ __forceinline__ void ef_pair_step(const am_v2f *__restrict__ c, float x1, float y1, float z1, const float (&rl)[10],
+__device__ __forceinline__ void ef_pair_step(const float (&f)[ef_need(CLS)], float x1, float y1, float z1, const float (&rl)[10],
                                              const float (&cl)[10], float t0, float &csum) {
-    const am_v2f dx = c[0] - x1, dy = c[1] - y1, dz = c[2] - z1;
+    auto c = [&](int i) { return am_v2f{f[2 * i], f[2 * i + 1]}; };
+    const am_v2f dx = c(0) - x1, dy = c(1) - y1, dz = c(2) - z1;
     const am_v2f d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));  // (rf::d2_fma's order)
     auto ex2 = [](am_v2f a) { return am_v2f{fast_exp2(a.x), fast_exp2(a.y)}; };
     am_v2f e1 = {0.f, 0.f}, e2 = e1, e3 = e1, e4 = e1, e5 = e1, e6 = e1, e7 = e1, e8 = e1;
-    if (CLS >= 4) { e8 = ex2(d2 * cl[8]); const am_v2f q = e8 * e8; e7 = q * q; }
-    if (CLS >= 3) { e6 = ex2(d2 * cl[6]); const am_v2f q = e6 * e6; e5 = q * q; }
-    if (CLS >= 2) { e4 = ex2(d2 * cl[4]); const am_v2f q = e4 * e4; e3 = q * q; }
-    if (CLS >= 1) { e2 = ex2(d2 * cl[2]); const am_v2f q = e2 * e2; e1 = q * q; }
+    if constexpr (CLS >= 4) { e8 = ex2(d2 * cl[8]); const am_v2f q = e8 * e8; e7 = q * q; }
+    if constexpr (CLS >= 3) { e6 = ex2(d2 * cl[6]); const am_v2f q = e6 * e6; e5 = q * q; }
+    if constexpr (CLS >= 2) { e4 = ex2(d2 * cl[4]); const am_v2f q = e4 * e4; e3 = q * q; }
+    if constexpr (CLS >= 1) { e2 = ex2(d2 * cl[2]); const am_v2f q = e2 * e2; e1 = q * q; }
     am_v2f acc = {0.f, 0.f};
     if (__ballot(d2.x < t0 || d2.y < t0) != 0ull) {  // (uniform) the sharpest level: beyond t0 its weight is exactly +0
         asm volatile("; level 0 kept");
-        acc = __builtin_elementwise_fma(rl[0] * ex2(d2 * cl[0]), c[4], acc);
+        acc = __builtin_elementwise_fma(rl[0] * ex2(d2 * cl[0]), c(4), acc);
     }
-    if (CLS >= 1) { acc = __builtin_elementwise_fma(rl[1] * e1, c[5], acc); acc = __builtin_elementwise_fma(rl[2] * e2, c[6], acc); }
-    if (CLS >= 2) { acc = __builtin_elementwise_fma(rl[3] * e3, c[7], acc); acc = __builtin_elementwise_fma(rl[4] * e4, c[8], acc); }
-    if (CLS >= 3) { acc = __builtin_elementwise_fma(rl[5] * e5, c[9], acc); acc = __builtin_elementwise_fma(rl[6] * e6, c[10], acc); }
-    if (CLS >= 4) {
-        acc = __builtin_elementwise_fma(rl[7] * e7, c[11], acc);
-        acc = __builtin_elementwise_fma(rl[8] * e8, c[12], acc);
-        acc = __builtin_elementwise_fma(rl[9] * am_v2f{1.0f, 1.0f}, c[13], acc);
+    if constexpr (CLS >= 1) { acc = __builtin_elementwise_fma(rl[1] * e1, c(5), acc); acc = __builtin_elementwise_fma(rl[2] * e2, c(6), acc); }
+    if constexpr (CLS >= 2) { acc = __builtin_elementwise_fma(rl[3] * e3, c(7), acc); acc = __builtin_elementwise_fma(rl[4] * e4, c(8), acc); }
+    if constexpr (CLS >= 3) { acc = __builtin_elementwise_fma(rl[5] * e5, c(9), acc); acc = __builtin_elementwise_fma(rl[6] * e6, c(10), acc); }
+    if constexpr (CLS >= 4) {
+        acc = __builtin_elementwise_fma(rl[7] * e7, c(11), acc);
+        acc = __builtin_elementwise_fma(rl[8] * e8, c(12), acc);
+        acc = __builtin_elementwise_fma(rl[9] * am_v2f{1.0f, 1.0f}, c(13), acc);
     }
-    csum = fmaf(sqrtf(d2.x), acc.x, csum);
-    csum = fmaf(sqrtf(d2.y), acc.y, csum);
+    // (v_sqrt_f32, 1 ulp: the correctly rounded sqrtf is 16 instructions, twice per step -- a third of a class-1 step; the cost's
+    // bar is rel 1e-5, and match_cost, the reference's op, keeps sqrtf)
+    csum = fmaf(__builtin_amdgcn_sqrtf(d2.x), acc.x, csum);
+    csum = fmaf(__builtin_amdgcn_sqrtf(d2.y), acc.y, csum);
 }
 
 // cost only, the reference schedule (ten levels, the last 0, quarter chain): a thread <-> EF_KPT rows k (TPB apart), a workgroup's
@@ -2135,13 +2140,33 @@ __global__ __launch_bounds__(TPB) void emd_fused_cls_kernel(int n, int lspan, co
     const int *__restrict__ co = coff + bi * 8;
     const int lbeg = by * lspan, lend = lbeg + lspan;  // (even; the class boundaries are even too)
     float csum = 0.f;
-#define EF_CLASS(CLS)                                                                                              \
-    {                                                                                                              \
-        const int a_ = max(lbeg, co[CLS]), e_ = min(lend, co[CLS + 1]);                                            \
-        for (int l = a_; l < e_; l += 2) {                                                                         \
-            const am_v2f *__restrict__ c_ = (const am_v2f *)(R + (size_t)l * EF_REC);                              \
-            _Pragma("unroll") for (int j = 0; j < EF_KPT; j++) ef_pair_step<CLS>(c_, x1[j], y1[j], z1[j], rl[j], cl, t0, csum); \
-        }                                                                                                          \
+    // a class's pairs with their records through TWO scalar register sets in turn (the sweeps' scheme): the next pair's loads are
+    // on their way while this one is worked on -- asked for at the top of its own step, a record was three waits per step
+    const cfloat *__restrict__ Rc = (const cfloat *)R;
+#define EF_FETCH(dst, CLS, l_)                                                                            \
+    _Pragma("unroll") for (int i = 0; i < ef_need(CLS); i++) dst[i] = Rc[(size_t)(l_) * EF_REC + i]
+#define EF_STEPS(src, CLS)                                                                                \
+    _Pragma("unroll") for (int j = 0; j < EF_KPT; j++) ef_pair_step<CLS>(src, x1[j], y1[j], z1[j], rl[j], cl, t0, csum)
+#define EF_CLASS(CLS)                                                                                     \
+    {                                                                                                     \
+        const int a_ = max(lbeg, co[CLS]), e_ = min(lend, co[CLS + 1]);                                   \
+        if (a_ < e_) {                                                                                    \
+            float fa[ef_need(CLS)], fb[ef_need(CLS)];                                                     \
+            EF_FETCH(fa, CLS, a_);                                                                        \
+            for (int l = a_; l < e_; l += 4) {                                                            \
+                __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0): set a has arrived */                   \
+                __builtin_amdgcn_sched_barrier(0);                                                        \
+                EF_FETCH(fb, CLS, min(l + 2, e_ - 2));                                                    \
+                __builtin_amdgcn_sched_barrier(0);                                                        \
+                EF_STEPS(fa, CLS);                                                                        \
+                if (l + 2 >= e_) break;                                                                   \
+                __builtin_amdgcn_s_waitcnt(0xC07F);                                                       \
+                __builtin_amdgcn_sched_barrier(0);                                                        \
+                EF_FETCH(fa, CLS, min(l + 4, e_ - 2));                                                    \
+                __builtin_amdgcn_sched_barrier(0);                                                        \
+                EF_STEPS(fb, CLS);                                                                        \
+            }                                                                                             \
+        }                                                                                                 \
     }
     EF_CLASS(0)
     EF_CLASS(1)
@@ -2149,6 +2174,8 @@ __global__ __launch_bounds__(TPB) void emd_fused_cls_kernel(int n, int lspan, co
     EF_CLASS(3)
     EF_CLASS(4)
 #undef EF_CLASS
+#undef EF_STEPS
+#undef EF_FETCH
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) csum += __shfl_down(csum, o, 64);
     if ((t & 63) == 0) wsum[t >> 6] = csum;
