@@ -37,6 +37,14 @@ m = re.search(r"^\s*32\s+16384\s+4096\s+64\s+inline\s+[\d.]+ us\s+auto\s+([\d.]+
 if m:
     vals.update({'TIG': f(float(m.group(1)),0), 'TIGTB': f(180.4e6/(float(m.group(1))*1e-6)/1e12,1), 'TIGFRAC': f(180.4e6/(float(m.group(1))*1e-6)/8e12,2)})
 vals['NGPU'] = sys.argv[3] if len(sys.argv) > 3 else '651'
+# rf_earth_mover over sizes (tools/ab_emd_cull.py base): profiles/r06_emd_sizes.txt
+try:
+    es = open(os.path.join(HERE, '..', '..', 'profiles', 'r06_emd_sizes.txt')).read()
+    for key, shape in (('BIGMS', '4x16384'), ('BIG8', '8x8192'), ('BIG4', '16x4096'), ('BIG2', '32x2048')):
+        mm = re.search(shape + r"\s+\{'total_ms': ([\d.]+)", es)
+        vals[key] = f(float(mm.group(1)), 2 if key != 'BIG2' else 3) if mm else '?'
+except OSError:
+    pass
 doc = head + s5.replace("History — every variant", "Source comments that cite \"DESIGN.md 5.x\" mean the section numbers of rounds 1–5, which DESIGN_NOTES.md keeps (Part II).\nHistory — every variant") + "\n" + s6 + "\n" + tail78 + s9
 for k_, v in vals.items():
     doc = doc.replace('@' + k_ + '@', str(v))

@@ -11,7 +11,9 @@ tail -4 "$O/pytest_gpu.txt"
 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$O/smoke.txt" 2>&1; tail -1 "$O/smoke.txt"
 bash tools/profile_bench.sh r06h/prof
 bash tools/profile_op.sh c4 r06h/c4
-bash tools/experiments/trace_emd.sh > "$O/emd_launches.txt" 2>&1
+bash tools/experiments/trace_emd.sh "" 34 > "$O/emd_launches.txt" 2>&1
+bash tools/experiments/trace_emd.sh 50 106 > "$O/emd50_launches.txt" 2>&1
+bash tools/experiments/trace_emd.sh big 26 > "$O/emd_big_launches.txt" 2>&1
 timeout 200 python3 tools/ab_emd_modes.py > "$O/ab_emd_modes.txt" 2>&1; cat "$O/ab_emd_modes.txt"
 timeout 300 python3 tools/ab_group_grad.py > "$O/ab_group_grad.txt" 2>&1; cut -c1-260 "$O/ab_group_grad.txt"
 timeout 200 python3 tools/ab_c3.py > "$O/ab_c3.txt" 2>&1; cat "$O/ab_c3.txt"
