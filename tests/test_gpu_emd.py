@@ -279,6 +279,34 @@ def test_earth_mover_abi_errors():
     assert lib.rf_earth_mover(0, 300, 300, None, None, None, None, None, None, 0, None) == 0
 
 
+@pytest.mark.parametrize("kind", ["box", "corners", "same", "near"])
+@pytest.mark.parametrize("b,n,m", [(2, 1500, 2500), (1, 3000, 1025), (1, 600, 5121)])
+def test_earth_mover_cost_by_column_classes(kind, b, n, m):
+    """The cost-only form walks set 2's columns by the CLASS of their last live level (emd_class_count / emd_pack_cols_sorted /
+    emd_fused_cls kernels): clouds that put every column in one class -- two clusters in opposite corners (nothing matches before the
+    broad levels: all columns live to the end), a cloud against itself (everything is used up at the sharpest level), a jittered copy --
+    and ragged sizes around the pack's 1024-column workgroups, against this library's own chain approx_match -> match_cost."""
+    from rfnet_amd import _raw
+    from pc_distance.tf_approxmatch import approx_match, match_cost
+    rng = np.random.RandomState(n + m)
+    if kind == "box":
+        a, c = rng.random_sample((b, n, 3)) - 0.5, rng.random_sample((b, m, 3)) - 0.5
+    elif kind == "corners":
+        a, c = rng.random_sample((b, n, 3)) * 0.1 - 0.5, rng.random_sample((b, m, 3)) * 0.1 + 0.4
+    else:
+        base = rng.random_sample((b, max(n, m), 3)) - 0.5
+        a, c = base[:, :n].copy(), base[:, :m].copy()
+        if kind == "near":
+            c += rng.normal(0, 2e-3, c.shape)
+    ta, tc = cu(a.astype(np.float32)), cu(c.astype(np.float32))
+    fused = _raw.earth_mover(ta, tc).cpu().numpy()
+    chain = match_cost(ta, tc, approx_match(ta, tc)).cpu().numpy()
+    assert np.isfinite(fused).all()
+    assert_rel(fused, chain, 1e-5, 1e-6, what=f"cost-only earth_mover vs chain ({kind} {b}x{n}x{m})")
+    swept = _raw.earth_mover(ta, tc, mode="swept").cpu().numpy()
+    assert_rel(swept, chain, 1e-5, 1e-6, what=f"swept route ({kind})")
+
+
 def test_earth_mover_fused_eval_size_16384():
     """The evaluation-size EMD (16384 vs 16384, recon_test.py / vv_recon.py:28 EVAL_SIZE micro-batches):
     the reference needs 1 GiB of match per sample; the fused op none.  Checked against this
