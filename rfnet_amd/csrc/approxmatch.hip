@@ -760,10 +760,7 @@ __global__ __launch_bounds__(CK_TPB) void am_compact_kernel(int m, const float *
 constexpr int PL_TPB = 256, PL_NW = PL_TPB / 64, PL_ROWS = 32, PL_CPL = 8, PL_RU = 2;  // (PL_RU rows' chains side by side)
 // An item walks its rows over ALL columns: at 16384 columns an item of 32 rows is 46 us long however few items a late level has
 // left (`tools/experiments/trace_emd.sh big`) -- clouds of more than PL_BIG_N points take their rows in items of PL_ROWS_BIG.
-#ifndef RFA_PL_ROWS_BIG
-#define RFA_PL_ROWS_BIG 8
-#endif
-constexpr int PL_ROWS_BIG = RFA_PL_ROWS_BIG, PL_BIG_N = 4096;
+constexpr int PL_ROWS_BIG = 8, PL_BIG_N = 4096;
 static_assert(PL_CPL % 2 == 0, "the columns of a lane go through packed fp32 operations in pairs");
 static_assert(PL_ROWS % PL_RU == 0 && PL_ROWS <= 64 && PL_ROWS_BIG % PL_RU == 0, "a row per lane of the running sums");
 template <bool ZERO, int ROWS = PL_ROWS>
@@ -2102,14 +2099,10 @@ __device__ __forceinline__ void ef_pair_step(const float (&f)[ef_need(CLS)], flo
     csum = fmaf(__builtin_amdgcn_sqrtf(d2.y), acc.y, csum);
 }
 
-// cost only, the reference schedule (ten levels, the last 0, quarter chain): a thread <-> EF_KPT rows k (TPB apart), a workgroup's
-// span of the class-sorted records [by * lspan, by * lspan + lspan) cut at the class boundaries.  (EF_KPT = 2 -- a step's 128
+// cost only, the reference schedule (ten levels, the last 0, quarter chain): thread <-> row k, a workgroup's span of the
+// class-sorted records [by * lspan, by * lspan + lspan) cut at the class boundaries.  (Two rows per thread -- a step's 128
 // bytes of scalar loads serving 128 rows -- measured SLOWER: fused earth_mover at C4 0.525 against 0.513 ms, 4 x 16384^2 911 against
 // 864 us for this kernel: 84 registers, five waves per SIMD.)
-#ifndef RFA_EF_KPT
-#define RFA_EF_KPT 1
-#endif
-constexpr int EF_KPT = RFA_EF_KPT;
 __global__ __launch_bounds__(TPB) void emd_fused_cls_kernel(int n, int lspan, const float *__restrict__ xyz1,
                                                             const float *__restrict__ rec, size_t rstride,
                                                             const int *__restrict__ coff, const float *__restrict__ ratios,
@@ -2124,18 +2117,16 @@ __global__ __launch_bounds__(TPB) void emd_fused_cls_kernel(int n, int lspan, co
     const int t = threadIdx.x;
     const float *__restrict__ A = xyz1 + (size_t)bi * n * 3;
     const float *__restrict__ R = rec + (size_t)bi * rstride * EF_REC;
-    float x1[EF_KPT], y1[EF_KPT], z1[EF_KPT], rl[EF_KPT][10], cl[10];
+    const int k = bx * TPB + t;
+    const bool live = k < n;
+    const int kk = live ? k : n - 1;
+    const float x1 = A[kk * 3], y1 = A[kk * 3 + 1], z1 = A[kk * 3 + 2];
+    float rl[10], cl[10];
 #pragma unroll
-    for (int j = 0; j < EF_KPT; j++) {
-        const int k = (bx * EF_KPT + j) * TPB + t;
-        const bool live = k < n;
-        const int kk = live ? k : n - 1;
-        x1[j] = A[kk * 3], y1[j] = A[kk * 3 + 1], z1[j] = A[kk * 3 + 2];
-#pragma unroll
-        for (int v = 0; v < 10; v++) rl[j][v] = live ? ratios[(size_t)bi * b_stride + (size_t)v * lv_stride + kk] : 0.f;  // (a row beyond n: every term 0)
+    for (int v = 0; v < 10; v++) {
+        rl[v] = live ? ratios[(size_t)bi * b_stride + (size_t)v * lv_stride + kk] : 0.f;  // (a row beyond n: every term 0)
+        cl[v] = lc.c[v];
     }
-#pragma unroll
-    for (int v = 0; v < 10; v++) cl[v] = lc.c[v];
     const float t0 = cl[0] < 0.f ? kSkipArg / -cl[0] : INFINITY;  // (uniform)
     const int *__restrict__ co = coff + bi * 8;
     const int lbeg = by * lspan, lend = lbeg + lspan;  // (even; the class boundaries are even too)
@@ -2145,8 +2136,7 @@ __global__ __launch_bounds__(TPB) void emd_fused_cls_kernel(int n, int lspan, co
     const cfloat *__restrict__ Rc = (const cfloat *)R;
 #define EF_FETCH(dst, CLS, l_)                                                                            \
     _Pragma("unroll") for (int i = 0; i < ef_need(CLS); i++) dst[i] = Rc[(size_t)(l_) * EF_REC + i]
-#define EF_STEPS(src, CLS)                                                                                \
-    _Pragma("unroll") for (int j = 0; j < EF_KPT; j++) ef_pair_step<CLS>(src, x1[j], y1[j], z1[j], rl[j], cl, t0, csum)
+#define EF_STEPS(src, CLS) ef_pair_step<CLS>(src, x1, y1, z1, rl, cl, t0, csum)
 #define EF_CLASS(CLS)                                                                                     \
     {                                                                                                     \
         const int a_ = max(lbeg, co[CLS]), e_ = min(lend, co[CLS + 1]);                                   \
@@ -2787,7 +2777,7 @@ int rf_earth_mover_mode(int b, int n, int m, const float *xyz1, const float *xyz
         RF_LAUNCH("emd_pack_cols", emd_class_count_kernel, gp, dim3(EP_TPB), 0, s, m, L.mpad, ratios, L.V, L.bstride, L.npad, wgcnt);
         RF_LAUNCH("emd_pack_cols", emd_pack_cols_sorted_kernel, gp, dim3(EP_TPB), 0, s, m, L.mpad, xyz2, ratios, L.V, L.bstride,
                   L.npad, (const int *)wgcnt, rec, E.rstride, coff);
-        const dim3 gc(rf::ceil_div(n, TPB * EF_KPT), E.lsplit, b);
+        const dim3 gc(rf::ceil_div(n, TPB), E.lsplit, b);
         RF_LAUNCH("emd_fused", emd_fused_cls_kernel, gc, dim3(TPB), 0, s, n, E.lspan, xyz1, (const float *)rec, E.rstride,
                   (const int *)coff, ratios, L.V, L.bstride, lc, partial);
         RF_LAUNCH("mc_final", mc_final_kernel, dim3(b), dim3(256), 0, s, (const float *)partial, (int)(gc.x * gc.y), cost);
