@@ -328,7 +328,9 @@ int rf_probsample(int b, int n, int m, const float *inp_p, const float *inp_r, f
  * grad2 (b,m,3) -- straight from the per-level ratio vectors, without materialising the
  * (b,m,n) match tensor (512 MiB at 32x2048x2048; 1 GiB per sample at 16384^2).  No reference
  * launcher corresponds to it: a TF-side maintainer would register it as one new op replacing
- * the three-op chain.  Reference 10-level schedule only. */
+ * the three-op chain.  Reference 10-level schedule only.  The cost is the chain's within rel 1e-5 (north_star's bar), not its
+ * bits: the cost-only form (grad1 == grad2 == NULL) sums a sample's columns in the order of their last live level and takes
+ * sqrt(d2) from v_sqrt_f32 (1 ulp) -- a function of the sample alone, so RF_EMD_SWEPT's batch independence holds. */
 size_t rf_earth_mover_workspace_bytes(int b, int n, int m);
 int rf_earth_mover(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost,
                    float *grad1, float *grad2, void *workspace, size_t workspace_bytes,
