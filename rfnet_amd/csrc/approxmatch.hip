@@ -144,7 +144,7 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
     constexpr bool HAS_P1 = P1 != 0;
     const int nseg = blockDim.x >> 6;
     const float *__restrict__ A = xyz1 + (size_t)bi * n * 3;
-    float x1[RPT], y1[RPT], z1[RPT], rl[RPT], acc3[RPT], acc1[RPT];
+    float x1[RPT], y1[RPT], z1[RPT], rl[RPT], rem0[RPT], acc3[RPT], acc1[RPT];
     int krow[RPT];  // the lane's rows (original indices; < 0: none)
 #pragma unroll
     for (int r = 0; r < RPT; r++) {
@@ -154,6 +154,7 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
         x1[r] = A[kk * 3]; y1[r] = A[kk * 3 + 1]; z1[r] = A[kk * 3 + 2];
         if (SKIP != 0 && krow[r] < 0) x1[r] = INFINITY;  // a lane without a row never keeps a column alive (d2 = inf)
         rl[r] = HAS_P3 ? ratioL_prev[(size_t)bi * stride + kk] : 0.f;
+        rem0[r] = remainL[(size_t)bi * stride + kk];  // (asked for here, used behind the sweep: read behind the barrier it was a round trip to memory at the launch's very end)
         acc3[r] = 0.f;
         acc1[r] = (seg == 0) ? 1e-9f : 0.f;
     }
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(1024) void am_rowk_kernel(
                 t3 += part3[g][r * 64 + lane];
                 t1 += part1[g][r * 64 + lane];
             }
-            float rem = remainL[(size_t)bi * stride + k];
+            float rem = rem0[r];
             if (HAS_P3) {
                 rem = fmaxf(0.0f, rem - t3);
                 remainL[(size_t)bi * stride + k] = rem;
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
     const int nseg = blockDim.x >> 6;
     if (LIST && bx * 64 * RPT >= ((const __attribute__((address_space(4))) int *)counts)[bi * 4 + 1]) return;  // (uniform)
     const float *__restrict__ B = xyz2 + (size_t)bi * m * 3;
-    float x2[RPT], y2[RPT], z2[RPT], acc[RPT];
+    float x2[RPT], y2[RPT], z2[RPT], rem0[RPT], acc[RPT];
     int lrow[RPT];  // the lane's rows (original indices; < 0: none); SKIP: in the cloud's spatial order (see am_rowk_kernel)
 #pragma unroll
     for (int r = 0; r < RPT; r++) {
@@ -464,6 +465,7 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
         const int ll = lrow[r] >= 0 ? lrow[r] : m - 1;
         x2[r] = B[ll * 3]; y2[r] = B[ll * 3 + 1]; z2[r] = B[ll * 3 + 2];
         if (SKIP && lrow[r] < 0) x2[r] = INFINITY;
+        rem0[r] = remainR[(size_t)bi * stride + ll];  // (asked for here, used behind the sweep: am_rowk_kernel)
         acc[r] = 0.f;
     }
     const float *__restrict__ C = xyz1p + (size_t)bi * xyz1p_stride;
@@ -650,7 +652,7 @@ __global__ __launch_bounds__(1024) void am_rowl_kernel(
             if (l < 0) continue;
             float sumr = part[0][r * 64 + lane];
             for (int g = 1; g < nseg; g++) sumr += part[g][r * 64 + lane];
-            const float rem = remainR[(size_t)bi * stride + l];
+            const float rem = rem0[r];
             const float t = sumr * rem;
             const float cons = fminf(rem / (t + 1e-9f), 1.0f);
             ratioR_out[(size_t)bi * stride + l] = rem * cons;
