@@ -70,6 +70,23 @@ def test_workspace_queries_are_pure_host_functions():
     assert w > 0 and w % 8 == 0
     assert lib.rf_approxmatch_workspace_bytes(32, 2048, 2048, 0) >= 32 * 4096 * 11 * 4
     assert lib.rf_approxmatch_workspace_bytes(1, 10, 20, 50) >= 30 * 51 * 4
+    # round 6: the route pin and the cost-only form's column records (16 floats per column, padded per class) + class tables
+    for fn in (lib.rf_approxmatch_mode_workspace_bytes, lib.rf_earth_mover_mode_workspace_bytes,
+               lib.rf_grouppoint_grad_workspace_bytes, lib.rf_threeinterpolate_grad_workspace_bytes):
+        fn.restype = ctypes.c_size_t
+    amw = lambda b, n, m, lv, mode: lib.rf_approxmatch_mode_workspace_bytes(b, n, m, lv, mode)
+    emw = lambda b, n, m, mode: lib.rf_earth_mover_mode_workspace_bytes(b, n, m, mode)
+    assert amw(32, 2048, 2048, 0, 0) == lib.rf_approxmatch_workspace_bytes(32, 2048, 2048, 0)
+    assert 0 < amw(32, 2048, 2048, 0, 1) <= amw(32, 2048, 2048, 0, 0)          # the swept route needs no sorted sets, lists or live sets
+    assert amw(32, 2048, 2048, 0, 2) == 0 and emw(32, 2048, 2048, 7) == 0      # unknown modes
+    for b, n, m in ((32, 2048, 2048), (4, 16384, 16384), (3, 700, 5000)):
+        e, a = emw(b, n, m, 0), amw(b, n, m, 10, 0)
+        assert e % 4 == 0 and e >= a + b * m * 16 * 4, (b, n, m, e, a)        # the levels' workspace + one 64-byte record per column
+        assert e < a + b * (m + 256) * 16 * 4 + b * ((n + 255) // 256) * 64 * 4 + (1 << 20)
+    assert emw(2, 64, 64, 0) > 0                                               # small clouds: match in the workspace
+    assert lib.rf_grouppoint_grad_workspace_bytes(32, 16384, 64, 1024, 32) > 0
+    assert lib.rf_grouppoint_grad_workspace_bytes(2, 16384, 16, 1024, 32) == 0   # below the threshold: the atomics, no workspace
+    assert lib.rf_threeinterpolate_grad_workspace_bytes(32, 16384, 64, 4096) > 0
     assert lib.rf_farthestpointsampling_temp_floats(32, 16384) == 0
     assert lib.rf_farthestpointsampling_temp_floats(2, 20000) == 40000
     # round-2 entry points: sizes are pure functions of the shape (no device, no state)
